@@ -1,0 +1,203 @@
+/*
+ * dwm_hip.h — C ABI of libdwm_hip.so: the MI355X (gfx950) kernels under the
+ * CTSD SD-3.5 MMDiT denoising hot path of OpenDWM.
+ *
+ * The reference (SenseTime-FVG/OpenDWM @ 2025-07-04) has NO native / FFI
+ * boundary on this path: every op below is, in the
+ * reference, a PyTorch/diffusers call made from Python.  Each entry point
+ * therefore cites the reference *call site(s)* it replaces; the Python-level
+ * drop-in boundary (the JSON "_class_name" model class, src/dwm/common.py:133-179)
+ * is mirrored by opendwm_amd/dit.py, which is the only caller of this ABI.
+ * INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers (HBM);
+ *   - "bf16" = raw uint16 bfloat16 storage; accumulation / statistics in fp32;
+ *   - nothing allocates, nothing synchronises, everything is enqueued on the
+ *     hipStream_t passed (void* here so the header needs no HIP include);
+ *   - every function returns 0 on success, a negative DWM_E* code on invalid
+ *     arguments (surfaced as RuntimeError by the Python shim) and the positive
+ *     hipError_t value if the launch itself failed;
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef DWM_HIP_H
+#define DWM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWM_OK 0
+#define DWM_EINVAL (-1)     /* bad shape / null pointer */
+#define DWM_EALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
+#define DWM_EUNSUPPORTED (-3)
+
+/* ABI version; bump on any struct change. */
+#define DWM_ABI_VERSION 4
+int dwm_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * GEMM:  C[M,Nout] = epilogue( A[M,K] · W[N,K]^T )
+ * bf16 in, fp32 accumulate on v_mfma_f32_32x32x16_bf16, bf16 out.
+ * W is a torch.nn.Linear weight ([out,in], K contiguous).  K % 64 == 0,
+ * N % 8 == 0, lda/ldc/... % 8 == 0 (16-byte rows).
+ *
+ * Replaces every torch.nn.Linear on the path:
+ *   diffusers JointTransformerBlock (called crossview_temporal_dit.py:517-521):
+ *     attn.to_q/k/v, add_{q,k,v}_proj, to_out.0, to_add_out, ff.net.*, norm1.linear ...
+ *   VTSelfAttentionBlock (crossview_temporal.py:562-582): ff_in, attn1.*, ff
+ *   pos_embed.proj (as im2col GEMM), context_embedder, time_text_embed,
+ *   view/time index MLPs (crossview_temporal_dit.py:421-439,528-568), proj_out (:600).
+ * ---------------------------------------------------------------------- */
+enum {
+    DWM_EPI_PLAIN = 0,   /* v = act(acc + bias)                                        */
+    DWM_EPI_GEGLU = 1,   /* W/bias packed in 64-row groups [32 value rows | 32 gate rows];
+                            out[:, j] = (acc_v + b_v) * gelu_erf(acc_g + b_g); Nout = N/2
+                            (diffusers FeedForward "geglu", crossview_temporal.py:548-560) */
+    DWM_EPI_RESID = 2,   /* v = act(acc + bias); v *= gate; v += res; v = a*blend + (1-a)*v
+                            (gated residual of JointTransformerBlock; residual adds of
+                            VTSelfAttentionBlock; AlphaBlender crossview_temporal.py:68-72) */
+    DWM_EPI_RMSHEAD = 3  /* v = acc + bias; per 64-column head RMSNorm (affine) on columns
+                            < rms_ncols (diffusers Attention qk_norm="rms_norm")          */
+};
+enum { DWM_ACT_NONE = 0, DWM_ACT_GELU_TANH = 1, DWM_ACT_SILU = 2 };
+
+typedef struct dwm_gemm_args {
+    const void* A;  int64_t lda;          /* bf16 [M,K], row stride lda elements          */
+    const void* W;                        /* bf16 [N,K] contiguous                        */
+    const void* bias;                     /* bf16 [N] or NULL                             */
+    void* C;        int64_t ldc;          /* bf16 [M,Nout]                                */
+    int64_t M, N, K;
+    int32_t epilogue;                     /* DWM_EPI_*                                    */
+    int32_t act;                          /* DWM_ACT_* (PLAIN / RESID)                    */
+    /* RESID */
+    const void* gate; int64_t ld_gate; int64_t rows_per_gate;   /* bf16 gate[row/rows_per_gate][n] or NULL */
+    const void* res;  int64_t ld_res;  int64_t res_mod;         /* bf16 res[res_mod ? row%res_mod : row][n] or NULL */
+    const void* blend; int64_t ld_blend;                        /* bf16 blend[row][n] or NULL               */
+    const float* alpha; int64_t rows_per_alpha;                 /* fp32 alpha[row/rows_per_alpha]           */
+    /* RMSHEAD */
+    const void* rms_w; int64_t rms_ncols; float rms_eps;        /* bf16 rms_w[rms_ncols]                    */
+    int32_t reserved;
+} dwm_gemm_args;
+
+int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused multi-head attention forward, head_dim 64, bf16, flash-style online
+ * softmax, S^T = K·Q^T on MFMA so each lane owns one query row.
+ *
+ * One "problem" p is one (batch-like index, head) softmax(QK^T*scale [+mask])V
+ * over L = L0 + L1 tokens: segment 0 (L0 "sample" tokens, rows addressed through
+ * the row map below) followed by segment 1 (L1 "context" tokens, dense rows
+ * p*L1 + l).  Q/K/V/O element (row, head h, d) lives at ptr[row*ld + h*64 + d].
+ *
+ * Row map of segment 0 (folds the einops.rearrange of
+ * crossview_temporal_dit.py:307-315,336-361 into addressing; no copies):
+ *   row(p, l) = sum_{i<3} ((p / pdiv[i]) % pmod[i]) * pstride[i]
+ *             + (l % ldiv[0]) * lstride[0] + ((l / ldiv[0]) % ldiv[1]) * lstride[1]
+ *             + (l / (ldiv[0] * ldiv[1])) * lstride[2]
+ *
+ * Mask (True/1 = attend), crossview_temporal_dit.py:301-305:
+ *   mode 0: none
+ *   mode 1: groups — allowed(q,k) = mask[(p/p_per_mask)*G*G + gq*G + gk],
+ *           g(l) = (l / group_size) % G      (mask is the [B,V,V] bool tensor)
+ *   mode 2: dense uint8 mask[p][Lq][Lk]      (generic VTSelfAttentionBlock API)
+ *
+ * Replaces F.scaled_dot_product_attention inside diffusers JointAttnProcessor2_0
+ * (JointTransformerBlock attn / attn2) and AttnProcessor2_0
+ * (VTSelfAttentionBlock.attn1, crossview_temporal.py:572-574).
+ * ---------------------------------------------------------------------- */
+typedef struct dwm_attn_args {
+    const void *q0, *k0, *v0; int64_t ld0;     /* segment 0 (bf16)            */
+    const void *q1, *k1, *v1; int64_t ld1;     /* segment 1 or NULL (L1 = 0)  */
+    void* o0; int64_t ldo0;
+    void* o1; int64_t ldo1;
+    int64_t L0, L1;
+    int64_t n_problems;                        /* batch-like count (excl. heads) */
+    int32_t heads; int32_t head_dim;           /* head_dim must be 64         */
+    float scale;
+    int32_t mask_mode;
+    int64_t pdiv[3], pmod[3], pstride[3];
+    int64_t ldiv[2], lstride[3];
+    const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
+    int32_t variant;                           /* 0 = auto; tuning knob, see attention.hip    */
+    int32_t reserved;
+} dwm_attn_args;
+
+int dwm_attention_fwd(const dwm_attn_args* args, void* stream);
+
+/* Diagnostic (tests only): one wave issues ds_read_b64_tr_b16 at LDS byte offset offs[lane]
+ * (8-byte aligned, < 8192) of an image with img16[i] = i; out[lane*4 + j] = element j. */
+int dwm_debug_tr_probe(const int32_t* offs, int16_t* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm family over the last dim D (D % 8 == 0, D <= 8192), one wave per row:
+ *   x' = x + addvec[row / rows_per_add]            (optional; x' also written to xsum)
+ *   n  = (x' - mean) * rsqrt(var + eps)            (biased variance, fp32 statistics)
+ *   y  = n * weight + bias                         (affine, optional)
+ *   y  = y * (1 + scale[row/rows_per_mod]) + shift[row/rows_per_mod]     (optional)
+ *   y2 = n * (1 + scale2[...]) + shift2[...]       (optional second output)
+ * Replaces: AdaLayerNormZero / SD35AdaLayerNormZeroX / AdaLayerNormContinuous
+ * normalise+modulate, JointTransformerBlock.norm2 + modulate, torch.nn.LayerNorm
+ * norm_in/norm1/norm3 of VTSelfAttentionBlock (crossview_temporal.py:545-558)
+ * and the "hidden_states + view_emb / sequence_emb" adds at
+ * crossview_temporal_dit.py:229-230,334.
+ * ---------------------------------------------------------------------- */
+typedef struct dwm_layernorm_args {
+    const void* x; int64_t ldx;                /* bf16 [rows, D]                      */
+    void* y;       int64_t ldy;                /* bf16                                */
+    void* y2;      int64_t ldy2;               /* bf16 or NULL                        */
+    void* xsum;    int64_t ldxsum;             /* bf16 or NULL                        */
+    int64_t rows; int32_t D; float eps;
+    const void* weight; const void* bias;      /* bf16 [D] or NULL                    */
+    const void* scale;  const void* shift;  int64_t ld_mod;  int64_t rows_per_mod;
+    const void* scale2; const void* shift2;    /* share ld_mod / rows_per_mod          */
+    const void* addvec; int64_t ld_add; int64_t rows_per_add;
+} dwm_layernorm_args;
+
+int dwm_layernorm(const dwm_layernorm_args* args, void* stream);
+
+/* Stand-alone per-head RMSNorm (in place) over 64-wide heads of x[rows, ncols]:
+ * x[r, c] = x[r, c] * rsqrt(mean_head(x^2) + eps) * w[c]; (fallback for shapes the
+ * GEMM RMSHEAD epilogue does not cover).  diffusers RMSNorm. */
+int dwm_rmsnorm_heads(void* x, int64_t ldx, int64_t rows, int64_t ncols,
+                      const void* w, float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Small element-wise kernels (HBM-bound glue)
+ * ---------------------------------------------------------------------- */
+/* y = silu(x), bf16, n elements (n % 8 == 0).  AdaLN "linear(silu(temb))" prologue. */
+int dwm_silu(const void* x, void* y, int64_t n, void* stream);
+
+/* diffusers Timesteps(C, flip_sin_to_cos=True, downscale_freq_shift=0):
+ * out[i, :C/2] = cos(t_i * f), out[i, C/2:] = sin(t_i * f), f_j = exp(-ln(1e4) * j / (C/2)).
+ * t fp32 [n]; out bf16 [n, C].  (crossview_temporal_dit.py:153-154,163-164,435,531,563) */
+int dwm_timestep_sinusoid(const float* t, int64_t n, int32_t C, void* out, void* stream);
+
+/* im2col for the p x p / stride p patch conv (SD3 PatchEmbed.proj):
+ * x [I, C, H, W] (fp32 if x_is_f32 else bf16) -> out bf16 [I*(H/p)*(W/p), ldo>=C*p*p],
+ * column = (c*p + py)*p + px; columns [C*p*p, ldo) are zero-filled. */
+int dwm_patchify(const void* x, int32_t x_is_f32, int64_t I, int32_t C, int32_t H, int32_t W,
+                 int32_t p, void* out, int64_t ldo, void* stream);
+
+/* inverse of the final einsum "nhwpqc->nchpwq" (crossview_temporal_dit.py:603-621):
+ * x bf16 [I*h*w, ldx] with column (py*p + px)*C + c  ->  out bf16 [I, C, h*p, w*p]. */
+int dwm_unpatchify(const void* x, int64_t ldx, int64_t I, int32_t C, int32_t h, int32_t w,
+                   int32_t p, void* out, void* stream);
+
+/* classifier-free guidance + FlowMatchEuler step (ctsd.py:1548-1575):
+ * pred bf16 [2, n] (uncond ; cond), latents fp32 [n] in/out:
+ *   latents += dsigma * (u + guidance * (c - u));  model_in bf16 [2, n] (optional) receives
+ *   the updated latents duplicated for the next step (ctsd.py:1528,1536-1538). */
+int dwm_cfg_euler_step(const void* pred, float* latents, void* model_in, int64_t n,
+                       float guidance, float dsigma, void* stream);
+
+/* dst bf16 <- src fp32 (n % 4 == 0) */
+int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DWM_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libdwm_hip.so (include/dwm_hip.h).  There is no CPU fallback:
+if the library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
+ABI_VERSION = 4
+
+EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
+
+_i64, _i32, _f32, _vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("lda", _i64), ("W", _vp), ("bias", _vp), ("C", _vp), ("ldc", _i64),
+        ("M", _i64), ("N", _i64), ("K", _i64), ("epilogue", _i32), ("act", _i32),
+        ("gate", _vp), ("ld_gate", _i64), ("rows_per_gate", _i64),
+        ("res", _vp), ("ld_res", _i64), ("res_mod", _i64),
+        ("blend", _vp), ("ld_blend", _i64), ("alpha", _vp), ("rows_per_alpha", _i64),
+        ("rms_w", _vp), ("rms_ncols", _i64), ("rms_eps", _f32), ("reserved", _i32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q0", _vp), ("k0", _vp), ("v0", _vp), ("ld0", _i64),
+        ("q1", _vp), ("k1", _vp), ("v1", _vp), ("ld1", _i64),
+        ("o0", _vp), ("ldo0", _i64), ("o1", _vp), ("ldo1", _i64),
+        ("L0", _i64), ("L1", _i64), ("n_problems", _i64),
+        ("heads", _i32), ("head_dim", _i32), ("scale", _f32), ("mask_mode", _i32),
+        ("pdiv", _i64 * 3), ("pmod", _i64 * 3), ("pstride", _i64 * 3),
+        ("ldiv", _i64 * 2), ("lstride", _i64 * 3),
+        ("mask", _vp), ("mask_G", _i64), ("group_size", _i64), ("p_per_mask", _i64),
+        ("variant", _i32), ("reserved", _i32),
+    ]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("ldx", _i64), ("y", _vp), ("ldy", _i64), ("y2", _vp), ("ldy2", _i64),
+        ("xsum", _vp), ("ldxsum", _i64), ("rows", _i64), ("D", _i32), ("eps", _f32),
+        ("weight", _vp), ("bias", _vp),
+        ("scale", _vp), ("shift", _vp), ("ld_mod", _i64), ("rows_per_mod", _i64),
+        ("scale2", _vp), ("shift2", _vp),
+        ("addvec", _vp), ("ld_add", _i64), ("rows_per_add", _i64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/dwm_hip.h declares
+SIGNATURES = {
+    "dwm_abi_version": (_i32, []),
+    "dwm_gemm_bf16": (_i32, [C.POINTER(GemmArgs), _vp]),
+    "dwm_attention_fwd": (_i32, [C.POINTER(AttnArgs), _vp]),
+    "dwm_debug_tr_probe": (_i32, [_vp, _vp, _vp]),
+    "dwm_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),
+    "dwm_rmsnorm_heads": (_i32, [_vp, _i64, _i64, _i64, _vp, _f32, _vp]),
+    "dwm_silu": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_timestep_sinusoid": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dwm_patchify": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "dwm_unpatchify": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dwm_cfg_euler_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    "dwm_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+}
+
+_ERR = {-1: "DWM_EINVAL (bad shape / null pointer)", -2: "DWM_EALIGN (alignment)",
+        -3: "DWM_EUNSUPPORTED (shape not supported by the kernel)"}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m opendwm_amd.build` "
+            "(there is no CPU / PyTorch fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.dwm_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libdwm_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = _ERR.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise RuntimeError(f"{what} failed: {msg}")

@@ -1,0 +1,417 @@
+// Fused attention forward for gfx950, head_dim 64, bf16 in/out, fp32 softmax.
+//
+// Geometry: a workgroup of NW waves owns NW*QT*32 queries of one (problem, head);
+// each wave owns QT 32-query tiles and walks the keys in tiles of 64.
+//   S^T = K·Q^T   (A-operand = K fragment from LDS, B-operand = Q fragment in VGPRs)
+// so after v_mfma_f32_32x32x16_bf16 lane (q = lane & 31, half = lane >> 5) holds, for ITS
+// query, the scores of keys (r & 3) + 8 (r >> 2) + 4 half  (r = 0..15) of a 32-key
+// sub-tile: the softmax row reduction is in-lane ops + one lane^32 exchange.
+//   O^T += V^T·P^T (A-operand = V^T fragment, B-operand = the P registers as they
+// are: the accumulator register -> key map of S^T is exactly the k-slot map chosen
+// for the second MFMA, so P never moves across lanes), leaving O^T with the query
+// again on the lane axis: the running max / sum rescale is a per-lane scalar.
+//
+// K tile in LDS: [64 keys][8 x 16-B chunks], chunk ^= (key >> 1) & 7 (conflict-free
+// ds_read_b128 fragments).  V tile, two interchangeable images (template VTR):
+//   VTR = 1: row-major like K, chunk ^= ((key >> 1) & 1) << 2, fragments fetched with
+//            the gfx950 transposing read ds_read_b64_tr_b16;
+//   VTR = 0: transposed VT[64 d][64 key-slots] with 144-B rows, written as packed key
+//            pairs (ds_write_b32), key slots permuted so a fragment is one 16-B read.
+// K/V tiles are register-staged and double-buffered: the global loads of tile t+1
+// are issued before the MFMAs of tile t and written to LDS after them (one barrier
+// per tile).
+//
+// Addressing: q/k/v/o rows of segment 0 go through the row map of dwm_attn_args,
+// which folds the reference's einops rearranges (crossview_temporal_dit.py:307-315,
+// 336-361) into the loads/stores; segment 1 (text context of the joint attention)
+// is dense.  Mask modes: none / [B,G,G] group mask (cross-view) / dense bytes.
+#include "common.h"
+#include "dwm_hip.h"
+
+namespace {
+
+constexpr int KT = 64;                        // keys per tile
+constexpr int K_TILE_BYTES = KT * 128;        // 8192
+constexpr int VT_ROW = 144;                   // bytes per d-row of the transposed V image
+constexpr int V_TILE_BYTES = 64 * VT_ROW;     // 9216 (>= 8192 needed by the row-major image)
+constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct RowMap {
+    int pdiv[3], pmod[3];
+    int64_t pstride[3];
+    int ldiv0, ldiv1;
+    int64_t lstride[3];
+};
+
+struct AttnParams {
+    const bf16_t *q0, *k0, *v0, *q1, *k1, *v1;
+    bf16_t *o0, *o1;
+    int64_t ld0, ld1, ldo0, ldo1;
+    int L0, L1, L;
+    int n_problems, heads, nqb;
+    float scale_log2;
+    int mask_mode;
+    const uint8_t* mask;
+    int mask_G, group_size, p_per_mask;
+    float inv_group_size, inv_G;
+    RowMap rm;
+};
+
+DWM_DEVINL int64_t seg0_base(const RowMap& rm, int p) {
+    int64_t b = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b += (int64_t)((p / rm.pdiv[i]) % rm.pmod[i]) * rm.pstride[i];
+    return b;
+}
+DWM_DEVINL int64_t seg0_row(const RowMap& rm, int64_t base, int l) {
+    const int q0 = l / rm.ldiv0, lo = l - q0 * rm.ldiv0;
+    const int hi = q0 / rm.ldiv1, mid = q0 - hi * rm.ldiv1;
+    return base + lo * rm.lstride[0] + mid * rm.lstride[1] + hi * rm.lstride[2];
+}
+// element offset (without the head offset) of token l of problem `prob` in the k / v buffers
+DWM_DEVINL int64_t kv_off(const AttnParams& P, int64_t base0, int prob, int l) {
+    l = l < P.L ? l : P.L - 1;
+    if (l < P.L0) return seg0_row(P.rm, base0, l) * P.ld0;
+    return ((int64_t)prob * P.L1 + (l - P.L0)) * P.ld1;
+}
+
+// slot of key kappa (0..63) inside a VT row: per 16-key step the order is
+// [k0..3 | k8..11 | k4..7 | k12..15] so lane-half h reads its 8 keys as one 16-B chunk.
+DWM_DEVINL int vt_slot(int kappa) {
+    const int w16 = kappa & 15, g = w16 >> 2;
+    return (kappa & ~15) + ((g & 1) << 3) + ((g >> 1) << 2) + (w16 & 3);
+}
+
+template <int NW, int QT, int VTR>
+__global__ void __launch_bounds__(NW * 64)
+attn_fwd_kernel(const AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QB = NW * QT * 32;          // queries per block
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    // block -> (problem, head, query block); query block fastest so the blocks that
+    // share one (problem, head)'s K/V are neighbours on one XCD.
+    int id = xcd_remap(blockIdx.x, P.n_problems * P.heads * P.nqb);
+    const int qb = id % P.nqb; id /= P.nqb;
+    const int head = id % P.heads;
+    const int prob = id / P.heads;
+
+    const int L = P.L, L0 = P.L0;
+    const int64_t base0 = seg0_base(P.rm, prob);
+    const int64_t hoff = (int64_t)head * 64;
+
+    // ---- this lane's queries
+    bf16x8 qf[QT][4];
+    bf16_t* optr[QT];
+    bool qok[QT];
+    uint32_t gbits[QT];
+    const uint8_t* dense_row[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int lq = qb * QB + (wave * QT + t) * 32 + l31;
+        qok[t] = lq < L;
+        const int lqc = qok[t] ? lq : L - 1;
+        const bf16_t* qptr;
+        if (lqc < L0) {
+            const int64_t r = seg0_row(P.rm, base0, lqc);
+            qptr = P.q0 + r * P.ld0 + hoff;
+            optr[t] = P.o0 + r * P.ldo0 + hoff;
+        } else {
+            const int64_t r = (int64_t)prob * P.L1 + (lqc - L0);
+            qptr = P.q1 + r * P.ld1 + hoff;
+            optr[t] = P.o1 + r * P.ldo1 + hoff;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *(const bf16x8*)(qptr + ks * 16 + half * 8);
+        gbits[t] = 0xffffffffu;
+        dense_row[t] = nullptr;
+        if (P.mask_mode == 1) {
+            const int gq = (lqc / P.group_size) % P.mask_G;
+            const uint8_t* mrow = P.mask + ((int64_t)(prob / P.p_per_mask) * P.mask_G + gq) * P.mask_G;
+            uint32_t bits = 0;
+            for (int g = 0; g < P.mask_G; ++g) bits |= (mrow[g] ? 1u : 0u) << g;
+            gbits[t] = bits;
+        } else if (P.mask_mode == 2) {
+            dense_row[t] = P.mask + ((int64_t)prob * L + lqc) * L;
+        }
+    }
+
+    // ---- staging coordinates (NT = 256 threads, two 16-B chunks per thread and operand).
+    // K (and V when VTR): chunk cid = tid + i*256 -> key = cid >> 3, dchunk = cid & 7.
+    // V when !VTR: pair pid = tid -> key pair kp = pid >> 3 (keys 2kp, 2kp+1), dchunk = pid & 7.
+    static_assert(NW == 4, "staging below is written for 256 threads");
+    const int nkt = (L + KT - 1) / KT;
+    const int sdc = tid & 7;                       // this thread's 16-B d-chunk
+    const int skey0 = tid >> 3, skey1 = skey0 + 32;   // K rows (and V rows when VTR)
+    const int vka = VTR ? skey0 : 2 * (tid >> 3);     // V rows
+    const int vkb = VTR ? skey1 : vka + 1;
+    uint4 kr0, kr1, vr0, vr1;
+
+#define DWM_LOAD_TILE(kt_)                                                                  \
+    do {                                                                                    \
+        const int kb_ = (kt_) * KT;                                                         \
+        const int a_ = kb_ + skey0 < L ? kb_ + skey0 : L - 1;                               \
+        const int b_ = kb_ + skey1 < L ? kb_ + skey1 : L - 1;                               \
+        kr0 = *(const uint4*)((a_ >= L0 ? P.k1 : P.k0) + kv_off(P, base0, prob, a_) + hoff + sdc * 8); \
+        kr1 = *(const uint4*)((b_ >= L0 ? P.k1 : P.k0) + kv_off(P, base0, prob, b_) + hoff + sdc * 8); \
+        const int c_ = kb_ + vka < L ? kb_ + vka : L - 1;                                   \
+        const int d_ = kb_ + vkb < L ? kb_ + vkb : L - 1;                                   \
+        vr0 = *(const uint4*)((c_ >= L0 ? P.v1 : P.v0) + kv_off(P, base0, prob, c_) + hoff + sdc * 8); \
+        vr1 = *(const uint4*)((d_ >= L0 ? P.v1 : P.v0) + kv_off(P, base0, prob, d_) + hoff + sdc * 8); \
+    } while (0)
+
+#define DWM_WRITE_TILE(buf_)                                                                \
+    do {                                                                                    \
+        char* kl_ = smem + (buf_) * STAGE_BYTES;                                            \
+        char* vl_ = kl_ + K_TILE_BYTES;                                                     \
+        *(uint4*)(kl_ + skey0 * 128 + ((sdc ^ ((skey0 >> 1) & 7)) << 4)) = kr0;             \
+        *(uint4*)(kl_ + skey1 * 128 + ((sdc ^ ((skey1 >> 1) & 7)) << 4)) = kr1;             \
+        if (VTR) {                                                                          \
+            *(uint4*)(vl_ + skey0 * 128 + ((sdc ^ (((skey0 >> 1) & 1) << 2)) << 4)) = vr0;  \
+            *(uint4*)(vl_ + skey1 * 128 + ((sdc ^ (((skey1 >> 1) & 1) << 2)) << 4)) = vr1;  \
+        } else {                                                                            \
+            char* dst = vl_ + (sdc * 8) * VT_ROW + vt_slot(vka) * 2;                        \
+            *(uint32_t*)(dst + 0 * VT_ROW) = (vr0.x & 0xffffu) | (vr1.x << 16);             \
+            *(uint32_t*)(dst + 1 * VT_ROW) = (vr0.x >> 16) | (vr1.x & 0xffff0000u);         \
+            *(uint32_t*)(dst + 2 * VT_ROW) = (vr0.y & 0xffffu) | (vr1.y << 16);             \
+            *(uint32_t*)(dst + 3 * VT_ROW) = (vr0.y >> 16) | (vr1.y & 0xffff0000u);         \
+            *(uint32_t*)(dst + 4 * VT_ROW) = (vr0.z & 0xffffu) | (vr1.z << 16);             \
+            *(uint32_t*)(dst + 5 * VT_ROW) = (vr0.z >> 16) | (vr1.z & 0xffff0000u);         \
+            *(uint32_t*)(dst + 6 * VT_ROW) = (vr0.w & 0xffffu) | (vr1.w << 16);             \
+            *(uint32_t*)(dst + 7 * VT_ROW) = (vr0.w >> 16) | (vr1.w & 0xffff0000u);         \
+        }                                                                                   \
+    } while (0)
+
+    f32x16 ot[QT][2];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -1e30f;
+        l_run[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
+    }
+
+    const int kswz = (lane >> 1) & 7;
+    // tr-read lane geometry (VTR): 16-lane group g covers d columns [16g, 16g+16) of a 32-d tile;
+    // lane u of the group supplies the address of V[key0 + (u >> 2)][.. + 4 (u & 3)] (8 bytes)
+    const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+
+    DWM_LOAD_TILE(0);
+    DWM_WRITE_TILE(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) DWM_LOAD_TILE(kt + 1);
+
+        const char* kl = smem + (kt & 1) * STAGE_BYTES;
+        const char* vl = kl + K_TILE_BYTES;
+
+        // ---- S^T = K Q^T for two 32-key sub-tiles (K fragments shared by the QT query tiles)
+        f32x16 st[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[t][j][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], st[t][j], 0, 0, 0);
+            }
+
+        // ---- scale (log2 domain), masks, online softmax; P^T fragments stay in registers
+        const int kbase = kt * KT;
+        const bool tail = kbase + KT > L;
+        bf16x8 pf[QT][4];                      // B-operand fragments, step s = 2*j + s2
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = st[t][j][r] * P.scale_log2;
+                    const int key = kbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (tail && key >= L) x = -INFINITY;
+                    if (P.mask_mode == 1) {
+                        int g = (int)(((float)key + 0.5f) * P.inv_group_size);
+                        g -= P.mask_G * (int)(((float)g + 0.5f) * P.inv_G);
+                        if (!((gbits[t] >> g) & 1u)) x = -INFINITY;
+                    } else if (P.mask_mode == 2) {
+                        if (key < L && dense_row[t][key] == 0) x = -INFINITY;
+                    }
+                    st[t][j][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = exp2f(m_run[t] - m_new);
+            m_run[t] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float pv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pv[e] = exp2f(st[t][j][s2 * 8 + e] - m_new);
+                        psum += pv[e];
+                    }
+                    const uint4 pk = pack8(pv);
+                    pf[t][j * 2 + s2] = *reinterpret_cast<const bf16x8*>(&pk);
+                }
+            l_run[t] = l_run[t] * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[t][i][r] *= alpha;
+        }
+
+        // ---- O^T += V^T P^T   (V fragments shared by the QT query tiles)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x8 vf;
+                if (VTR) {
+                    // keys 16s + 4half + {0..3} and 16s + 8 + 4half + {0..3}, column d = 32dt + l31
+                    const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;          // first of 4 d this lane addresses
+                    const int keyA = s * 16 + half * 4 + (tr_u >> 2);
+                    const int keyB = keyA + 8;
+                    const char* pa = vl + keyA * 128 + ((((dcol >> 3)) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+                    const char* pb = vl + keyB * 128 + ((((dcol >> 3)) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pb);
+                    vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    vf = *(const bf16x8*)(vl + (dt * 32 + l31) * VT_ROW + (s * 16 + half * 8) * 2);
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    ot[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], ot[t][dt], 0, 0, 0);
+            }
+
+        if (more) DWM_WRITE_TILE((kt + 1) & 1);
+        __syncthreads();
+    }
+#undef DWM_LOAD_TILE
+#undef DWM_WRITE_TILE
+
+    // ---- finalize and store: lane (q, half) reg r of ot[dt] -> d = dt*32 + (r&3) + 8(r>>2) + 4 half
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+        const float inv = 1.f / l_tot;
+        if (qok[t]) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = ot[t][dt][rg * 4 + j] * inv;
+                    *(uint2*)(optr[t] + dt * 32 + rg * 8 + half * 4) = pack4(v);
+                }
+        }
+    }
+}
+
+// diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
+// image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
+__global__ void __launch_bounds__(64)
+tr_probe_kernel(const int* __restrict__ offs, short* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) short img[4096];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 4096; i += 64) img[i] = (short)i;
+    __syncthreads();
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)((char*)img + offs[lane]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
+}
+
+template <int NW, int QT, int VTR>
+void launch_attn(const AttnParams& P, hipStream_t s) {
+    const int64_t nblk = (int64_t)P.n_problems * P.heads * P.nqb;
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, QT, VTR>), dim3((unsigned)nblk), dim3(NW * 64), 2 * STAGE_BYTES, s, P);
+}
+
+}  // namespace
+
+extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
+    if (a == nullptr || a->q0 == nullptr || a->k0 == nullptr || a->v0 == nullptr || a->o0 == nullptr) return DWM_EINVAL;
+    if (a->head_dim != 64) return DWM_EUNSUPPORTED;
+    if (a->L0 <= 0 || a->L1 < 0 || a->n_problems <= 0 || a->heads <= 0) return DWM_EINVAL;
+    if (a->L1 > 0 && (a->q1 == nullptr || a->k1 == nullptr || a->v1 == nullptr || a->o1 == nullptr)) return DWM_EINVAL;
+    if (a->ld0 % 8 != 0 || a->ldo0 % 4 != 0 || (a->L1 > 0 && (a->ld1 % 8 != 0 || a->ldo1 % 4 != 0))) return DWM_EALIGN;
+    if (!dwm_aligned16(a->q0) || !dwm_aligned16(a->k0) || !dwm_aligned16(a->v0) || (((uintptr_t)a->o0) & 7u)) return DWM_EALIGN;
+    if (a->L1 > 0 && (!dwm_aligned16(a->q1) || !dwm_aligned16(a->k1) || !dwm_aligned16(a->v1) || (((uintptr_t)a->o1) & 7u)))
+        return DWM_EALIGN;
+    if (a->ldiv[0] <= 0 || a->ldiv[1] <= 0) return DWM_EINVAL;
+    if (a->mask_mode < 0 || a->mask_mode > 2) return DWM_EINVAL;
+    if (a->mask_mode != 0 && a->mask == nullptr) return DWM_EINVAL;
+    if (a->mask_mode == 1 && (a->mask_G <= 0 || a->mask_G > 32 || a->group_size <= 0 || a->p_per_mask <= 0)) return DWM_EINVAL;
+    const int64_t L = a->L0 + a->L1;
+    if (L >= (1 << 22) || a->n_problems >= (1ll << 30)) return DWM_EUNSUPPORTED;
+
+    AttnParams P;
+    P.q0 = (const bf16_t*)a->q0; P.k0 = (const bf16_t*)a->k0; P.v0 = (const bf16_t*)a->v0;
+    P.q1 = (const bf16_t*)a->q1; P.k1 = (const bf16_t*)a->k1; P.v1 = (const bf16_t*)a->v1;
+    P.o0 = (bf16_t*)a->o0; P.o1 = (bf16_t*)a->o1;
+    P.ld0 = a->ld0; P.ld1 = a->ld1; P.ldo0 = a->ldo0; P.ldo1 = a->ldo1;
+    P.L0 = (int)a->L0; P.L1 = (int)a->L1; P.L = (int)L;
+    P.n_problems = (int)a->n_problems; P.heads = a->heads;
+    P.scale_log2 = a->scale * 1.4426950408889634f;
+    P.mask_mode = a->mask_mode; P.mask = a->mask;
+    P.mask_G = (int)a->mask_G; P.group_size = (int)a->group_size; P.p_per_mask = (int)a->p_per_mask;
+    P.inv_group_size = a->group_size > 0 ? 1.f / (float)a->group_size : 0.f;
+    P.inv_G = a->mask_G > 0 ? 1.f / (float)a->mask_G : 0.f;
+    for (int i = 0; i < 3; ++i) {
+        if (a->pdiv[i] <= 0 || a->pmod[i] <= 0) return DWM_EINVAL;
+        P.rm.pdiv[i] = (int)a->pdiv[i]; P.rm.pmod[i] = (int)a->pmod[i]; P.rm.pstride[i] = a->pstride[i];
+    }
+    P.rm.ldiv0 = (int)a->ldiv[0]; P.rm.ldiv1 = (int)a->ldiv[1];
+    for (int i = 0; i < 3; ++i) P.rm.lstride[i] = a->lstride[i];
+
+    // variant: bits 0-3 = queries per wave / 32 (1 or 2; 0 = auto), bit 4 = 1 selects the
+    // transposed-write V image instead of the transposing LDS read (ds_read_b64_tr_b16).
+    int qt = a->variant & 15;
+    const int vtr = ((a->variant >> 4) & 1) ? 0 : 1;
+    if (qt == 0) {
+        const int64_t pad1 = (L + 127) / 128 * 128 - L, pad2 = (L + 255) / 256 * 256 - L;
+        qt = (pad2 <= pad1 + 32 && L > 128) ? 2 : 1;
+    }
+    if (qt != 1 && qt != 2) return DWM_EINVAL;
+    const int qblock = qt * 128;
+    P.nqb = (int)((L + qblock - 1) / qblock);
+    if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (qt == 1) { if (vtr) launch_attn<4, 1, 1>(P, s); else launch_attn<4, 1, 0>(P, s); }
+    else { if (vtr) launch_attn<4, 2, 1>(P, s); else launch_attn<4, 2, 0>(P, s); }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}
+
+extern "C" int dwm_debug_tr_probe(const int32_t* offs, int16_t* out, void* stream) {
+    if (offs == nullptr || out == nullptr) return DWM_EINVAL;
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)offs, (short*)out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}

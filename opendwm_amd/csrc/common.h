@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libdwm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                         // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(8))) short bf16x8;        // MFMA A/B operand (8 bf16, 4 VGPR)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;       // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+
+#define DWM_DEVINL __device__ __forceinline__
+
+DWM_DEVINL float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// two fp32 -> packed bf16x2 (round-to-nearest-even), lowers to v_cvt_pk_bf16_f32
+DWM_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    bf16x2_hw b = __builtin_convertvector(v, bf16x2_hw);
+    return *reinterpret_cast<uint32_t*>(&b);
+}
+DWM_DEVINL bf16_t f32_to_bf16(float v) { return (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+
+DWM_DEVINL float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+DWM_DEVINL float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// 8 bf16 (16 B) -> 8 fp32
+DWM_DEVINL void unpack8(const uint4& v, float* f) {
+    f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+    f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+DWM_DEVINL uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+DWM_DEVINL void unpack4(const uint2& v, float* f) {
+    f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+}
+DWM_DEVINL uint2 pack4(const float* f) {
+    uint2 v; v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]); return v;
+}
+
+DWM_DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+DWM_DEVINL float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), tanh(u) = 1 - 2 / (exp(2u) + 1)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float t = 1.f - 2.f / (__expf(2.f * u) + 1.f);
+    return 0.5f * x * (1.f + t);
+}
+DWM_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
+DWM_DEVINL float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+DWM_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives every
+// XCD a contiguous range of logical ids so neighbouring tiles share that XCD's L2.
+DWM_DEVINL int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+static inline bool dwm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

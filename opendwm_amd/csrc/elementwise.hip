@@ -1,0 +1,166 @@
+// Small HBM-bound glue kernels of the denoise step (gfx950): 16-B vector accesses,
+// grid sized to the data, no LDS.
+#include "common.h"
+#include "dwm_hip.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    unpack8(*(const uint4*)(x + i * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+    *(uint4*)(y + i * 8) = pack8(v);
+}
+
+// out[i, j] = cos(t_i f_j) for j < C/2, sin(t_i f_{j - C/2}) otherwise
+__global__ void __launch_bounds__(256)
+sinusoid_kernel(const float* __restrict__ t, int64_t n, int C, bf16_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int half = C >> 1;
+    if (idx >= n * half) return;
+    const int64_t i = idx / half;
+    const int j = (int)(idx - i * half);
+    const float f = expf(-9.210340371976184f * (float)j / (float)half);   // ln(10000)
+    const float a = t[i] * f;
+    out[i * C + j] = f32_to_bf16(cosf(a));
+    out[i * C + half + j] = f32_to_bf16(sinf(a));
+}
+
+DWM_DEVINL float ld_as_f32(const float* p, int64_t i) { return p[i]; }
+DWM_DEVINL float ld_as_f32(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+
+// one thread per output element of the im2col matrix
+template <typename TIN>
+__global__ void __launch_bounds__(256)
+patchify_kernel(const TIN* __restrict__ x, int64_t I, int C, int H, int W, int p,
+                bf16_t* __restrict__ out, int64_t ldo) {
+    const int h = H / p, w = W / p;
+    const int cols = C * p * p;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = I * h * w * ldo;
+    if (idx >= total) return;
+    const int64_t tok = idx / ldo;
+    const int col = (int)(idx - tok * ldo);
+    float v = 0.f;
+    if (col < cols) {
+        const int px = col % p, py = (col / p) % p, c = col / (p * p);
+        const int ww = (int)(tok % w), hh = (int)((tok / w) % h);
+        const int64_t img = tok / ((int64_t)w * h);
+        v = ld_as_f32(x, ((img * C + c) * H + hh * p + py) * W + ww * p + px);
+    }
+    out[idx] = f32_to_bf16(v);
+}
+// out[n, c, hh*p+py, ww*p+px] = x[(n*h + hh)*w + ww, (py*p + px)*C + c]; one thread per output element
+__global__ void __launch_bounds__(256)
+unpatchify_kernel(const bf16_t* __restrict__ x, int64_t ldx, int64_t I, int C, int h, int w, int p,
+                  bf16_t* __restrict__ out) {
+    const int H = h * p, W = w * p;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= I * C * H * W) return;
+    const int X = (int)(idx % W), Y = (int)((idx / W) % H);
+    const int c = (int)((idx / ((int64_t)W * H)) % C);
+    const int64_t n = idx / ((int64_t)W * H * C);
+    const int ww = X / p, px = X - ww * p, hh = Y / p, py = Y - hh * p;
+    out[idx] = x[((n * h + hh) * w + ww) * ldx + (py * p + px) * C + c];
+}
+
+__global__ void __launch_bounds__(256)
+cfg_euler_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat, bf16_t* __restrict__ model_in,
+                 int64_t n, float guidance, float dsigma) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float u[4], c[4];
+    unpack4(*(const uint2*)(pred + i), u);
+    unpack4(*(const uint2*)(pred + n + i), c);
+    float4 l = *(const float4*)(lat + i);
+    float o[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += dsigma * (u[j] + guidance * (c[j] - u[j]));
+    *(float4*)(lat + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (model_in) {
+        const uint2 b = pack4(o);
+        *(uint2*)(model_in + i) = b;
+        *(uint2*)(model_in + n + i) = b;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 l = *(const float4*)(src + i);
+    const float o[4] = {l.x, l.y, l.z, l.w};
+    *(uint2*)(dst + i) = pack4(o);
+}
+
+inline int finish() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int dwm_abi_version(void) { return DWM_ABI_VERSION; }
+
+extern "C" int dwm_silu(const void* x, void* y, int64_t n, void* stream) {
+    if (x == nullptr || y == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 8 != 0 || !dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    hipLaunchKernelGGL(silu_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, n / 8);
+    return finish();
+}
+
+extern "C" int dwm_timestep_sinusoid(const float* t, int64_t n, int32_t C, void* out, void* stream) {
+    if (t == nullptr || out == nullptr || n <= 0 || C <= 0) return DWM_EINVAL;
+    if (C % 2 != 0) return DWM_EUNSUPPORTED;
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(blocks_for(n * (C / 2))), dim3(256), 0, (hipStream_t)stream,
+                       t, n, C, (bf16_t*)out);
+    return finish();
+}
+
+extern "C" int dwm_patchify(const void* x, int32_t x_is_f32, int64_t I, int32_t C, int32_t H, int32_t W,
+                            int32_t p, void* out, int64_t ldo, void* stream) {
+    if (x == nullptr || out == nullptr || I <= 0 || C <= 0 || H <= 0 || W <= 0 || p <= 0) return DWM_EINVAL;
+    if (H % p != 0 || W % p != 0 || ldo < (int64_t)C * p * p) return DWM_EINVAL;
+    const int64_t total = I * (H / p) * (W / p) * ldo;
+    if (x_is_f32)
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, I, C, H, W, p, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, I, C, H, W, p, (bf16_t*)out, ldo);
+    return finish();
+}
+
+extern "C" int dwm_unpatchify(const void* x, int64_t ldx, int64_t I, int32_t C, int32_t h, int32_t w,
+                              int32_t p, void* out, void* stream) {
+    if (x == nullptr || out == nullptr || I <= 0 || C <= 0 || h <= 0 || w <= 0 || p <= 0) return DWM_EINVAL;
+    if (ldx < (int64_t)C * p * p) return DWM_EINVAL;
+    const int64_t total = I * C * h * p * w * p;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, I, C, h, w, p, (bf16_t*)out);
+    return finish();
+}
+
+extern "C" int dwm_cfg_euler_step(const void* pred, float* latents, void* model_in, int64_t n,
+                                  float guidance, float dsigma, void* stream) {
+    if (pred == nullptr || latents == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 4 != 0 || (((uintptr_t)pred) & 7u) || !dwm_aligned16(latents) || (model_in && (((uintptr_t)model_in) & 7u)))
+        return DWM_EALIGN;
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, latents, (bf16_t*)model_in, n, guidance, dsigma);
+    return finish();
+}
+
+extern "C" int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (src == nullptr || dst == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 4 != 0 || !dwm_aligned16(src) || (((uintptr_t)dst) & 7u)) return DWM_EALIGN;
+    hipLaunchKernelGGL(cast_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, n);
+    return finish();
+}

@@ -1,0 +1,379 @@
+"""MI355X-native drop-in for the reference's CTSD MMDiT denoiser
+
+    dwm.models.crossview_temporal_dit.DiTCrossviewTemporalConditionModel
+    (src/dwm/models/crossview_temporal_dit.py:105-630)
+
+Same constructor kwargs (reference kwargs :107-130 + the SD3Transformer2DModel kwargs the
+JSON configs pass, e.g. examples/ctsd_35_6views_video_generation.json:45-107), same
+forward signature and 3-tuple return (:372-391, :623-630), same state-dict keys
+(SURVEY.md §8b), so `"_class_name": "opendwm_amd.dit.DiTCrossviewTemporalConditionModel"`
+in a pipeline JSON is the whole integration (src/dwm/common.py:133-179).
+
+The forward is inference-only in this round (no autograd graph is recorded); all
+arithmetic runs in bf16 storage / fp32 accumulation through libdwm_hip.so.  There is no
+eager-PyTorch fallback: on a machine without the built library or without a GPU the
+forward raises.
+"""
+from __future__ import annotations
+
+import math
+import types
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .blocks import (AlphaBlender, CombinedTimestepTextProjEmbeddings, JointTransformerBlock,
+                     TimestepEmbedding, VTSelfAttentionBlock, _AdaNorm, _bf)
+from .ops import EPI_RESID
+
+bf16 = torch.bfloat16
+
+try:   # when diffusers is importable, satisfy ctsd.py's isinstance(model, diffusers.SD3Transformer2DModel)
+    import diffusers as _diffusers   # noqa: F401
+    _Base = _diffusers.SD3Transformer2DModel
+except Exception:   # diffusers absent (this container): plain nn.Module
+    _Base = nn.Module
+
+
+def _sincos_1d(embed_dim: int, pos: torch.Tensor) -> torch.Tensor:
+    omega = torch.arange(embed_dim // 2, dtype=torch.float64) / (embed_dim / 2.0)
+    omega = 1.0 / 10000 ** omega
+    out = pos.reshape(-1).double()[:, None] * omega[None, :]
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1)
+
+
+def sincos_pos_embed_2d(embed_dim: int, grid_size: int, base_size: int) -> torch.Tensor:
+    """diffusers get_2d_sincos_pos_embed as SD3's PatchEmbed builds its buffer."""
+    g = torch.arange(grid_size, dtype=torch.float32) / (grid_size / base_size)
+    gw, gh = torch.meshgrid(g, g, indexing="xy")
+    return torch.cat([_sincos_1d(embed_dim // 2, gw), _sincos_1d(embed_dim // 2, gh)], dim=1).float()[None]
+
+
+class PatchEmbed(nn.Module):
+    """SD3 PatchEmbed: keys pos_embed.proj.{weight,bias}, persistent buffer pos_embed.pos_embed."""
+
+    def __init__(self, sample_size: int, patch_size: int, in_channels: int, embed_dim: int,
+                 pos_embed_max_size: int):
+        super().__init__()
+        self.patch_size, self.pos_embed_max_size = patch_size, pos_embed_max_size
+        self.proj = nn.Conv2d(in_channels, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
+        self.register_buffer("pos_embed", sincos_pos_embed_2d(embed_dim, pos_embed_max_size,
+                                                              sample_size // patch_size), persistent=True)
+        self._cache = {}
+        self._wcache = {}
+
+    def cropped(self, h: int, w: int) -> torch.Tensor:
+        key = (h, w, self.pos_embed.device, self.pos_embed.data_ptr())
+        if key not in self._cache:
+            m = self.pos_embed_max_size
+            if h > m or w > m:
+                raise ValueError(f"Height/width ({h},{w}) exceed pos_embed_max_size {m}")
+            top, left = (m - h) // 2, (m - w) // 2
+            t = self.pos_embed.reshape(1, m, m, -1)[:, top:top + h, left:left + w, :]
+            self._cache = {key: t.reshape(h * w, -1).to(bf16).contiguous()}
+        return self._cache[key]
+
+    def packed_weight(self):
+        key = (self.proj.weight.data_ptr(), self.proj.weight._version)
+        if key not in self._wcache:
+            w = self.proj.weight.detach().reshape(self.proj.weight.shape[0], -1)
+            k = w.shape[1]
+            kp = (k + 63) // 64 * 64
+            wp = torch.zeros((w.shape[0], kp), dtype=bf16, device=w.device)
+            wp[:, :k] = w
+            self._wcache = {key: wp}
+        return self._wcache[key]
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        """x [I, C, H, W] -> bf16 [I*h*w, D] = conv(x) + cropped pos embed."""
+        p = self.patch_size
+        h, w = x.shape[-2] // p, x.shape[-1] // p
+        wp = self.packed_weight()
+        cols = ops.patchify(x, p, wp.shape[1])
+        return ops.gemm(cols, wp, _bf(self.proj.bias), epilogue=EPI_RESID, res=self.cropped(h, w), res_mod=h * w)
+
+
+class DiTCrossviewTemporalConditionModel(_Base):
+    def __init__(
+        self,
+        patch_size: int = 2,
+        num_layers: int = 18,
+        attention_head_dim: int = 64,
+        num_attention_heads: int = 18,
+        projection_class_embeddings_input_dim: int = None,
+        condition_image_adapter_config: Optional[dict] = None,
+        enable_crossview: bool = False,
+        enable_temporal: bool = False,
+        crossview_attention_type: str = None,
+        temporal_attention_type: str = None,
+        merge_factor: float = 2, merge_strategy="learned_with_images",
+        crossview_block_layers: Optional[list] = None,
+        temporal_block_layers: Optional[list] = None,
+        crossview_gradient_checkpointing: bool = False,
+        temporal_gradient_checkpointing: bool = False,
+        mixer_type: str = "AlphaBlender",
+        perspective_modeling_type: str = "",
+        disable_view_emb_on_temporal_module: bool = False,
+        qk_norm_on_additional_modules=None,
+        mask_module=None,
+        # --- diffusers.SD3Transformer2DModel kwargs (0.31.0 defaults)
+        sample_size: int = 128,
+        in_channels: int = 16,
+        joint_attention_dim: int = 4096,
+        caption_projection_dim: int = 1152,
+        pooled_projection_dim: int = 2048,
+        out_channels: int = 16,
+        pos_embed_max_size: int = 96,
+        dual_attention_layers=(),
+        qk_norm: Optional[str] = None,
+    ):
+        nn.Module.__init__(self)
+        if condition_image_adapter_config is not None:
+            raise NotImplementedError("condition_image_adapter (layout ImageAdapter) is not built yet (SURVEY.md §8 a9)")
+        if mask_module is not None:
+            raise NotImplementedError("mask_module (MaskGWM) is training-only and out of scope (SURVEY.md §2)")
+        if mixer_type != "AlphaBlender":
+            raise NotImplementedError("only mixer_type='AlphaBlender' (every shipped config) is supported")
+        if perspective_modeling_type not in ("", "implicit"):
+            raise NotImplementedError("perspective_modeling_type='explicit' (UniMLVG RayEncoder) is not built yet")
+        if attention_head_dim != 64:
+            raise NotImplementedError("the attention kernel is built for head_dim 64 (SD 3 / 3.5)")
+
+        inner_dim = attention_head_dim * num_attention_heads
+        self.inner_dim = inner_dim
+        self.out_channels = out_channels if out_channels is not None else in_channels
+        self._cfg = types.SimpleNamespace(
+            patch_size=patch_size, num_layers=num_layers, attention_head_dim=attention_head_dim,
+            num_attention_heads=num_attention_heads, sample_size=sample_size, in_channels=in_channels,
+            joint_attention_dim=joint_attention_dim, caption_projection_dim=caption_projection_dim,
+            pooled_projection_dim=pooled_projection_dim, out_channels=self.out_channels,
+            pos_embed_max_size=pos_embed_max_size, dual_attention_layers=tuple(dual_attention_layers),
+            qk_norm=qk_norm)
+        self.gradient_checkpointing = False
+        self.crossview_gradient_checkpointing = crossview_gradient_checkpointing
+        self.temporal_gradient_checkpointing = temporal_gradient_checkpointing
+        self.disable_view_emb_on_temporal_module = disable_view_emb_on_temporal_module
+        self.num_attention_heads = num_attention_heads
+
+        # ---- SD3Transformer2DModel members
+        self.pos_embed = PatchEmbed(sample_size, patch_size, in_channels, inner_dim, pos_embed_max_size)
+        self.time_text_embed = CombinedTimestepTextProjEmbeddings(inner_dim, pooled_projection_dim)
+        self.context_embedder = nn.Linear(joint_attention_dim, caption_projection_dim)
+        self.transformer_blocks = nn.ModuleList([
+            JointTransformerBlock(inner_dim, num_attention_heads, attention_head_dim,
+                                  context_pre_only=i == num_layers - 1, qk_norm=qk_norm,
+                                  use_dual_attention=i in dual_attention_layers)
+            for i in range(num_layers)])
+        self.norm_out = _AdaNorm(inner_dim, 2)
+        self.proj_out = nn.Linear(inner_dim, patch_size * patch_size * self.out_channels)
+
+        # ---- reference members (crossview_temporal_dit.py:142-221)
+        self.condition_image_adapter = None
+        self.perspective_modeling_type = perspective_modeling_type
+        if perspective_modeling_type == "implicit":
+            self.view_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, inner_dim)
+
+        self.enable_crossview = enable_crossview
+        self.crossview_attention_type = crossview_attention_type
+        self.crossview_block_layers = crossview_block_layers
+        if enable_crossview:
+            n = len(crossview_block_layers)
+            self.view_pos_embeds = nn.ModuleList([
+                TimestepEmbedding(inner_dim, inner_dim * 4, out_dim=inner_dim) for _ in range(n)])
+            self.crossview_transformer_blocks = nn.ModuleList([
+                VTSelfAttentionBlock(inner_dim, inner_dim, num_attention_heads, attention_head_dim,
+                                     qk_norm=qk_norm_on_additional_modules) for _ in range(n)])
+            self.view_mixers = nn.ModuleList([
+                AlphaBlender(merge_factor, merge_strategy=merge_strategy) for _ in range(n)])
+
+        self.enable_temporal = enable_temporal
+        self.temporal_attention_type = temporal_attention_type
+        self.temporal_block_layers = temporal_block_layers
+        if enable_temporal:
+            n = len(temporal_block_layers)
+            self.time_pos_embeds = nn.ModuleList([
+                TimestepEmbedding(inner_dim, inner_dim * 4, out_dim=inner_dim) for _ in range(n)])
+            self.temporal_transformer_blocks = nn.ModuleList([
+                VTSelfAttentionBlock(inner_dim, inner_dim, num_attention_heads, attention_head_dim,
+                                     qk_norm=qk_norm_on_additional_modules) for _ in range(n)])
+            self.time_mixers = nn.ModuleList([
+                AlphaBlender(merge_factor, merge_strategy=merge_strategy) for _ in range(n)])
+
+        self.depth_net = None
+        self.mask_module = None
+
+    # ---- nn.Module / ModelMixin protocol used by ctsd.py
+    @property
+    def config(self):
+        return self._cfg
+
+    def enable_gradient_checkpointing(self):
+        self.gradient_checkpointing = True
+
+    def _invalidate_packed(self):
+        for m in self.modules():
+            if hasattr(m, "_pk"):
+                m._pk = None
+            if hasattr(m, "_cache"):
+                m._cache = {}
+            if hasattr(m, "_wcache"):
+                m._wcache = {}
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._invalidate_packed()
+        return out
+
+    def load_state_dict(self, state_dict, *a, **kw):
+        out = super().load_state_dict(state_dict, *a, **kw)
+        self._invalidate_packed()
+        return out
+
+    # ---- forward (crossview_temporal_dit.py:372-630)
+    @torch.no_grad()
+    def forward(
+        self,
+        sample: torch.FloatTensor,
+        timestep: torch.LongTensor = None,
+        frustum_bev_residuals: torch.Tensor = None,
+        encoder_hidden_states: torch.FloatTensor = None,
+        pooled_projections: torch.FloatTensor = None,
+        condition_image_tensor: torch.Tensor = None,
+        disable_crossview: torch.BoolTensor = None,
+        disable_temporal: torch.BoolTensor = None,
+        crossview_attention_mask: torch.Tensor = None,
+        crossview_attention_index: torch.Tensor = None,
+        camera_intrinsics: torch.Tensor = None,
+        camera_transforms: torch.Tensor = None,
+        camera_intrinsics_norm: torch.Tensor = None,
+        camera2referego: torch.Tensor = None,
+        added_time_ids: torch.Tensor = None,
+        noise: torch.Tensor = None,
+        return_dict: bool = False,
+    ):
+        if not sample.is_cuda:
+            raise RuntimeError("opendwm_amd runs on an MI355X (HIP) device only; got a CPU tensor")
+        should_add_dim = sample.dim() < 6
+        if should_add_dim:
+            sample = sample.unsqueeze(2)
+            timestep = timestep.unsqueeze(2)
+            if encoder_hidden_states is not None:
+                encoder_hidden_states = encoder_hidden_states.unsqueeze(2)
+            if disable_temporal is not None:
+                disable_temporal = disable_temporal.unsqueeze(2)
+            if pooled_projections is not None:
+                pooled_projections = pooled_projections.unsqueeze(2)
+
+        B, T, V, _, H, W = sample.shape
+        p = self._cfg.patch_size
+        height, width = H // p, W // p
+        N, I, D = height * width, B * T * V, self.inner_dim
+        self.view_count, self.width = V, width
+
+        def as_bf16(t):
+            return t if t.dtype == bf16 else (ops.cast_bf16(t.contiguous()) if t.dtype == torch.float32 else t.to(bf16))
+
+        x = sample.flatten(0, 2).contiguous()
+        if x.dtype not in (torch.float32, bf16):
+            x = x.to(bf16)
+        h = self.pos_embed.run(x)                                                      # [I*N, D]
+        ehs = as_bf16(encoder_hidden_states.flatten(0, 2))
+        Lc = ehs.shape[1]
+        c = ops.gemm(ehs.reshape(I * Lc, -1), _bf(self.context_embedder.weight), _bf(self.context_embedder.bias))
+        pooled = as_bf16(pooled_projections.flatten(0, 2)).contiguous()
+        temb = self.time_text_embed.run(timestep.flatten(), pooled)                    # [I, D]
+        silu_temb = ops.silu(temb)
+
+        view_cam_emb = None
+        if self.perspective_modeling_type == "implicit":
+            ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256).view(I, -1)
+            view_cam_emb = self.view_embedding.run(ve)                                 # [I, D]
+
+        if self.enable_crossview and disable_crossview is None:
+            disable_crossview = torch.zeros(B, dtype=torch.bool, device=sample.device)
+        if self.enable_temporal and disable_temporal is None:
+            disable_temporal = torch.zeros(B, dtype=torch.bool, device=sample.device)
+
+        for i, block in enumerate(self.transformer_blocks):
+            c, h = block.run(h, c, silu_temb, I)
+
+            if self.enable_temporal and i in self.temporal_block_layers:
+                k = self.temporal_block_layers.index(i)
+                idx = torch.arange(T, device=h.device).view(1, T, 1).expand(B, T, V)
+                seq = ops.timestep_sinusoid(idx, D)
+                use_cam = self.enable_crossview and not self.disable_view_emb_on_temporal_module \
+                    and view_cam_emb is not None
+                seq_emb = self.time_pos_embeds[k].run(seq, res=view_cam_emb if use_cam else None)
+                tt = self.temporal_attention_type
+                mk = ops.rowmap_temporal_full if tt == "full" else \
+                    ops.rowmap_temporal_rowwise if tt == "rowwise" else ops.rowmap_temporal_pointwise
+                alpha = self.time_mixers[k].get_alpha(disable_temporal, B)
+                self.temporal_transformer_blocks[k].run(
+                    h, mk(B, T, V, height, width), emb=seq_emb, rows_per_emb=N,
+                    blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
+
+            if self.enable_crossview and i in self.crossview_block_layers:
+                k = self.crossview_block_layers.index(i)
+                idx = torch.arange(V, device=h.device).view(1, 1, V).expand(B, T, V)
+                ve = ops.timestep_sinusoid(idx, D)
+                view_emb = self.view_pos_embeds[k].run(ve, res=view_cam_emb)
+                ct = self.crossview_attention_type
+                gmask = dmask = None
+                if ct == "rowwise":
+                    rm = ops.rowmap_crossview_rowwise(B, T, V, height, width)
+                    gmask = crossview_attention_mask
+                elif ct == "full":
+                    rm = ops.rowmap_crossview_full(B, T, V, height, width)
+                    dmask = crossview_attention_mask       # reference passes it through un-expanded
+                else:
+                    raise NotImplementedError(f"Not support {ct}")
+                alpha = self.view_mixers[k].get_alpha(disable_crossview, B)
+                self.crossview_transformer_blocks[k].run(
+                    h, rm, emb=view_emb, rows_per_emb=N, group_mask=gmask, dense_mask=dmask,
+                    blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
+
+        # norm_out (AdaLayerNormContinuous: scale first) + proj_out + unpatchify
+        mod = ops.gemm(silu_temb, _bf(self.norm_out.linear.weight), _bf(self.norm_out.linear.bias))
+        nh = ops.layernorm(h, eps=1e-6, scale=mod[:, :D], shift=mod[:, D:], rows_per_mod=N)
+        y = ops.gemm(nh, _bf(self.proj_out.weight), _bf(self.proj_out.bias))
+        out = ops.unpatchify(y, I, self.out_channels, height, width, p)
+        output = out.view(B, T, V, self.out_channels, height * p, width * p)
+
+        result = [output]
+        if should_add_dim:
+            output = output.squeeze(2)
+        if return_dict:
+            return {"noise_pred": output}
+        return result, None, None
+
+
+def model_flops(cfg: dict, B: int, T: int, V: int, H: int, W: int, text_len: int = 154) -> dict:
+    """Algorithmic FLOPs of one forward: 2·MAC per Linear + 4·L²·d per
+    attention problem.  `cfg` = constructor kwargs."""
+    d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    p = cfg.get("patch_size", 2)
+    h, w = H // p, W // p
+    N, I = h * w, B * T * V
+    tok, ctx = I * N, I * text_len
+    nl = cfg["num_layers"]
+    nd = len(cfg.get("dual_attention_layers", ()))
+    ncv = len(cfg.get("crossview_block_layers") or []) if cfg.get("enable_crossview") else 0
+    ntm = len(cfg.get("temporal_block_layers") or []) if cfg.get("enable_temporal") else 0
+    f = {}
+    f["joint_linear"] = tok * 2 * 12 * d * d * nl + ctx * 2 * 12 * d * d * (nl - 1) + ctx * 2 * 3 * d * d \
+        + tok * 2 * 4 * d * d * nd + I * 2 * d * (9 * d * nd + 6 * d * (nl - nd) + 6 * d * (nl - 1) + 2 * d)
+    f["joint_attn"] = I * 4 * (N + text_len) ** 2 * d * nl + I * 4 * N * N * d * nd
+    f["vt_linear"] = tok * 2 * 28 * d * d * (ncv + ntm)
+    f["cv_attn"] = ((B * T * h) * 4 * (V * w) ** 2 * d if cfg.get("crossview_attention_type") == "rowwise"
+                    else (B * T) * 4 * (V * N) ** 2 * d) * ncv
+    tt = cfg.get("temporal_attention_type")
+    f["t_attn"] = ((B * V * h) * 4 * (T * w) ** 2 * d if tt == "rowwise" else
+                   (B * V) * 4 * (T * N) ** 2 * d if tt == "full" else (B * V * N) * 4 * T * T * d) * ntm
+    cj, pd = cfg.get("joint_attention_dim", 4096), cfg.get("pooled_projection_dim", 2048)
+    f["embeds"] = tok * 2 * 64 * d + ctx * 2 * cj * d + I * 2 * (256 * d + d * d + pd * d + d * d) \
+        + I * 2 * (11 * 256 * d + d * d) + (ncv + ntm) * I * 2 * 8 * d * d + I * 4 * d * d + tok * 2 * 64 * d
+    f["attention"] = f["joint_attn"] + f["cv_attn"] + f["t_attn"]
+    f["total"] = f["joint_linear"] + f["vt_linear"] + f["attention"] + f["embeds"]
+    return f

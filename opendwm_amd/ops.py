@@ -1,0 +1,333 @@
+"""Tensor-level wrappers around the C ABI (include/dwm_hip.h).  PyTorch supplies device
+memory and the current HIP stream; all arithmetic happens in libdwm_hip.so.  Every
+function raises if its tensors are not bf16 CUDA(HIP) tensors — there is no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU_TANH, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_RESID,
+                   EPI_RMSHEAD)
+
+BIG = 1 << 30
+bf16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t: torch.Tensor, name: str, dtype=bf16):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"{name}: expected a 2-D tensor with contiguous rows, got {tuple(t.shape)} strides {t.stride()}")
+
+
+def _chkvec(t: Optional[torch.Tensor], name: str, dtype=bf16):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous {dtype} device tensor")
+
+
+# --------------------------------------------------------------------------------- GEMM
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+         out: Optional[torch.Tensor] = None, epilogue: int = EPI_PLAIN, act: int = ACT_NONE,
+         gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
+         res: Optional[torch.Tensor] = None, res_mod: int = 0,
+         blend: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
+         rows_per_alpha: int = 1,
+         rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6) -> torch.Tensor:
+    """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16."""
+    _chk2d(a, "a")
+    _chk2d(w, "w")
+    if not w.is_contiguous():
+        raise RuntimeError("w must be contiguous [N, K]")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
+    nout = N // 2 if epilogue == EPI_GEGLU else N
+    if out is None:
+        out = torch.empty((M, nout), dtype=bf16, device=a.device)
+    _chk2d(out, "out")
+    if out.shape != (M, nout):
+        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(M, nout)}")
+    _chkvec(bias, "bias")
+    g = _lib.GemmArgs()
+    g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)
+    g.M, g.N, g.K, g.epilogue, g.act = M, N, K, epilogue, act
+    if gate is not None:
+        _chk2d(gate, "gate")
+        g.gate, g.ld_gate, g.rows_per_gate = gate.data_ptr(), gate.stride(0), rows_per_gate
+    if res is not None:
+        _chk2d(res, "res")
+        g.res, g.ld_res, g.res_mod = res.data_ptr(), res.stride(0), res_mod
+    if blend is not None:
+        _chk2d(blend, "blend")
+        _chkvec(alpha, "alpha", torch.float32)
+        g.blend, g.ld_blend, g.alpha, g.rows_per_alpha = blend.data_ptr(), blend.stride(0), alpha.data_ptr(), rows_per_alpha
+    if rms_w is not None:
+        _chkvec(rms_w, "rms_w")
+        g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
+    _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
+    return out
+
+
+# ---------------------------------------------------------------------------- attention
+@dataclass
+class RowMap:
+    """row(p, l) of include/dwm_hip.h; see the constructors below for the reference
+    rearranges (crossview_temporal_dit.py:300-361) they encode."""
+    L0: int
+    n_problems: int
+    pdiv: Sequence[int] = (1, 1, 1)
+    pmod: Sequence[int] = (BIG, 1, 1)
+    pstride: Sequence[int] = (0, 0, 0)
+    ldiv: Sequence[int] = (BIG, BIG)
+    lstride: Sequence[int] = (1, 0, 0)
+    # group mask geometry (cross-view): mask index = p // p_per_mask, group(l) = (l // group_size) % G
+    p_per_mask: int = 1
+    group_size: int = 1
+
+    def rows(self) -> torch.Tensor:
+        """[n_problems, L0] int64 row indices (host reference of the kernel's addressing)."""
+        p = torch.arange(self.n_problems)[:, None]
+        l = torch.arange(self.L0)[None, :]
+        r = torch.zeros(self.n_problems, self.L0, dtype=torch.int64)
+        for d, m, s in zip(self.pdiv, self.pmod, self.pstride):
+            r = r + ((p // d) % m) * s
+        r = r + (l % self.ldiv[0]) * self.lstride[0] + ((l // self.ldiv[0]) % self.ldiv[1]) * self.lstride[1] \
+            + (l // (self.ldiv[0] * self.ldiv[1])) * self.lstride[2]
+        return r
+
+
+def rowmap_identity(n_problems: int, L0: int) -> RowMap:
+    """(b) n c: problem p owns rows p*L0 .. p*L0+L0-1 (joint / dual attention)."""
+    return RowMap(L0=L0, n_problems=n_problems, pstride=(L0, 0, 0))
+
+
+def rowmap_crossview_rowwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
+    """(bt v) (h w) c -> (bt h) (v w) c   (crossview_temporal_dit.py:307-309)."""
+    return RowMap(L0=V * w, n_problems=B * T * h,
+                  pdiv=(h, 1, 1), pmod=(BIG, h, 1), pstride=(V * h * w, w, 0),
+                  ldiv=(w, BIG), lstride=(1, h * w, 0), p_per_mask=T * h, group_size=w)
+
+
+def rowmap_crossview_full(B: int, T: int, V: int, h: int, w: int) -> RowMap:
+    """(bt v) (h w) c -> bt (h v w) c   (crossview_temporal_dit.py:290-292)."""
+    return RowMap(L0=h * V * w, n_problems=B * T,
+                  pstride=(V * h * w, 0, 0),
+                  ldiv=(w, V), lstride=(1, h * w, w), p_per_mask=T, group_size=w)
+
+
+def rowmap_temporal_rowwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
+    """(b t v) (h w) c -> (b v h) (t w) c   (crossview_temporal_dit.py:345-347)."""
+    return RowMap(L0=T * w, n_problems=B * V * h,
+                  pdiv=(V * h, h, 1), pmod=(BIG, V, h), pstride=(T * V * h * w, h * w, w),
+                  ldiv=(w, BIG), lstride=(1, V * h * w, 0))
+
+
+def rowmap_temporal_full(B: int, T: int, V: int, h: int, w: int) -> RowMap:
+    """(b t v) hw c -> (b v) (t hw) c   (crossview_temporal_dit.py:336-338)."""
+    return RowMap(L0=T * h * w, n_problems=B * V,
+                  pdiv=(V, 1, 1), pmod=(BIG, V, 1), pstride=(T * V * h * w, h * w, 0),
+                  ldiv=(h * w, BIG), lstride=(1, V * h * w, 0))
+
+
+def rowmap_temporal_pointwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
+    """(b t v) hw c -> (b v hw) t c   (crossview_temporal_dit.py:354-356)."""
+    hw = h * w
+    return RowMap(L0=T, n_problems=B * V * hw,
+                  pdiv=(V * hw, hw, 1), pmod=(BIG, V, hw), pstride=(T * V * hw, hw, 1),
+                  ldiv=(BIG, BIG), lstride=(V * hw, 0, 0))
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+              rowmap: RowMap, heads: int, *,
+              q1: Optional[torch.Tensor] = None, k1: Optional[torch.Tensor] = None,
+              v1: Optional[torch.Tensor] = None, out1: Optional[torch.Tensor] = None,
+              scale: Optional[float] = None,
+              group_mask: Optional[torch.Tensor] = None, dense_mask: Optional[torch.Tensor] = None,
+              variant: int = 0) -> None:
+    """softmax(QK^T * scale [+mask]) V per (problem, head); q/k/v/out are 2-D [rows, heads*64]
+    views sharing a row stride (e.g. column slices of a fused qkv buffer).  Segment 1
+    (q1/k1/v1/out1: [n_problems*L1, heads*64]) is appended to every problem's key/query
+    sequence (text context of the joint attention).  group_mask: bool/uint8 [Bm, G, G];
+    dense_mask: bool/uint8 [n_problems, L, L]."""
+    for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        _chk2d(t, name)
+    if not (q.stride(0) == k.stride(0) == v.stride(0)):
+        raise RuntimeError("q, k, v must share a row stride")
+    a = _lib.AttnArgs()
+    a.q0, a.k0, a.v0, a.ld0 = q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0)
+    a.o0, a.ldo0 = out.data_ptr(), out.stride(0)
+    a.L0, a.L1, a.n_problems = rowmap.L0, 0, rowmap.n_problems
+    if q1 is not None:
+        for name, t in (("q1", q1), ("k1", k1), ("v1", v1), ("out1", out1)):
+            _chk2d(t, name)
+        if q1.shape[0] % rowmap.n_problems != 0:
+            raise RuntimeError("segment 1 rows must be n_problems * L1")
+        a.q1, a.k1, a.v1, a.ld1 = q1.data_ptr(), k1.data_ptr(), v1.data_ptr(), q1.stride(0)
+        a.o1, a.ldo1 = out1.data_ptr(), out1.stride(0)
+        a.L1 = q1.shape[0] // rowmap.n_problems
+    a.heads, a.head_dim = heads, 64
+    if q.shape[1] != heads * 64:
+        raise RuntimeError("attention: head_dim must be 64")
+    a.scale = float(scale) if scale is not None else 64 ** -0.5
+    for i in range(3):
+        a.pdiv[i], a.pmod[i], a.pstride[i] = rowmap.pdiv[i], rowmap.pmod[i], rowmap.pstride[i]
+        a.lstride[i] = rowmap.lstride[i]
+    a.ldiv[0], a.ldiv[1] = rowmap.ldiv
+    a.mask_mode = 0
+    keep = None
+    if group_mask is not None:
+        keep = group_mask.to(torch.uint8).contiguous()
+        a.mask_mode, a.mask = 1, keep.data_ptr()
+        a.mask_G, a.group_size, a.p_per_mask = keep.shape[-1], rowmap.group_size, rowmap.p_per_mask
+    elif dense_mask is not None:
+        keep = dense_mask.to(torch.uint8).contiguous()
+        a.mask_mode, a.mask = 2, keep.data_ptr()
+    a.variant = variant
+    _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
+    if keep is not None:
+        keep.record_stream(torch.cuda.current_stream())
+
+
+# -------------------------------------------------------------------------------- norms
+def layernorm(x: torch.Tensor, *, eps: float, out: Optional[torch.Tensor] = None,
+              weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+              scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+              rows_per_mod: int = 0,
+              scale2: Optional[torch.Tensor] = None, shift2: Optional[torch.Tensor] = None,
+              out2: Optional[torch.Tensor] = None,
+              addvec: Optional[torch.Tensor] = None, rows_per_add: int = 0,
+              xsum: Optional[torch.Tensor] = None):
+    """See dwm_layernorm.  scale/shift (and scale2/shift2) are 2-D views sharing one row
+    stride (column slices of the AdaLN modulation matrix)."""
+    _chk2d(x, "x")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), dtype=bf16, device=x.device)
+    _chk2d(out, "out")
+    a = _lib.LayerNormArgs()
+    a.x, a.ldx, a.y, a.ldy = x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0)
+    a.rows, a.D, a.eps = rows, D, eps
+    _chkvec(weight, "weight")
+    _chkvec(bias, "bias")
+    a.weight, a.bias = _p(weight), _p(bias)
+    if scale is not None:
+        _chk2d(scale, "scale")
+        _chk2d(shift, "shift")
+        if scale.stride(0) != shift.stride(0):
+            raise RuntimeError("scale/shift must share a row stride")
+        a.scale, a.shift, a.ld_mod, a.rows_per_mod = scale.data_ptr(), shift.data_ptr(), scale.stride(0), rows_per_mod
+    if out2 is not None:
+        _chk2d(out2, "out2")
+        _chk2d(scale2, "scale2")
+        _chk2d(shift2, "shift2")
+        if scale2.stride(0) != a.ld_mod or shift2.stride(0) != a.ld_mod:
+            raise RuntimeError("scale2/shift2 must share the row stride of scale/shift")
+        a.y2, a.ldy2, a.scale2, a.shift2 = out2.data_ptr(), out2.stride(0), scale2.data_ptr(), shift2.data_ptr()
+    if addvec is not None:
+        _chk2d(addvec, "addvec")
+        a.addvec, a.ld_add, a.rows_per_add = addvec.data_ptr(), addvec.stride(0), rows_per_add
+        if xsum is not None:
+            _chk2d(xsum, "xsum")
+            a.xsum, a.ldxsum = xsum.data_ptr(), xsum.stride(0)
+    _lib.check(_lib.load().dwm_layernorm(C.byref(a), _stream()), "dwm_layernorm")
+    return out
+
+
+def rmsnorm_heads_(x: torch.Tensor, w_expanded: torch.Tensor, eps: float) -> torch.Tensor:
+    """In-place per-64-wide-head RMSNorm of x[rows, ncols]; w_expanded [ncols]."""
+    _chk2d(x, "x")
+    _chkvec(w_expanded, "w")
+    _lib.check(_lib.load().dwm_rmsnorm_heads(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1],
+                                             w_expanded.data_ptr(), eps, _stream()), "dwm_rmsnorm_heads")
+    return x
+
+
+# -------------------------------------------------------------------------- elementwise
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _chkvec(x, "x")
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().dwm_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "dwm_silu")
+    return y
+
+
+def timestep_sinusoid(t: torch.Tensor, channels: int) -> torch.Tensor:
+    """diffusers Timesteps(channels, flip_sin_to_cos=True, downscale_freq_shift=0) -> bf16 [n, channels]."""
+    t = t.reshape(-1).to(torch.float32).contiguous()
+    if not t.is_cuda:
+        raise RuntimeError("timestep_sinusoid: expected a device tensor")
+    out = torch.empty((t.numel(), channels), dtype=bf16, device=t.device)
+    _lib.check(_lib.load().dwm_timestep_sinusoid(t.data_ptr(), t.numel(), channels, out.data_ptr(), _stream()),
+               "dwm_timestep_sinusoid")
+    return out
+
+
+def patchify(x: torch.Tensor, p: int, ldo: Optional[int] = None) -> torch.Tensor:
+    """[I, C, H, W] (fp32 / bf16) -> bf16 [I*(H/p)*(W/p), ldo] im2col rows (zero padded to ldo)."""
+    if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, bf16):
+        raise RuntimeError("patchify: expected a contiguous fp32/bf16 [I,C,H,W] device tensor")
+    I, Cc, H, W = x.shape
+    cols = Cc * p * p
+    ldo = ldo or (cols + 63) // 64 * 64
+    out = torch.empty((I * (H // p) * (W // p), ldo), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_patchify(x.data_ptr(), int(x.dtype == torch.float32), I, Cc, H, W, p,
+                                        out.data_ptr(), ldo, _stream()), "dwm_patchify")
+    return out
+
+
+def unpatchify(x: torch.Tensor, I: int, Cc: int, h: int, w: int, p: int) -> torch.Tensor:
+    _chk2d(x, "x")
+    out = torch.empty((I, Cc, h * p, w * p), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_unpatchify(x.data_ptr(), x.stride(0), I, Cc, h, w, p, out.data_ptr(), _stream()),
+               "dwm_unpatchify")
+    return out
+
+
+def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, dsigma: float,
+                   model_in: Optional[torch.Tensor] = None) -> None:
+    """latents(fp32, in place) += dsigma * (u + g (c - u)) with pred = [uncond; cond] bf16."""
+    n = latents.numel()
+    if pred.dtype != bf16 or pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda:
+        raise RuntimeError("cfg_euler_step: pred must be contiguous bf16 with 2x the latent elements")
+    if latents.dtype != torch.float32 or not latents.is_contiguous() or not latents.is_cuda:
+        raise RuntimeError("cfg_euler_step: latents must be contiguous fp32")
+    if model_in is not None and (model_in.dtype != bf16 or model_in.numel() != 2 * n or not model_in.is_contiguous()):
+        raise RuntimeError("cfg_euler_step: model_in must be contiguous bf16 [2, n]")
+    _lib.check(_lib.load().dwm_cfg_euler_step(pred.data_ptr(), latents.data_ptr(), _p(model_in), n,
+                                              float(guidance), float(dsigma), _stream()), "dwm_cfg_euler_step")
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == bf16:
+        return x
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise RuntimeError("cast_bf16: expected an fp32 device tensor")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()),
+               "dwm_cast_f32_to_bf16")
+    return out
+
+
+def tr_probe(offsets: torch.Tensor) -> torch.Tensor:
+    """Diagnostic: semantics probe of ds_read_b64_tr_b16 (tests only)."""
+    offsets = offsets.to(torch.int32).contiguous()
+    out = torch.empty((64, 4), dtype=torch.int16, device=offsets.device)
+    _lib.check(_lib.load().dwm_debug_tr_probe(offsets.data_ptr(), out.data_ptr(), _stream()), "dwm_debug_tr_probe")
+    return out
