@@ -1,0 +1,264 @@
+"""denoise-steps/sec of the CTSD SD-3.5 MMDiT hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot loop of ctsd.py:1496-1575 over one synthetic sample:
+model forward at the CFG batch (2 x [16 frames x 6 views x 16 x 32 x 56] latents, 154 text
+tokens) + guidance combine + FlowMatch-Euler update, weights random-initialised (no
+checkpoints offline), everything resident in HBM when the clock starts.  With N > 1 every rank
+denoises its own sample (replicas; the path has no exchange step), so
+value = N*K / max-over-ranks time ("weak" scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+# model kwargs of examples/ctsd_35_6views_video_generation.json:45-107 (reference repo)
+MODEL_KWARGS = dict(
+    dual_attention_layers=list(range(13)), attention_head_dim=64, caption_projection_dim=1536,
+    in_channels=16, joint_attention_dim=4096, num_attention_heads=24, num_layers=24, out_channels=16,
+    patch_size=2, pooled_projection_dim=2048, pos_embed_max_size=384, qk_norm="rms_norm",
+    qk_norm_on_additional_modules="rms_norm", sample_size=128, perspective_modeling_type="implicit",
+    projection_class_embeddings_input_dim=2816, enable_crossview=True, crossview_attention_type="rowwise",
+    crossview_block_layers=[1, 5, 9, 13, 17, 21], crossview_gradient_checkpointing=True,
+    enable_temporal=True, temporal_attention_type="rowwise",
+    temporal_block_layers=[2, 3, 6, 7, 10, 11, 14, 15, 18, 19, 22, 23],
+    temporal_gradient_checkpointing=True, mixer_type="AlphaBlender", merge_factor=2)
+WORKLOAD = dict(B=1, T=16, V=6, C=16, H=32, W=56, text_len=154, guidance_scale=4.0, inference_steps=40)
+
+
+def synth_init_(model, seed: int):
+    """Seeded synthetic weights on the device (the rule of oracle.synth_param)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("mix_factor"):
+                p.fill_(2.0)
+            elif p.dim() == 1:
+                p.normal_(0.0, 0.05, generator=g)
+                if name.endswith(".weight"):
+                    p.add_(1.0)
+            else:
+                fan_in = p[0].numel()
+                std = fan_in ** -0.5
+                if ".norm1.linear" in name or ".norm1_context.linear" in name or name.startswith("norm_out.linear"):
+                    std *= 0.5
+                p.normal_(0.0, std, generator=g)
+
+
+def build_model(kwargs, dev, seed=0):
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = DiTCrossviewTemporalConditionModel(**kwargs)
+    finally:
+        torch.set_default_dtype(old)
+    synth_init_(model, seed)
+    return model.eval()
+
+
+def make_conditions(dev, seed, w=WORKLOAD):
+    g = torch.Generator(device="cuda").manual_seed(1000 + seed)
+    B2, T, V = 2 * w["B"], w["T"], w["V"]
+    ring = torch.zeros(V, V, dtype=torch.bool)
+    for i in range(V):
+        for d in (-1, 0, 1):
+            ring[i, (i + d) % V] = True
+    return dict(
+        encoder_hidden_states=(torch.randn(B2, T, V, w["text_len"], 4096, device=dev, generator=g) * 0.1).to(torch.bfloat16),
+        pooled_projections=(torch.randn(B2, T, V, 2048, device=dev, generator=g) * 0.1).to(torch.bfloat16),
+        disable_crossview=torch.zeros(B2, dtype=torch.bool, device=dev),
+        disable_temporal=torch.zeros(B2, dtype=torch.bool, device=dev),
+        crossview_attention_mask=ring[None].repeat(B2, 1, 1).to(dev),
+        added_time_ids=torch.rand(B2, T, V, 11, device=dev, generator=g) * 2 - 1,
+    )
+
+
+class KernelTimer:
+    """HIP-event bracket around every dwm_gemm_bf16 / dwm_attention_fwd launch, recorded on the
+    stream the kernel is launched on; durations are read after the timed region."""
+
+    def __init__(self):
+        self.records = []           # (kind, flops, start_event, end_event)
+        self.enabled = False
+
+    def install(self):
+        from opendwm_amd import ops
+        gemm0, attn0 = ops.gemm, ops.attention
+        timer = self
+
+        def gemm(a, w, *args, **kw):
+            if not timer.enabled:
+                return gemm0(a, w, *args, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            s.record(st)
+            out = gemm0(a, w, *args, **kw)
+            e.record(st)
+            timer.records.append(("gemm", 2.0 * a.shape[0] * w.shape[0] * a.shape[1], s, e))
+            return out
+
+        def attention(q, k, v, out, rowmap, heads, **kw):
+            if not timer.enabled:
+                return attn0(q, k, v, out, rowmap, heads, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            s.record(st)
+            attn0(q, k, v, out, rowmap, heads, **kw)
+            e.record(st)
+            L = rowmap.L0 + (kw["q1"].shape[0] // rowmap.n_problems if kw.get("q1") is not None else 0)
+            timer.records.append(("attn", 4.0 * rowmap.n_problems * heads * L * L * 64, s, e))
+
+        ops.gemm, ops.attention = gemm, attention
+        import opendwm_amd.blocks as blocks
+        import opendwm_amd.dit as dit
+        for mod in (blocks, dit):
+            mod.ops = ops
+        return self
+
+    def summary(self):
+        out = {}
+        for kind in ("gemm", "attn"):
+            rs = [(f, s.elapsed_time(e)) for k, f, s, e in self.records if k == kind]
+            if rs:
+                fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
+                out[kind] = dict(launches=len(rs), flops=fl, ms=ms, tflops=fl / ms / 1e9,
+                                 avg_us=1e3 * ms / len(rs))
+        return out
+
+
+def cpu_baseline(threads: int):
+    """The fp32 CPU oracle (the restated reference path) on the host cores, on a bounded sample of
+    the same workload; reported in denoise-steps/s by FLOP ratio."""
+    from oracle import ctsd_oracle as O
+    from opendwm_amd.dit import model_flops
+    torch.set_num_threads(threads)
+    cfg = O.make_config(num_layers=3, dual_attention_layers=[0, 1, 2], crossview_block_layers=[1],
+                        temporal_block_layers=[2], pos_embed_max_size=64, sample_size=128)
+    gen = torch.Generator().manual_seed(0)
+    sd = {n: O.synth_param(n, s, cfg, gen) for n, s in O.param_shapes(cfg).items()}
+    T = 2
+    inp = O.make_inputs(cfg, 2, T, 6, 32, 56, seed=0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.dit_forward(sd, cfg, **inp)
+        dt = time.perf_counter() - t0
+    sample_flops = model_flops(cfg, 2, T, 6, 32, 56)["total"]
+    full_flops = model_flops(MODEL_KWARGS, 2, WORKLOAD["T"], WORKLOAD["V"], WORKLOAD["H"], WORKLOAD["W"])["total"]
+    return dict(value=(sample_flops / dt) / full_flops, unit="denoise-steps/s", cores=threads, kind="port",
+                sample=f"fp32 PyTorch-CPU oracle, CFG forward of 6 views x {T} frames x 32x56 latents, first 3 layers "
+                       f"(dual joint blocks + 1 cross-view + 1 temporal VT block) at full width d=1536: "
+                       f"{sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {sample_flops / dt / 1e12:.3f} TFLOP/s, scaled by "
+                       f"the {full_flops / 1e12:.1f} TFLOP of one full step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a bench line)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from opendwm_amd import _lib
+    from opendwm_amd.dit import model_flops
+    from opendwm_amd.pipeline import CTSDDenoiser
+    _lib.load()
+
+    kwargs = dict(MODEL_KWARGS)
+    if args.layers is not None:
+        n = args.layers
+        kwargs.update(num_layers=n, dual_attention_layers=[i for i in kwargs["dual_attention_layers"] if i < n],
+                      crossview_block_layers=[i for i in kwargs["crossview_block_layers"] if i < n],
+                      temporal_block_layers=[i for i in kwargs["temporal_block_layers"] if i < n])
+    timer = KernelTimer().install()
+    model = build_model(kwargs, dev, seed=0)
+    w = WORKLOAD
+    cond = make_conditions(dev, seed=rank)
+    g = torch.Generator(device="cuda").manual_seed(rank)
+    latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
+    den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"]).prepare(latents, cond)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        den.step(i % w["inference_steps"])
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        den.step((args.warmup + i) % w["inference_steps"])
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    finite = bool(torch.isfinite(den.latents).all().item())
+
+    if rank == 0:
+        fl = model_flops(kwargs, 2 * w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])
+        ks = timer.summary()
+        step_ms = 1e3 * dt / args.steps
+        gm, at = ks.get("gemm", {}), ks.get("attn", {})
+        line = {
+            "metric": "denoise-steps/sec (6-view x16f 448x256), SD-3.5 CTSD",
+            "value": world * args.steps / dt, "unit": "denoise-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
+            "config": {"workload": "CTSD SD-3.5 MMDiT (24 joint blocks, 13 dual, 6 cross-view + 12 temporal VT blocks, "
+                                   "rowwise), 6 views x 16 frames x 448x256 px (latents [1,16,6,16,32,56]), CFG g=4 -> "
+                                   "model batch 2, 154 text tokens, FlowMatch-Euler; one replica per GPU",
+                       "layers": kwargs["num_layers"], "flop_per_step": fl["total"], "finite": finite},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
+                         "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
+                         "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": at.get("tflops"),
+                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
+                                   "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
+                                   "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms},
+            "whole_step_mfma_frac": fl["total"] / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, smoke, bench (+ rocprofv3 kernel stats). Logs under gpurun_out/.
+# usage: scripts/gpu_check.sh [tag]
+TAG=${1:-r1}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+rm -f gpurun_out/gpu_parity.log
+rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/device.txt
+nproc >> $OUT/device.txt
+echo "== pytest -m gpu" 
+timeout 1500 python -m pytest tests -m gpu -q -n 1 -rA --tb=short -p no:cacheprovider > $OUT/pytest.log 2>&1
+echo "pytest exit $?" | tee -a $OUT/pytest.log
+tail -60 $OUT/pytest.log
+cp gpurun_out/gpu_parity.log $OUT/gpu_parity.log 2>/dev/null
+echo "== smoke"
+timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -5 $OUT/smoke.log
+echo "== bench"
+timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/bench.log; tail -5 $OUT/bench.log
+echo "== rocprof"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1)
+find /tmp/prof_$TAG -name "*stats*" | head
+for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv"); do cp $f $OUT/; done
+for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1); do head -25 $f; done

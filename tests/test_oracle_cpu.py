@@ -1,0 +1,283 @@
+"""CPU leg (`-m "not gpu"`): the oracle against its golden fixtures and internal
+cross-checks, the host-side logic (row maps, weight packing, schedule, FLOP model) and the
+C-ABI surface.  No kernel is executed here."""
+import ctypes
+import os
+import re
+
+import einops
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctsd_oracle as O
+from tests.common import GOLDEN, rel_err, small_config, small_inputs
+
+torch.set_num_threads(4)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ oracle vs golden
+def test_oracle_forward_matches_golden(small_cfg):
+    sd = O.make_state_dict(small_cfg, seed=0)
+    inp = small_inputs(small_cfg, seed=0)
+    tr = {}
+    y = O.dit_forward(sd, small_cfg, trace=tr, **inp)
+    gold = torch.load(os.path.join(GOLDEN, "dit_small_forward.pt"))
+    assert y.shape == (2, 3, 3, 16, 8, 12)
+    assert rel_err(y, gold["output"]) < 1e-5
+    for k, v in gold["trace"].items():
+        assert rel_err(tr[k], v) < 1e-5, k
+
+
+@pytest.mark.parametrize("tt", ["pointwise", "full"])
+def test_oracle_temporal_variants_match_golden(tt):
+    cfg = small_config(temporal_attention_type=tt)
+    sd = O.make_state_dict(small_config(), seed=0)
+    y = O.dit_forward(sd, cfg, **small_inputs(cfg, seed=0))
+    gold = torch.load(os.path.join(GOLDEN, f"dit_small_forward_{tt}.pt"))
+    assert rel_err(y, gold["output"]) < 1e-5
+
+
+def test_oracle_denoise_matches_golden(small_cfg):
+    sd = O.make_state_dict(small_cfg, seed=0)
+    inp = small_inputs(small_cfg, seed=0)
+    gold = torch.load(os.path.join(GOLDEN, "denoise_small_2steps.pt"))
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    out = O.denoise(sd, small_cfg, gold["latents_in"], cond, steps=4, guidance_scale=4.0, stop=2)
+    assert rel_err(out, gold["latents_out"]) < 1e-5
+
+
+# ------------------------------------------------------------- oracle internal cross-checks
+def test_sdpa_matches_torch_and_fp64():
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(3, 2, 37, 64, generator=g) for _ in range(3))
+    mask = torch.rand(3, 1, 37, 37, generator=g) > 0.3
+    mask[..., 0] = True
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    assert rel_err(O.sdpa(q, k, v, mask), ref) < 1e-5
+    ref64 = O.sdpa(q.double(), k.double(), v.double(), mask)
+    assert rel_err(O.sdpa(q, k, v, mask), ref64) < 1e-5
+
+
+def test_flash_style_online_softmax_equals_naive():
+    """The tiling / online-softmax algebra the HIP kernel uses (64-key tiles, running max in
+    the log2 domain, deferred normalisation) restated in torch must equal naive softmax."""
+    g = torch.Generator().manual_seed(2)
+    L, d = 150, 64
+    q, k, v = (torch.randn(L, d, generator=g) for _ in range(3))
+    scale_log2 = d ** -0.5 * 1.4426950408889634
+    m = torch.full((L,), -1e30)
+    l = torch.zeros(L)
+    o = torch.zeros(L, d)
+    for k0 in range(0, L, 64):
+        s = (q @ k[k0:k0 + 64].T) * scale_log2
+        m_new = torch.maximum(m, s.max(-1).values)
+        alpha = torch.exp2(m - m_new)
+        p = torch.exp2(s - m_new[:, None])
+        l = l * alpha + p.sum(-1)
+        o = o * alpha[:, None] + p @ v[k0:k0 + 64]
+        m = m_new
+    out = o / l[:, None]
+    ref = O.sdpa(q[None, None], k[None, None], v[None, None])[0, 0]
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_layernorm_and_rmsnorm_restatements():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 7, 128, generator=g) * 3 + 1
+    mean = x.mean(-1, keepdim=True)
+    var = x.var(-1, unbiased=False, keepdim=True)
+    assert rel_err(O.layer_norm_noaffine(x), (x - mean) / torch.sqrt(var + 1e-6)) < 1e-5
+    w = torch.randn(64, generator=g)
+    xx = torch.randn(2, 3, 4, 64, generator=g)
+    ref = xx / torch.sqrt((xx * xx).mean(-1, keepdim=True) + 1e-5) * w
+    assert rel_err(O.rms_norm(xx, w, 1e-5), ref) < 1e-5
+
+
+def test_timesteps_sinusoid_layout():
+    t = torch.tensor([0.0, 1.0, 500.0])
+    e = O.timesteps_sinusoid(t, 8)
+    f = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(4) / 4)
+    assert torch.allclose(e[:, :4], torch.cos(t[:, None] * f), atol=1e-6)     # flip_sin_to_cos: cos first
+    assert torch.allclose(e[:, 4:], torch.sin(t[:, None] * f), atol=1e-6)
+
+
+def test_patch_embed_equals_im2col_gemm(small_cfg):
+    """patchify column order used by the HIP im2col: col = (c*p + py)*p + px."""
+    sd = O.make_state_dict(small_cfg, seed=0)
+    x = torch.randn(4, 16, 8, 12)
+    ref = O.patch_embed(sd, small_cfg, x)
+    p = 2
+    cols = x.reshape(4, 16, 4, p, 6, p).permute(0, 2, 4, 1, 3, 5).reshape(4 * 24, 64)
+    w = sd["pos_embed.proj.weight"].reshape(-1, 64)
+    y = cols @ w.T + sd["pos_embed.proj.bias"]
+    pos = O.cropped_pos_embed(sd["pos_embed.pos_embed"], 4, 6, small_cfg["pos_embed_max_size"])[0]
+    y = y.view(4, 24, -1) + pos
+    assert rel_err(y, ref) < 1e-5
+
+
+def test_vt_block_is_tokenwise_except_attention(small_cfg):
+    """The HIP model never materialises the einops rearranges: every op of the VT block but
+    the attention is per-token, so permuting tokens commutes with it.  Check on the oracle."""
+    sd = O.make_state_dict(small_cfg, seed=0)
+    x = torch.randn(6, 9, 128)
+    perm = torch.randperm(9)
+    a = O.vt_self_attention_block(sd, "temporal_transformer_blocks.0", 2, x)
+    b = O.vt_self_attention_block(sd, "temporal_transformer_blocks.0", 2, x[:, perm])
+    assert rel_err(b, a[:, perm]) < 1e-5
+
+
+def test_flow_match_sigmas_properties():
+    s = O.flow_match_sigmas(40, shift=3.0)
+    assert s.shape == (41,) and s[-1] == 0 and abs(s[0].item() - 1.0) < 1e-6
+    assert torch.all(s[:-1] > s[1:])
+    # diffusers applies the shift to the training table (giving sigma_max/min) and again to the
+    # linspace between them: sigma = 3 t / (1 + 2 t), t in linspace(1, 3e-3/(1+2e-3), n)
+    t = torch.linspace(1.0, 0.003 / 1.002, 40)
+    assert torch.allclose(s[:-1], 3 * t / (1 + 2 * t), atol=1e-6)
+
+
+def test_flop_model_matches_survey():
+    f = O.flops_per_forward(O.make_config(), 2, 16, 6, 32, 56)
+    assert abs(f["total"] / 1e12 - 398.98) < 0.2
+    assert abs(f["attention"] / 1e12 - 16.71) < 0.02
+    from opendwm_amd.dit import model_flops
+    g = model_flops(O.make_config(), 2, 16, 6, 32, 56)
+    assert g["total"] == f["total"] and g["attention"] == f["attention"]
+
+
+# --------------------------------------------------------------------- host-side logic
+def _tokens(B, T, V, h, w):
+    return torch.arange(B * T * V * h * w).view(B * T * V, h * w, 1)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4, 2, 5), (1, 16, 6, 16, 28)])
+def test_rowmaps_equal_reference_rearranges(shape):
+    """RowMap.rows() (the kernel's addressing, restated on the host) must enumerate exactly the
+    rows the reference's einops.rearrange would copy (crossview_temporal_dit.py:290-361)."""
+    from opendwm_amd import ops
+    B, T, V, h, w = shape
+    x = _tokens(B, T, V, h, w)
+    cases = [
+        (ops.rowmap_crossview_rowwise, "(bt v) (h w) c -> (bt h) (v w) c", dict(v=V, w=w)),
+        (ops.rowmap_crossview_full, "(bt v) (h w) c -> bt (h v w) c", dict(v=V, w=w)),
+        (ops.rowmap_temporal_rowwise, "(b t v) (h w) c -> (b v h) (t w) c", dict(b=B, v=V, w=w)),
+        (ops.rowmap_temporal_full, "(b t v) hw c -> (b v) (t hw) c", dict(b=B, t=T)),
+        (ops.rowmap_temporal_pointwise, "(b t v) hw c -> (b v hw) t c", dict(b=B, t=T)),
+    ]
+    for mk, pattern, kw in cases:
+        rm = mk(B, T, V, h, w)
+        ref = einops.rearrange(x, pattern, **kw)[..., 0]
+        assert (rm.n_problems, rm.L0) == tuple(ref.shape), pattern
+        assert torch.equal(rm.rows(), ref), pattern
+    rm = ops.rowmap_identity(B * T * V, h * w)
+    assert torch.equal(rm.rows(), x[..., 0])
+
+
+def test_group_mask_equals_reference_expansion():
+    """mode-1 mask semantics of dwm_attention_fwd == the repeat_interleave expansion of
+    crossview_temporal_dit.py:301-305."""
+    from opendwm_amd import ops
+    B, T, V, h, w = 2, 3, 4, 2, 5
+    g = torch.Generator().manual_seed(0)
+    m = torch.rand(B, V, V, generator=g) > 0.4
+    ref = m.repeat_interleave(w, 2).repeat_interleave(w, 1).repeat_interleave(T * h, 0)
+    rm = ops.rowmap_crossview_rowwise(B, T, V, h, w)
+    p = torch.arange(rm.n_problems)[:, None, None]
+    lq = torch.arange(rm.L0)[None, :, None]
+    lk = torch.arange(rm.L0)[None, None, :]
+    mine = m[p // rm.p_per_mask, (lq // rm.group_size) % V, (lk // rm.group_size) % V]
+    assert torch.equal(mine, ref)
+
+
+def test_geglu_pack_matches_kernel_epilogue_contract():
+    """DWM_EPI_GEGLU: within each 64 packed rows, row j < 32 is the value and row j + 32 the gate
+    of output column (group*32 + j)."""
+    from opendwm_amd.blocks import geglu_pack
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 64, generator=g)
+    w = torch.randn(256, 64, generator=g)
+    b = torch.randn(256, generator=g)
+    y = x @ w.T + b
+    hv, gate = y.chunk(2, -1)
+    ref = hv * F.gelu(gate)
+    wp, bp = geglu_pack(w), geglu_pack(b)
+    yp = (x @ wp.T + bp).view(5, -1, 2, 32)
+    mine = (yp[:, :, 0] * F.gelu(yp[:, :, 1])).reshape(5, -1)
+    assert rel_err(mine, ref) < 1e-6
+
+
+def test_model_state_dict_keys_equal_reference_tree(small_cfg):
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    m = DiTCrossviewTemporalConditionModel(**small_cfg)
+    sd = O.make_state_dict(small_cfg, seed=0)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    missing, unexpected = m.load_state_dict(sd)
+    assert not missing and not unexpected
+    for k, v in m.state_dict().items():
+        assert v.shape == sd[k].shape, k
+    # spot-check the names the reference / diffusers module tree uses
+    for k in ("transformer_blocks.0.attn.add_k_proj.bias", "transformer_blocks.0.attn2.norm_q.weight",
+              "transformer_blocks.3.norm1_context.linear.weight", "transformer_blocks.0.ff.net.0.proj.weight",
+              "crossview_transformer_blocks.0.ff_in.net.2.weight", "temporal_transformer_blocks.1.attn1.to_out.0.bias",
+              "view_mixers.0.mix_factor", "time_pos_embeds.0.linear_2.weight", "view_embedding.linear_1.weight",
+              "pos_embed.proj.weight", "pos_embed.pos_embed", "norm_out.linear.weight", "proj_out.bias"):
+        assert k in sd, k
+    assert "transformer_blocks.3.attn.to_add_out.weight" not in sd      # context_pre_only last block
+
+
+def test_model_pos_embed_buffer_equals_oracle_table(small_cfg):
+    from opendwm_amd.dit import sincos_pos_embed_2d
+    a = sincos_pos_embed_2d(128, 32, 16)
+    b = O.make_pos_embed_table(128, 32, 16)
+    assert torch.equal(a, b)
+
+
+def test_model_rejects_cpu_inputs(small_cfg):
+    """No silent CPU / eager fallback: a CPU call must raise."""
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    m = DiTCrossviewTemporalConditionModel(**small_cfg)
+    inp = small_inputs(small_cfg)
+    with pytest.raises(RuntimeError):
+        m(inp.pop("sample"), inp.pop("timestep"), **inp)
+
+
+def test_schedule_equals_oracle():
+    from opendwm_amd.pipeline import FlowMatchEulerSchedule
+    s = FlowMatchEulerSchedule(shift=3.0).set_timesteps(40)
+    assert torch.allclose(s.sigmas, O.flow_match_sigmas(40, 3.0), atol=1e-7)
+    assert torch.allclose(s.timesteps, s.sigmas[:-1] * 1000)
+
+
+# ---------------------------------------------------------------------------- C ABI
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
+    return sorted(set(re.findall(r"^\s*int\s+(dwm_[a-z0-9_]+)\s*\(", hdr, flags=re.M)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from opendwm_amd import _lib, build
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_lib.SIGNATURES) == set(declared)
+    assert lib.dwm_abi_version() == _lib.ABI_VERSION
+
+
+def test_ctypes_structs_match_header_field_order():
+    """Field names of the ctypes mirrors must appear in the header structs in the same order."""
+    from opendwm_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
+    for cname, cls in (("dwm_gemm_args", _lib.GemmArgs), ("dwm_attn_args", _lib.AttnArgs),
+                       ("dwm_layernorm_args", _lib.LayerNormArgs)):
+        body = hdr[hdr.index(f"typedef struct {cname}"):hdr.index(f"}} {cname};")]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        pos = -1
+        for fname, _ in cls._fields_:
+            m = re.search(rf"[\s\*,]{fname}\s*(\[\d+\])?\s*[,;]", body[pos + 1:])
+            assert m, (cname, fname)
+            pos = pos + 1 + m.start()
