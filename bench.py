@@ -66,6 +66,7 @@ def build_model(kwargs, dev, seed=0):
             model = DiTCrossviewTemporalConditionModel(**kwargs)
     finally:
         torch.set_default_dtype(old)
+    model = model.to(device=dev, dtype=torch.bfloat16)
     synth_init_(model, seed)
     return model.eval()
 

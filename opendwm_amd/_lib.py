@@ -78,6 +78,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; it must be in the process before libdwm_hip.so is
+    # dlopen'ed so both bind to the SAME HIP runtime (otherwise launches fail with hipErrorNoDevice).
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m opendwm_amd.build` "

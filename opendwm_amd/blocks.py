@@ -247,9 +247,9 @@ class AlphaBlender(nn.Module):
             raise ValueError("merge_strategy needs to be in {}".format(AlphaBlender.strategies))
         self.merge_strategy = merge_strategy
         if merge_strategy == "fixed":
-            self.register_buffer("mix_factor", torch.Tensor([alpha]))
+            self.register_buffer("mix_factor", torch.tensor([float(alpha)]))
         else:
-            self.register_parameter("mix_factor", nn.Parameter(torch.Tensor([alpha])))
+            self.register_parameter("mix_factor", nn.Parameter(torch.tensor([float(alpha)])))
 
     def get_alpha(self, image_only_indicator: Optional[torch.Tensor], batch: int) -> torch.Tensor:
         """fp32 alpha[batch] (crossview_temporal.py:33-51)."""

@@ -38,7 +38,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "dwm_hip.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the
+    # VALU epilogues / softmax read them without v_accvgpr_read/write copies
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
              "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"]
     jobs = []
     for src in SOURCES:

@@ -12,11 +12,8 @@
 // again on the lane axis: the running max / sum rescale is a per-lane scalar.
 //
 // K tile in LDS: [64 keys][8 x 16-B chunks], chunk ^= (key >> 1) & 7 (conflict-free
-// ds_read_b128 fragments).  V tile, two interchangeable images (template VTR):
-//   VTR = 1: row-major like K, chunk ^= ((key >> 1) & 1) << 2, fragments fetched with
-//            the gfx950 transposing read ds_read_b64_tr_b16;
-//   VTR = 0: transposed VT[64 d][64 key-slots] with 144-B rows, written as packed key
-//            pairs (ds_write_b32), key slots permuted so a fragment is one 16-B read.
+// ds_read_b128 fragments).  V tile: row-major like K, chunk ^= ((key >> 1) & 1) << 2, its
+// (transposed) fragments fetched with the gfx950 transposing read ds_read_b64_tr_b16.
 // K/V tiles are register-staged and double-buffered: the global loads of tile t+1
 // are issued before the MFMAs of tile t and written to LDS after them (one barrier
 // per tile).
@@ -32,8 +29,7 @@ namespace {
 
 constexpr int KT = 64;                        // keys per tile
 constexpr int K_TILE_BYTES = KT * 128;        // 8192
-constexpr int VT_ROW = 144;                   // bytes per d-row of the transposed V image
-constexpr int V_TILE_BYTES = 64 * VT_ROW;     // 9216 (>= 8192 needed by the row-major image)
+constexpr int V_TILE_BYTES = KT * 128;        // 8192
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -50,6 +46,7 @@ struct AttnParams {
     bf16_t *o0, *o1;
     int64_t ld0, ld1, ldo0, ldo1;
     int L0, L1, L;
+    int64_t seg1_delta;      // (q1 - q0) == (k1 - k0) == (v1 - v0) in elements
     int n_problems, heads, nqb;
     float scale_log2;
     int mask_mode;
@@ -70,25 +67,15 @@ DWM_DEVINL int64_t seg0_row(const RowMap& rm, int64_t base, int l) {
     const int hi = q0 / rm.ldiv1, mid = q0 - hi * rm.ldiv1;
     return base + lo * rm.lstride[0] + mid * rm.lstride[1] + hi * rm.lstride[2];
 }
-// element offset (without the head offset) of token l of problem `prob` in the k / v buffers
-DWM_DEVINL int64_t kv_off(const AttnParams& P, int64_t base0, int prob, int l) {
-    l = l < P.L ? l : P.L - 1;
-    if (l < P.L0) return seg0_row(P.rm, base0, l) * P.ld0;
-    return ((int64_t)prob * P.L1 + (l - P.L0)) * P.ld1;
-}
-
-// slot of key kappa (0..63) inside a VT row: per 16-key step the order is
-// [k0..3 | k8..11 | k4..7 | k12..15] so lane-half h reads its 8 keys as one 16-B chunk.
-DWM_DEVINL int vt_slot(int kappa) {
-    const int w16 = kappa & 15, g = w16 >> 2;
-    return (kappa & ~15) + ((g & 1) << 3) + ((g >> 1) << 2) + (w16 & 3);
-}
-
-template <int NW, int QT, int VTR>
-__global__ void __launch_bounds__(NW * 64)
+// MASK: 0 none, 1 group mask, 2 dense byte mask.  NW = 4 waves (256 threads).
+template <int QT, int MASK>
+__global__ void __launch_bounds__(256)
 attn_fwd_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 4;
     constexpr int QB = NW * QT * 32;          // queries per block
+    // [L] element offset (row * ld, relative to the segment-0 base pointer) of every token of this problem
+    int64_t* __restrict__ rowtab = (int64_t*)(smem + 2 * STAGE_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,8 +91,17 @@ attn_fwd_kernel(const AttnParams P) {
     const int prob = id / P.heads;
 
     const int L = P.L, L0 = P.L0;
-    const int64_t base0 = seg0_base(P.rm, prob);
     const int64_t hoff = (int64_t)head * 64;
+
+    // ---- row table: token l -> row index in its segment's buffers (one div/mod chain per token
+    //      per block instead of one per staged 16-B chunk)
+    {
+        const int64_t base0 = seg0_base(P.rm, prob);
+        for (int l = tid; l < L; l += 256)
+            rowtab[l] = l < L0 ? seg0_row(P.rm, base0, l) * P.ld0
+                               : P.seg1_delta + ((int64_t)prob * P.L1 + (l - L0)) * P.ld1;
+    }
+    __syncthreads();
 
     // ---- this lane's queries
     bf16x8 qf[QT][4];
@@ -118,40 +114,34 @@ attn_fwd_kernel(const AttnParams P) {
         const int lq = qb * QB + (wave * QT + t) * 32 + l31;
         qok[t] = lq < L;
         const int lqc = qok[t] ? lq : L - 1;
-        const bf16_t* qptr;
-        if (lqc < L0) {
-            const int64_t r = seg0_row(P.rm, base0, lqc);
-            qptr = P.q0 + r * P.ld0 + hoff;
-            optr[t] = P.o0 + r * P.ldo0 + hoff;
-        } else {
-            const int64_t r = (int64_t)prob * P.L1 + (lqc - L0);
-            qptr = P.q1 + r * P.ld1 + hoff;
-            optr[t] = P.o1 + r * P.ldo1 + hoff;
-        }
+        const bf16_t* qptr = P.q0 + rowtab[lqc] + hoff;      // q, k, v share the offset table
+        if (lqc < L0) optr[t] = P.o0 + seg0_row(P.rm, seg0_base(P.rm, prob), lqc) * P.ldo0 + hoff;
+        else optr[t] = P.o1 + ((int64_t)prob * P.L1 + (lqc - L0)) * P.ldo1 + hoff;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *(const bf16x8*)(qptr + ks * 16 + half * 8);
         gbits[t] = 0xffffffffu;
         dense_row[t] = nullptr;
-        if (P.mask_mode == 1) {
+        if (MASK == 1) {
             const int gq = (lqc / P.group_size) % P.mask_G;
             const uint8_t* mrow = P.mask + ((int64_t)(prob / P.p_per_mask) * P.mask_G + gq) * P.mask_G;
             uint32_t bits = 0;
             for (int g = 0; g < P.mask_G; ++g) bits |= (mrow[g] ? 1u : 0u) << g;
             gbits[t] = bits;
-        } else if (P.mask_mode == 2) {
+        } else if (MASK == 2) {
             dense_row[t] = P.mask + ((int64_t)prob * L + lqc) * L;
         }
     }
 
-    // ---- staging coordinates (NT = 256 threads, two 16-B chunks per thread and operand).
-    // K (and V when VTR): chunk cid = tid + i*256 -> key = cid >> 3, dchunk = cid & 7.
-    // V when !VTR: pair pid = tid -> key pair kp = pid >> 3 (keys 2kp, 2kp+1), dchunk = pid & 7.
-    static_assert(NW == 4, "staging below is written for 256 threads");
+    // ---- staging coordinates: two 16-B chunks per thread and operand per 64-key tile:
+    //      chunk (key = tid >> 3 [+32], dchunk = tid & 7), same for K and V.
     const int nkt = (L + KT - 1) / KT;
-    const int sdc = tid & 7;                       // this thread's 16-B d-chunk
-    const int skey0 = tid >> 3, skey1 = skey0 + 32;   // K rows (and V rows when VTR)
-    const int vka = VTR ? skey0 : 2 * (tid >> 3);     // V rows
-    const int vkb = VTR ? skey1 : vka + 1;
+    const int sdc = tid & 7;
+    const int skey0 = tid >> 3, skey1 = skey0 + 32;
+    const int kw0 = skey0 * 128 + ((sdc ^ ((skey0 >> 1) & 7)) << 4);      // K image byte offsets
+    const int kw1 = skey1 * 128 + ((sdc ^ ((skey1 >> 1) & 7)) << 4);
+    const int vw0 = skey0 * 128 + ((sdc ^ (((skey0 >> 1) & 1) << 2)) << 4);  // V image byte offsets
+    const int vw1 = skey1 * 128 + ((sdc ^ (((skey1 >> 1) & 1) << 2)) << 4);
+    const int64_t coff = hoff + sdc * 8;
     uint4 kr0, kr1, vr0, vr1;
 
 #define DWM_LOAD_TILE(kt_)                                                                  \
@@ -159,38 +149,25 @@ attn_fwd_kernel(const AttnParams P) {
         const int kb_ = (kt_) * KT;                                                         \
         const int a_ = kb_ + skey0 < L ? kb_ + skey0 : L - 1;                               \
         const int b_ = kb_ + skey1 < L ? kb_ + skey1 : L - 1;                               \
-        kr0 = *(const uint4*)((a_ >= L0 ? P.k1 : P.k0) + kv_off(P, base0, prob, a_) + hoff + sdc * 8); \
-        kr1 = *(const uint4*)((b_ >= L0 ? P.k1 : P.k0) + kv_off(P, base0, prob, b_) + hoff + sdc * 8); \
-        const int c_ = kb_ + vka < L ? kb_ + vka : L - 1;                                   \
-        const int d_ = kb_ + vkb < L ? kb_ + vkb : L - 1;                                   \
-        vr0 = *(const uint4*)((c_ >= L0 ? P.v1 : P.v0) + kv_off(P, base0, prob, c_) + hoff + sdc * 8); \
-        vr1 = *(const uint4*)((d_ >= L0 ? P.v1 : P.v0) + kv_off(P, base0, prob, d_) + hoff + sdc * 8); \
+        const int64_t oa_ = rowtab[a_] + coff, ob_ = rowtab[b_] + coff;                     \
+        kr0 = *(const uint4*)(P.k0 + oa_);                                                  \
+        vr0 = *(const uint4*)(P.v0 + oa_);                                                  \
+        kr1 = *(const uint4*)(P.k0 + ob_);                                                  \
+        vr1 = *(const uint4*)(P.v0 + ob_);                                                  \
     } while (0)
 
 #define DWM_WRITE_TILE(buf_)                                                                \
     do {                                                                                    \
         char* kl_ = smem + (buf_) * STAGE_BYTES;                                            \
         char* vl_ = kl_ + K_TILE_BYTES;                                                     \
-        *(uint4*)(kl_ + skey0 * 128 + ((sdc ^ ((skey0 >> 1) & 7)) << 4)) = kr0;             \
-        *(uint4*)(kl_ + skey1 * 128 + ((sdc ^ ((skey1 >> 1) & 7)) << 4)) = kr1;             \
-        if (VTR) {                                                                          \
-            *(uint4*)(vl_ + skey0 * 128 + ((sdc ^ (((skey0 >> 1) & 1) << 2)) << 4)) = vr0;  \
-            *(uint4*)(vl_ + skey1 * 128 + ((sdc ^ (((skey1 >> 1) & 1) << 2)) << 4)) = vr1;  \
-        } else {                                                                            \
-            char* dst = vl_ + (sdc * 8) * VT_ROW + vt_slot(vka) * 2;                        \
-            *(uint32_t*)(dst + 0 * VT_ROW) = (vr0.x & 0xffffu) | (vr1.x << 16);             \
-            *(uint32_t*)(dst + 1 * VT_ROW) = (vr0.x >> 16) | (vr1.x & 0xffff0000u);         \
-            *(uint32_t*)(dst + 2 * VT_ROW) = (vr0.y & 0xffffu) | (vr1.y << 16);             \
-            *(uint32_t*)(dst + 3 * VT_ROW) = (vr0.y >> 16) | (vr1.y & 0xffff0000u);         \
-            *(uint32_t*)(dst + 4 * VT_ROW) = (vr0.z & 0xffffu) | (vr1.z << 16);             \
-            *(uint32_t*)(dst + 5 * VT_ROW) = (vr0.z >> 16) | (vr1.z & 0xffff0000u);         \
-            *(uint32_t*)(dst + 6 * VT_ROW) = (vr0.w & 0xffffu) | (vr1.w << 16);             \
-            *(uint32_t*)(dst + 7 * VT_ROW) = (vr0.w >> 16) | (vr1.w & 0xffff0000u);         \
-        }                                                                                   \
+        *(uint4*)(kl_ + kw0) = kr0;                                                         \
+        *(uint4*)(kl_ + kw1) = kr1;                                                         \
+        *(uint4*)(vl_ + vw0) = vr0;                                                         \
+        *(uint4*)(vl_ + vw1) = vr1;                                                         \
     } while (0)
 
     f32x16 ot[QT][2];
-    float m_run[QT], l_run[QT];
+    float m_run[QT], l_run[QT];          // running max (already multiplied by scale_log2) and partial row sum
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         m_run[t] = -1e30f;
@@ -202,29 +179,37 @@ attn_fwd_kernel(const AttnParams P) {
     }
 
     const int kswz = (lane >> 1) & 7;
-    // tr-read lane geometry (VTR): 16-lane group g covers d columns [16g, 16g+16) of a 32-d tile;
-    // lane u of the group supplies the address of V[key0 + (u >> 2)][.. + 4 (u & 3)] (8 bytes)
+    // tr-read lane geometry: 16-lane group g covers d columns [16g, 16g+16) of a 32-d tile; lane u
+    // of the group supplies the address of V[key0 + (u >> 2)][.. + 4 (u & 3)] (8 bytes) and receives
+    // column u: elements V[key0 + 0..3][16 g + u]
     const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+    int vra[2], vrb[2];                   // per d-tile byte offsets of the two tr reads at step s = 0
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+        const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+        vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+    }
+    const float c = P.scale_log2;
 
     DWM_LOAD_TILE(0);
     DWM_WRITE_TILE(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // Q fragments landed before the loop
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) DWM_LOAD_TILE(kt + 1);
+        // unconditional prefetch keeps the loop body branch-free: past the end it re-fetches the
+        // last tile (addresses are clamped) into the buffer nobody reads again
+        DWM_LOAD_TILE(kt + 1 < nkt ? kt + 1 : kt);
 
         const char* kl = smem + (kt & 1) * STAGE_BYTES;
         const char* vl = kl + K_TILE_BYTES;
 
         // ---- S^T = K Q^T for two 32-key sub-tiles (K fragments shared by the QT query tiles)
         f32x16 st[QT][2];
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[t][j][r] = 0.f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -232,37 +217,67 @@ attn_fwd_kernel(const AttnParams P) {
                 const bf16x8 kf = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], st[t][j], 0, 0, 0);
+                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], ks == 0 ? zero16 : st[t][j], 0, 0, 0);
             }
+        __builtin_amdgcn_s_setprio(0);
 
-        // ---- scale (log2 domain), masks, online softmax; P^T fragments stay in registers
+        // ---- masks (raw-score domain), online softmax; P^T fragments stay in registers
         const int kbase = kt * KT;
-        const bool tail = kbase + KT > L;
-        bf16x8 pf[QT][4];                      // B-operand fragments, step s = 2*j + s2
+        if (kbase + KT > L) {                       // ragged last tile (wave-uniform)
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float mx = -INFINITY;
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[t][j][r] = -INFINITY;
+        }
+        if (MASK == 1) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float x = st[t][j][r] * P.scale_log2;
                     const int key = kbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (tail && key >= L) x = -INFINITY;
-                    if (P.mask_mode == 1) {
-                        int g = (int)(((float)key + 0.5f) * P.inv_group_size);
-                        g -= P.mask_G * (int)(((float)g + 0.5f) * P.inv_G);
-                        if (!((gbits[t] >> g) & 1u)) x = -INFINITY;
-                    } else if (P.mask_mode == 2) {
-                        if (key < L && dense_row[t][key] == 0) x = -INFINITY;
-                    }
-                    st[t][j][r] = x;
-                    mx = fmaxf(mx, x);
+                    int g = (int)(((float)key + 0.5f) * P.inv_group_size);
+                    g -= P.mask_G * (int)(((float)g + 0.5f) * P.inv_G);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t)
+                        if (!((gbits[t] >> g) & 1u)) st[t][j][r] = -INFINITY;
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[t], mx);
-            const float alpha = exp2f(m_run[t] - m_new);
-            m_run[t] = m_new;
+        } else if (MASK == 2) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (key < L && dense_row[t][key] == 0) st[t][j][r] = -INFINITY;
+                    }
+        }
+
+        bf16x8 pf[QT][4];                      // B-operand fragments, step s = 2*j + s2
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = st[t][0][0];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;          // c > 0: max commutes with the scale
+            // deferred rescale: keep the old running max while the new one exceeds it by < 2^6
+            // (P <= 64, exact in the fp32 sums; bf16 P keeps its relative precision)
+            if (!__all(mx <= m_run[t] + 6.f)) {
+                const float m_new = fmaxf(m_run[t], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+                m_run[t] = m_new;
+                l_run[t] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[t][i][r] *= alpha;
+            }
+            const float mneg = -m_run[t];
             float psum = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -271,44 +286,33 @@ attn_fwd_kernel(const AttnParams P) {
                     float pv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        pv[e] = exp2f(st[t][j][s2 * 8 + e] - m_new);
+                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][j][s2 * 8 + e], c, mneg));
                         psum += pv[e];
                     }
                     const uint4 pk = pack8(pv);
                     pf[t][j * 2 + s2] = *reinterpret_cast<const bf16x8*>(&pk);
                 }
-            l_run[t] = l_run[t] * alpha + psum;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ot[t][i][r] *= alpha;
+            l_run[t] += psum;
         }
 
         // ---- O^T += V^T P^T   (V fragments shared by the QT query tiles)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                bf16x8 vf;
-                if (VTR) {
-                    // keys 16s + 4half + {0..3} and 16s + 8 + 4half + {0..3}, column d = 32dt + l31
-                    const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;          // first of 4 d this lane addresses
-                    const int keyA = s * 16 + half * 4 + (tr_u >> 2);
-                    const int keyB = keyA + 8;
-                    const char* pa = vl + keyA * 128 + ((((dcol >> 3)) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
-                    const char* pb = vl + keyB * 128 + ((((dcol >> 3)) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
-                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
-                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pb);
-                    vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-                } else {
-                    vf = *(const bf16x8*)(vl + (dt * 32 + l31) * VT_ROW + (s * 16 + half * 8) * 2);
-                }
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s * (16 * 128)));
+                const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s * (16 * 128)));
+                const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
                     ot[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], ot[t][dt], 0, 0, 0);
             }
+        __builtin_amdgcn_s_setprio(0);
 
-        if (more) DWM_WRITE_TILE((kt + 1) & 1);
+        DWM_WRITE_TILE((kt + 1) & 1);
         __syncthreads();
     }
 #undef DWM_LOAD_TILE
@@ -347,10 +351,11 @@ tr_probe_kernel(const int* __restrict__ offs, short* __restrict__ out) {
     for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
 }
 
-template <int NW, int QT, int VTR>
+template <int QT, int MASK>
 void launch_attn(const AttnParams& P, hipStream_t s) {
     const int64_t nblk = (int64_t)P.n_problems * P.heads * P.nqb;
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, QT, VTR>), dim3((unsigned)nblk), dim3(NW * 64), 2 * STAGE_BYTES, s, P);
+    const size_t lds = 2 * STAGE_BYTES + (size_t)((P.L + 1) & ~1) * sizeof(int64_t);
+    hipLaunchKernelGGL((attn_fwd_kernel<QT, MASK>), dim3((unsigned)nblk), dim3(256), lds, s, P);
 }
 
 }  // namespace
@@ -377,6 +382,13 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     P.o0 = (bf16_t*)a->o0; P.o1 = (bf16_t*)a->o1;
     P.ld0 = a->ld0; P.ld1 = a->ld1; P.ldo0 = a->ldo0; P.ldo1 = a->ldo1;
     P.L0 = (int)a->L0; P.L1 = (int)a->L1; P.L = (int)L;
+    P.seg1_delta = 0;
+    if (a->L1 > 0) {
+        // the kernel addresses both segments through one offset table relative to q0/k0/v0
+        const int64_t dq = P.q1 - P.q0, dk = P.k1 - P.k0, dv = P.v1 - P.v0;
+        if (dq != dk || dk != dv) return DWM_EUNSUPPORTED;
+        P.seg1_delta = dq;
+    }
     P.n_problems = (int)a->n_problems; P.heads = a->heads;
     P.scale_log2 = a->scale * 1.4426950408889634f;
     P.mask_mode = a->mask_mode; P.mask = a->mask;
@@ -390,21 +402,23 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     P.rm.ldiv0 = (int)a->ldiv[0]; P.rm.ldiv1 = (int)a->ldiv[1];
     for (int i = 0; i < 3; ++i) P.rm.lstride[i] = a->lstride[i];
 
-    // variant: bits 0-3 = queries per wave / 32 (1 or 2; 0 = auto), bit 4 = 1 selects the
-    // transposed-write V image instead of the transposing LDS read (ds_read_b64_tr_b16).
+    // variant: 0 = auto; 1 / 2 = 32 / 64 queries per wave (128 / 256 per workgroup)
     int qt = a->variant & 15;
-    const int vtr = ((a->variant >> 4) & 1) ? 0 : 1;
-    if (qt == 0) {
-        const int64_t pad1 = (L + 127) / 128 * 128 - L, pad2 = (L + 255) / 256 * 256 - L;
-        qt = (pad2 <= pad1 + 32 && L > 128) ? 2 : 1;
-    }
+    if (qt == 0) qt = 1;
     if (qt != 1 && qt != 2) return DWM_EINVAL;
     const int qblock = qt * 128;
     P.nqb = (int)((L + qblock - 1) / qblock);
     if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
+    if (2 * STAGE_BYTES + L * 8 + 16 > 64 * 1024) return DWM_EUNSUPPORTED;   // row table must fit the default LDS window
     hipStream_t s = (hipStream_t)stream;
-    if (qt == 1) { if (vtr) launch_attn<4, 1, 1>(P, s); else launch_attn<4, 1, 0>(P, s); }
-    else { if (vtr) launch_attn<4, 2, 1>(P, s); else launch_attn<4, 2, 0>(P, s); }
+#define DWM_ATTN(QT_)                                              \
+    do {                                                           \
+        if (P.mask_mode == 0) launch_attn<QT_, 0>(P, s);           \
+        else if (P.mask_mode == 1) launch_attn<QT_, 1>(P, s);      \
+        else launch_attn<QT_, 2>(P, s);                            \
+    } while (0)
+    if (qt == 1) DWM_ATTN(1); else DWM_ATTN(2);
+#undef DWM_ATTN
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }

@@ -1,0 +1,105 @@
+"""Per-kernel microbenchmarks on BASELINE config-3 shapes (runs on the GPU box).
+usage: python scripts/microbench.py [attn] [gemm] [ln]"""
+import json
+import os
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from opendwm_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+bf16 = torch.bfloat16
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(bf16)
+
+
+def bench_attn(variants):
+    H, D = 24, 1536
+    B, T, V, h, w = 2, 16, 6, 16, 28
+    I, N, Lc = B * T * V, h * w, 154
+    qkv = rnd(I * N, 3 * D)
+    cqkv = rnd(I * Lc, 3 * D)
+    out = torch.empty(I * N, D, device=dev, dtype=bf16)
+    cout = torch.empty(I * Lc, D, device=dev, dtype=bf16)
+    mask = torch.ones(B, V, V, dtype=torch.bool, device=dev)
+    cases = {
+        "joint L=602": (ops.rowmap_identity(I, N), dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout), 602),
+        "dual L=448": (ops.rowmap_identity(I, N), {}, 448),
+        "crossview L=168 mask": (ops.rowmap_crossview_rowwise(B, T, V, h, w), dict(group_mask=mask), 168),
+        "temporal rowwise L=448": (ops.rowmap_temporal_rowwise(B, T, V, h, w), {}, 448),
+        "temporal pointwise L=16": (ops.rowmap_temporal_pointwise(B, T, V, h, w), {}, 16),
+    }
+    for name, (rm, kw, L) in cases.items():
+        fl = 4.0 * rm.n_problems * H * L * L * 64
+        for var in variants:
+            ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var, **kw))
+            print(json.dumps({"kernel": "attn", "case": name, "variant": var, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
+
+
+def bench_gemm():
+    from opendwm_amd.blocks import geglu_pack
+    shapes = [("qkv rmshead", 86016, 4608, 1536, "rms"), ("out-proj resid", 86016, 1536, 1536, "resid"),
+              ("ff1 gelu", 86016, 6144, 1536, "gelu"), ("ff2 resid", 86016, 1536, 6144, "resid"),
+              ("vt geglu", 86016, 12288, 1536, "geglu"), ("ctx qkv", 29568, 4608, 1536, "plain"),
+              ("ctx embed", 29568, 1536, 4096, "plain"), ("adaln M=192", 192, 13824, 1536, "plain"),
+              ("plain 8192^3", 8192, 8192, 8192, "plain")]
+    for name, M, N, K, kind in shapes:
+        a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+        fl = 2.0 * M * N * K
+        if kind == "rms":
+            rms = rnd(2 * 1536) * 0.1 + 1
+            f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=3072, rms_eps=1e-6)
+        elif kind == "resid":
+            gate, res = rnd(M // 448 + 1, N), rnd(M, N)
+            f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=res, out=res)
+        elif kind == "gelu":
+            f = lambda: ops.gemm(a, w, b, act=ops.ACT_GELU_TANH)
+        elif kind == "geglu":
+            wp, bp = geglu_pack(w), geglu_pack(b)
+            f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU)
+        else:
+            f = lambda: ops.gemm(a, w, b)
+        ms = timeit(f)
+        ms_t = timeit(lambda: torch.matmul(a, w.t()))
+        print(json.dumps({"kernel": "gemm", "case": name, "M": M, "N": N, "K": K, "ms": round(ms, 4),
+                          "tflops": round(fl / ms / 1e9, 1), "hipblaslt_plain_tflops": round(fl / ms_t / 1e9, 1)}), flush=True)
+
+
+def bench_ln():
+    x = rnd(86016, 1536)
+    mod = rnd(192, 9 * 1536)
+    y2 = torch.empty_like(x)
+    D = 1536
+    ms = timeit(lambda: ops.layernorm(x, eps=1e-6, scale=mod[:, D:2 * D], shift=mod[:, :D], rows_per_mod=448))
+    print(json.dumps({"kernel": "ln-mod", "ms": round(ms, 4), "GBps": round(2 * x.numel() * 2 / ms / 1e6, 1)}))
+    ms = timeit(lambda: ops.layernorm(x, eps=1e-6, scale=mod[:, D:2 * D], shift=mod[:, :D], rows_per_mod=448,
+                                      scale2=mod[:, 7 * D:8 * D], shift2=mod[:, 6 * D:7 * D], out2=y2))
+    print(json.dumps({"kernel": "ln-mod-dual", "ms": round(ms, 4), "GBps": round(3 * x.numel() * 2 / ms / 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["attn", "gemm", "ln"]
+    print(torch.cuda.get_device_name(0))
+    if "attn" in what:
+        bench_attn([1, 2])
+    if "gemm" in what:
+        bench_gemm()
+    if "ln" in what:
+        bench_ln()
