@@ -49,14 +49,26 @@ DWM_DEVINL float wave_sum(float v) {
     return v;
 }
 
+// 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3); one v_exp + one v_rcp
 DWM_DEVINL float gelu_tanh_f(float x) {
-    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), tanh(u) = 1 - 2 / (exp(2u) + 1)
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float t = 1.f - 2.f / (__expf(2.f * u) + 1.f);
-    return 0.5f * x * (1.f + t);
+    const float z = x * (2.302208198f + 0.1029432397f * x * x);          // 2 u log2(e)
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z));
 }
-DWM_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
-DWM_DEVINL float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output resolution)
+DWM_DEVINL float erf_fast_f(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = 1.f - p * t * e;
+    return __builtin_copysignf(r, x);
+}
+DWM_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.f + erf_fast_f(x * 0.7071067811865476f)); }
+DWM_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
 DWM_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {

@@ -48,7 +48,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          res: Optional[torch.Tensor] = None, res_mod: int = 0,
          blend: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
          rows_per_alpha: int = 1,
-         rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6) -> torch.Tensor:
+         rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
+         _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16."""
     _chk2d(a, "a")
     _chk2d(w, "w")
@@ -81,6 +82,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if rms_w is not None:
         _chkvec(rms_w, "rms_w")
         g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
+    g.reserved = _debug
     _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
     return out
 

@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 bf16 = torch.bfloat16
 
 
-def timeit(fn, iters=5, warm=2):
+def timeit(fn, iters=10, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
