@@ -255,7 +255,7 @@ def main():
             "whole_step_mfma_frac": fl["total"] / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))))
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
