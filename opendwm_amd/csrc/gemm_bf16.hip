@@ -40,8 +40,17 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
+    // XCD-contiguous ids, then grouped rasterisation: consecutive ids walk GM row-tiles down a
+    // column before moving to the next column, so the ~32 tiles resident on one XCD at a time form
+    // a compact GM x (32/GM) block that shares A and W panels in that XCD's L2.
     const int id = xcd_remap(blockIdx.x, ntm * ntn);
-    const int tm = id / ntn, tn = id - tm * ntn;
+    int gm_ = (p.reserved >> 4) & 31;
+    if (gm_ == 0) gm_ = 8;
+    const int per_group = gm_ * ntn;
+    const int grp_id = id / per_group, in_grp = id - grp_id * per_group;
+    const int first_m = grp_id * gm_;
+    const int gsize = ntm - first_m < gm_ ? ntm - first_m : gm_;
+    const int tm = first_m + in_grp % gsize, tn = in_grp / gsize;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t M = p.M, N = p.N, K = p.K;
 
@@ -83,8 +92,15 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
     const int swz = (lane >> 1) & 7;       // ((row >> 1) & 7) with row = 32*t + (lane & 31)
     const int a_row_off = (wm * 128 + l31) * 128;
     const int w_row_off = (wn * 64 + l31) * 128;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + half) ^ swz) << 4;
 
     const int nk = (int)(K / BK);
+
+    // ---- main loop: one barrier per K tile; inside a tile the fragment reads of k-substep s+1 are
+    // issued before the MFMAs of substep s (two register sets), so the matrix pipe does not wait
+    // for LDS latency at every substep.
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -92,22 +108,27 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* la = smem + (kt & 1) * STAGE_BYTES;
         const char* lb = la + TILE_BYTES;
+        bf16x8 af[2][4], wf[2][2];
+#define DWM_LOAD_FRAGS(SET, KS)                                                                     \
+        do {                                                                                        \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+                af[SET][mt] = *(const bf16x8*)(la + a_row_off + mt * (32 * 128) + coff[KS]);        \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
+                wf[SET][nt] = *(const bf16x8*)(lb + w_row_off + nt * (32 * 128) + coff[KS]);        \
+        } while (0)
+        DWM_LOAD_FRAGS(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int coff = ((2 * ks + half) ^ swz) << 4;
-            bf16x8 af[4], wf[2];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                af[mt] = *(const bf16x8*)(la + a_row_off + mt * (32 * 128) + coff);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                wf[nt] = *(const bf16x8*)(lb + w_row_off + nt * (32 * 128) + coff);
+            if (ks < 3) DWM_LOAD_FRAGS((ks + 1) & 1, ks + 1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
+#undef DWM_LOAD_FRAGS
     }
 
     // ------------------------------------------------------------------ epilogue
