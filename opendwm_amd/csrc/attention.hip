@@ -35,9 +35,9 @@ constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct RowMap {
-    int pdiv[3], pmod[3];
+    FastDiv pdiv[3], pmod[3];
     int64_t pstride[3];
-    int ldiv0, ldiv1;
+    FastDiv ldiv0, ldiv1;
     int64_t lstride[3];
 };
 
@@ -48,10 +48,12 @@ struct AttnParams {
     int L0, L1, L;
     int64_t seg1_delta;      // (q1 - q0) == (k1 - k0) == (v1 - v0) in elements
     int n_problems, heads, nqb;
+    FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;
     float scale_log2;
     int mask_mode;
     const uint8_t* mask;
     int mask_G, group_size, p_per_mask;
+    int dbg;                 // ablation bits (benchmarks only): 1 no in-loop loads, 2 no exp, 4 no LDS restage
     float inv_group_size, inv_G;
     RowMap rm;
 };
@@ -59,17 +61,18 @@ struct AttnParams {
 DWM_DEVINL int64_t seg0_base(const RowMap& rm, int p) {
     int64_t b = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) b += (int64_t)((p / rm.pdiv[i]) % rm.pmod[i]) * rm.pstride[i];
+    for (int i = 0; i < 3; ++i) b += (int64_t)fmod_u(fdiv((uint32_t)p, rm.pdiv[i]), rm.pmod[i]) * rm.pstride[i];
     return b;
 }
 DWM_DEVINL int64_t seg0_row(const RowMap& rm, int64_t base, int l) {
-    const int q0 = l / rm.ldiv0, lo = l - q0 * rm.ldiv0;
-    const int hi = q0 / rm.ldiv1, mid = q0 - hi * rm.ldiv1;
-    return base + lo * rm.lstride[0] + mid * rm.lstride[1] + hi * rm.lstride[2];
+    const uint32_t q0 = fdiv((uint32_t)l, rm.ldiv0), lo = (uint32_t)l - q0 * rm.ldiv0.d;
+    const uint32_t hi = fdiv(q0, rm.ldiv1), mid = q0 - hi * rm.ldiv1.d;
+    return base + (int64_t)lo * rm.lstride[0] + (int64_t)mid * rm.lstride[1] + (int64_t)hi * rm.lstride[2];
 }
 // MASK: 0 none, 1 group mask, 2 dense byte mask.  NW = 4 waves (256 threads).
+// occupancy target: 3 workgroups (waves per SIMD) for 32 queries/wave, 2 for 64 queries/wave
 template <int QT, int MASK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, QT == 1 ? 3 : 2)
 attn_fwd_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 4;
@@ -85,10 +88,11 @@ attn_fwd_kernel(const AttnParams P) {
 
     // block -> (problem, head, query block); query block fastest so the blocks that
     // share one (problem, head)'s K/V are neighbours on one XCD.
-    int id = xcd_remap(blockIdx.x, P.n_problems * P.heads * P.nqb);
-    const int qb = id % P.nqb; id /= P.nqb;
-    const int head = id % P.heads;
-    const int prob = id / P.heads;
+    uint32_t id = (uint32_t)xcd_remap(blockIdx.x, P.n_problems * P.heads * P.nqb);
+    const uint32_t id1 = fdiv(id, P.fd_nqb);
+    const int qb = (int)(id - id1 * P.fd_nqb.d);
+    const int prob = (int)fdiv(id1, P.fd_heads);
+    const int head = (int)(id1 - (uint32_t)prob * P.fd_heads.d);
 
     const int L = P.L, L0 = P.L0;
     const int64_t hoff = (int64_t)head * 64;
@@ -122,8 +126,8 @@ attn_fwd_kernel(const AttnParams P) {
         gbits[t] = 0xffffffffu;
         dense_row[t] = nullptr;
         if (MASK == 1) {
-            const int gq = (lqc / P.group_size) % P.mask_G;
-            const uint8_t* mrow = P.mask + ((int64_t)(prob / P.p_per_mask) * P.mask_G + gq) * P.mask_G;
+            const int gq = (int)fmod_u(fdiv((uint32_t)lqc, P.fd_gs), P.fd_G);
+            const uint8_t* mrow = P.mask + ((int64_t)fdiv((uint32_t)prob, P.fd_ppm) * P.mask_G + gq) * P.mask_G;
             uint32_t bits = 0;
             for (int g = 0; g < P.mask_G; ++g) bits |= (mrow[g] ? 1u : 0u) << g;
             gbits[t] = bits;
@@ -183,6 +187,7 @@ attn_fwd_kernel(const AttnParams P) {
     // of the group supplies the address of V[key0 + (u >> 2)][.. + 4 (u & 3)] (8 bytes) and receives
     // column u: elements V[key0 + 0..3][16 g + u]
     const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+    const float c = P.scale_log2;
     int vra[2], vrb[2];                   // per d-tile byte offsets of the two tr reads at step s = 0
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
@@ -191,7 +196,6 @@ attn_fwd_kernel(const AttnParams P) {
         vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
         vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
     }
-    const float c = P.scale_log2;
 
     DWM_LOAD_TILE(0);
     DWM_WRITE_TILE(0);
@@ -201,7 +205,7 @@ attn_fwd_kernel(const AttnParams P) {
     for (int kt = 0; kt < nkt; ++kt) {
         // unconditional prefetch keeps the loop body branch-free: past the end it re-fetches the
         // last tile (addresses are clamped) into the buffer nobody reads again
-        DWM_LOAD_TILE(kt + 1 < nkt ? kt + 1 : kt);
+        if (!(P.dbg & 1)) DWM_LOAD_TILE(kt + 1 < nkt ? kt + 1 : kt);
 
         const char* kl = smem + (kt & 1) * STAGE_BYTES;
         const char* vl = kl + K_TILE_BYTES;
@@ -259,11 +263,17 @@ attn_fwd_kernel(const AttnParams P) {
         bf16x8 pf[QT][4];                      // B-operand fragments, step s = 2*j + s2
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = st[t][0][0];
+            // 4 independent max chains (ILP) instead of one 32-deep chain
+            float mxa = fmaxf(st[t][0][0], st[t][0][1]), mxb = fmaxf(st[t][0][2], st[t][0][3]);
+            float mxc = fmaxf(st[t][1][0], st[t][1][1]), mxd = fmaxf(st[t][1][2], st[t][1][3]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][j][r]);
+            for (int r = 4; r < 16; r += 4) {
+                mxa = fmaxf(mxa, fmaxf(st[t][0][r], st[t][0][r + 1]));
+                mxb = fmaxf(mxb, fmaxf(st[t][0][r + 2], st[t][0][r + 3]));
+                mxc = fmaxf(mxc, fmaxf(st[t][1][r], st[t][1][r + 1]));
+                mxd = fmaxf(mxd, fmaxf(st[t][1][r + 2], st[t][1][r + 3]));
+            }
+            float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;          // c > 0: max commutes with the scale
             // deferred rescale: keep the old running max while the new one exceeds it by < 2^6
             // (P <= 64, exact in the fp32 sums; bf16 P keeps its relative precision)
@@ -278,7 +288,7 @@ attn_fwd_kernel(const AttnParams P) {
                     for (int r = 0; r < 16; ++r) ot[t][i][r] *= alpha;
             }
             const float mneg = -m_run[t];
-            float psum = 0.f;
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};          // 4 independent partial row sums (ILP)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -286,12 +296,13 @@ attn_fwd_kernel(const AttnParams P) {
                     float pv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][j][s2 * 8 + e], c, mneg));
-                        psum += pv[e];
+                        pv[e] = (P.dbg & 2) ? st[t][j][s2 * 8 + e] : __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][j][s2 * 8 + e], c, mneg));
+                        ps[e & 3] += pv[e];
                     }
                     const uint4 pk = pack8(pv);
                     pf[t][j * 2 + s2] = *reinterpret_cast<const bf16x8*>(&pk);
                 }
+            const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
             l_run[t] += psum;
         }
 
@@ -312,8 +323,10 @@ attn_fwd_kernel(const AttnParams P) {
             }
         __builtin_amdgcn_s_setprio(0);
 
-        DWM_WRITE_TILE((kt + 1) & 1);
-        __syncthreads();
+        if (!(P.dbg & 4)) {
+            DWM_WRITE_TILE((kt + 1) & 1);
+            __syncthreads();
+        }
     }
 #undef DWM_LOAD_TILE
 #undef DWM_WRITE_TILE
@@ -322,7 +335,7 @@ attn_fwd_kernel(const AttnParams P) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
-        const float inv = 1.f / l_tot;
+        const float inv = __builtin_amdgcn_rcpf(l_tot);
         if (qok[t]) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -396,18 +409,25 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     P.inv_group_size = a->group_size > 0 ? 1.f / (float)a->group_size : 0.f;
     P.inv_G = a->mask_G > 0 ? 1.f / (float)a->mask_G : 0.f;
     for (int i = 0; i < 3; ++i) {
-        if (a->pdiv[i] <= 0 || a->pmod[i] <= 0) return DWM_EINVAL;
-        P.rm.pdiv[i] = (int)a->pdiv[i]; P.rm.pmod[i] = (int)a->pmod[i]; P.rm.pstride[i] = a->pstride[i];
+        if (a->pdiv[i] <= 0 || a->pmod[i] <= 0 || a->pdiv[i] > (1ll << 30) || a->pmod[i] > (1ll << 30)) return DWM_EINVAL;
+        P.rm.pdiv[i] = make_fastdiv((uint32_t)a->pdiv[i]); P.rm.pmod[i] = make_fastdiv((uint32_t)a->pmod[i]);
+        P.rm.pstride[i] = a->pstride[i];
     }
-    P.rm.ldiv0 = (int)a->ldiv[0]; P.rm.ldiv1 = (int)a->ldiv[1];
+    if (a->ldiv[0] > (1ll << 30) || a->ldiv[1] > (1ll << 30)) return DWM_EINVAL;
+    P.rm.ldiv0 = make_fastdiv((uint32_t)a->ldiv[0]); P.rm.ldiv1 = make_fastdiv((uint32_t)a->ldiv[1]);
     for (int i = 0; i < 3; ++i) P.rm.lstride[i] = a->lstride[i];
 
     // variant: 0 = auto; 1 / 2 = 32 / 64 queries per wave (128 / 256 per workgroup)
+    P.dbg = (a->variant >> 8) & 15;
     int qt = a->variant & 15;
-    if (qt == 0) qt = 1;
+    if (qt == 0) qt = L > 128 ? 2 : 1;
     if (qt != 1 && qt != 2) return DWM_EINVAL;
     const int qblock = qt * 128;
     P.nqb = (int)((L + qblock - 1) / qblock);
+    P.fd_nqb = make_fastdiv((uint32_t)P.nqb); P.fd_heads = make_fastdiv((uint32_t)P.heads);
+    P.fd_gs = make_fastdiv((uint32_t)(P.group_size > 0 ? P.group_size : 1));
+    P.fd_G = make_fastdiv((uint32_t)(P.mask_G > 0 ? P.mask_G : 1));
+    P.fd_ppm = make_fastdiv((uint32_t)(P.p_per_mask > 0 ? P.p_per_mask : 1));
     if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
     if (2 * STAGE_BYTES + L * 8 + 16 > 64 * 1024) return DWM_EUNSUPPORTED;   // row table must fit the default LDS window
     hipStream_t s = (hipStream_t)stream;

@@ -85,4 +85,22 @@ DWM_DEVINL int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Division by a launch-invariant divisor d >= 1 for n < 2^31 (Granlund-Montgomery round-up
+// form): q = (mulhi(m, n) + n) >> s,  s = ceil(log2 d),  m = floor(2^32 (2^s - d) / d) + 1.
+// Replaces ~40-instruction runtime integer divides in per-block address arithmetic.
+struct FastDiv {
+    uint32_t m, s, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+    return f;
+}
+DWM_DEVINL uint32_t fdiv(uint32_t n, const FastDiv& f) { return (__umulhi(f.m, n) + n) >> f.s; }
+DWM_DEVINL uint32_t fmod_u(uint32_t n, const FastDiv& f) { return n - fdiv(n, f) * f.d; }
+
 static inline bool dwm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
