@@ -175,16 +175,12 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a bench line)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from opendwm_amd import dist as D
+    rank, local_rank, world = D.env_ranks()
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    D.init("nccl", dev)          # "nccl" == RCCL on ROCm; no-op for a single process
 
     from opendwm_amd import _lib
     from opendwm_amd.dit import model_flops
@@ -205,26 +201,14 @@ def main():
     latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
     den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"]).prepare(latents, cond)
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    ninf = w["inference_steps"]
 
-    for i in range(args.warmup):
-        den.step(i % w["inference_steps"])
-    sync()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        den.step((args.warmup + i) % w["inference_steps"])
-    sync()
-    dt = time.perf_counter() - t0
+    def step(i):
+        timer.enabled = i >= args.warmup
+        den.step(i % ninf)
+
+    dt = D.timed_steps(step, args.steps, args.warmup, dev)
     timer.enabled = False
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
     finite = bool(torch.isfinite(den.latents).all().item())
 
     if rank == 0:
@@ -257,8 +241,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))))
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

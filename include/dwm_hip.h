@@ -35,12 +35,13 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 4
+#define DWM_ABI_VERSION 5
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
  * GEMM:  C[M,Nout] = epilogue( A[M,K] · W[N,K]^T )
- * bf16 in, fp32 accumulate on v_mfma_f32_32x32x16_bf16, bf16 out.
+ * bf16 in, fp32 accumulate on v_mfma_f32_32x32x16_bf16, bf16 out.  Optionally an implicit-GEMM
+ * convolution (a_map / c_map / tap_shift below).
  * W is a torch.nn.Linear weight ([out,in], K contiguous).  K % 64 == 0,
  * N % 8 == 0, lda/ldc/... % 8 == 0 (16-byte rows).
  *
@@ -62,7 +63,18 @@ enum {
     DWM_EPI_RMSHEAD = 3  /* v = acc + bias; per 64-column head RMSNorm (affine) on columns
                             < rms_ncols (diffusers Attention qk_norm="rms_norm")          */
 };
-enum { DWM_ACT_NONE = 0, DWM_ACT_GELU_TANH = 1, DWM_ACT_SILU = 2 };
+enum { DWM_ACT_NONE = 0, DWM_ACT_GELU_TANH = 1, DWM_ACT_SILU = 2, DWM_ACT_RELU = 3 };
+
+/* Row map "compact pixel index -> row of a zero-padded [I, rh+2, rw+2] token grid":
+ *   row(m) = (m / (rw*rh)) * ipitch + ((m / rw) % rh) * rpitch + (m % rw) + origin
+ * rw == 0 means identity (row(m) = m).  Used to run the 3x3 convolutions of the layout
+ * ImageAdapter (diffusers AdapterResnetBlock.block1, src/dwm/models/adapters.py:20-22) as
+ * implicit GEMM on token-major activations without materialising im2col or padding copies. */
+typedef struct dwm_rowmap2d {
+    int64_t rw, rh;          /* interior width / height (pixels)                 */
+    int64_t rpitch, ipitch;  /* padded row pitch (rw+2) and image pitch, in rows  */
+    int64_t origin;          /* row of interior pixel (0,0): rpitch + 1           */
+} dwm_rowmap2d;
 
 typedef struct dwm_gemm_args {
     const void* A;  int64_t lda;          /* bf16 [M,K], row stride lda elements          */
@@ -79,7 +91,13 @@ typedef struct dwm_gemm_args {
     const float* alpha; int64_t rows_per_alpha;                 /* fp32 alpha[row/rows_per_alpha]           */
     /* RMSHEAD */
     const void* rms_w; int64_t rms_ncols; float rms_eps;        /* bf16 rms_w[rms_ncols]                    */
-    int32_t reserved;
+    int32_t reserved;                                           /* tuning / ablation knobs, 0 in production  */
+    /* implicit-GEMM convolution (all zero / rw == 0 for a plain GEMM):
+     * K = ntaps * k_per_tap; K index (t, c) reads A[a_map(m) + tap_shift[t]][c].  W is [N, ntaps*k_per_tap]. */
+    dwm_rowmap2d a_map;                                         /* A rows                                    */
+    dwm_rowmap2d c_map;                                         /* C, res and blend rows                     */
+    int32_t ntaps; int32_t k_per_tap;
+    int64_t tap_shift[9];                                       /* in rows                                   */
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
@@ -193,6 +211,19 @@ int dwm_unpatchify(const void* x, int64_t ldx, int64_t I, int32_t C, int32_t h, 
  *   the updated latents duplicated for the next step (ctsd.py:1528,1536-1538). */
 int dwm_cfg_euler_step(const void* pred, float* latents, void* model_in, int64_t n,
                        float guidance, float dsigma, void* stream);
+
+/* torch.nn.PixelUnshuffle(r) of x [I, C, H, W] (fp32 if x_is_f32 else bf16), written token-major:
+ * out bf16 [I*(H/r)*(W/r), ldo >= C*r*r], column = (c*r + dy)*r + dx, zero padded to ldo
+ * (src/dwm/models/adapters.py:42). */
+int dwm_unshuffle_tokens(const void* x, int32_t x_is_f32, int64_t I, int32_t C, int32_t H, int32_t W,
+                         int32_t r, void* out, int64_t ldo, void* stream);
+
+/* torch.nn.AvgPool2d(2, 2) on token-major bf16 [I, h, w, C] -> [I, h/2, w/2, C] (diffusers
+ * AdapterBlock.downsample); h, w even, C % 8 == 0. */
+int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t w, int32_t C, void* out, void* stream);
+
+/* y += x, bf16, n % 8 == 0 (hidden_states + condition_residual, crossview_temporal_dit.py:491-494). */
+int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream);
 
 /* dst bf16 <- src fp32 (n % 4 == 0) */
 int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -7,12 +7,16 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
-ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 
 _i64, _i32, _f32, _vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class RowMap2D(C.Structure):
+    _fields_ = [("rw", _i64), ("rh", _i64), ("rpitch", _i64), ("ipitch", _i64), ("origin", _i64)]
 
 
 class GemmArgs(C.Structure):
@@ -23,6 +27,8 @@ class GemmArgs(C.Structure):
         ("res", _vp), ("ld_res", _i64), ("res_mod", _i64),
         ("blend", _vp), ("ld_blend", _i64), ("alpha", _vp), ("rows_per_alpha", _i64),
         ("rms_w", _vp), ("rms_ncols", _i64), ("rms_eps", _f32), ("reserved", _i32),
+        ("a_map", RowMap2D), ("c_map", RowMap2D), ("ntaps", _i32), ("k_per_tap", _i32),
+        ("tap_shift", _i64 * 9),
     ]
 
 
@@ -65,6 +71,9 @@ SIGNATURES = {
     "dwm_unpatchify": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dwm_cfg_euler_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
     "dwm_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_unshuffle_tokens": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "dwm_avgpool2_tokens": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "dwm_add_inplace": (_i32, [_vp, _vp, _i64, _vp]),
 }
 
 _ERR = {-1: "DWM_EINVAL (bad shape / null pointer)", -2: "DWM_EALIGN (alignment)",

@@ -1,0 +1,148 @@
+"""MI355X-native layout condition adapter: drop-in for dwm.models.adapters.ImageAdapter
+(src/dwm/models/adapters.py:6-60; diffusers T2I AdapterBlock / AdapterResnetBlock underneath).
+
+State-dict keys equal the reference's: body.{i}.in_conv.*, body.{i}.resnets.{j}.block1.* /
+block2.*, zero_convs.{i}.*, zero_gates.  All features are produced token-major
+([I*h*w, C], the layout the MMDiT adds them in, crossview_temporal_dit.py:491-494); the 3x3
+convolutions run as implicit GEMMs of dwm_gemm_bf16 over a zero-padded token grid."""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .blocks import _bf
+from .ops import ACT_RELU, EPI_RESID, PaddedGrid
+
+bf16 = torch.bfloat16
+
+
+class AdapterResnetBlock(nn.Module):
+    """x + block2(relu(block1(x))): Conv3x3(pad 1) -> ReLU -> Conv1x1 (diffusers)."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.block1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.act = nn.ReLU()
+        self.block2 = nn.Conv2d(channels, channels, kernel_size=1)
+        self._pk = None
+
+    def packed(self):
+        if self._pk is None:
+            w = _bf(self.block1.weight)                    # [N, C, 3, 3] -> tap-major [N, 9*C]
+            self._pk = {"w3": w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(),
+                        "w1": _bf(self.block2.weight).reshape(self.block2.weight.shape[0], -1).contiguous()}
+        return self._pk
+
+    def run(self, x_pad: torch.Tensor, grid: PaddedGrid) -> torch.Tensor:
+        """x_pad: padded token grid [grid.rows, C] (zero border), updated in place."""
+        pk = self.packed()
+        h1 = ops.gemm(x_pad, pk["w3"], _bf(self.block1.bias), act=ACT_RELU, a_grid=grid, conv3x3=True)
+        ops.gemm(h1, pk["w1"], _bf(self.block2.bias), epilogue=EPI_RESID, res=x_pad, out=x_pad, c_grid=grid)
+        return x_pad
+
+
+class AdapterBlock(nn.Module):
+    """diffusers AdapterBlock(in_channels, out_channels, num_res_blocks, down)."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_res_blocks: int, down: bool = False):
+        super().__init__()
+        self.downsample = nn.AvgPool2d(kernel_size=2, stride=2, ceil_mode=True) if down else None
+        self.in_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else None
+        self.resnets = nn.Sequential(*[AdapterResnetBlock(out_channels) for _ in range(num_res_blocks)])
+        self.out_channels = out_channels
+
+
+class ImageAdapter(nn.Module):
+    def __init__(
+        self, in_channels: int = 3,
+        channels: list = [320, 320, 640, 1280, 1280],
+        is_downblocks: list = [False, True, True, True, False],
+        num_res_blocks: int = 2, downscale_factor: int = 8,
+        use_zero_convs: bool = False, zero_gate_coef: Optional[float] = None,
+        gradient_checkpointing: bool = True
+    ):
+        super().__init__()
+        self.downscale_factor = downscale_factor
+        in_channels = in_channels * downscale_factor ** 2
+        self.unshuffle = nn.PixelUnshuffle(downscale_factor)
+        self.body = nn.ModuleList([
+            AdapterBlock(in_channels if i == 0 else channels[i - 1], channels[i], num_res_blocks,
+                         down=is_downblocks[i])
+            for i in range(len(channels))])
+        self.gradient_checkpointing = gradient_checkpointing
+        self.zero_convs = nn.ModuleList([nn.Conv2d(c, c, 1) for c in channels]) if use_zero_convs \
+            else [None for _ in channels]
+        for z in self.zero_convs:
+            if z is not None:
+                nn.init.zeros_(z.weight)
+                nn.init.zeros_(z.bias)
+        self.zero_gate_coef = zero_gate_coef
+        self.zero_gates = nn.Parameter(torch.zeros(len(channels))) if zero_gate_coef else None
+        if any(c % 64 != 0 for c in channels):
+            raise NotImplementedError("ImageAdapter channels must be multiples of 64 (GEMM K granularity)")
+
+    @torch.no_grad()
+    def run(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """x [..., C, H, W] -> list of token-major features [I*h_i*w_i, channels[i]] (bf16), I = prod(leading)."""
+        if self.zero_gates is not None:
+            raise NotImplementedError("zero_gates (zero_gate_coef) is not used by any shipped CTSD config")
+        x = x.flatten(0, -4).contiguous()
+        if x.dtype not in (torch.float32, bf16):
+            x = x.to(bf16)
+        I, _, H, W = x.shape
+        r = self.downscale_factor
+        h, w = H // r, W // r
+        cur = ops.unshuffle_tokens(x, r)                    # compact tokens [I*h*w, Cin padded to 64]
+        cur_pad: Optional[torch.Tensor] = None
+        grid: Optional[PaddedGrid] = None
+        feats = []
+        for blk, zc in zip(self.body, self.zero_convs):
+            if blk.downsample is not None:
+                if cur is None:                             # leave the padded grid of the previous level
+                    cur = cur_pad[grid.interior_index().to(cur_pad.device)]
+                if h % 2 or w % 2:
+                    raise NotImplementedError("AvgPool2d(ceil_mode) on odd sizes")
+                cur = ops.avgpool2_tokens(cur, I, h, w)
+                h, w = h // 2, w // 2
+                cur_pad = None
+            new_grid = PaddedGrid(I, h, w)
+            if cur_pad is None:
+                grid = new_grid
+                if blk.in_conv is not None:
+                    wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1)
+                    if wi.shape[1] != cur.shape[1]:          # K padded to a multiple of 64 by unshuffle_tokens
+                        wp = torch.zeros((wi.shape[0], cur.shape[1]), dtype=bf16, device=wi.device)
+                        wp[:, :wi.shape[1]] = wi
+                        wi = wp
+                    cur_pad = ops.gemm(cur, wi.contiguous(), _bf(blk.in_conv.bias), c_grid=grid)
+                else:
+                    cur_pad = torch.zeros((grid.rows, cur.shape[1]), dtype=bf16, device=cur.device)
+                    cur_pad[grid.interior_index().to(cur.device)] = cur
+                cur = None
+            elif blk.in_conv is not None:
+                wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1).contiguous()
+                cur_pad = ops.gemm(cur_pad, wi, _bf(blk.in_conv.bias), a_grid=grid, c_grid=grid)
+            for res in blk.resnets:
+                res.run(cur_pad, grid)
+            if zc is not None:
+                wz = _bf(zc.weight).reshape(zc.weight.shape[0], -1).contiguous()
+                feats.append(ops.gemm(cur_pad, wz, _bf(zc.bias), a_grid=grid))
+            else:
+                feats.append(cur_pad[grid.interior_index().to(cur_pad.device)])
+        return feats
+
+    def forward(self, x: torch.Tensor, return_features: bool = False):
+        """Reference signature (adapters.py:40): features shaped [*base_shape, C, h, w]."""
+        base_shape = x.shape[:-3]
+        r = self.downscale_factor
+        h, w = x.shape[-2] // r, x.shape[-1] // r
+        out = []
+        for blk, f in zip(self.body, self.run(x)):
+            if blk.downsample is not None:
+                h, w = h // 2, w // 2
+            out.append(f.view(*base_shape, h, w, f.shape[-1]).movedim(-1, -3))
+        return out if not return_features else out[-1]

@@ -97,6 +97,65 @@ cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) 
     *(uint2*)(dst + i) = pack4(o);
 }
 
+// PixelUnshuffle(r) of an NCHW image batch written token-major:
+//   out[(i*h + y)*w + x][c*r*r + dy*r + dx] = in[i][c][y*r + dy][x*r + dx],  h = H/r, w = W/r
+template <typename TIN>
+__global__ void __launch_bounds__(256)
+unshuffle_tokens_kernel(const TIN* __restrict__ x, int64_t I, int C, int H, int W, int r,
+                        bf16_t* __restrict__ out, int64_t ldo) {
+    const int h = H / r, w = W / r, cols = C * r * r;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= I * h * w * ldo) return;
+    const int64_t tok = idx / ldo;
+    const int col = (int)(idx - tok * ldo);
+    float v = 0.f;
+    if (col < cols) {
+        const int dx = col % r, dy = (col / r) % r, c = col / (r * r);
+        const int xx = (int)(tok % w), yy = (int)((tok / w) % h);
+        const int64_t img = tok / ((int64_t)w * h);
+        v = ld_as_f32(x, ((img * C + c) * H + yy * r + dy) * W + xx * r + dx);
+    }
+    out[idx] = f32_to_bf16(v);
+}
+
+// AvgPool2d(2, stride 2) on token-major [I, h, w, C] -> [I, h/2, w/2, C]; 8 channels per thread
+__global__ void __launch_bounds__(256)
+avgpool2_tokens_kernel(const bf16_t* __restrict__ x, int64_t I, int h, int w, int C8,
+                       bf16_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ho = h / 2, wo = w / 2;
+    if (idx >= I * ho * wo * C8) return;
+    const int c8 = (int)(idx % C8);
+    const int64_t tok = idx / C8;
+    const int xo = (int)(tok % wo), yo = (int)((tok / wo) % ho);
+    const int64_t img = tok / ((int64_t)wo * ho);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t[8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t src = ((img * h + 2 * yo + a) * w + 2 * xo + b) * (int64_t)C8 + c8;
+            unpack8(*(const uint4*)(x + src * 8), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += t[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
+    *(uint4*)(out + idx * 8) = pack8(acc);
+}
+
+__global__ void __launch_bounds__(256)
+add_inplace_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float a[8], b[8];
+    unpack8(*(const uint4*)(y + i * 8), a);
+    unpack8(*(const uint4*)(x + i * 8), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    *(uint4*)(y + i * 8) = pack8(a);
+}
+
 inline int finish() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
@@ -162,5 +221,37 @@ extern "C" int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void
     if (n % 4 != 0 || !dwm_aligned16(src) || (((uintptr_t)dst) & 7u)) return DWM_EALIGN;
     hipLaunchKernelGGL(cast_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src,
                        (bf16_t*)dst, n);
+    return finish();
+}
+
+extern "C" int dwm_unshuffle_tokens(const void* x, int32_t x_is_f32, int64_t I, int32_t C, int32_t H, int32_t W,
+                                    int32_t r, void* out, int64_t ldo, void* stream) {
+    if (x == nullptr || out == nullptr || I <= 0 || C <= 0 || H <= 0 || W <= 0 || r <= 0) return DWM_EINVAL;
+    if (H % r != 0 || W % r != 0 || ldo < (int64_t)C * r * r) return DWM_EINVAL;
+    const int64_t total = I * (H / r) * (W / r) * ldo;
+    if (x_is_f32)
+        hipLaunchKernelGGL(unshuffle_tokens_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, I, C, H, W, r, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL(unshuffle_tokens_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, I, C, H, W, r, (bf16_t*)out, ldo);
+    return finish();
+}
+
+extern "C" int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t w, int32_t C, void* out, void* stream) {
+    if (x == nullptr || out == nullptr || I <= 0 || h <= 0 || w <= 0 || C <= 0) return DWM_EINVAL;
+    if (h % 2 != 0 || w % 2 != 0 || C % 8 != 0) return DWM_EUNSUPPORTED;
+    if (!dwm_aligned16(x) || !dwm_aligned16(out)) return DWM_EALIGN;
+    const int64_t total = I * (h / 2) * (w / 2) * (C / 8);
+    hipLaunchKernelGGL(avgpool2_tokens_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, I, h, w, C / 8, (bf16_t*)out);
+    return finish();
+}
+
+extern "C" int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream) {
+    if (x == nullptr || y == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 8 != 0 || !dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)y, (const bf16_t*)x, n / 8);
     return finish();
 }

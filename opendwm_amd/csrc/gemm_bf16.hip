@@ -27,9 +27,27 @@ constexpr int TILE_BYTES = BM * BK * 2;            // 32 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // double buffered = 128 KiB
 
+struct DevRowMap {
+    FastDiv rw, rh;
+    int64_t rpitch, ipitch, origin;
+    int enabled;
+};
+struct ConvParams {
+    DevRowMap a, c;
+    int steps_per_tap;          // k_per_tap / BK
+    FastDiv fd_steps;
+    int64_t tap_shift[9];
+};
+DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
+    if (!rm.enabled) return m;
+    const uint32_t q = fdiv((uint32_t)m, rm.rw), x = (uint32_t)m - q * rm.rw.d;
+    const uint32_t i = fdiv(q, rm.rh), y = q - i * rm.rh.d;
+    return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + x + rm.origin;
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(NTHREADS, 2)
-gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
+gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -65,17 +83,22 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
         const int c = (lane & 7) ^ ((row >> 1) & 7);          // logical 16-B chunk this lane fetches
         int64_t gm = m0 + row; gm = gm < M ? gm : M - 1;
         int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
-        a_src[j] = (const char*)(Ap + gm * p.lda + c * 8);
+        a_src[j] = (const char*)(Ap + map_row(cp.a, gm) * p.lda + c * 8);
         w_src[j] = (const char*)(Wp + gn * K + c * 8);
     }
+    // K step kt covers tap t = kt / steps_per_tap and channels (kt % steps_per_tap)*64.. of it; the A
+    // source moves by tap_shift[t] rows (0 for a plain GEMM), the W source is simply contiguous in K
+    const int64_t lda_bytes = p.lda * 2;
     auto stage = [&](int buf, int kt) {
         char* la = smem + buf * STAGE_BYTES;
         char* lb = la + TILE_BYTES;
         const int64_t koff = (int64_t)kt * (BK * 2);
+        const uint32_t tap = fdiv((uint32_t)kt, cp.fd_steps);
+        const int64_t aoff = cp.tap_shift[tap] * lda_bytes + (int64_t)(kt - tap * cp.steps_per_tap) * (BK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r0 = (wave * 4 + j) * 8;
-            glds16(a_src[j] + koff, la + r0 * 128);
+            glds16(a_src[j] + aoff, la + r0 * 128);
             glds16(w_src[j] + koff, lb + r0 * 128);
         }
     };
@@ -237,6 +260,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
                     float x = acc[mt][nt][r] + bv[nt][r];
                     if (p.act == DWM_ACT_GELU_TANH) x = gelu_tanh_f(x);
                     else if (p.act == DWM_ACT_SILU) x = silu_f(x);
+                    else if (p.act == DWM_ACT_RELU) x = fmaxf(x, 0.f);
                     acc[mt][nt][r] = x;
                 }
         }
@@ -264,12 +288,13 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
                 m = m < M ? m : M - 1;
                 const int64_t nc = nok ? ncol : 0;
                 if (p.gate) gq[st] = *(const uint4*)((const bf16_t*)p.gate + (int64_t)((uint32_t)m / (uint32_t)p.rows_per_gate) * p.ld_gate + nc);
+                const int64_t mr = map_row(cp.c, m);
                 if (p.res) {
-                    const int64_t rr = p.res_mod > 0 ? (int64_t)((uint32_t)m % (uint32_t)p.res_mod) : m;
+                    const int64_t rr = p.res_mod > 0 ? (int64_t)((uint32_t)m % (uint32_t)p.res_mod) : mr;
                     rq[st] = *(const uint4*)((const bf16_t*)p.res + rr * p.ld_res + nc);
                 }
                 if (p.blend) {
-                    bq[st] = *(const uint4*)((const bf16_t*)p.blend + m * p.ld_blend + nc);
+                    bq[st] = *(const uint4*)((const bf16_t*)p.blend + mr * p.ld_blend + nc);
                     al[st] = p.alpha[(uint32_t)m / (uint32_t)p.rows_per_alpha];
                 }
             }
@@ -281,6 +306,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
             const float4 x1 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8 + 1) ^ (r & (CW / 4 - 1))) << 4));
             float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             const int64_t m = m0 + wm * 128 + mt * 32 + r;
+            const int64_t mrow = map_row(cp.c, m < M ? m : M - 1);
             if constexpr (EPI == DWM_EPI_RESID) {
                 float t[8];
                 if (p.gate) {
@@ -299,7 +325,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const int ntm, const int ntn) {
                     for (int j = 0; j < 8; ++j) v[j] = al[st] * t[j] + (1.f - al[st]) * v[j];
                 }
             }
-            if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + m * p.ldc + ncol) = pack8(v);
+            if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
         }
     }
 }
@@ -310,7 +336,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 31) || a->N >= (1ll << 31)) return DWM_EINVAL;
     if (a->K % BK != 0 || a->N % 8 != 0) return DWM_EUNSUPPORTED;
-    if (a->lda % 8 != 0 || a->ldc % 8 != 0 || a->lda < a->K) return DWM_EALIGN;
+    if (a->lda % 8 != 0 || a->ldc % 8 != 0) return DWM_EALIGN;
     if (!dwm_aligned16(a->A) || !dwm_aligned16(a->W) || !dwm_aligned16(a->C)) return DWM_EALIGN;
     if (a->bias && (((uintptr_t)a->bias) & 7u)) return DWM_EALIGN;
     const int64_t nout = a->epilogue == DWM_EPI_GEGLU ? a->N / 2 : a->N;
@@ -330,6 +356,24 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
             break;
         default: return DWM_EINVAL;
     }
+    ConvParams cp;
+    auto mk = [](const dwm_rowmap2d& r, DevRowMap& d) -> bool {
+        d.enabled = r.rw > 0;
+        if (!d.enabled) { d.rw = make_fastdiv(1); d.rh = make_fastdiv(1); d.rpitch = d.ipitch = d.origin = 0; return true; }
+        if (r.rh <= 0 || r.rw >= (1ll << 30) || r.rh >= (1ll << 30)) return false;
+        d.rw = make_fastdiv((uint32_t)r.rw); d.rh = make_fastdiv((uint32_t)r.rh);
+        d.rpitch = r.rpitch; d.ipitch = r.ipitch; d.origin = r.origin;
+        return true;
+    };
+    if (!mk(a->a_map, cp.a) || !mk(a->c_map, cp.c)) return DWM_EINVAL;
+    const int ntaps = a->ntaps > 0 ? a->ntaps : 1;
+    if (ntaps > 9) return DWM_EINVAL;
+    const int64_t kpt = a->ntaps > 0 ? a->k_per_tap : a->K;
+    if (kpt <= 0 || kpt % BK != 0 || kpt * ntaps != a->K) return DWM_EINVAL;
+    cp.steps_per_tap = (int)(kpt / BK);
+    cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
+    for (int t = 0; t < 9; ++t) cp.tap_shift[t] = (a->ntaps > 0 && t < ntaps) ? a->tap_shift[t] : 0;
+    if (a->lda < kpt) return DWM_EINVAL;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
     const dim3 grid((unsigned)(ntm * ntn)), block(NTHREADS);
     hipStream_t s = (hipStream_t)stream;
@@ -343,7 +387,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
             if (e != hipSuccess) return (int)e;                                                      \
             attr_set = true;                                                                         \
         }                                                                                            \
-        hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, LDS_BYTES, s, *a, ntm, ntn);          \
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);          \
     } while (0)
     switch (a->epilogue) {
         case DWM_EPI_PLAIN: DWM_LAUNCH(DWM_EPI_PLAIN); break;

@@ -130,8 +130,6 @@ class DiTCrossviewTemporalConditionModel(_Base):
         qk_norm: Optional[str] = None,
     ):
         nn.Module.__init__(self)
-        if condition_image_adapter_config is not None:
-            raise NotImplementedError("condition_image_adapter (layout ImageAdapter) is not built yet (SURVEY.md §8 a9)")
         if mask_module is not None:
             raise NotImplementedError("mask_module (MaskGWM) is training-only and out of scope (SURVEY.md §2)")
         if mixer_type != "AlphaBlender":
@@ -170,7 +168,12 @@ class DiTCrossviewTemporalConditionModel(_Base):
         self.proj_out = nn.Linear(inner_dim, patch_size * patch_size * self.out_channels)
 
         # ---- reference members (crossview_temporal_dit.py:142-221)
-        self.condition_image_adapter = None
+        if condition_image_adapter_config is not None:
+            from .adapters import ImageAdapter
+            self.condition_image_adapter = ImageAdapter(**condition_image_adapter_config)
+        else:
+            self.condition_image_adapter = None
+        self._adapter_cache = (None, None)
         self.perspective_modeling_type = perspective_modeling_type
         if perspective_modeling_type == "implicit":
             self.view_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, inner_dim)
@@ -220,6 +223,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 m._cache = {}
             if hasattr(m, "_wcache"):
                 m._wcache = {}
+        self._adapter_cache = (None, None)
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -296,7 +300,21 @@ class DiTCrossviewTemporalConditionModel(_Base):
         if self.enable_temporal and disable_temporal is None:
             disable_temporal = torch.zeros(B, dtype=torch.bool, device=sample.device)
 
+        # layout residuals (crossview_temporal_dit.py:459-462).  They depend only on the condition
+        # images, which do not change across denoise steps: cached on the tensor's identity.
+        condition_residuals = None
+        if self.condition_image_adapter is not None and condition_image_tensor is not None:
+            key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape))
+            if self._adapter_cache[0] != key:
+                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor))
+            condition_residuals = list(self._adapter_cache[1])
+            for f in condition_residuals:
+                if f.shape != h.shape:
+                    raise RuntimeError(f"condition residual {tuple(f.shape)} does not match hidden states {tuple(h.shape)}")
+
         for i, block in enumerate(self.transformer_blocks):
+            if condition_residuals:
+                ops.add_(h, condition_residuals.pop(0))                                 # :491-494
             c, h = block.run(h, c, silu_temb, I)
 
             if self.enable_temporal and i in self.temporal_block_layers:

@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_TANH, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_RESID,
+from ._lib import (ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_RESID,
                    EPI_RMSHEAD)
 
 BIG = 1 << 30
@@ -42,6 +42,39 @@ def _chkvec(t: Optional[torch.Tensor], name: str, dtype=bf16):
 
 
 # --------------------------------------------------------------------------------- GEMM
+@dataclass
+class PaddedGrid:
+    """Zero-padded token grid [I, h+2, w+2] used by the implicit-GEMM 3x3 convolutions: compact pixel
+    index m = (i*h + y)*w + x lives at row i*(h+2)(w+2) + (y+1)(w+2) + (x+1) of the padded matrix."""
+    I: int
+    h: int
+    w: int
+
+    @property
+    def rows(self) -> int:
+        return self.I * (self.h + 2) * (self.w + 2)
+
+    @property
+    def pixels(self) -> int:
+        return self.I * self.h * self.w
+
+    def fill(self, m: "_lib.RowMap2D") -> None:
+        m.rw, m.rh = self.w, self.h
+        m.rpitch, m.ipitch = self.w + 2, (self.h + 2) * (self.w + 2)
+        m.origin = self.w + 2 + 1
+
+    def tap_shifts(self):
+        """row shift of tap (dy, dx), dy/dx in {-1,0,1}, in the order of a [N, 3, 3, C] weight"""
+        return [(dy - 1) * (self.w + 2) + (dx - 1) for dy in range(3) for dx in range(3)]
+
+    def interior_index(self) -> torch.Tensor:
+        """[pixels] int64 padded-row index of every compact pixel (host reference of the kernel's map)"""
+        i = torch.arange(self.I)[:, None, None]
+        y = torch.arange(self.h)[None, :, None]
+        x = torch.arange(self.w)[None, None, :]
+        return (i * (self.h + 2) * (self.w + 2) + (y + 1) * (self.w + 2) + x + 1).reshape(-1)
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, epilogue: int = EPI_PLAIN, act: int = ACT_NONE,
          gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
@@ -49,22 +82,33 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          blend: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
          rows_per_alpha: int = 1,
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
-         _debug: int = 0) -> torch.Tensor:
-    """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16."""
+         a_grid: Optional[PaddedGrid] = None, conv3x3: bool = False, c_grid: Optional[PaddedGrid] = None,
+         rows: Optional[int] = None, _debug: int = 0) -> torch.Tensor:
+    """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
+    a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
+    axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids."""
     _chk2d(a, "a")
     _chk2d(w, "w")
     if not w.is_contiguous():
         raise RuntimeError("w must be contiguous [N, K]")
-    M, K = a.shape
-    N = w.shape[0]
-    if w.shape[1] != K:
-        raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
+    N, K = w.shape
+    if a_grid is not None:
+        if a.shape[0] != a_grid.rows or a.shape[1] * (9 if conv3x3 else 1) != K:
+            raise RuntimeError(f"gemm: padded A {tuple(a.shape)} does not match grid / weight {tuple(w.shape)}")
+        M = a_grid.pixels
+    else:
+        M = a.shape[0] if rows is None else rows
+        if a.shape[1] != K:
+            raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
     nout = N // 2 if epilogue == EPI_GEGLU else N
+    orow = c_grid.rows if c_grid is not None else M
+    if c_grid is not None and c_grid.pixels != M:
+        raise RuntimeError("gemm: c_grid pixel count != M")
     if out is None:
-        out = torch.empty((M, nout), dtype=bf16, device=a.device)
+        out = (torch.zeros if c_grid is not None else torch.empty)((orow, nout), dtype=bf16, device=a.device)
     _chk2d(out, "out")
-    if out.shape != (M, nout):
-        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(M, nout)}")
+    if out.shape != (orow, nout):
+        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(orow, nout)}")
     _chkvec(bias, "bias")
     g = _lib.GemmArgs()
     g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)
@@ -82,6 +126,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if rms_w is not None:
         _chkvec(rms_w, "rms_w")
         g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
+    if a_grid is not None:
+        a_grid.fill(g.a_map)
+        if conv3x3:
+            g.ntaps, g.k_per_tap = 9, a.shape[1]
+            for t, sh in enumerate(a_grid.tap_shifts()):
+                g.tap_shift[t] = sh
+    if c_grid is not None:
+        c_grid.fill(g.c_map)
+        for name, t in (("res", res), ("blend", blend)):
+            if t is not None and t.shape[0] != c_grid.rows:
+                raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
     _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
     return out
@@ -313,6 +368,38 @@ def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, d
         raise RuntimeError("cfg_euler_step: model_in must be contiguous bf16 [2, n]")
     _lib.check(_lib.load().dwm_cfg_euler_step(pred.data_ptr(), latents.data_ptr(), _p(model_in), n,
                                               float(guidance), float(dsigma), _stream()), "dwm_cfg_euler_step")
+
+
+def unshuffle_tokens(x: torch.Tensor, r: int, ldo: Optional[int] = None) -> torch.Tensor:
+    """PixelUnshuffle(r): [I, C, H, W] (fp32 / bf16) -> token-major bf16 [I*(H/r)*(W/r), ldo]."""
+    if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, bf16):
+        raise RuntimeError("unshuffle_tokens: expected a contiguous fp32/bf16 [I,C,H,W] device tensor")
+    I, Cc, H, W = x.shape
+    cols = Cc * r * r
+    ldo = ldo or (cols + 63) // 64 * 64
+    out = torch.empty((I * (H // r) * (W // r), ldo), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_unshuffle_tokens(x.data_ptr(), int(x.dtype == torch.float32), I, Cc, H, W, r,
+                                                out.data_ptr(), ldo, _stream()), "dwm_unshuffle_tokens")
+    return out
+
+
+def avgpool2_tokens(x: torch.Tensor, I: int, h: int, w: int) -> torch.Tensor:
+    """AvgPool2d(2) on token-major [I*h*w, C] -> [I*(h/2)*(w/2), C]."""
+    _chk2d(x, "x")
+    if not x.is_contiguous() or x.shape[0] != I * h * w:
+        raise RuntimeError("avgpool2_tokens: x must be contiguous [I*h*w, C]")
+    out = torch.empty((I * (h // 2) * (w // 2), x.shape[1]), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_avgpool2_tokens(x.data_ptr(), I, h, w, x.shape[1], out.data_ptr(), _stream()),
+               "dwm_avgpool2_tokens")
+    return out
+
+
+def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """y += x (bf16, contiguous, same shape)."""
+    if y.shape != x.shape or y.dtype != bf16 or x.dtype != bf16 or not y.is_contiguous() or not x.is_contiguous() or not y.is_cuda:
+        raise RuntimeError("add_: expected contiguous bf16 device tensors of one shape")
+    _lib.check(_lib.load().dwm_add_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_inplace")
+    return y
 
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:

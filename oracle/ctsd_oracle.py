@@ -332,6 +332,32 @@ def temporal_block_and_mix(sd: SD, cfg: dict, k: int, h: Tensor, seq_emb: Tensor
                          disable_temporal).flatten(0, 1)
 
 
+def image_adapter(sd: SD, cfg: dict, x: Tensor, prefix: str = "condition_image_adapter") -> List[Tensor]:
+    """``ImageAdapter.forward`` (src/dwm/models/adapters.py:40-60) with diffusers T2I
+    ``AdapterBlock`` = [AvgPool2d(2, ceil_mode) if down] -> [Conv1x1 if in != out] ->
+    num_res_blocks x AdapterResnetBlock (x + Conv1x1(ReLU(Conv3x3(x)))); optional zero 1x1 convs.
+    x [..., C, H, W]; returns features [*base_shape, C_i, h_i, w_i]."""
+    ac = cfg["condition_image_adapter_config"]
+    base_shape = x.shape[:-3]
+    x = F.pixel_unshuffle(x.flatten(0, -4), ac.get("downscale_factor", 8))
+    feats = []
+    for i, down in enumerate(ac["is_downblocks"]):
+        b = f"{prefix}.body.{i}"
+        if down:
+            x = F.avg_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
+        if (b + ".in_conv.weight") in sd:
+            x = F.conv2d(x, sd[b + ".in_conv.weight"], sd[b + ".in_conv.bias"])
+        for j in range(ac.get("num_res_blocks", 2)):
+            r = f"{b}.resnets.{j}"
+            hh = F.relu(F.conv2d(x, sd[r + ".block1.weight"], sd[r + ".block1.bias"], padding=1))
+            x = x + F.conv2d(hh, sd[r + ".block2.weight"], sd[r + ".block2.bias"])
+        x_out = x
+        if ac.get("use_zero_convs", False):
+            x_out = F.conv2d(x, sd[f"{prefix}.zero_convs.{i}.weight"], sd[f"{prefix}.zero_convs.{i}.bias"])
+        feats.append(x_out.view(*base_shape, *x_out.shape[1:]))
+    return feats
+
+
 # --------------------------------------------------------------------------
 # the model forward
 # --------------------------------------------------------------------------
@@ -342,6 +368,7 @@ def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
                 disable_temporal: Optional[Tensor] = None,
                 crossview_attention_mask: Optional[Tensor] = None,
                 added_time_ids: Optional[Tensor] = None,
+                condition_image_tensor: Optional[Tensor] = None,
                 trace: Optional[dict] = None) -> Tensor:
     """``DiTCrossviewTemporalConditionModel.forward`` (crossview_temporal_dit.py:372-630)
     for 6-D inputs, implicit / no perspective modelling, no image adapter and no
@@ -367,6 +394,10 @@ def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
         ve = timesteps_sinusoid(added_time_ids.flatten(), 256).to(h.dtype)
         view_cam_emb = timestep_embedding_mlp(sd, "view_embedding", ve.view(B * T * V, -1)).unsqueeze(1)
 
+    condition_residuals = None
+    if cfg.get("condition_image_adapter_config") is not None and condition_image_tensor is not None:
+        condition_residuals = image_adapter(sd, cfg, condition_image_tensor)     # :459-462
+
     if trace is not None:
         trace["hidden0"] = h
         trace["context0"] = c
@@ -375,6 +406,8 @@ def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
     t_layers = list(cfg.get("temporal_block_layers") or [])
     v_layers = list(cfg.get("crossview_block_layers") or [])
     for i in range(cfg["num_layers"]):
+        if condition_residuals is not None and len(condition_residuals) > 0:                    # :491-494
+            h = h + condition_residuals.pop(0).flatten(0, 2).flatten(2).permute(0, 2, 1)
         c, h = joint_transformer_block(sd, f"transformer_blocks.{i}", cfg, i, h, c, temb)
         if trace is not None:
             trace[f"joint{i}"] = h
@@ -525,6 +558,24 @@ def param_shapes(cfg: dict) -> Dict[str, tuple]:
         lin("view_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], D)
         lin("view_embedding.linear_2", D, D)
 
+    ac = cfg.get("condition_image_adapter_config")
+    if ac is not None:
+        cin = ac.get("in_channels", 3) * ac.get("downscale_factor", 8) ** 2
+        for i, ch in enumerate(ac["channels"]):
+            b = f"condition_image_adapter.body.{i}"
+            prev = cin if i == 0 else ac["channels"][i - 1]
+            if prev != ch:
+                S[b + ".in_conv.weight"] = (ch, prev, 1, 1)
+                S[b + ".in_conv.bias"] = (ch,)
+            for j in range(ac.get("num_res_blocks", 2)):
+                S[f"{b}.resnets.{j}.block1.weight"] = (ch, ch, 3, 3)
+                S[f"{b}.resnets.{j}.block1.bias"] = (ch,)
+                S[f"{b}.resnets.{j}.block2.weight"] = (ch, ch, 1, 1)
+                S[f"{b}.resnets.{j}.block2.bias"] = (ch,)
+            if ac.get("use_zero_convs", False):
+                S[f"condition_image_adapter.zero_convs.{i}.weight"] = (ch, ch, 1, 1)
+                S[f"condition_image_adapter.zero_convs.{i}.bias"] = (ch,)
+
     def vt(b):
         for nm in ("norm_in", "norm1", "norm3"):
             S[b + f".{nm}.weight"] = (D,)
@@ -578,6 +629,8 @@ def synth_param(name: str, shape: tuple, cfg: dict, gen: torch.Generator,
         fan_in *= s
     std = fan_in ** -0.5
     if ".norm1.linear" in name or ".norm1_context.linear" in name or name.startswith("norm_out.linear"):
+        std *= 0.5
+    if name.startswith("condition_image_adapter.") and (".block2." in name or ".zero_convs." in name):
         std *= 0.5
     return rn(*shape, std=std).to(device)
 

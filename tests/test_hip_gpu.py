@@ -326,6 +326,90 @@ def test_elementwise_kernels(dev):
     assert torch.equal(ops.cast_bf16(l0), l0.to(bf16))
 
 
+# ------------------------------------------------------------------ layout ImageAdapter
+def test_layout_kernels(dev):
+    from opendwm_amd import ops
+    x = torch.rand(5, 6, 64, 96, device=dev)
+    t = ops.unshuffle_tokens(x, 8)
+    ref = F.pixel_unshuffle(x, 8).permute(0, 2, 3, 1).reshape(5 * 8 * 12, 384)
+    assert torch.equal(t, ref.to(bf16))
+    t2 = ops.unshuffle_tokens(x[:, :3].contiguous(), 8, 256)            # K padded 192 -> 256 with zeros
+    assert torch.equal(t2[:, :192], F.pixel_unshuffle(x[:, :3], 8).permute(0, 2, 3, 1).reshape(-1, 192).to(bf16))
+    assert torch.count_nonzero(t2[:, 192:]) == 0
+    p = ops.avgpool2_tokens(t, 5, 8, 12)
+    refp = F.avg_pool2d(t.float().view(5, 8, 12, 384).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, 384)
+    assert rel_err(p, refp) < TOL_KERNEL
+    a, b = _rand((100, 256), dev, 1), _rand((100, 256), dev, 2)
+    assert torch.equal(ops.add_(a.clone(), b), (a.float() + b.float()).to(bf16))
+
+
+@pytest.mark.parametrize("I,h,w,C,N", [(3, 16, 28, 128, 128), (2, 4, 6, 64, 192), (7, 5, 3, 256, 64)])
+def test_gemm_implicit_conv3x3(dev, I, h, w, C, N):
+    """3x3 conv (pad 1) as implicit GEMM over the padded token grid == F.conv2d, plus the padded
+    output path (c_grid) with an in-place residual."""
+    from opendwm_amd import ops
+    grid = ops.PaddedGrid(I, h, w)
+    x = _rand((I, C, h, w), dev, 1)
+    wt, b = _rand((N, C, 3, 3), dev, 2, (9 * C) ** -0.5), _rand((N,), dev, 3)
+    ref = F.relu(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).permute(0, 2, 3, 1).reshape(-1, N)
+    idx = grid.interior_index().to(dev)
+    xp = torch.zeros((grid.rows, C), dtype=bf16, device=dev)
+    xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    wp = wt.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    out = ops.gemm(xp, wp, b, act=ops.ACT_RELU, a_grid=grid, conv3x3=True)
+    e = rel_err(out, ref)
+    # 1x1 conv from compact rows into the padded grid, accumulating onto a padded residual in place
+    w1 = _rand((C, N), dev, 4, N ** -0.5)
+    res = xp.clone()
+    ops.gemm(out, w1, None, epilogue=ops.EPI_RESID, res=res, out=res, c_grid=grid)
+    ref2 = x.float().permute(0, 2, 3, 1).reshape(-1, C) + out.float() @ w1.float().T
+    e2 = rel_err(res[idx], ref2)
+    border = torch.ones(grid.rows, dtype=torch.bool, device=dev)
+    border[idx] = False
+    _log("gemm_conv3x3", I=I, h=h, w=w, C=C, N=N, rel=e, rel_padded_out=e2)
+    assert e < TOL_KERNEL and e2 < TOL_KERNEL and torch.count_nonzero(res[border]) == 0
+
+
+def _adapter_cfg():
+    return dict(in_channels=6, channels=[128, 128, 128], is_downblocks=[True, False, False], num_res_blocks=2,
+                downscale_factor=8, use_zero_convs=True)
+
+
+def test_image_adapter_vs_oracle(dev):
+    cfg = small_config(condition_image_adapter_config=_adapter_cfg())
+    sd = _bf16_round_sd(O.make_state_dict(cfg, 0))
+    m = _hip_model(cfg, sd, dev)
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 3, 6, 64, 96, generator=g).to(bf16).float()
+    ref = O.image_adapter(sd, cfg, img)
+    got = m.condition_image_adapter(img.to(dev))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert a.shape == b.shape
+        e = rel_err(a, b)
+        _log("image_adapter", level=i, rel=e)
+        assert e < TOL_MODEL
+
+
+def test_model_with_layout_adapter_vs_oracle(dev):
+    cfg = small_config(condition_image_adapter_config=_adapter_cfg(), temporal_attention_type="pointwise")
+    sd = _bf16_round_sd(O.make_state_dict(cfg, 0))
+    m = _hip_model(cfg, sd, dev)
+    inp = small_inputs(cfg, 0)
+    g = torch.Generator().manual_seed(5)
+    inp["condition_image_tensor"] = torch.rand(2, 3, 3, 6, 64, 96, generator=g)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v)
+           for k, v in inp.items()}
+    ref = O.dit_forward(sd, cfg, **inp)
+    di = to_dev(inp, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e = rel_err(out[0], ref)
+    _log("model_layout_adapter", rel=e)
+    assert e < TOL_MODEL
+    di = to_dev(inp, dev)                       # second call hits the adapter cache: identical result
+    out2, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    assert torch.equal(out2[0], out[0])
+
+
 # ----------------------------------------------------------------------- blocks / model
 def _bf16_round_sd(sd):
     return {k: v.to(bf16).float() for k, v in sd.items()}

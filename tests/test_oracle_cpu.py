@@ -250,6 +250,41 @@ def test_schedule_equals_oracle():
     assert torch.allclose(s.timesteps, s.sigmas[:-1] * 1000)
 
 
+def test_padded_grid_shift_gemm_equals_conv2d():
+    """Host restatement of the implicit-GEMM 3x3 convolution (padded token grid + 9 row shifts +
+    tap-major weights) the HIP GEMM runs for the ImageAdapter == F.conv2d(padding=1)."""
+    from opendwm_amd.ops import PaddedGrid
+    g = torch.Generator().manual_seed(0)
+    I, h, w, C, N = 3, 4, 6, 8, 5
+    x = torch.randn(I, C, h, w, generator=g)
+    wt = torch.randn(N, C, 3, 3, generator=g)
+    ref = F.conv2d(x, wt, padding=1)                                   # [I, N, h, w]
+    grid = PaddedGrid(I, h, w)
+    xp = torch.zeros(grid.rows, C)
+    idx = grid.interior_index()
+    xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, C)                      # token-major interior
+    wp = wt.permute(0, 2, 3, 1).reshape(N, 9 * C)                       # [N, (dy, dx, c)]
+    out = torch.zeros(grid.pixels, N)
+    for t, sh in enumerate(grid.tap_shifts()):
+        out += xp[idx + sh] @ wp[:, t * C:(t + 1) * C].T
+    assert rel_err(out, ref.permute(0, 2, 3, 1).reshape(-1, N)) < 1e-5
+
+
+def test_oracle_image_adapter_shapes(small_cfg):
+    ac = dict(in_channels=6, channels=[128, 128, 128], is_downblocks=[True, False, False], num_res_blocks=2,
+              downscale_factor=8, use_zero_convs=True)
+    cfg = small_config(condition_image_adapter_config=ac)
+    sd = O.make_state_dict(cfg, 0)
+    feats = O.image_adapter(sd, cfg, torch.rand(2, 3, 3, 6, 64, 96))
+    assert [tuple(f.shape) for f in feats] == [(2, 3, 3, 128, 4, 6)] * 3
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    m = DiTCrossviewTemporalConditionModel(**cfg)
+    assert set(m.state_dict()) == set(sd)
+    for k in ("condition_image_adapter.body.0.in_conv.weight", "condition_image_adapter.body.2.resnets.1.block2.bias",
+              "condition_image_adapter.zero_convs.1.weight"):
+        assert k in sd
+
+
 # ---------------------------------------------------------------------------- C ABI
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
