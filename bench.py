@@ -71,7 +71,7 @@ def build_model(kwargs, dev, seed=0):
     return model.eval()
 
 
-def make_conditions(dev, seed, w=WORKLOAD):
+def make_conditions(dev, seed, w=WORKLOAD, n_time_ids=11):
     g = torch.Generator(device="cuda").manual_seed(1000 + seed)
     B2, T, V = 2 * w["B"], w["T"], w["V"]
     ring = torch.zeros(V, V, dtype=torch.bool)
@@ -84,7 +84,7 @@ def make_conditions(dev, seed, w=WORKLOAD):
         disable_crossview=torch.zeros(B2, dtype=torch.bool, device=dev),
         disable_temporal=torch.zeros(B2, dtype=torch.bool, device=dev),
         crossview_attention_mask=ring[None].repeat(B2, 1, 1).to(dev),
-        added_time_ids=torch.rand(B2, T, V, 11, device=dev, generator=g) * 2 - 1,
+        added_time_ids=torch.rand(B2, T, V, n_time_ids, device=dev, generator=g) * 2 - 1,
     )
 
 
@@ -173,6 +173,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a bench line)")
+    ap.add_argument("--layout", action="store_true",
+                    help="text+layout variant (examples/ctsd_35_df16_6views_video_generation_with_layout.json model: "
+                         "ImageAdapter + point-wise temporal attention, 13 added time ids)")
+    ap.add_argument("--no-adapter-cache", action="store_true", help="with --layout: recompute the adapter every step as the reference does")
     args = ap.parse_args()
 
     from opendwm_amd import dist as D
@@ -188,6 +192,11 @@ def main():
     _lib.load()
 
     kwargs = dict(MODEL_KWARGS)
+    if args.layout:
+        kwargs.update(temporal_attention_type="pointwise", projection_class_embeddings_input_dim=3328,
+                      condition_image_adapter_config=dict(in_channels=6, channels=[1536] * 6,
+                                                          is_downblocks=[True] + [False] * 5, num_res_blocks=2,
+                                                          downscale_factor=8, use_zero_convs=True))
     if args.layers is not None:
         n = args.layers
         kwargs.update(num_layers=n, dual_attention_layers=[i for i in kwargs["dual_attention_layers"] if i < n],
@@ -196,7 +205,10 @@ def main():
     timer = KernelTimer().install()
     model = build_model(kwargs, dev, seed=0)
     w = WORKLOAD
-    cond = make_conditions(dev, seed=rank)
+    cond = make_conditions(dev, seed=rank, n_time_ids=13 if args.layout else 11)
+    if args.layout:
+        gl = torch.Generator(device="cuda").manual_seed(77 + rank)
+        cond["condition_image_tensor"] = torch.rand(2 * w["B"], w["T"], w["V"], 6, 256, 448, device=dev, generator=gl).to(torch.bfloat16)
     g = torch.Generator(device="cuda").manual_seed(rank)
     latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
     den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"]).prepare(latents, cond)
@@ -205,6 +217,8 @@ def main():
 
     def step(i):
         timer.enabled = i >= args.warmup
+        if args.no_adapter_cache:
+            model._adapter_cache = (None, None)
         den.step(i % ninf)
 
     dt = D.timed_steps(step, args.steps, args.warmup, dev)
@@ -225,7 +239,8 @@ def main():
             "config": {"workload": "CTSD SD-3.5 MMDiT (24 joint blocks, 13 dual, 6 cross-view + 12 temporal VT blocks, "
                                    "rowwise), 6 views x 16 frames x 448x256 px (latents [1,16,6,16,32,56]), CFG g=4 -> "
                                    "model batch 2, 154 text tokens, FlowMatch-Euler; one replica per GPU",
-                       "layers": kwargs["num_layers"], "flop_per_step": fl["total"], "finite": finite},
+                       "layers": kwargs["num_layers"], "flop_per_step": fl["total"], "finite": finite,
+                       "variant": ("text+layout (ImageAdapter, pointwise temporal)" + ("" if not args.no_adapter_cache else ", adapter recomputed every step")) if args.layout else "text (rowwise temporal)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": None,

@@ -390,8 +390,17 @@ def model_flops(cfg: dict, B: int, T: int, V: int, H: int, W: int, text_len: int
     f["t_attn"] = ((B * V * h) * 4 * (T * w) ** 2 * d if tt == "rowwise" else
                    (B * V) * 4 * (T * N) ** 2 * d if tt == "full" else (B * V * N) * 4 * T * T * d) * ntm
     cj, pd = cfg.get("joint_attention_dim", 4096), cfg.get("pooled_projection_dim", 2048)
+    ac = cfg.get("condition_image_adapter_config")
+    f["adapter"] = 0
+    if ac is not None:      # convs on the token grid: 3x3 (K = 9C) + 1x1 per resnet, in_conv, zero convs
+        chs = ac["channels"]
+        cin = ac.get("in_channels", 3) * ac.get("downscale_factor", 8) ** 2
+        for i, ch in enumerate(chs):
+            prev = cin if i == 0 else chs[i - 1]
+            f["adapter"] += tok * 2 * ((prev * ch if prev != ch else 0) + ac.get("num_res_blocks", 2) * 10 * ch * ch
+                                       + (ch * ch if ac.get("use_zero_convs") else 0))
     f["embeds"] = tok * 2 * 64 * d + ctx * 2 * cj * d + I * 2 * (256 * d + d * d + pd * d + d * d) \
         + I * 2 * (11 * 256 * d + d * d) + (ncv + ntm) * I * 2 * 8 * d * d + I * 4 * d * d + tok * 2 * 64 * d
     f["attention"] = f["joint_attn"] + f["cv_attn"] + f["t_attn"]
-    f["total"] = f["joint_linear"] + f["vt_linear"] + f["attention"] + f["embeds"]
+    f["total"] = f["joint_linear"] + f["vt_linear"] + f["attention"] + f["embeds"]      # adapter reported separately
     return f
