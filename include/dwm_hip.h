@@ -225,6 +225,25 @@ int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t w, int32_t 
 /* y += x, bf16, n % 8 == 0 (hidden_states + condition_residual, crossview_temporal_dit.py:491-494). */
 int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------
+ * VAE blocks (diffusers AutoencoderKL, called at src/dwm/pipelines/ctsd.py:1213-1218,1634-1640)
+ * on token-major activations x [I, P, C] (P = pixels per image).
+ * ---------------------------------------------------------------------- */
+/* torch.nn.GroupNorm(G, C, eps) [+ SiLU]: statistics over (P, C/G) per image and group (fp32,
+ * `stats` = caller scratch of 2*G*I floats), y = (x - mean) * rstd * gamma + beta [then x*sigmoid(x)].
+ * If out_map (rw > 0) is given, y is written into the zero-padded token grid that feeds a 3x3
+ * implicit-GEMM convolution (borders must have been zeroed once by the caller).  C/G % 4 == 0. */
+int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                       const void* gamma, const void* beta, int32_t silu, float* stats,
+                       const dwm_rowmap2d* out_map, void* stream);
+
+/* F.interpolate(scale_factor=2, mode="nearest") of token-major x [I, h, w, C], written into the
+ * padded grid y [I, 2h+2, 2w+2, C] (diffusers Upsample2D before its 3x3 conv). */
+int dwm_upsample2_padded(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream);
+
+/* y[r, :L] = softmax(scale * x[r, :L]) (fp32 math, bf16 storage; single-head mid-block attention). */
+int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream);
+
 /* dst bf16 <- src fp32 (n % 4 == 0) */
 int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 

@@ -74,6 +74,9 @@ SIGNATURES = {
     "dwm_unshuffle_tokens": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "dwm_avgpool2_tokens": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dwm_add_inplace": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_groupnorm_silu": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), _vp]),
+    "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dwm_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
 }
 
 _ERR = {-1: "DWM_EINVAL (bad shape / null pointer)", -2: "DWM_EALIGN (alignment)",

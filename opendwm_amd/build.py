@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdwm_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "norm.hip", "elementwise.hip", "vae.hip"]
 ARCH = "gfx950"
 
 

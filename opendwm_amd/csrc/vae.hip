@@ -1,0 +1,198 @@
+// Kernels for the AutoencoderKL decode / encode blocks on token-major activations (gfx950):
+// GroupNorm statistics + fused normalise/affine/SiLU (optionally writing into the zero-padded
+// token grid that feeds the implicit-GEMM 3x3 convolutions), nearest 2x upsample into a padded
+// grid, and a row softmax for the single-head mid-block attention.  All HBM-bound, 16-B accesses.
+#include "common.h"
+#include "dwm_hip.h"
+
+namespace {
+
+// ---- GroupNorm statistics: x [I, P, C] token-major, G groups of CG = C/G channels.
+// grid (chunks, I); each block reduces PPB pixels for all groups of image i and atomically adds
+// (sum, sumsq) into stats[i][g][2] (fp32, zeroed by the caller's memset node).
+__global__ void __launch_bounds__(256)
+gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ stats) {
+    extern __shared__ float red[];            // [2 * G]
+    const int i = blockIdx.y;
+    const int C8 = C >> 3, CG = C / G;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = p0 + ppb < P ? p0 + ppb : P;
+    for (int t = threadIdx.x; t < 2 * G; t += 256) red[t] = 0.f;
+    __syncthreads();
+    // thread t owns channel chunk c8 = t % C8 (8 channels) and strides over pixels
+    const int c8 = threadIdx.x % C8;
+    const int prow = threadIdx.x / C8, pstep = 256 / C8;
+    // a thread's 8 channels span one group (CG >= 8) or two (CG == 4): split sums by 4-channel half
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    if (prow < pstep) {
+        for (int64_t p = p0 + prow; p < p1; p += pstep) {
+            float v[8];
+            unpack8(*(const uint4*)(x + ((int64_t)i * P + p) * C + c8 * 8), v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0 += v[j]; q0 += v[j] * v[j]; s1 += v[j + 4]; q1 += v[j + 4] * v[j + 4]; }
+        }
+        const int g0 = (c8 * 8) / CG, g1 = (c8 * 8 + 4) / CG;
+        atomicAdd(&red[2 * g0], s0);
+        atomicAdd(&red[2 * g0 + 1], q0);
+        atomicAdd(&red[2 * g1], s1);
+        atomicAdd(&red[2 * g1 + 1], q1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * G; t += 256) atomicAdd(&stats[(int64_t)i * 2 * G + t], red[t]);
+}
+
+// ---- y = silu?( (x - mean) * rstd * gamma + beta ), written compact or into a padded grid.
+struct PadMap { int enabled; FastDiv rw, rh; int64_t rpitch, ipitch, origin; };
+DWM_DEVINL int64_t pad_row(const PadMap& m, int64_t r) {
+    if (!m.enabled) return r;
+    const uint32_t q = fdiv((uint32_t)r, m.rw), xx = (uint32_t)r - q * m.rw.d;
+    const uint32_t i = fdiv(q, m.rh), yy = q - i * m.rh.d;
+    return (int64_t)i * m.ipitch + (int64_t)yy * m.rpitch + xx + m.origin;
+}
+
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int64_t P, int C, int G,
+                const float* __restrict__ stats, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                float eps, int silu, PadMap pm) {
+    const int C8 = C >> 3, CG = C / G;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C8) return;
+    const int c8 = (int)(idx % C8);
+    const int64_t r = idx / C8;
+    const int64_t i = r / P;
+    const float n = (float)P * (float)CG;
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int g = (c8 * 8 + 4 * hf) / CG;
+        mean[hf] = stats[(i * G + g) * 2] / n;
+        const float var = fmaxf(stats[(i * G + g) * 2 + 1] / n - mean[hf] * mean[hf], 0.f);
+        rstd[hf] = rsqrtf(var + eps);
+    }
+    float v[8], ga[8], be[8];
+    unpack8(*(const uint4*)(x + r * C + c8 * 8), v);
+    unpack8(*(const uint4*)(gamma + c8 * 8), ga);
+    unpack8(*(const uint4*)(beta + c8 * 8), be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = (v[j] - mean[j >> 2]) * rstd[j >> 2] * ga[j] + be[j];
+        v[j] = silu ? silu_f(t) : t;
+    }
+    *(uint4*)(y + pad_row(pm, r) * C + c8 * 8) = pack8(v);
+}
+
+// ---- nearest 2x upsample of token-major [I, h, w, C] into the padded grid of the [I, 2h, 2w] image
+__global__ void __launch_bounds__(256)
+upsample2_pad_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I, int h, int w, int C8) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int H = 2 * h, W = 2 * w;
+    if (idx >= I * H * W * C8) return;
+    const int c8 = (int)(idx % C8);
+    const int64_t r = idx / C8;
+    const int X = (int)(r % W), Y = (int)((r / W) % H);
+    const int64_t i = r / ((int64_t)W * H);
+    const uint4 v = *(const uint4*)(x + (((i * h + (Y >> 1)) * w + (X >> 1)) * (int64_t)C8 + c8) * 8);
+    const int64_t orow = i * (int64_t)(H + 2) * (W + 2) + (int64_t)(Y + 1) * (W + 2) + X + 1;
+    *(uint4*)(y + (orow * C8 + c8) * 8) = v;
+}
+
+// ---- row softmax (fp32 math) of bf16 x[rows, L] * scale, one wave per row, L <= 4096, L % 8 == 0
+template <int NI>
+__global__ void __launch_bounds__(256)
+softmax_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int L, int64_t ld, float scale_log2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NI][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < L) {
+            unpack8(*(const uint4*)(x + row * ld + c), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] *= scale_log2; mx = fmaxf(mx, v[i][j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[i][j] = __builtin_amdgcn_exp2f(v[i][j] - mx); s += v[i][j]; }
+    s = wave_sum(s);
+    const float inv = __builtin_amdgcn_rcpf(s);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < L) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] *= inv;
+            *(uint4*)(y + row * ld + c) = pack8(v[i]);
+        }
+    }
+}
+
+inline int finish() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                                  const void* gamma, const void* beta, int32_t silu, float* stats,
+                                  const dwm_rowmap2d* out_map, void* stream) {
+    if (x == nullptr || y == nullptr || gamma == nullptr || beta == nullptr || stats == nullptr) return DWM_EINVAL;
+    if (I <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G != 0) return DWM_EINVAL;
+    const int CG = C / G;
+    if (C % 8 != 0 || CG % 4 != 0 || C / 8 > 256 || 256 % (C / 8) != 0 || I > 65535) return DWM_EUNSUPPORTED;
+    if (!dwm_aligned16(x) || !dwm_aligned16(y) || !dwm_aligned16(gamma) || !dwm_aligned16(beta)) return DWM_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * G * I, s);
+    if (e != hipSuccess) return (int)e;
+    const int64_t ppb = 2048;
+    const dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)I);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), sizeof(float) * 2 * G, s, (const bf16_t*)x, P, C, G, ppb, stats);
+    PadMap pm;
+    pm.enabled = out_map != nullptr && out_map->rw > 0;
+    if (pm.enabled) {
+        if (out_map->rh <= 0 || out_map->rw * out_map->rh != P) return DWM_EINVAL;
+        pm.rw = make_fastdiv((uint32_t)out_map->rw); pm.rh = make_fastdiv((uint32_t)out_map->rh);
+        pm.rpitch = out_map->rpitch; pm.ipitch = out_map->ipitch; pm.origin = out_map->origin;
+    } else {
+        pm.rw = make_fastdiv(1); pm.rh = make_fastdiv(1); pm.rpitch = pm.ipitch = pm.origin = 0;
+    }
+    const int64_t total = I * P * (C / 8);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
+                       (bf16_t*)y, I * P, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm);
+    return finish();
+}
+
+extern "C" int dwm_upsample2_padded(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream) {
+    if (x == nullptr || y == nullptr || I <= 0 || h <= 0 || w <= 0 || C <= 0) return DWM_EINVAL;
+    if (C % 8 != 0) return DWM_EUNSUPPORTED;
+    if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    const int64_t total = I * 4 * h * w * (C / 8);
+    hipLaunchKernelGGL(upsample2_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, I, h, w, C / 8);
+    return finish();
+}
+
+extern "C" int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream) {
+    if (x == nullptr || y == nullptr || rows <= 0 || L <= 0) return DWM_EINVAL;
+    if (L % 8 != 0 || L > 4096 || ld % 8 != 0 || ld < L) return DWM_EUNSUPPORTED;
+    if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const float sl = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    const int ni = (L + 511) / 512;
+    if (ni <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
+    else if (ni <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
+    else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
+    return finish();
+}

@@ -402,6 +402,53 @@ def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                   eps: float, silu: bool = True, out: Optional[torch.Tensor] = None,
+                   out_grid: Optional[PaddedGrid] = None) -> torch.Tensor:
+    """GroupNorm(groups) [+ SiLU] of token-major x [I*P, C]; with out_grid the result lands in the
+    interior of a padded grid `out` [out_grid.rows, C] whose border must already be zero."""
+    _chk2d(x, "x")
+    if not x.is_contiguous() or x.shape[0] != I * P:
+        raise RuntimeError("groupnorm_silu: x must be contiguous [I*P, C]")
+    Cc = x.shape[1]
+    _chkvec(gamma, "gamma")
+    _chkvec(beta, "beta")
+    rows = out_grid.rows if out_grid is not None else I * P
+    if out is None:
+        out = (torch.zeros if out_grid is not None else torch.empty)((rows, Cc), dtype=bf16, device=x.device)
+    if out.shape != (rows, Cc) or not out.is_contiguous() or out.dtype != bf16:
+        raise RuntimeError("groupnorm_silu: bad out")
+    stats = torch.empty(2 * groups * I, dtype=torch.float32, device=x.device)
+    m = _lib.RowMap2D()
+    if out_grid is not None:
+        out_grid.fill(m)
+    _lib.check(_lib.load().dwm_groupnorm_silu(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
+                                              beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), _stream()),
+               "dwm_groupnorm_silu")
+    return out
+
+
+def upsample2_padded(x: torch.Tensor, I: int, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nearest 2x upsample of token-major [I*h*w, C] into the padded grid of the [I, 2h, 2w] image."""
+    _chk2d(x, "x")
+    if not x.is_contiguous() or x.shape[0] != I * h * w:
+        raise RuntimeError("upsample2_padded: x must be contiguous [I*h*w, C]")
+    g = PaddedGrid(I, 2 * h, 2 * w)
+    if out is None:
+        out = torch.zeros((g.rows, x.shape[1]), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_upsample2_padded(x.data_ptr(), out.data_ptr(), I, h, w, x.shape[1], _stream()),
+               "dwm_upsample2_padded")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk2d(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().dwm_softmax_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
+                                            float(scale), _stream()), "dwm_softmax_rows")
+    return out
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     if x.dtype == bf16:
         return x

@@ -1,0 +1,223 @@
+"""MI355X-native decoder of diffusers' AutoencoderKL (the SD 3 / 3.5 VAE the CTSD pipeline
+decodes with: src/dwm/pipelines/ctsd.py:953-964 construction, :1634-1640 decode call through
+dwm.functional.memory_efficient_split_call, src/dwm/functional.py:184-193).
+
+Module tree / state-dict keys follow diffusers 0.31.0 (decoder.conv_in, decoder.mid_block.resnets.N,
+decoder.mid_block.attentions.0.{group_norm,to_q,to_k,to_v,to_out.0}, decoder.up_blocks.N.resnets.M,
+decoder.up_blocks.N.upsamplers.0.conv, decoder.conv_norm_out, decoder.conv_out) so a released
+`vae/diffusion_pytorch_model.safetensors` loads with strict=False (encoder keys are ignored until
+the encoder is built).  Activations are token-major [I*H*W, C] bf16; every 3x3 convolution is an
+implicit GEMM of dwm_gemm_bf16 over a zero-padded token grid; GroupNorm+SiLU, the nearest
+upsample and the mid-block softmax are HIP kernels (csrc/vae.hip)."""
+from __future__ import annotations
+
+import types
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .blocks import _bf
+from .ops import EPI_RESID, PaddedGrid
+
+bf16 = torch.bfloat16
+
+
+def _conv3_w(conv: nn.Conv2d, k_pad: Optional[int] = None) -> torch.Tensor:
+    """[N, C, 3, 3] -> tap-major [N, 9*Cp] (channels zero-padded to Cp for K granularity 64)."""
+    w = _bf(conv.weight)
+    n, c = w.shape[:2]
+    cp = k_pad or c
+    t = torch.zeros((n, 3, 3, cp), dtype=bf16, device=w.device)
+    t[..., :c] = w.permute(0, 2, 3, 1)
+    return t.reshape(n, 9 * cp).contiguous()
+
+
+class ResnetBlock2D(nn.Module):
+    """diffusers ResnetBlock2D(temb_channels=None, groups=32, eps=1e-6, output_scale_factor=1)."""
+
+    def __init__(self, in_channels: int, out_channels: int, groups: int = 32, eps: float = 1e-6):
+        super().__init__()
+        self.groups, self.eps = groups, eps
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self._pk = None
+
+    def packed(self):
+        if self._pk is None:
+            self._pk = {"w1": _conv3_w(self.conv1), "w2": _conv3_w(self.conv2)}
+            if self.conv_shortcut is not None:
+                self._pk["ws"] = _bf(self.conv_shortcut.weight).reshape(self.conv_shortcut.weight.shape[0], -1).contiguous()
+        return self._pk
+
+    def run(self, x: torch.Tensor, grid: PaddedGrid, scratch) -> torch.Tensor:
+        pk = self.packed()
+        I, P = grid.I, grid.h * grid.w
+        p1 = ops.groupnorm_silu(x, I, P, _bf(self.norm1.weight), _bf(self.norm1.bias), self.groups, self.eps,
+                                out=scratch(grid, x.shape[1]), out_grid=grid)
+        h1 = ops.gemm(p1, pk["w1"], _bf(self.conv1.bias), a_grid=grid, conv3x3=True)
+        p2 = ops.groupnorm_silu(h1, I, P, _bf(self.norm2.weight), _bf(self.norm2.bias), self.groups, self.eps,
+                                out=scratch(grid, h1.shape[1]), out_grid=grid)
+        sc = x if self.conv_shortcut is None else ops.gemm(x, pk["ws"], _bf(self.conv_shortcut.bias))
+        return ops.gemm(p2, pk["w2"], _bf(self.conv2.bias), epilogue=EPI_RESID, res=sc, a_grid=grid, conv3x3=True, out=h1)
+
+
+class _VaeAttention(nn.Module):
+    """diffusers Attention as the VAE mid block builds it: one head of dim C, GroupNorm(32) first,
+    biased q/k/v/out projections, residual connection."""
+
+    def __init__(self, channels: int, groups: int = 32, eps: float = 1e-6):
+        super().__init__()
+        self.channels, self.groups, self.eps = channels, groups, eps
+        self.group_norm = nn.GroupNorm(groups, channels, eps=eps)
+        self.to_q = nn.Linear(channels, channels)
+        self.to_k = nn.Linear(channels, channels)
+        self.to_v = nn.Linear(channels, channels)
+        self.to_out = nn.ModuleList([nn.Linear(channels, channels), nn.Identity()])
+
+    def run(self, x: torch.Tensor, I: int, P: int) -> torch.Tensor:
+        Cc = self.channels
+        if P % 64 != 0:
+            raise NotImplementedError("VAE mid attention needs pixels-per-image % 64 == 0 (GEMM K granularity)")
+        xn = ops.groupnorm_silu(x, I, P, _bf(self.group_norm.weight), _bf(self.group_norm.bias), self.groups, self.eps,
+                                silu=False)
+        q = ops.gemm(xn, _bf(self.to_q.weight), _bf(self.to_q.bias))
+        k = ops.gemm(xn, _bf(self.to_k.weight), _bf(self.to_k.bias))
+        o = torch.empty_like(x)
+        wv = _bf(self.to_v.weight)
+        for i in range(I):
+            sl = slice(i * P, (i + 1) * P)
+            s = ops.gemm(q[sl], k[sl])                                   # [P, P] scores
+            ops.softmax_rows(s, Cc ** -0.5, out=s)
+            vt = ops.gemm(wv, xn[sl])                                    # V^T without bias: [C, P]
+            # rows of softmax sum to 1, so P @ (V + 1 b^T) = P @ V + b^T: the v bias is the column bias here
+            ops.gemm(s, vt, _bf(self.to_v.bias), out=o[sl])
+        to = self.to_out[0]
+        return ops.gemm(o, _bf(to.weight), _bf(to.bias), epilogue=EPI_RESID, res=x, out=o)
+
+
+class _MidBlock(nn.Module):
+    def __init__(self, channels: int, groups: int, eps: float, add_attention: bool):
+        super().__init__()
+        self.attentions = nn.ModuleList([_VaeAttention(channels, groups, eps)] if add_attention else [])
+        self.resnets = nn.ModuleList([ResnetBlock2D(channels, channels, groups, eps) for _ in range(2)])
+
+
+class _Upsampler(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, n_res: int, groups: int, eps: float, add_upsample: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_ch if j == 0 else out_ch, out_ch, groups, eps) for j in range(n_res)])
+        self.upsamplers = nn.ModuleList([_Upsampler(out_ch)]) if add_upsample else None
+
+
+class Decoder(nn.Module):
+    def __init__(self, latent_channels: int, out_channels: int, block_out_channels, layers_per_block: int,
+                 groups: int, eps: float = 1e-6, mid_block_add_attention: bool = True):
+        super().__init__()
+        self.groups, self.eps, self.out_channels = groups, eps, out_channels
+        ch = list(block_out_channels)
+        self.conv_in = nn.Conv2d(latent_channels, ch[-1], 3, padding=1)
+        self.mid_block = _MidBlock(ch[-1], groups, eps, mid_block_add_attention)
+        rev = ch[::-1]
+        ups, prev = [], rev[0]
+        for i, oc in enumerate(rev):
+            ups.append(_UpBlock(prev, oc, layers_per_block + 1, groups, eps, add_upsample=i != len(rev) - 1))
+            prev = oc
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = nn.GroupNorm(groups, ch[0], eps=eps)
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+
+
+class AutoencoderKL(nn.Module):
+    """decode(z)-only stand-in for diffusers.AutoencoderKL (SD 3.5 medium VAE defaults)."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 16,
+                 block_out_channels=(128, 256, 512, 512), layers_per_block: int = 2, norm_num_groups: int = 32,
+                 scaling_factor: float = 1.5305, shift_factor: Optional[float] = 0.0609,
+                 use_quant_conv: bool = False, use_post_quant_conv: bool = False,
+                 mid_block_add_attention: bool = True, **unused):
+        super().__init__()
+        if use_post_quant_conv:
+            raise NotImplementedError("post_quant_conv (SD 2.1 VAE) is not built yet")
+        self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups,
+                               mid_block_add_attention=mid_block_add_attention)
+        self.config = types.SimpleNamespace(scaling_factor=scaling_factor, shift_factor=shift_factor,
+                                            latent_channels=latent_channels, block_out_channels=tuple(block_out_channels))
+        self._scratch: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    @property
+    def dtype(self):
+        return self.decoder.conv_in.weight.dtype
+
+    def _pad_scratch(self, grid: PaddedGrid, channels: int) -> torch.Tensor:
+        """zero-bordered padded buffers, reused (every producer rewrites the whole interior)."""
+        key = (grid.I, grid.h, grid.w, channels)
+        dev = self.decoder.conv_in.weight.device
+        buf = self._scratch.get(key)
+        if buf is None or buf.device != dev:
+            self._scratch = {k: v for k, v in self._scratch.items() if k[:3] == key[:3]}   # drop other resolutions
+            buf = torch.zeros((grid.rows, channels), dtype=bf16, device=dev)
+            self._scratch[key] = buf
+        return buf
+
+    def encode(self, x):
+        raise NotImplementedError("AutoencoderKL.encode is not built yet (DESIGN.md §0, row a12)")
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = False, chunk: int = 8):
+        """z [I, latent_channels, h, w] -> images [I, 3, 8h, 8w] (bf16).  Returns a 1-tuple like
+        diffusers' decode(..., return_dict=False)."""
+        if not z.is_cuda:
+            raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
+        outs = [self._decode_chunk(z[i:i + chunk]) for i in range(0, z.shape[0], chunk)]
+        img = torch.cat(outs, 0)
+        if return_dict:
+            return types.SimpleNamespace(sample=img)
+        return (img,)
+
+    def _decode_chunk(self, z: torch.Tensor) -> torch.Tensor:
+        d = self.decoder
+        I, lc, h, w = z.shape
+        z = z.contiguous()
+        if z.dtype not in (torch.float32, bf16):
+            z = z.to(bf16)
+        grid = PaddedGrid(I, h, w)
+        scratch = self._pad_scratch
+        tok = ops.unshuffle_tokens(z, 1, 64 * ((lc + 63) // 64))                  # [I*h*w, 64], zero padded channels
+        zp = scratch(grid, tok.shape[1])
+        zp[grid.interior_index().to(zp.device)] = tok
+        x = ops.gemm(zp, _conv3_w(d.conv_in, tok.shape[1]), _bf(d.conv_in.bias), a_grid=grid, conv3x3=True)
+        x = d.mid_block.resnets[0].run(x, grid, scratch)
+        for attn in d.mid_block.attentions:
+            x = attn.run(x, I, h * w)
+        x = d.mid_block.resnets[1].run(x, grid, scratch)
+        for ub in d.up_blocks:
+            for res in ub.resnets:
+                x = res.run(x, grid, scratch)
+            if ub.upsamplers is not None:
+                up = ub.upsamplers[0]
+                g2 = PaddedGrid(I, 2 * grid.h, 2 * grid.w)
+                xp = ops.upsample2_padded(x, I, grid.h, grid.w, out=scratch(g2, x.shape[1]))
+                x = ops.gemm(xp, _conv3_w(up.conv), _bf(up.conv.bias), a_grid=g2, conv3x3=True)
+                grid = g2
+        P = grid.h * grid.w
+        xp = ops.groupnorm_silu(x, I, P, _bf(d.conv_norm_out.weight), _bf(d.conv_norm_out.bias), d.groups, d.eps,
+                                out=scratch(grid, x.shape[1]), out_grid=grid)
+        oc = d.out_channels
+        w_out = _conv3_w(d.conv_out)
+        wp = torch.zeros((8, w_out.shape[1]), dtype=bf16, device=w_out.device)      # N padded 3 -> 8
+        wp[:oc] = w_out
+        bp = torch.zeros(8, dtype=bf16, device=w_out.device)
+        bp[:oc] = _bf(d.conv_out.bias)
+        y = ops.gemm(xp, wp, bp, a_grid=grid, conv3x3=True)                          # [I*P, 8]
+        return y[:, :oc].reshape(I, grid.h, grid.w, oc).permute(0, 3, 1, 2).contiguous()

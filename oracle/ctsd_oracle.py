@@ -446,6 +446,112 @@ def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
 
 
 # --------------------------------------------------------------------------
+# VAE decoder (diffusers AutoencoderKL 0.31.0; called at ctsd.py:1634-1640)
+# --------------------------------------------------------------------------
+
+def _vae_resnet(sd: SD, p: str, x: Tensor, groups: int, eps: float) -> Tensor:
+    """diffusers ResnetBlock2D with temb_channels=None, output_scale_factor=1."""
+    h = F.silu(F.group_norm(x, groups, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps))
+    h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = F.silu(F.group_norm(h, groups, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps))
+    h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if (p + ".conv_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
+    return x + h
+
+
+def _vae_attention(sd: SD, p: str, x: Tensor, groups: int, eps: float) -> Tensor:
+    """diffusers Attention in the VAE mid block: heads = 1, GroupNorm first, residual connection."""
+    b, c, hh, ww = x.shape
+    res = x
+    y = F.group_norm(x.view(b, c, hh * ww), groups, sd[p + ".group_norm.weight"], sd[p + ".group_norm.bias"], eps)
+    y = y.transpose(1, 2)
+    q, k, v = linear(sd, p + ".to_q", y), linear(sd, p + ".to_k", y), linear(sd, p + ".to_v", y)
+    o = sdpa(q[:, None], k[:, None], v[:, None])[:, 0]
+    o = linear(sd, p + ".to_out.0", o)
+    return o.transpose(1, 2).reshape(b, c, hh, ww) + res
+
+
+def vae_decode(sd: SD, vcfg: dict, z: Tensor) -> Tensor:
+    """``AutoencoderKL.decode`` -> ``Decoder.forward`` (no post_quant_conv, SD 3 / 3.5):
+    conv_in -> mid (resnet, attention, resnet) -> 4 up blocks (3 resnets [+ nearest-2x + conv]) ->
+    GroupNorm -> SiLU -> conv_out."""
+    g, eps = vcfg.get("norm_num_groups", 32), 1e-6
+    x = F.conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    x = _vae_resnet(sd, "decoder.mid_block.resnets.0", x, g, eps)
+    if vcfg.get("mid_block_add_attention", True):
+        x = _vae_attention(sd, "decoder.mid_block.attentions.0", x, g, eps)
+    x = _vae_resnet(sd, "decoder.mid_block.resnets.1", x, g, eps)
+    nb = len(vcfg["block_out_channels"])
+    for i in range(nb):
+        for j in range(vcfg.get("layers_per_block", 2) + 1):
+            x = _vae_resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", x, g, eps)
+        if i != nb - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = F.conv2d(x, sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"],
+                         sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
+    x = F.silu(F.group_norm(x, g, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps))
+    return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+def vae_decoder_shapes(vcfg: dict) -> Dict[str, tuple]:
+    ch = list(vcfg["block_out_channels"])
+    lc, oc = vcfg.get("latent_channels", 16), vcfg.get("out_channels", 3)
+    S: Dict[str, tuple] = {}
+
+    def conv(n, i, o, k):
+        S[n + ".weight"] = (o, i, k, k)
+        S[n + ".bias"] = (o,)
+
+    def norm(n, c):
+        S[n + ".weight"] = (c,)
+        S[n + ".bias"] = (c,)
+
+    def resnet(n, i, o):
+        norm(n + ".norm1", i); conv(n + ".conv1", i, o, 3); norm(n + ".norm2", o); conv(n + ".conv2", o, o, 3)
+        if i != o:
+            conv(n + ".conv_shortcut", i, o, 1)
+
+    conv("decoder.conv_in", lc, ch[-1], 3)
+    resnet("decoder.mid_block.resnets.0", ch[-1], ch[-1])
+    resnet("decoder.mid_block.resnets.1", ch[-1], ch[-1])
+    if vcfg.get("mid_block_add_attention", True):
+        a = "decoder.mid_block.attentions.0"
+        norm(a + ".group_norm", ch[-1])
+        for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+            S[f"{a}.{nm}.weight"] = (ch[-1], ch[-1])
+            S[f"{a}.{nm}.bias"] = (ch[-1],)
+    prev = ch[-1]
+    for i, o in enumerate(ch[::-1]):
+        for j in range(vcfg.get("layers_per_block", 2) + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else o, o)
+        if i != len(ch) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", o, o, 3)
+        prev = o
+    norm("decoder.conv_norm_out", ch[0])
+    conv("decoder.conv_out", ch[0], oc, 3)
+    return S
+
+
+def make_vae_state_dict(vcfg: dict, seed: int = 0) -> SD:
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in vae_decoder_shapes(vcfg).items():
+        if len(shape) == 1:
+            v = torch.randn(*shape, generator=gen) * 0.05
+            sd[name] = 1.0 + v if name.endswith(".weight") else v
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            std = fan_in ** -0.5
+            if ".conv2." in name or ".to_out." in name:
+                std *= 0.5
+            sd[name] = torch.randn(*shape, generator=gen) * std
+    return sd
+
+
+# --------------------------------------------------------------------------
 # scheduler + denoise loop (ctsd.py:1496-1575; diffusers FlowMatchEulerDiscreteScheduler)
 # --------------------------------------------------------------------------
 

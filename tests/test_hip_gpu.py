@@ -410,6 +410,59 @@ def test_model_with_layout_adapter_vs_oracle(dev):
     assert torch.equal(out2[0], out[0])
 
 
+# --------------------------------------------------------------------------------- VAE
+@pytest.mark.parametrize("I,h,w,C,G", [(3, 8, 12, 128, 32), (2, 16, 16, 64, 8), (5, 4, 4, 512, 32)])
+def test_groupnorm_silu_and_upsample(dev, I, h, w, C, G):
+    from opendwm_amd import ops
+    P = h * w
+    x = _rand((I * P, C), dev, 1, 2.0) + 0.3
+    ga, be = _rand((C,), dev, 2) * 0.2 + 1, _rand((C,), dev, 3)
+    xn = x.float().view(I, P, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xn, G, ga.float(), be.float(), 1e-6)).permute(0, 2, 1).reshape(I * P, C)
+    e1 = rel_err(ops.groupnorm_silu(x, I, P, ga, be, G, 1e-6), ref)
+    grid = ops.PaddedGrid(I, h, w)
+    yp = ops.groupnorm_silu(x, I, P, ga, be, G, 1e-6, out_grid=grid)
+    idx = grid.interior_index().to(dev)
+    e2 = rel_err(yp[idx], ref)
+    border = torch.ones(grid.rows, dtype=torch.bool, device=dev)
+    border[idx] = False
+    ref3 = F.group_norm(xn, G, ga.float(), be.float(), 1e-6).permute(0, 2, 1).reshape(I * P, C)
+    e3 = rel_err(ops.groupnorm_silu(x, I, P, ga, be, G, 1e-6, silu=False), ref3)
+    up = ops.upsample2_padded(x, I, h, w)
+    g2 = ops.PaddedGrid(I, 2 * h, 2 * w)
+    refu = F.interpolate(x.float().view(I, h, w, C).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    ok_up = torch.equal(up[g2.interior_index().to(dev)], refu.permute(0, 2, 3, 1).reshape(-1, C).to(bf16))
+    _log("groupnorm", I=I, C=C, G=G, e=[e1, e2, e3], upsample_exact=ok_up)
+    assert max(e1, e2, e3) < TOL_KERNEL and torch.count_nonzero(yp[border]) == 0 and ok_up
+
+
+def test_softmax_rows(dev):
+    from opendwm_amd import ops
+    for L in (64, 448, 1792):
+        x = _rand((300, L), dev, 1, 3.0)
+        ref = torch.softmax(x.float() * 0.2, -1)
+        e = rel_err(ops.softmax_rows(x, 0.2), ref)
+        assert e < TOL_KERNEL, (L, e)
+
+
+def test_vae_decode_vs_oracle(dev):
+    """AutoencoderKL.decode (ctsd.py:1634-1640) at reduced width: every block type of the SD 3.5 VAE
+    decoder (mid attention, channel-changing resnets with conv_shortcut, 3 nearest-2x upsamplers)."""
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
+    sd = _bf16_round_sd(O.make_vae_state_dict(vcfg, 0))
+    vae = AutoencoderKL(**vcfg)
+    vae.load_state_dict(sd)
+    vae = vae.to(dev).to(bf16).eval()
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(3, 16, 8, 8, generator=g).to(bf16).float()
+    ref = O.vae_decode(sd, vcfg, z)
+    out = vae.decode(z.to(dev), return_dict=False, chunk=2)[0]
+    e = rel_err(out, ref)
+    _log("vae_decode", rel=e, shape=list(out.shape))
+    assert out.shape == (3, 3, 64, 64) and e < TOL_MODEL
+
+
 # ----------------------------------------------------------------------- blocks / model
 def _bf16_round_sd(sd):
     return {k: v.to(bf16).float() for k, v in sd.items()}
