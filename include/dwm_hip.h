@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 5
+#define DWM_ABI_VERSION 6
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -66,14 +66,16 @@ enum {
 enum { DWM_ACT_NONE = 0, DWM_ACT_GELU_TANH = 1, DWM_ACT_SILU = 2, DWM_ACT_RELU = 3 };
 
 /* Row map "compact pixel index -> row of a zero-padded [I, rh+2, rw+2] token grid":
- *   row(m) = (m / (rw*rh)) * ipitch + ((m / rw) % rh) * rpitch + (m % rw) + origin
- * rw == 0 means identity (row(m) = m).  Used to run the 3x3 convolutions of the layout
+ *   row(m) = (m / (rw*rh)) * ipitch + ((m / rw) % rh) * rpitch + (m % rw) * xstep + origin
+ * rw == 0 means identity (row(m) = m); xstep == 0 is read as 1.  xstep = 2 with a doubled rpitch
+ * addresses every second pixel (stride-2 Downsample2D of the VAE encoder).  Used to run the 3x3 convolutions of the layout
  * ImageAdapter (diffusers AdapterResnetBlock.block1, src/dwm/models/adapters.py:20-22) as
  * implicit GEMM on token-major activations without materialising im2col or padding copies. */
 typedef struct dwm_rowmap2d {
     int64_t rw, rh;          /* interior width / height (pixels)                 */
     int64_t rpitch, ipitch;  /* padded row pitch (rw+2) and image pitch, in rows  */
     int64_t origin;          /* row of interior pixel (0,0): rpitch + 1           */
+    int64_t xstep;           /* column step (0 or 1 = dense, 2 = stride-2 conv)   */
 } dwm_rowmap2d;
 
 typedef struct dwm_gemm_args {
@@ -240,6 +242,10 @@ int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, 
 /* F.interpolate(scale_factor=2, mode="nearest") of token-major x [I, h, w, C], written into the
  * padded grid y [I, 2h+2, 2w+2, C] (diffusers Upsample2D before its 3x3 conv). */
 int dwm_upsample2_padded(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream);
+
+/* copy compact token rows x [I*rh*rw, C] into the interior of the zero-bordered padded grid y
+ * described by map (input staging of a 3x3 implicit-GEMM convolution). */
+int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream);
 
 /* y[r, :L] = softmax(scale * x[r, :L]) (fp32 math, bf16 storage; single-head mid-block attention). */
 int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream);

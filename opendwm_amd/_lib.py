@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -16,7 +16,7 @@ _i64, _i32, _f32, _vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
 
 class RowMap2D(C.Structure):
-    _fields_ = [("rw", _i64), ("rh", _i64), ("rpitch", _i64), ("ipitch", _i64), ("origin", _i64)]
+    _fields_ = [("rw", _i64), ("rh", _i64), ("rpitch", _i64), ("ipitch", _i64), ("origin", _i64), ("xstep", _i64)]
 
 
 class GemmArgs(C.Structure):
@@ -76,6 +76,7 @@ SIGNATURES = {
     "dwm_add_inplace": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_groupnorm_silu": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), _vp]),
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dwm_pad_tokens": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(RowMap2D), _vp]),
     "dwm_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
 }
 

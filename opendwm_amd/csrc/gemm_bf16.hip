@@ -30,7 +30,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // double buffered = 128 KiB
 struct DevRowMap {
     FastDiv rw, rh;
     int64_t rpitch, ipitch, origin;
-    int enabled;
+    int enabled, xstep;
 };
 struct ConvParams {
     DevRowMap a, c;
@@ -42,7 +42,7 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     if (!rm.enabled) return m;
     const uint32_t q = fdiv((uint32_t)m, rm.rw), x = (uint32_t)m - q * rm.rw.d;
     const uint32_t i = fdiv(q, rm.rh), y = q - i * rm.rh.d;
-    return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + x + rm.origin;
+    return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + (int64_t)x * rm.xstep + rm.origin;
 }
 
 template <int EPI>
@@ -359,6 +359,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     ConvParams cp;
     auto mk = [](const dwm_rowmap2d& r, DevRowMap& d) -> bool {
         d.enabled = r.rw > 0;
+        d.xstep = r.xstep > 0 ? (int)r.xstep : 1;
         if (!d.enabled) { d.rw = make_fastdiv(1); d.rh = make_fastdiv(1); d.rpitch = d.ipitch = d.origin = 0; return true; }
         if (r.rh <= 0 || r.rw >= (1ll << 30) || r.rh >= (1ll << 30)) return false;
         d.rw = make_fastdiv((uint32_t)r.rw); d.rh = make_fastdiv((uint32_t)r.rh);

@@ -81,6 +81,16 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t ro
     *(uint4*)(y + pad_row(pm, r) * C + c8 * 8) = pack8(v);
 }
 
+// ---- copy compact token rows into a (zero-bordered) padded grid
+__global__ void __launch_bounds__(256)
+pad_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int C8, PadMap pm) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C8) return;
+    const int c8 = (int)(idx % C8);
+    const int64_t r = idx / C8;
+    *(uint4*)(y + (pad_row(pm, r) * C8 + c8) * 8) = *(const uint4*)(x + idx * 8);
+}
+
 // ---- nearest 2x upsample of token-major [I, h, w, C] into the padded grid of the [I, 2h, 2w] image
 __global__ void __launch_bounds__(256)
 upsample2_pad_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I, int h, int w, int C8) {
@@ -194,5 +204,19 @@ extern "C" int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L,
     if (ni <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
     else if (ni <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
     else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
+    return finish();
+}
+
+extern "C" int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream) {
+    if (x == nullptr || y == nullptr || map == nullptr || rows <= 0 || C <= 0 || map->rw <= 0 || map->rh <= 0) return DWM_EINVAL;
+    if (C % 8 != 0 || rows % (map->rw * map->rh) != 0) return DWM_EUNSUPPORTED;
+    if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    PadMap pm;
+    pm.enabled = 1;
+    pm.rw = make_fastdiv((uint32_t)map->rw); pm.rh = make_fastdiv((uint32_t)map->rh);
+    pm.rpitch = map->rpitch; pm.ipitch = map->ipitch; pm.origin = map->origin;
+    const int64_t total = rows * (C / 8);
+    hipLaunchKernelGGL(pad_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, rows, C / 8, pm);
     return finish();
 }

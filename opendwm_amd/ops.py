@@ -67,6 +67,18 @@ class PaddedGrid:
         """row shift of tap (dy, dx), dy/dx in {-1,0,1}, in the order of a [N, 3, 3, C] weight"""
         return [(dy - 1) * (self.w + 2) + (dx - 1) for dy in range(3) for dx in range(3)]
 
+    def fill_stride2(self, m: "_lib.RowMap2D") -> None:
+        """map of the (h/2 x w/2) OUTPUT pixels of a stride-2 3x3 conv with diffusers' (0,1,0,1) padding onto
+        this grid: output (y, x) reads input rows (2y + dy, 2x + dx), dy, dx in 0..2, i.e. padded rows
+        (2y + 1 + dy, 2x + 1 + dx): origin = first interior row, taps shift by dy*(w+2) + dx."""
+        m.rw, m.rh = self.w // 2, self.h // 2
+        m.rpitch, m.ipitch = 2 * (self.w + 2), (self.h + 2) * (self.w + 2)
+        m.origin = self.w + 2 + 1
+        m.xstep = 2
+
+    def tap_shifts_stride2(self):
+        return [dy * (self.w + 2) + dx for dy in range(3) for dx in range(3)]
+
     def interior_index(self) -> torch.Tensor:
         """[pixels] int64 padded-row index of every compact pixel (host reference of the kernel's map)"""
         i = torch.arange(self.I)[:, None, None]
@@ -82,7 +94,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          blend: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
          rows_per_alpha: int = 1,
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
-         a_grid: Optional[PaddedGrid] = None, conv3x3: bool = False, c_grid: Optional[PaddedGrid] = None,
+         a_grid: Optional[PaddedGrid] = None, conv3x3: bool = False, stride2: bool = False,
+         c_grid: Optional[PaddedGrid] = None,
          rows: Optional[int] = None, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
     a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
@@ -95,7 +108,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if a_grid is not None:
         if a.shape[0] != a_grid.rows or a.shape[1] * (9 if conv3x3 else 1) != K:
             raise RuntimeError(f"gemm: padded A {tuple(a.shape)} does not match grid / weight {tuple(w.shape)}")
-        M = a_grid.pixels
+        M = a_grid.pixels // 4 if stride2 else a_grid.pixels
     else:
         M = a.shape[0] if rows is None else rows
         if a.shape[1] != K:
@@ -127,10 +140,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _chkvec(rms_w, "rms_w")
         g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
     if a_grid is not None:
-        a_grid.fill(g.a_map)
+        if stride2:
+            if not conv3x3 or a_grid.h % 2 or a_grid.w % 2:
+                raise RuntimeError("gemm: stride2 needs conv3x3 on an even-sized grid")
+            a_grid.fill_stride2(g.a_map)
+        else:
+            a_grid.fill(g.a_map)
         if conv3x3:
             g.ntaps, g.k_per_tap = 9, a.shape[1]
-            for t, sh in enumerate(a_grid.tap_shifts()):
+            for t, sh in enumerate(a_grid.tap_shifts_stride2() if stride2 else a_grid.tap_shifts()):
                 g.tap_shift[t] = sh
     if c_grid is not None:
         c_grid.fill(g.c_map)
@@ -438,6 +456,20 @@ def upsample2_padded(x: torch.Tensor, I: int, h: int, w: int, out: Optional[torc
         out = torch.zeros((g.rows, x.shape[1]), dtype=bf16, device=x.device)
     _lib.check(_lib.load().dwm_upsample2_padded(x.data_ptr(), out.data_ptr(), I, h, w, x.shape[1], _stream()),
                "dwm_upsample2_padded")
+    return out
+
+
+def pad_tokens(x: torch.Tensor, grid: PaddedGrid, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """compact token rows [grid.pixels, C] -> interior of a zero-bordered padded grid [grid.rows, C]."""
+    _chk2d(x, "x")
+    if not x.is_contiguous() or x.shape[0] != grid.pixels:
+        raise RuntimeError("pad_tokens: x must be contiguous [grid.pixels, C]")
+    if out is None:
+        out = torch.zeros((grid.rows, x.shape[1]), dtype=bf16, device=x.device)
+    m = _lib.RowMap2D()
+    grid.fill(m)
+    _lib.check(_lib.load().dwm_pad_tokens(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], C.byref(m), _stream()),
+               "dwm_pad_tokens")
     return out
 
 

@@ -5,8 +5,7 @@ dwm.functional.memory_efficient_split_call, src/dwm/functional.py:184-193).
 Module tree / state-dict keys follow diffusers 0.31.0 (decoder.conv_in, decoder.mid_block.resnets.N,
 decoder.mid_block.attentions.0.{group_norm,to_q,to_k,to_v,to_out.0}, decoder.up_blocks.N.resnets.M,
 decoder.up_blocks.N.upsamplers.0.conv, decoder.conv_norm_out, decoder.conv_out) so a released
-`vae/diffusion_pytorch_model.safetensors` loads with strict=False (encoder keys are ignored until
-the encoder is built).  Activations are token-major [I*H*W, C] bf16; every 3x3 convolution is an
+`vae/diffusion_pytorch_model.safetensors` loads with strict=True.  Activations are token-major [I*H*W, C] bf16; every 3x3 convolution is an
 implicit GEMM of dwm_gemm_bf16 over a zero-padded token grid; GroupNorm+SiLU, the nearest
 upsample and the mid-block softmax are HIP kernels (csrc/vae.hip)."""
 from __future__ import annotations
@@ -138,8 +137,58 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
 
 
+class _Downsampler(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=0)
+
+
+class _DownBlock(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, n_res: int, groups: int, eps: float, add_downsample: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_ch if j == 0 else out_ch, out_ch, groups, eps) for j in range(n_res)])
+        self.downsamplers = nn.ModuleList([_Downsampler(out_ch)]) if add_downsample else None
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels: int, latent_channels: int, block_out_channels, layers_per_block: int,
+                 groups: int, eps: float = 1e-6, mid_block_add_attention: bool = True):
+        super().__init__()
+        self.groups, self.eps = groups, eps
+        ch = list(block_out_channels)
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        downs, prev = [], ch[0]
+        for i, oc in enumerate(ch):
+            downs.append(_DownBlock(prev, oc, layers_per_block, groups, eps, add_downsample=i != len(ch) - 1))
+            prev = oc
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = _MidBlock(ch[-1], groups, eps, mid_block_add_attention)
+        self.conv_norm_out = nn.GroupNorm(groups, ch[-1], eps=eps)
+        self.conv_out = nn.Conv2d(ch[-1], 2 * latent_channels, 3, padding=1)
+
+
+class DiagonalGaussianDistribution:
+    """diffusers DiagonalGaussianDistribution over the encoder moments [I, 2*latent, h, w]."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        noise = torch.randn(self.mean.shape, generator=generator,
+                            device=self.mean.device if generator is None or generator.device.type != "cpu" else "cpu",
+                            dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
 class AutoencoderKL(nn.Module):
-    """decode(z)-only stand-in for diffusers.AutoencoderKL (SD 3.5 medium VAE defaults)."""
+    """encode / decode stand-in for diffusers.AutoencoderKL (SD 3.5 medium VAE defaults)."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 16,
                  block_out_channels=(128, 256, 512, 512), layers_per_block: int = 2, norm_num_groups: int = 32,
@@ -149,6 +198,10 @@ class AutoencoderKL(nn.Module):
         super().__init__()
         if use_post_quant_conv:
             raise NotImplementedError("post_quant_conv (SD 2.1 VAE) is not built yet")
+        if use_quant_conv:
+            raise NotImplementedError("quant_conv (SD 2.1 VAE) is not built yet")
+        self.encoder = Encoder(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups,
+                               mid_block_add_attention=mid_block_add_attention)
         self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups,
                                mid_block_add_attention=mid_block_add_attention)
         self.config = types.SimpleNamespace(scaling_factor=scaling_factor, shift_factor=shift_factor,
@@ -170,8 +223,47 @@ class AutoencoderKL(nn.Module):
             self._scratch[key] = buf
         return buf
 
-    def encode(self, x):
-        raise NotImplementedError("AutoencoderKL.encode is not built yet (DESIGN.md §0, row a12)")
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True, chunk: int = 8):
+        """x [I, 3, H, W] in [-1, 1] -> object with .latent_dist (sample() / mode()), as ctsd.py uses it
+        (ctsd.py:1213-1218 `.latent_dist.sample()`, :1689-1694 `.mode()`)."""
+        if not x.is_cuda:
+            raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
+        moments = torch.cat([self._encode_chunk(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)], 0)
+        dist = DiagonalGaussianDistribution(moments.float())
+        if return_dict:
+            return types.SimpleNamespace(latent_dist=dist)
+        return (dist,)
+
+    def _encode_chunk(self, x: torch.Tensor) -> torch.Tensor:
+        e = self.encoder
+        I, ic, H, W = x.shape
+        x = x.contiguous()
+        if x.dtype not in (torch.float32, bf16):
+            x = x.to(bf16)
+        scratch = self._pad_scratch
+        grid = PaddedGrid(I, H, W)
+        tok = ops.unshuffle_tokens(x, 1, 64 * ((ic + 63) // 64))
+        xp = ops.pad_tokens(tok, grid, out=scratch(grid, tok.shape[1]))
+        h = ops.gemm(xp, _conv3_w(e.conv_in, tok.shape[1]), _bf(e.conv_in.bias), a_grid=grid, conv3x3=True)
+        for db in e.down_blocks:
+            for res in db.resnets:
+                h = res.run(h, grid, scratch)
+            if db.downsamplers is not None:
+                ds = db.downsamplers[0]
+                if grid.h % 2 or grid.w % 2:
+                    raise NotImplementedError("VAE encoder needs even feature-map sizes at every downsample")
+                hp = ops.pad_tokens(h, grid, out=scratch(grid, h.shape[1]))
+                h = ops.gemm(hp, _conv3_w(ds.conv), _bf(ds.conv.bias), a_grid=grid, conv3x3=True, stride2=True)
+                grid = PaddedGrid(I, grid.h // 2, grid.w // 2)
+        h = e.mid_block.resnets[0].run(h, grid, scratch)
+        for attn in e.mid_block.attentions:
+            h = attn.run(h, I, grid.h * grid.w)
+        h = e.mid_block.resnets[1].run(h, grid, scratch)
+        hp = ops.groupnorm_silu(h, I, grid.h * grid.w, _bf(e.conv_norm_out.weight), _bf(e.conv_norm_out.bias), e.groups,
+                                e.eps, out=scratch(grid, h.shape[1]), out_grid=grid)
+        m = ops.gemm(hp, _conv3_w(e.conv_out), _bf(e.conv_out.bias), a_grid=grid, conv3x3=True)      # [I*P, 2*latent]
+        return m.reshape(I, grid.h, grid.w, -1).permute(0, 3, 1, 2).contiguous()
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False, chunk: int = 8):
@@ -194,8 +286,7 @@ class AutoencoderKL(nn.Module):
         grid = PaddedGrid(I, h, w)
         scratch = self._pad_scratch
         tok = ops.unshuffle_tokens(z, 1, 64 * ((lc + 63) // 64))                  # [I*h*w, 64], zero padded channels
-        zp = scratch(grid, tok.shape[1])
-        zp[grid.interior_index().to(zp.device)] = tok
+        zp = ops.pad_tokens(tok, grid, out=scratch(grid, tok.shape[1]))
         x = ops.gemm(zp, _conv3_w(d.conv_in, tok.shape[1]), _bf(d.conv_in.bias), a_grid=grid, conv3x3=True)
         x = d.mid_block.resnets[0].run(x, grid, scratch)
         for attn in d.mid_block.attentions:

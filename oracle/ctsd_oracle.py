@@ -494,6 +494,29 @@ def vae_decode(sd: SD, vcfg: dict, z: Tensor) -> Tensor:
     return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
 
 
+def vae_encode_moments(sd: SD, vcfg: dict, x: Tensor) -> Tensor:
+    """``AutoencoderKL.encode`` -> ``Encoder.forward`` (no quant_conv): conv_in -> 4 DownEncoderBlock2D
+    (2 resnets [+ Downsample2D: F.pad(0,1,0,1) + 3x3 stride-2 conv]) -> mid -> GroupNorm -> SiLU -> conv_out;
+    returns the moments [I, 2*latent, h, w] (mean ‖ logvar) of the DiagonalGaussianDistribution
+    (ctsd.py:1213-1218 samples it, :1689-1694 takes the mode)."""
+    g, eps = vcfg.get("norm_num_groups", 32), 1e-6
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    nb = len(vcfg["block_out_channels"])
+    for i in range(nb):
+        for j in range(vcfg.get("layers_per_block", 2)):
+            h = _vae_resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, g, eps)
+        if i != nb - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"],
+                         sd[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"], stride=2)
+    h = _vae_resnet(sd, "encoder.mid_block.resnets.0", h, g, eps)
+    if vcfg.get("mid_block_add_attention", True):
+        h = _vae_attention(sd, "encoder.mid_block.attentions.0", h, g, eps)
+    h = _vae_resnet(sd, "encoder.mid_block.resnets.1", h, g, eps)
+    h = F.silu(F.group_norm(h, g, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], eps))
+    return F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+
+
 def vae_decoder_shapes(vcfg: dict) -> Dict[str, tuple]:
     ch = list(vcfg["block_out_channels"])
     lc, oc = vcfg.get("latent_channels", 16), vcfg.get("out_channels", 3)
@@ -530,6 +553,25 @@ def vae_decoder_shapes(vcfg: dict) -> Dict[str, tuple]:
         prev = o
     norm("decoder.conv_norm_out", ch[0])
     conv("decoder.conv_out", ch[0], oc, 3)
+    # encoder
+    conv("encoder.conv_in", vcfg.get("in_channels", 3), ch[0], 3)
+    prev = ch[0]
+    for i, o in enumerate(ch):
+        for j in range(vcfg.get("layers_per_block", 2)):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else o, o)
+        if i != len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", o, o, 3)
+        prev = o
+    resnet("encoder.mid_block.resnets.0", ch[-1], ch[-1])
+    resnet("encoder.mid_block.resnets.1", ch[-1], ch[-1])
+    if vcfg.get("mid_block_add_attention", True):
+        a = "encoder.mid_block.attentions.0"
+        norm(a + ".group_norm", ch[-1])
+        for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+            S[f"{a}.{nm}.weight"] = (ch[-1], ch[-1])
+            S[f"{a}.{nm}.bias"] = (ch[-1],)
+    norm("encoder.conv_norm_out", ch[-1])
+    conv("encoder.conv_out", ch[-1], 2 * lc, 3)
     return S
 
 

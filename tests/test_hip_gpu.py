@@ -463,6 +463,28 @@ def test_vae_decode_vs_oracle(dev):
     assert out.shape == (3, 3, 64, 64) and e < TOL_MODEL
 
 
+def test_vae_encode_vs_oracle(dev):
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
+    sd = _bf16_round_sd(O.make_vae_state_dict(vcfg, 0))
+    vae = AutoencoderKL(**vcfg)
+    missing, unexpected = vae.load_state_dict(sd)
+    assert not missing and not unexpected
+    vae = vae.to(dev).to(bf16).eval()
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(3, 3, 64, 64, generator=g) * 2 - 1).to(bf16).float()
+    ref = O.vae_encode_moments(sd, vcfg, x)
+    dist = vae.encode(x.to(dev), chunk=2).latent_dist
+    e = rel_err(dist.parameters, ref)
+    _log("vae_encode", rel=e, shape=list(dist.parameters.shape))
+    assert dist.parameters.shape == (3, 32, 8, 8) and e < TOL_MODEL
+    assert torch.equal(dist.mode(), dist.mean) and dist.sample().shape == (3, 16, 8, 8)
+    # encode -> decode round trip runs end to end at the pipeline's scaling (ctsd.py:1216-1218,1636-1637)
+    lat = (dist.mode() - vae.config.shift_factor) * vae.config.scaling_factor
+    img = vae.decode(lat / vae.config.scaling_factor + vae.config.shift_factor)[0]
+    assert img.shape == (3, 3, 64, 64) and torch.isfinite(img.float()).all()
+
+
 # ----------------------------------------------------------------------- blocks / model
 def _bf16_round_sd(sd):
     return {k: v.to(bf16).float() for k, v in sd.items()}
