@@ -205,12 +205,35 @@ class AutoencoderKL(nn.Module):
         self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups,
                                mid_block_add_attention=mid_block_add_attention)
         self.config = types.SimpleNamespace(scaling_factor=scaling_factor, shift_factor=shift_factor,
-                                            latent_channels=latent_channels, block_out_channels=tuple(block_out_channels))
+                                            latent_channels=latent_channels, block_out_channels=tuple(block_out_channels),
+                                            in_channels=in_channels, out_channels=out_channels,
+                                            layers_per_block=layers_per_block, norm_num_groups=norm_num_groups)
         self._scratch: Dict[Tuple[int, int], torch.Tensor] = {}
 
     @property
     def dtype(self):
         return self.decoder.conv_in.weight.dtype
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, subfolder: Optional[str] = None, **kwargs):
+        """Local-directory equivalent of diffusers' ModelMixin.from_pretrained as ctsd.py calls it
+        (`vae_type.from_pretrained(path, subfolder="vae")`, src/dwm/pipelines/ctsd.py:953-959; the class is
+        chosen by common_config["vae"]): reads <path>/<subfolder>/config.json and
+        diffusion_pytorch_model.safetensors (or .bin)."""
+        import json
+        import os
+        root = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
+        with open(os.path.join(root, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        model = cls(**cfg)
+        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(root, "diffusion_pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(sd)
+        return model.eval()
 
     def _pad_scratch(self, grid: PaddedGrid, channels: int) -> torch.Tensor:
         """zero-bordered padded buffers, reused (every producer rewrites the whole interior)."""

@@ -285,6 +285,42 @@ def test_oracle_image_adapter_shapes(small_cfg):
         assert k in sd
 
 
+def test_vae_from_pretrained_layout_and_keys(tmp_path):
+    """The VAE drop-in loads a diffusers-style directory (config.json + safetensors) exactly as
+    ctsd.py:953-959 calls it, with the diffusers AutoencoderKL key names."""
+    import json
+    from safetensors.torch import save_file
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(in_channels=3, out_channels=3, latent_channels=16, block_out_channels=[64, 64, 128, 128],
+                layers_per_block=2, norm_num_groups=16, scaling_factor=1.5305, shift_factor=0.0609,
+                use_quant_conv=False, use_post_quant_conv=False)
+    sd = O.make_vae_state_dict(vcfg, 0)
+    d = tmp_path / "vae"
+    d.mkdir()
+    json.dump({**vcfg, "_class_name": "AutoencoderKL", "_diffusers_version": "0.31.0"}, open(d / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    vae = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    got = vae.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert vae.config.scaling_factor == 1.5305 and len(vae.config.block_out_channels) == 4
+    for k in ("decoder.mid_block.attentions.0.to_q.weight", "decoder.up_blocks.2.resnets.0.conv_shortcut.weight",
+              "decoder.up_blocks.0.upsamplers.0.conv.bias", "encoder.down_blocks.1.downsamplers.0.conv.weight",
+              "encoder.conv_out.bias", "decoder.conv_norm_out.weight"):
+        assert k in sd
+    with pytest.raises(RuntimeError):
+        vae.decode(torch.zeros(1, 16, 8, 8))          # CPU call must fail loudly
+
+
+def test_oracle_vae_round_trip_shapes():
+    vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
+    sd = O.make_vae_state_dict(vcfg, 0)
+    x = torch.rand(2, 3, 32, 48) * 2 - 1
+    mom = O.vae_encode_moments(sd, vcfg, x)
+    assert mom.shape == (2, 32, 4, 6)
+    img = O.vae_decode(sd, vcfg, mom[:, :16])
+    assert img.shape == x.shape
+
+
 # ---------------------------------------------------------------------------- C ABI
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
