@@ -141,6 +141,17 @@ class KernelTimer:
         return out
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (scripts/pmc_traffic.sh -> profiles/r1_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
+    Counters cannot be collected inside the timed run, so the bench line cites the committed measurement."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(threads: int):
     """The fp32 CPU oracle (the restated reference path) on the host cores, on a bounded sample of
     the same workload; reported in denoise-steps/s by FLOP ratio."""
@@ -243,7 +254,9 @@ def main():
                        "variant": ("text+layout (ImageAdapter, pointwise temporal)" + ("" if not args.no_adapter_cache else ", adapter recomputed every step")) if args.layout else "text (rowwise temporal)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_bf16_kernel"),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r1_pmc_traffic.json)",
+                         "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
             "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": at.get("tflops"),

@@ -1,0 +1,33 @@
+#!/bin/bash
+# HBM traffic of the bench's kernels from the TCC counters (separate --pmc passes, MI355X_MICROARCH.md §HBM):
+#   bytes_read  = FETCH_SIZE [KiB] * 1024 * 2   (gfx950: FETCH_SIZE reports half the bytes of wide streaming reads)
+#   bytes_write = WRITE_SIZE [KiB] * 1024
+# usage: scripts/pmc_traffic.sh <tag>   -> gpurun_out/<tag>/pmc_traffic.json
+TAG=${1:-r1}
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmct_${TAG}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+done
+python - "$OUT" /tmp/pmct_${TAG}_FETCH_SIZE /tmp/pmct_${TAG}_WRITE_SIZE <<'PY'
+import csv, glob, json, sys, collections
+out, dirs = sys.argv[1], sys.argv[2:]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+for d in dirs:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            k = "gemm_bf16_kernel" if "gemm_bf16_kernel" in k else "attn_fwd_kernel" if "attn_fwd_kernel" in k else "layernorm_kernel" if "layernorm_kernel" in k else None
+            if k is None: continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "FETCH_SIZE": calls[k] += 1
+res = {}
+for k, d in agg.items():
+    n = max(calls[k], 1)
+    rd, wr = d.get("FETCH_SIZE", 0) * 1024 * 2, d.get("WRITE_SIZE", 0) * 1024
+    res[k] = {"launches": n, "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
+              "hbm_bytes_per_launch": (rd + wr) / n, "note": "FETCH_SIZE KiB*1024*2 (gfx950 wide-load correction) + WRITE_SIZE KiB*1024; 2 bench steps (1 warmup + 1)"}
+json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
