@@ -214,6 +214,13 @@ int dwm_unpatchify(const void* x, int64_t ldx, int64_t I, int32_t C, int32_t h, 
 int dwm_cfg_euler_step(const void* pred, float* latents, void* model_in, int64_t n,
                        float guidance, float dsigma, void* stream);
 
+/* the same with a per-group step dsigma[i / group_elems] (group = one [C,H,W] frame latent): the
+ * per-frame scheduler of the diffusion-forcing mode, FlowMatchEulerDiscreteScheduler.step_by_indices
+ * (src/dwm/schedulers/temporal_independent.py:176-197) fused with the `torch.where(in_schedule_range, ...)`
+ * of ctsd.py:1565-1572 (pass dsigma = 0 for frames outside the schedule range). */
+int dwm_cfg_euler_step_grouped(const void* pred, float* latents, void* model_in, int64_t n, float guidance,
+                               const float* dsigma, int64_t group_elems, void* stream);
+
 /* torch.nn.PixelUnshuffle(r) of x [I, C, H, W] (fp32 if x_is_f32 else bf16), written token-major:
  * out bf16 [I*(H/r)*(W/r), ldo >= C*r*r], column = (c*r + dy)*r + dx, zero padded to ldo
  * (src/dwm/models/adapters.py:42). */

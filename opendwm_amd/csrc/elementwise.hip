@@ -70,9 +70,10 @@ unpatchify_kernel(const bf16_t* __restrict__ x, int64_t ldx, int64_t I, int C, i
 
 __global__ void __launch_bounds__(256)
 cfg_euler_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat, bf16_t* __restrict__ model_in,
-                 int64_t n, float guidance, float dsigma) {
+                 int64_t n, float guidance, float dsigma, const float* __restrict__ dsigma_group, int64_t group_elems) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
+    if (dsigma_group != nullptr) dsigma = dsigma_group[i / group_elems];     // per-frame step (diffusion forcing)
     float u[4], c[4];
     unpack4(*(const uint2*)(pred + i), u);
     unpack4(*(const uint2*)(pred + n + i), c);
@@ -212,7 +213,18 @@ extern "C" int dwm_cfg_euler_step(const void* pred, float* latents, void* model_
     if (n % 4 != 0 || (((uintptr_t)pred) & 7u) || !dwm_aligned16(latents) || (model_in && (((uintptr_t)model_in) & 7u)))
         return DWM_EALIGN;
     hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, latents, (bf16_t*)model_in, n, guidance, dsigma);
+                       (const bf16_t*)pred, latents, (bf16_t*)model_in, n, guidance, dsigma, (const float*)nullptr, (int64_t)1);
+    return finish();
+}
+
+extern "C" int dwm_cfg_euler_step_grouped(const void* pred, float* latents, void* model_in, int64_t n, float guidance,
+                                          const float* dsigma, int64_t group_elems, void* stream) {
+    if (pred == nullptr || latents == nullptr || dsigma == nullptr || n <= 0 || group_elems <= 0) return DWM_EINVAL;
+    if (n % 4 != 0 || group_elems % 4 != 0 || n % group_elems != 0 || (((uintptr_t)pred) & 7u) || !dwm_aligned16(latents) ||
+        (model_in && (((uintptr_t)model_in) & 7u)))
+        return DWM_EALIGN;
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, latents, (bf16_t*)model_in, n, guidance, 0.f, dsigma, group_elems);
     return finish();
 }
 

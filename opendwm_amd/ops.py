@@ -374,8 +374,8 @@ def unpatchify(x: torch.Tensor, I: int, Cc: int, h: int, w: int, p: int) -> torc
     return out
 
 
-def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, dsigma: float,
-                   model_in: Optional[torch.Tensor] = None) -> None:
+def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, dsigma,
+                   model_in: Optional[torch.Tensor] = None, group_elems: int = 0) -> None:
     """latents(fp32, in place) += dsigma * (u + g (c - u)) with pred = [uncond; cond] bf16."""
     n = latents.numel()
     if pred.dtype != bf16 or pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda:
@@ -384,6 +384,12 @@ def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, d
         raise RuntimeError("cfg_euler_step: latents must be contiguous fp32")
     if model_in is not None and (model_in.dtype != bf16 or model_in.numel() != 2 * n or not model_in.is_contiguous()):
         raise RuntimeError("cfg_euler_step: model_in must be contiguous bf16 [2, n]")
+    if torch.is_tensor(dsigma):          # per-frame steps [n / group_elems] fp32 (diffusion forcing)
+        if dsigma.dtype != torch.float32 or not dsigma.is_cuda or not dsigma.is_contiguous() or dsigma.numel() * group_elems != n:
+            raise RuntimeError("cfg_euler_step: dsigma must be a contiguous fp32 device tensor with n / group_elems entries")
+        _lib.check(_lib.load().dwm_cfg_euler_step_grouped(pred.data_ptr(), latents.data_ptr(), _p(model_in), n, float(guidance),
+                                                          dsigma.data_ptr(), group_elems, _stream()), "dwm_cfg_euler_step_grouped")
+        return
     _lib.check(_lib.load().dwm_cfg_euler_step(pred.data_ptr(), latents.data_ptr(), _p(model_in), n,
                                               float(guidance), float(dsigma), _stream()), "dwm_cfg_euler_step")
 

@@ -613,24 +613,45 @@ def flow_match_sigmas(num_inference_steps: int, shift: float = 3.0,
 
 
 def denoise(sd: SD, cfg: dict, latents: Tensor, conditions: dict, steps: int,
-            guidance_scale: float, shift: float = 3.0, stop: Optional[int] = None):
-    """``inference_pipeline`` hot loop (ctsd.py:1496-1575), full-sequence mode with
-    classifier-free guidance.  ``conditions`` hold the CFG-doubled tensors
-    ([2B,...], uncond first, as get_conditions builds them).  latents fp32
-    [B,T,V,C,H,W]."""
+            guidance_scale: float, shift: float = 3.0, stop: Optional[int] = None, start: int = 0,
+            image_latents: Optional[Tensor] = None, reference_frame_count: int = 0,
+            diffusion_forcing: bool = False, take_time: int = 0, clear_reference_frame_count: int = 0):
+    """``inference_pipeline`` hot loop (ctsd.py:1496-1575) with classifier-free guidance and the
+    FlowMatch-Euler scheduler, in its three modes: full-sequence; reference-frame injection
+    (:1514-1526, :1623-1627); diffusion forcing with per-frame timestep indices and
+    ``step_by_indices`` (:1498-1507, :1554-1572; schedulers/temporal_independent.py:176-197).
+    ``conditions`` hold the CFG-doubled tensors ([2B,...], uncond first).  latents fp32 [B,T,V,C,H,W]."""
     sigmas = flow_match_sigmas(steps, shift)
     timesteps = sigmas[:-1] * 1000
-    lat = latents.float()
+    if diffusion_forcing and image_latents is not None:
+        lat = image_latents.float()
+        image_latents = None
+    else:
+        lat = latents.float()
     B, T, V = lat.shape[:3]
-    for i in range(steps if stop is None else stop):
-        t = timesteps[i]
-        ts = t.reshape(1, 1, 1).repeat(B, T, V)
-        x = torch.cat([lat, lat])
-        tt = torch.cat([ts, ts])
-        pred = dit_forward(sd, cfg, x, tt, **conditions)
+    spi = steps // (T - clear_reference_frame_count) if diffusion_forcing else None
+    for i in range(start, steps if stop is None else stop):
+        if diffusion_forcing:
+            idx = torch.tensor([min(i - take_time * spi, max(0, i - j * spi)) for j in range(T)])
+            ts = timesteps[idx].view(1, T, 1).repeat(B, 1, V)
+        else:
+            ts = timesteps[i].reshape(1, 1, 1).repeat(B, T, V)
+        x = lat
+        if not diffusion_forcing and image_latents is not None:
+            x = torch.cat([image_latents[:, :reference_frame_count].float(), lat[:, reference_frame_count:]], 1)
+            ts = torch.cat([torch.zeros(B, reference_frame_count, V), ts[:, reference_frame_count:]], 1)
+        pred = dit_forward(sd, cfg, torch.cat([x, x]), torch.cat([ts, ts]), **conditions)
         u, cnd = pred.chunk(2)
         noise_pred = u + guidance_scale * (cnd - u)
-        lat = lat + (sigmas[i + 1] - sigmas[i]) * noise_pred.float()
+        if diffusion_forcing:
+            ii = idx.view(1, T, 1, 1, 1, 1)
+            staging = lat + (sigmas[ii + 1] - sigmas[ii]) * noise_pred.float()
+            in_range = torch.tensor([i - j * spi >= 0 for j in range(T)]).view(1, T, 1, 1, 1, 1)
+            lat = torch.where(in_range, staging, lat)
+        else:
+            lat = lat + (sigmas[i + 1] - sigmas[i]) * noise_pred.float()
+    if not diffusion_forcing and image_latents is not None:
+        lat = torch.cat([image_latents[:, :reference_frame_count].float(), lat[:, reference_frame_count:]], 1)
     return lat
 
 

@@ -594,6 +594,34 @@ def test_denoise_two_steps_vs_golden(dev, small_cfg):
     assert out.dtype == torch.float32 and e < TOL_MODEL
 
 
+@pytest.mark.parametrize("mode", ["reference_frames", "diffusion_forcing"])
+def test_denoise_modes_vs_oracle(dev, small_cfg, mode):
+    """Reference-frame injection and diffusion forcing of inference_pipeline (ctsd.py:1498-1572)."""
+    from opendwm_amd.pipeline import CTSDDenoiser
+    sd = _bf16_round_sd(O.make_state_dict(small_cfg, 0))
+    m = _hip_model(small_cfg, sd, dev)
+    inp = small_inputs(small_cfg, 0)
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 3, 3, 16, 8, 12, generator=g)
+    img = torch.randn(1, 3, 3, 16, 8, 12, generator=g)
+    if mode == "reference_frames":
+        kw = dict(image_latents=img, reference_frame_count=1)
+        steps, stop = 4, 2
+    else:
+        kw = dict(image_latents=img, diffusion_forcing=True, take_time=0)
+        steps, stop = 6, 3
+    ref = O.denoise(sd, small_cfg, lat, cond, steps=steps, guidance_scale=4.0, stop=stop, **kw)
+    den = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=steps)
+    kwd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    out = den.run(lat.to(dev), to_dev(cond, dev), stop=stop, **kwd)
+    e = rel_err(out, ref)
+    _log("denoise_mode", mode=mode, rel=e)
+    assert e < TOL_MODEL
+    if mode == "reference_frames":
+        assert torch.equal(out[:, :1].cpu(), img[:, :1])
+
+
 def test_full_width_block_stack_vs_oracle_on_device(dev):
     """BASELINE config-3 token geometry (6 views x 16 frames x 32x56 latents, CFG batch 2,
     d = 1536, 24 heads, 154 text tokens) with the first 6 layers of the schedule (dual blocks,

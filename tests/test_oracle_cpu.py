@@ -48,6 +48,21 @@ def test_oracle_denoise_matches_golden(small_cfg):
     assert rel_err(out, gold["latents_out"]) < 1e-5
 
 
+def test_oracle_denoise_modes_reduce_to_plain(small_cfg):
+    """reference_frame_count=0 and take_time large reduce the mode code paths to the plain loop."""
+    sd = O.make_state_dict(small_cfg, seed=0)
+    inp = small_inputs(small_cfg, seed=0)
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, 3, 3, 16, 8, 12, generator=g)
+    a = O.denoise(sd, small_cfg, lat, cond, steps=3, guidance_scale=4.0, stop=1)
+    b = O.denoise(sd, small_cfg, lat, cond, steps=3, guidance_scale=4.0, stop=1, image_latents=lat, reference_frame_count=0)
+    assert torch.equal(a, b)
+    # diffusion forcing, step 0: only frame 0 is in schedule range, every frame is evaluated at timestep index 0
+    c = O.denoise(sd, small_cfg, lat, cond, steps=3, guidance_scale=4.0, stop=1, diffusion_forcing=True)
+    assert torch.equal(c[:, 1:], lat[:, 1:]) and rel_err(c[:, :1], a[:, :1]) < 1e-5
+
+
 # ------------------------------------------------------------- oracle internal cross-checks
 def test_sdpa_matches_torch_and_fp64():
     g = torch.Generator().manual_seed(1)
