@@ -53,7 +53,6 @@ struct AttnParams {
     int mask_mode;
     const uint8_t* mask;
     int mask_G, group_size, p_per_mask;
-    int dbg;                 // ablation bits (benchmarks only): 1 no in-loop loads, 2 no exp, 4 no LDS restage
     float inv_group_size, inv_G;
     RowMap rm;
 };
@@ -205,7 +204,7 @@ attn_fwd_kernel(const AttnParams P) {
     for (int kt = 0; kt < nkt; ++kt) {
         // unconditional prefetch keeps the loop body branch-free: past the end it re-fetches the
         // last tile (addresses are clamped) into the buffer nobody reads again
-        if (!(P.dbg & 1)) DWM_LOAD_TILE(kt + 1 < nkt ? kt + 1 : kt);
+        DWM_LOAD_TILE(kt + 1 < nkt ? kt + 1 : kt);
 
         const char* kl = smem + (kt & 1) * STAGE_BYTES;
         const char* vl = kl + K_TILE_BYTES;
@@ -296,7 +295,7 @@ attn_fwd_kernel(const AttnParams P) {
                     float pv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        pv[e] = (P.dbg & 2) ? st[t][j][s2 * 8 + e] : __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][j][s2 * 8 + e], c, mneg));
+                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][j][s2 * 8 + e], c, mneg));
                         ps[e & 3] += pv[e];
                     }
                     const uint4 pk = pack8(pv);
@@ -323,10 +322,8 @@ attn_fwd_kernel(const AttnParams P) {
             }
         __builtin_amdgcn_s_setprio(0);
 
-        if (!(P.dbg & 4)) {
-            DWM_WRITE_TILE((kt + 1) & 1);
-            __syncthreads();
-        }
+        DWM_WRITE_TILE((kt + 1) & 1);
+        __syncthreads();
     }
 #undef DWM_LOAD_TILE
 #undef DWM_WRITE_TILE
@@ -418,9 +415,8 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     for (int i = 0; i < 3; ++i) P.rm.lstride[i] = a->lstride[i];
 
     // variant: 0 = auto; 1 / 2 = 32 / 64 queries per wave (128 / 256 per workgroup)
-    P.dbg = (a->variant >> 8) & 15;
     int qt = a->variant & 15;
-    if (qt == 0) qt = L > 128 ? 2 : 1;
+    if (qt == 0) qt = 1;   // 32 queries per wave (3 workgroups per CU) measured faster in the full step than 64
     if (qt != 1 && qt != 2) return DWM_EINVAL;
     const int qblock = qt * 128;
     P.nqb = (int)((L + qblock - 1) / qblock);

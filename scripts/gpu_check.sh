@@ -16,7 +16,7 @@ cp gpurun_out/gpu_parity.log $OUT/gpu_parity.log 2>/dev/null
 echo "== smoke"
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -5 $OUT/smoke.log
 echo "== bench"
-timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/bench.log; tail -5 $OUT/bench.log
+timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/bench.log; tail -5 $OUT/bench.log
 echo "== rocprof"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1)
 find /tmp/prof_$TAG -name "*stats*" | head

@@ -99,8 +99,6 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     if "attn" in what:
         bench_attn([1, 2])
-    if "attn_ablate" in what:
-        bench_attn([1, 1 + 256, 1 + 512, 1 + 1024, 1 + 256 + 1024, 1 + 256 + 512 + 1024])
     if "gemm" in what:
         bench_gemm()
     if "ln" in what:
