@@ -68,6 +68,39 @@ DWM_DEVINL int64_t seg0_row(const RowMap& rm, int64_t base, int l) {
     const uint32_t hi = fdiv(q0, rm.ldiv1), mid = q0 - hi * rm.ldiv1.d;
     return base + (int64_t)lo * rm.lstride[0] + (int64_t)mid * rm.lstride[1] + (int64_t)hi * rm.lstride[2];
 }
+DWM_DEVINL float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // fmaxf() adds a canonicalising v_max per MFMA output
+    return r;
+}
+// max over the 32 scores a lane holds for one query (two 32-key sub-tiles), combined with the
+// partner lane (lane ^ 32) that holds the other keys of the same query
+DWM_DEVINL float tile_max32(const f32x16& s0, const f32x16& s1) {
+    float mxa = max3f(s0[0], s0[1], s0[2]), mxb = max3f(s0[3], s0[4], s0[5]);
+    float mxc = max3f(s1[0], s1[1], s1[2]), mxd = max3f(s1[3], s1[4], s1[5]);
+#pragma unroll
+    for (int r = 6; r < 14; r += 4) {
+        mxa = max3f(mxa, s0[r], s0[r + 1]);
+        mxb = max3f(mxb, s0[r + 2], s0[r + 3]);
+        mxc = max3f(mxc, s1[r], s1[r + 1]);
+        mxd = max3f(mxd, s1[r + 2], s1[r + 3]);
+    }
+    mxa = max3f(mxa, s0[14], s0[15]);
+    mxc = max3f(mxc, s1[14], s1[15]);
+    const float mx = max3f(max3f(mxa, mxb, mxc), mxd, -INFINITY);
+    return max3f(mx, __shfl_xor(mx, 32, 64), -INFINITY);
+}
+// 8 bf16 * c -> 8 bf16 (folds softmax scale * log2(e) into the Q fragments)
+DWM_DEVINL bf16x8 scale_frag(const bf16x8& v, float c) {
+    const uint4 u = *reinterpret_cast<const uint4*>(&v);
+    float f[8];
+    unpack8(u, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] *= c;
+    const uint4 o = pack8(f);
+    return *reinterpret_cast<const bf16x8*>(&o);
+}
+
 // MASK: 0 none, 1 group mask, 2 dense byte mask.  NW = 4 waves (256 threads).
 // occupancy target: 3 workgroups (waves per SIMD) for 32 queries/wave, 2 for 64 queries/wave
 template <int QT, int MASK>
@@ -121,7 +154,7 @@ attn_fwd_kernel(const AttnParams P) {
         if (lqc < L0) optr[t] = P.o0 + seg0_row(P.rm, seg0_base(P.rm, prob), lqc) * P.ldo0 + hoff;
         else optr[t] = P.o1 + ((int64_t)prob * P.L1 + (lqc - L0)) * P.ldo1 + hoff;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *(const bf16x8*)(qptr + ks * 16 + half * 8);
+        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = scale_frag(*(const bf16x8*)(qptr + ks * 16 + half * 8), P.scale_log2);
         gbits[t] = 0xffffffffu;
         dense_row[t] = nullptr;
         if (MASK == 1) {
@@ -169,12 +202,18 @@ attn_fwd_kernel(const AttnParams P) {
         *(uint4*)(vl_ + vw1) = vr1;                                                         \
     } while (0)
 
-    f32x16 ot[QT][2];
-    float m_run[QT], l_run[QT];          // running max (already multiplied by scale_log2) and partial row sum
+    // Softmax bookkeeping in the exponent domain: Q is pre-multiplied by scale*log2(e) and the S MFMAs
+    // start from C = -m (negm holds -m_run in all 16 registers), so the accumulator already is
+    // s*c - m and the exponentials need no per-score multiply-add.
+    f32x16 ot[QT][2], negm[QT];
+    float l_run[QT];
+    bool mvalid[QT];                     // m_run has been set from a finite score
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = -1e30f;
         l_run[t] = 0.f;
+        mvalid[t] = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[t][r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -186,7 +225,6 @@ attn_fwd_kernel(const AttnParams P) {
     // of the group supplies the address of V[key0 + (u >> 2)][.. + 4 (u & 3)] (8 bytes) and receives
     // column u: elements V[key0 + 0..3][16 g + u]
     const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
-    const float c = P.scale_log2;
     int vra[2], vrb[2];                   // per d-tile byte offsets of the two tr reads at step s = 0
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
@@ -211,7 +249,6 @@ attn_fwd_kernel(const AttnParams P) {
 
         // ---- S^T = K Q^T for two 32-key sub-tiles (K fragments shared by the QT query tiles)
         f32x16 st[QT][2];
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -220,7 +257,7 @@ attn_fwd_kernel(const AttnParams P) {
                 const bf16x8 kf = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], ks == 0 ? zero16 : st[t][j], 0, 0, 0);
+                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], ks == 0 ? negm[t] : st[t][j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
 
@@ -262,47 +299,41 @@ attn_fwd_kernel(const AttnParams P) {
         bf16x8 pf[QT][4];                      // B-operand fragments, step s = 2*j + s2
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            // 4 independent max chains (ILP) instead of one 32-deep chain
-            float mxa = fmaxf(st[t][0][0], st[t][0][1]), mxb = fmaxf(st[t][0][2], st[t][0][3]);
-            float mxc = fmaxf(st[t][1][0], st[t][1][1]), mxd = fmaxf(st[t][1][2], st[t][1][3]);
-#pragma unroll
-            for (int r = 4; r < 16; r += 4) {
-                mxa = fmaxf(mxa, fmaxf(st[t][0][r], st[t][0][r + 1]));
-                mxb = fmaxf(mxb, fmaxf(st[t][0][r + 2], st[t][0][r + 3]));
-                mxc = fmaxf(mxc, fmaxf(st[t][1][r], st[t][1][r + 1]));
-                mxd = fmaxf(mxd, fmaxf(st[t][1][r + 2], st[t][1][r + 3]));
-            }
-            float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;          // c > 0: max commutes with the scale
+            const float mx = tile_max32(st[t][0], st[t][1]);     // relative to the running max
             // deferred rescale: keep the old running max while the new one exceeds it by < 2^6
-            // (P <= 64, exact in the fp32 sums; bf16 P keeps its relative precision)
-            if (!__all(mx <= m_run[t] + 6.f)) {
-                const float m_new = fmaxf(m_run[t], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-                m_run[t] = m_new;
+            // (P <= 64, exact in the fp32 sums; bf16 P keeps its relative precision); the first
+            // finite score of a row always sets it
+            const bool finite = mx > -INFINITY;
+            if (__any((mx > 6.f) || (!mvalid[t] && finite))) {
+                const float delta = mvalid[t] ? fmaxf(mx, 0.f) : (finite ? mx : 0.f);
+                const float alpha = mvalid[t] ? __builtin_amdgcn_exp2f(-delta) : 0.f;   // nothing accumulated before the first finite score
+                mvalid[t] = mvalid[t] || finite;
                 l_run[t] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[t][r] -= delta;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[t][j][r] -= delta;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ot[t][i][r] *= alpha;
             }
-            const float mneg = -m_run[t];
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};          // 4 independent partial row sums (ILP)
+            f32x2 ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};     // packed-fp32 partial row sums (v_pk_add_f32)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float pv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][j][s2 * 8 + e], c, mneg));
-                        ps[e & 3] += pv[e];
-                    }
+                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(st[t][j][s2 * 8 + e]);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) ps2[(e >> 1) & 1] += (f32x2){pv[e], pv[e + 1]};
                     const uint4 pk = pack8(pv);
                     pf[t][j * 2 + s2] = *reinterpret_cast<const bf16x8*>(&pk);
                 }
-            const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            l_run[t] += psum;
+            l_run[t] += (ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]);
         }
 
         // ---- O^T += V^T P^T   (V fragments shared by the QT query tiles)

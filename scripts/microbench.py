@@ -98,7 +98,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["attn", "gemm", "ln"]
     print(torch.cuda.get_device_name(0))
     if "attn" in what:
-        bench_attn([1, 2])
+        bench_attn([1])
     if "gemm" in what:
         bench_gemm()
     if "ln" in what:
