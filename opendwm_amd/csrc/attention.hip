@@ -14,9 +14,11 @@
 // K tile in LDS: [64 keys][8 x 16-B chunks], chunk ^= (key >> 1) & 7 (conflict-free
 // ds_read_b128 fragments).  V tile: row-major like K, chunk ^= ((key >> 1) & 1) << 2, its
 // (transposed) fragments fetched with the gfx950 transposing read ds_read_b64_tr_b16.
-// K/V tiles are register-staged and double-buffered: the global loads of tile t+1
-// are issued before the MFMAs of tile t and written to LDS after them (one barrier
-// per tile).
+// K/V tiles go global -> LDS by LDS-DMA (global_load_lds, no staging registers, no ds_write)
+// into a ring of 3 stages: tile t+3 is requested right after the barrier that retires
+// tile t, so two tiles are always in flight behind the one being consumed (first-touch HBM
+// latency of a (problem, head)'s K/V is ~2 tile times) and the per-tile wait is a counted
+// vmcnt, never a drain.
 //
 // Addressing: q/k/v/o rows of segment 0 go through the row map of dwm_attn_args,
 // which folds the reference's einops rearranges (crossview_temporal_dit.py:307-315,
@@ -31,6 +33,8 @@ constexpr int KT = 64;                        // keys per tile
 constexpr int K_TILE_BYTES = KT * 128;        // 8192
 constexpr int V_TILE_BYTES = KT * 128;        // 8192
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+constexpr int MAX_LDS_BYTES = 96 * 1024;
+constexpr int NSTAGE = 3;                     // LDS ring depth (tiles t, t+1, t+2 resident or in flight)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -109,8 +113,8 @@ attn_fwd_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 4;
     constexpr int QB = NW * QT * 32;          // queries per block
-    // [L] element offset (row * ld, relative to the segment-0 base pointer) of every token of this problem
-    int64_t* __restrict__ rowtab = (int64_t*)(smem + 2 * STAGE_BYTES);
+    // [L] offset (in 16-byte units, relative to the segment-0 base pointer) of every token row of this problem
+    int32_t* __restrict__ rowtab = (int32_t*)(smem + NSTAGE * STAGE_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,8 +138,8 @@ attn_fwd_kernel(const AttnParams P) {
     {
         const int64_t base0 = seg0_base(P.rm, prob);
         for (int l = tid; l < L; l += 256)
-            rowtab[l] = l < L0 ? seg0_row(P.rm, base0, l) * P.ld0
-                               : P.seg1_delta + ((int64_t)prob * P.L1 + (l - L0)) * P.ld1;
+            rowtab[l] = (int32_t)((l < L0 ? seg0_row(P.rm, base0, l) * P.ld0
+                                          : P.seg1_delta + ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
     }
     __syncthreads();
 
@@ -150,7 +154,7 @@ attn_fwd_kernel(const AttnParams P) {
         const int lq = qb * QB + (wave * QT + t) * 32 + l31;
         qok[t] = lq < L;
         const int lqc = qok[t] ? lq : L - 1;
-        const bf16_t* qptr = P.q0 + rowtab[lqc] + hoff;      // q, k, v share the offset table
+        const bf16_t* qptr = P.q0 + ((int64_t)rowtab[lqc] << 3) + hoff;      // q, k, v share the offset table
         if (lqc < L0) optr[t] = P.o0 + seg0_row(P.rm, seg0_base(P.rm, prob), lqc) * P.ldo0 + hoff;
         else optr[t] = P.o1 + ((int64_t)prob * P.L1 + (lqc - L0)) * P.ldo1 + hoff;
 #pragma unroll
@@ -168,38 +172,27 @@ attn_fwd_kernel(const AttnParams P) {
         }
     }
 
-    // ---- staging coordinates: two 16-B chunks per thread and operand per 64-key tile:
-    //      chunk (key = tid >> 3 [+32], dchunk = tid & 7), same for K and V.
+    // ---- staging by LDS-DMA: 16 B per lane, LDS destination lane-linear, so wave w's instruction i
+    //      fills tile rows 16 w + 8 i + (lane >> 3) and the chunk swizzle is applied on the *source*
+    //      column: LDS chunk position (lane & 7) of row r holds global chunk (lane & 7) ^ swz(r).
     const int nkt = (L + KT - 1) / KT;
-    const int sdc = tid & 7;
-    const int skey0 = tid >> 3, skey1 = skey0 + 32;
-    const int kw0 = skey0 * 128 + ((sdc ^ ((skey0 >> 1) & 7)) << 4);      // K image byte offsets
-    const int kw1 = skey1 * 128 + ((sdc ^ ((skey1 >> 1) & 7)) << 4);
-    const int vw0 = skey0 * 128 + ((sdc ^ (((skey0 >> 1) & 1) << 2)) << 4);  // V image byte offsets
-    const int vw1 = skey1 * 128 + ((sdc ^ (((skey1 >> 1) & 1) << 2)) << 4);
-    const int64_t coff = hoff + sdc * 8;
-    uint4 kr0, kr1, vr0, vr1;
+    const int srow0 = wave * 16 + (lane >> 3), srow1 = srow0 + 8;
+    const bf16_t* const kg0 = P.k0 + hoff + (((lane & 7) ^ ((srow0 >> 1) & 7)) << 3);
+    const bf16_t* const kg1 = P.k0 + hoff + (((lane & 7) ^ ((srow1 >> 1) & 7)) << 3);
+    const bf16_t* const vg0 = P.v0 + hoff + (((lane & 7) ^ (((srow0 >> 1) & 1) << 2)) << 3);
+    const bf16_t* const vg1 = P.v0 + hoff + (((lane & 7) ^ (((srow1 >> 1) & 1) << 2)) << 3);
+    const int sdst = wave * 2048;                     // wave-uniform byte offset of this wave's rows in a tile image
 
-#define DWM_LOAD_TILE(kt_)                                                                  \
+#define DWM_DMA_TILE(kt_, stage_)                                                           \
     do {                                                                                    \
         const int kb_ = (kt_) * KT;                                                         \
-        const int a_ = kb_ + skey0 < L ? kb_ + skey0 : L - 1;                               \
-        const int b_ = kb_ + skey1 < L ? kb_ + skey1 : L - 1;                               \
-        const int64_t oa_ = rowtab[a_] + coff, ob_ = rowtab[b_] + coff;                     \
-        kr0 = *(const uint4*)(P.k0 + oa_);                                                  \
-        vr0 = *(const uint4*)(P.v0 + oa_);                                                  \
-        kr1 = *(const uint4*)(P.k0 + ob_);                                                  \
-        vr1 = *(const uint4*)(P.v0 + ob_);                                                  \
-    } while (0)
-
-#define DWM_WRITE_TILE(buf_)                                                                \
-    do {                                                                                    \
-        char* kl_ = smem + (buf_) * STAGE_BYTES;                                            \
-        char* vl_ = kl_ + K_TILE_BYTES;                                                     \
-        *(uint4*)(kl_ + kw0) = kr0;                                                         \
-        *(uint4*)(kl_ + kw1) = kr1;                                                         \
-        *(uint4*)(vl_ + vw0) = vr0;                                                         \
-        *(uint4*)(vl_ + vw1) = vr1;                                                         \
+        const int64_t oa_ = (int64_t)rowtab[kb_ + srow0 < L ? kb_ + srow0 : L - 1] << 3;    \
+        const int64_t ob_ = (int64_t)rowtab[kb_ + srow1 < L ? kb_ + srow1 : L - 1] << 3;    \
+        char* kl_ = smem + (stage_) * STAGE_BYTES + sdst;                                   \
+        glds16(kg0 + oa_, kl_);                                                             \
+        glds16(kg1 + ob_, kl_ + 1024);                                                      \
+        glds16(vg0 + oa_, kl_ + K_TILE_BYTES);                                              \
+        glds16(vg1 + ob_, kl_ + K_TILE_BYTES + 1024);                                       \
     } while (0)
 
     // Softmax bookkeeping in the exponent domain: Q is pre-multiplied by scale*log2(e) and the S MFMAs
@@ -234,18 +227,24 @@ attn_fwd_kernel(const AttnParams P) {
         vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
     }
 
-    DWM_LOAD_TILE(0);
-    DWM_WRITE_TILE(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // Q fragments landed before the loop
+    // prologue: tiles 0, 1, 2 requested (4 DMA instructions per wave and tile; the Q fragment loads
+    // were issued before them, so "vmcnt(8)" also covers Q)
+    DWM_DMA_TILE(0, 0);
+    if (nkt > 1) DWM_DMA_TILE(1, 1);
+    if (NSTAGE > 2 && nkt > 2) DWM_DMA_TILE(2, NSTAGE > 2 ? 2 : 0);
+    if (NSTAGE > 2 && nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // a wave whose queries all lie past the end of the sequence (last query block) only takes part
+    // in the staging and the barriers
+    const bool wave_active = qb * QB + wave * QT * 32 < L;
+    int stage = 0;                        // ring slot of tile kt
     for (int kt = 0; kt < nkt; ++kt) {
-        // unconditional prefetch keeps the loop body branch-free: past the end it re-fetches the
-        // last tile (addresses are clamped) into the buffer nobody reads again
-        DWM_LOAD_TILE(kt + 1 < nkt ? kt + 1 : kt);
-
-        const char* kl = smem + (kt & 1) * STAGE_BYTES;
+        const char* kl = smem + stage * STAGE_BYTES;
         const char* vl = kl + K_TILE_BYTES;
+        if (wave_active) {
 
         // ---- S^T = K Q^T for two 32-key sub-tiles (K fragments shared by the QT query tiles)
         f32x16 st[QT][2];
@@ -352,12 +351,17 @@ attn_fwd_kernel(const AttnParams P) {
                     ot[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], ot[t][dt], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
+        }
 
-        DWM_WRITE_TILE((kt + 1) & 1);
+        // tile kt+1 landed (tile kt+2 may stay in flight), everyone is done with tile kt's slot,
+        // which then receives tile kt+3
+        if (NSTAGE > 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (kt + NSTAGE < nkt) DWM_DMA_TILE(kt + NSTAGE, stage);
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }
-#undef DWM_LOAD_TILE
-#undef DWM_WRITE_TILE
+#undef DWM_DMA_TILE
 
     // ---- finalize and store: lane (q, half) reg r of ot[dt] -> d = dt*32 + (r&3) + 8(r>>2) + 4 half
 #pragma unroll
@@ -395,7 +399,12 @@ tr_probe_kernel(const int* __restrict__ offs, short* __restrict__ out) {
 template <int QT, int MASK>
 void launch_attn(const AttnParams& P, hipStream_t s) {
     const int64_t nblk = (int64_t)P.n_problems * P.heads * P.nqb;
-    const size_t lds = 2 * STAGE_BYTES + (size_t)((P.L + 1) & ~1) * sizeof(int64_t);
+    const size_t lds = NSTAGE * STAGE_BYTES + (size_t)((P.L + 3) & ~3) * sizeof(int32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<QT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        attr_set = true;
+    }
     hipLaunchKernelGGL((attn_fwd_kernel<QT, MASK>), dim3((unsigned)nblk), dim3(256), lds, s, P);
 }
 
@@ -456,7 +465,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     P.fd_G = make_fastdiv((uint32_t)(P.mask_G > 0 ? P.mask_G : 1));
     P.fd_ppm = make_fastdiv((uint32_t)(P.p_per_mask > 0 ? P.p_per_mask : 1));
     if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
-    if (2 * STAGE_BYTES + L * 8 + 16 > 64 * 1024) return DWM_EUNSUPPORTED;   // row table must fit the default LDS window
+    if (NSTAGE * STAGE_BYTES + L * 4 + 16 > MAX_LDS_BYTES) return DWM_EUNSUPPORTED;   // ring + row table must fit the LDS window
     hipStream_t s = (hipStream_t)stream;
 #define DWM_ATTN(QT_)                                              \
     do {                                                           \
