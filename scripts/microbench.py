@@ -53,7 +53,7 @@ def bench_attn(variants):
             print(json.dumps({"kernel": "attn", "case": name, "variant": var, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
 
 
-def bench_gemm():
+def bench_gemm(dbg_list=(0, 1)):
     from opendwm_amd.blocks import geglu_pack
     shapes = [("qkv rmshead", 86016, 4608, 1536, "rms"), ("out-proj resid", 86016, 1536, 1536, "resid"),
               ("ff1 gelu", 86016, 6144, 1536, "gelu"), ("ff2 resid", 86016, 1536, 6144, "resid"),
@@ -63,23 +63,26 @@ def bench_gemm():
     for name, M, N, K, kind in shapes:
         a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
         fl = 2.0 * M * N * K
-        if kind == "rms":
-            rms = rnd(2 * 1536) * 0.1 + 1
-            f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=3072, rms_eps=1e-6)
-        elif kind == "resid":
-            gate, res = rnd(M // 448 + 1, N), rnd(M, N)
-            f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=res, out=res)
-        elif kind == "gelu":
-            f = lambda: ops.gemm(a, w, b, act=ops.ACT_GELU_TANH)
-        elif kind == "geglu":
-            wp, bp = geglu_pack(w), geglu_pack(b)
-            f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU)
-        else:
-            f = lambda: ops.gemm(a, w, b)
-        ms = timeit(f)
+        res = {}
+        for dbg in dbg_list:
+            if kind == "rms":
+                rms = rnd(2 * 1536) * 0.1 + 1
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=3072, rms_eps=1e-6, _debug=dbg)
+            elif kind == "resid":
+                gate, res_t = rnd(M // 448 + 1, N), rnd(M, N)
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=res_t, out=res_t, _debug=dbg)
+            elif kind == "gelu":
+                f = lambda: ops.gemm(a, w, b, act=ops.ACT_GELU_TANH, _debug=dbg)
+            elif kind == "geglu":
+                wp, bp = geglu_pack(w), geglu_pack(b)
+                f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU, _debug=dbg)
+            else:
+                f = lambda: ops.gemm(a, w, b, _debug=dbg)
+            ms = timeit(f)
+            res[{0: "w8", 1 << 11: "w8-nostagger", 1 << 10: "w4", 1: "w8-noepi"}[dbg]] = round(fl / ms / 1e9, 1)
         ms_t = timeit(lambda: torch.matmul(a, w.t()))
-        print(json.dumps({"kernel": "gemm", "case": name, "M": M, "N": N, "K": K, "ms": round(ms, 4),
-                          "tflops": round(fl / ms / 1e9, 1), "hipblaslt_plain_tflops": round(fl / ms_t / 1e9, 1)}), flush=True)
+        print(json.dumps({"kernel": "gemm", "case": name, "M": M, "N": N, "K": K, "tflops": res,
+                          "hipblaslt_plain_tflops": round(fl / ms_t / 1e9, 1)}), flush=True)
 
 
 def bench_ln():
