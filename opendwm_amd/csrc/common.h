@@ -70,6 +70,31 @@ DWM_DEVINL float erf_fast_f(float x) {
 DWM_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.f + erf_fast_f(x * 0.7071067811865476f)); }
 DWM_DEVINL float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
+// ---- packed-fp32 forms (v_pk_mul/add/fma_f32 process two lanes' worth of values per issue slot; the
+//      transcendental ops stay scalar).  Used by the GEMM epilogues, which are VALU-issue bound.
+DWM_DEVINL f32x2 splat2(float v) { return (f32x2){v, v}; }
+DWM_DEVINL f32x2 exp2_2(f32x2 z) { return (f32x2){__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])}; }
+DWM_DEVINL f32x2 rcp_2(f32x2 d) { return (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}; }
+DWM_DEVINL f32x2 gelu_tanh2(f32x2 x) {
+    const f32x2 u = (x * x) * splat2(-0.1029432397f) + splat2(-2.302208198f);    // -(2 log2e sqrt(2/pi)) (1 + 0.044715 x^2)
+    return x * rcp_2(exp2_2(x * u) + splat2(1.f));
+}
+DWM_DEVINL f32x2 silu2(f32x2 x) { return x * rcp_2(exp2_2(x * splat2(-1.4426950408889634f)) + splat2(1.f)); }
+DWM_DEVINL f32x2 relu2(f32x2 x) { return (f32x2){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)}; }
+DWM_DEVINL f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = (f32x2){__builtin_fabsf(x[0]), __builtin_fabsf(x[1])} * splat2(0.7071067811865476f);   // |x| / sqrt 2
+    const f32x2 t = rcp_2(ax * splat2(0.3275911f) + splat2(1.f));
+    f32x2 pl = t * splat2(1.061405429f) + splat2(-1.453152027f);
+    pl = pl * t + splat2(1.421413741f);
+    pl = pl * t + splat2(-0.284496736f);
+    pl = pl * t + splat2(0.254829592f);
+    const f32x2 e = exp2_2((ax * ax) * splat2(-1.4426950408889634f));
+    const f32x2 r = splat2(1.f) - (pl * t) * e;                                   // erf(|x| / sqrt 2), Abramowitz-Stegun 7.1.26
+    const f32x2 hx = x * splat2(0.5f);
+    const f32x2 er = (f32x2){__builtin_copysignf(r[0], x[0]), __builtin_copysignf(r[1], x[1])};
+    return hx * er + hx;
+}
+
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
 DWM_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(

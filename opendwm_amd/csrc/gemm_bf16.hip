@@ -1,7 +1,384 @@
-// C entry point of the bf16 GEMM and the 8-wave (2 x 4, 128x64 per wave) instantiation; the kernel is in gemm_kernel.h
-#include "gemm_kernel.h"
+// bf16 GEMM with fused epilogues for gfx950:  C[M,Nout] = epi(A[M,K] · W[N,K]^T)
+//
+// Block tile 256x256x64, 512 threads = 8 waves laid out 2 (M) x 4 (N); each wave
+// owns a 128x64 output tile = 4x2 v_mfma_f32_32x32x16_bf16 accumulators (128 fp32
+// VGPR/lane).  The MFMA is issued "swapped" (A-operand = W fragment, B-operand =
+// activation fragment) so a lane owns ONE output row m and, per accumulator
+// register group, FOUR CONSECUTIVE output columns n:
+//     m = lane & 31,  n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)      (r = 0..15)
+// That makes every epilogue lane-local: 8-byte bf16x4 stores, GEGLU pairs
+// (value / gate sub-tiles of the same wave), and the per-head (64 col) RMSNorm of
+// q/k needs one lane^32 exchange.
+//
+// Global -> LDS staging is the gfx950 LDS-DMA (global_load_lds_dwordx4): the LDS
+// image of a tile is [256 rows][8 x 16-B chunks] with chunk XOR-swizzled by
+// ((row >> 1) & 7); the swizzle is applied on the per-lane SOURCE address (the DMA
+// destination is lane-linear) and again on the ds_read_b128 fragment reads, which
+// makes those reads bank-conflict free.  Two LDS stages (128 KiB), one barrier per
+// K step: tile k+1 streams in while tile k is on the matrix cores.
+#include "common.h"
+#include "dwm_hip.h"
 
-using namespace dwm_gemm;
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;            // 32 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A + W
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // double buffered = 128 KiB
+
+struct DevRowMap {
+    FastDiv rw, rh;
+    int64_t rpitch, ipitch, origin;
+    int enabled, xstep;
+};
+struct ConvParams {
+    DevRowMap a, c;
+    int steps_per_tap;          // k_per_tap / BK
+    FastDiv fd_steps;
+    int64_t tap_shift[9];
+};
+DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
+    if (!rm.enabled) return m;
+    const uint32_t q = fdiv((uint32_t)m, rm.rw), x = (uint32_t)m - q * rm.rw.d;
+    const uint32_t i = fdiv(q, rm.rh), y = q - i * rm.rh.d;
+    return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + (int64_t)x * rm.xstep + rm.origin;
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
+    constexpr int NWN = 4;                       // wave columns of the 2 x 4 wave grid
+    constexpr int NTHREADS = 128 * NWN;
+    constexpr int WCOLS = BN / NWN;              // output columns per wave: 64 / 128
+    constexpr int NTW = WCOLS / 32;              // 32-column accumulator tiles per wave: 2 / 4
+    constexpr int NJ = BM / (NTHREADS / 8);      // staging rounds per operand tile: 4 / 8
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN;             // 0..1  (128-row slab)
+    const int wn = wave % NWN;             // column slab of WCOLS
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    // XCD-contiguous ids, then grouped rasterisation: consecutive ids walk GM row-tiles down a
+    // column before moving to the next column, so the ~32 tiles resident on one XCD at a time form
+    // a compact GM x (32/GM) block that shares A and W panels in that XCD's L2.
+    const int id = xcd_remap(blockIdx.x, ntm * ntn);
+    int gm_ = (p.reserved >> 4) & 31;
+    if (gm_ == 0) gm_ = 8;
+    const int per_group = gm_ * ntn;
+    const int grp_id = id / per_group, in_grp = id - grp_id * per_group;
+    const int first_m = grp_id * gm_;
+    const int gsize = ntm - first_m < gm_ ? ntm - first_m : gm_;
+    const int tm = first_m + in_grp % gsize, tn = in_grp / gsize;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t M = p.M, N = p.N, K = p.K;
+
+    // ---- staging addresses: wave w copies row groups (w*NJ + j)*8 .. +8, j = 0..NJ-1
+    const bf16_t* __restrict__ Ap = (const bf16_t*)p.A;
+    const bf16_t* __restrict__ Wp = (const bf16_t*)p.W;
+    const char* a_src[NJ];
+    const char* w_src[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int row = (wave * NJ + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);          // logical 16-B chunk this lane fetches
+        int64_t gm = m0 + row; gm = gm < M ? gm : M - 1;
+        int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
+        a_src[j] = (const char*)(Ap + map_row(cp.a, gm) * p.lda + c * 8);
+        w_src[j] = (const char*)(Wp + gn * K + c * 8);
+    }
+    // K step kt covers tap t = kt / steps_per_tap and channels (kt % steps_per_tap)*64.. of it; the A
+    // source moves by tap_shift[t] rows (0 for a plain GEMM), the W source is simply contiguous in K
+    const int64_t lda_bytes = p.lda * 2;
+    auto tile_offsets = [&](int kt, int64_t& aoff, int64_t& koff) {
+        koff = (int64_t)kt * (BK * 2);
+        const uint32_t tap = fdiv((uint32_t)kt, cp.fd_steps);
+        aoff = cp.tap_shift[tap] * lda_bytes + (int64_t)(kt - tap * cp.steps_per_tap) * (BK * 2);
+    };
+
+    f32x16 acc[4][NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (bytes) inside a tile: row*128 + ((chunk ^ swz) << 4)
+    const int swz = (lane >> 1) & 7;       // ((row >> 1) & 7) with row = 32*t + (lane & 31)
+    const int a_row_off = (wm * 128 + l31) * 128;
+    const int w_row_off = (wn * WCOLS + l31) * 128;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + half) ^ swz) << 4;
+
+    const int nk = (int)(K / BK);
+
+    // ---- main loop.  Per K tile: 4 sub-steps x 8 chunks of { NTW/2 MFMAs, one fragment read for the
+    // next sub-step, a share of the DMA issue }, fenced with sched_barrier so LDS reads and DMA
+    // issues sit in the shadow of the MFMAs.  The single barrier of a tile sits at the START of its
+    // last sub-step: by then every wave holds its last fragments of tile kt in registers (buffer
+    // kt&1 is free for tile kt+2) and its share of tile kt+1 has landed, so the fragment reads of
+    // tile kt+1's first sub-step and the barrier skew hide under the MFMAs of sub-step 3.  DMA of
+    // tile kt+2 is issued right after that barrier and in sub-step 0 of the next tile, i.e. it is
+    // > 2 sub-steps old when its vmcnt(0) comes.
+    auto stage_round = [&](int buf, int64_t aoff, int64_t koff, int j) {
+        const int r0 = (wave * NJ + j) * 8;
+        glds16(a_src[j] + aoff, smem + buf * STAGE_BYTES + r0 * 128);
+        glds16(w_src[j] + koff, smem + buf * STAGE_BYTES + TILE_BYTES + r0 * 128);
+    };
+    constexpr int MPC = NTW / 2;                       // MFMAs per chunk
+    constexpr int NDS = 4 + NTW;                       // fragment reads per sub-step
+    bf16x8 af[2][4], wf[2][NTW];
+    int64_t aoff1, koff1;                              // offsets of the tile whose second half is staged in sub-step 0
+    {
+        int64_t aoff, koff;
+        tile_offsets(0, aoff, koff);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) stage_round(0, aoff, koff, j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tile_offsets(nk > 1 ? 1 : 0, aoff1, koff1);
+#pragma unroll
+        for (int j = 0; j < NJ / 2; ++j) stage_round(1, aoff1, koff1, j);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * 128) + coff[0]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + TILE_BYTES + w_row_off + nt * (32 * 128) + coff[0]);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * STAGE_BYTES;
+        const char* lb = la + TILE_BYTES;
+        const char* lan = smem + ((kt + 1) & 1) * STAGE_BYTES;     // tile kt+1
+        const char* lbn = lan + TILE_BYTES;
+        int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
+        tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (ks == 3 && c == 0) {
+                    // own last fragments read, own share of tile kt+1 landed -> barrier
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int u = 0; u < MPC; ++u) {
+                    const int idx = c * MPC + u, mt = idx / NTW, nt = idx % NTW;
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
+                }
+                if (c < NDS) {
+                    const char* fa = ks < 3 ? la : lan;
+                    const char* fb = ks < 3 ? lb : lbn;
+                    const int kn = ks < 3 ? ks + 1 : 0;
+                    if (c < 4) af[(ks + 1) & 1][c] = *(const bf16x8*)(fa + a_row_off + c * (32 * 128) + coff[kn]);
+                    else wf[(ks + 1) & 1][c - 4] = *(const bf16x8*)(fb + w_row_off + (c - 4) * (32 * 128) + coff[kn]);
+                }
+                if (ks == 0 && c < NJ / 2) stage_round((kt + 1) & 1, aoff1, koff1, NJ / 2 + c);       // 2nd half of tile kt+1
+                if (ks == 3 && c >= 1 && c <= NJ / 2) stage_round(kt & 1, aoff2, koff2, c - 1);       // 1st half of tile kt+2
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        aoff1 = aoff2;
+        koff1 = koff2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant last DMA must not land in the epilogue scratch
+
+    // ------------------------------------------------------------------ epilogue
+    // Stage A (MFMA layout, lane = one row x 4-column groups): bias, activation, GEGLU product,
+    // per-head RMSNorm.  Stage B: each wave transposes its tile through a private, XOR-swizzled
+    // 8 KiB LDS region (32 rows x 64 fp32 per pass) so that gate / residual / blend loads and
+    // the bf16 stores are row-major 16-B accesses (8 rows x 128 B per wave instruction).
+    if (p.reserved & 1) {        // ablation knob (benchmarks only): main loop without the epilogue
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) sink += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+        if (sink == 123.456f) ((float*)p.C)[0] = sink;
+        return;
+    }
+    const bf16_t* __restrict__ bias = (const bf16_t*)p.bias;
+    bf16_t* __restrict__ Cp = (bf16_t*)p.C;
+
+    __syncthreads();                                       // every wave is done with the operand tiles
+    char* scr = smem + wave * 8192;                        // this wave's transpose region
+    // a wave's WCOLS columns are handled as NTW/2 slabs of 64 (one q/k head, one GEGLU value/gate
+    // pair, one 8 KiB transpose pass each)
+#pragma unroll
+    for (int ch = 0; ch < NTW / 2; ++ch) {
+        const int64_t nw = n0 + wn * WCOLS + ch * 64;         // first column of this slab
+        // bias for this lane's 2 x 16 columns (MFMA layout)
+        float bv[2][16];
+    #pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int64_t n = nw + nt * 32 + rg * 8 + half * 4;
+                if (bias != nullptr && n < N) {
+                    const uint2 b = *(const uint2*)(bias + n);
+                    unpack4(b, &bv[nt][rg * 4]);
+                } else {
+                    bv[nt][rg * 4 + 0] = bv[nt][rg * 4 + 1] = bv[nt][rg * 4 + 2] = bv[nt][rg * 4 + 3] = 0.f;
+                }
+            }
+        float rw[2][16];                                       // RMSHEAD: per-column norm weights
+        bool do_norm = false;
+        if constexpr (EPI == DWM_EPI_RMSHEAD) {
+            do_norm = nw < p.rms_ncols;                        // wave-uniform: this slab is a q/k head
+            const bf16_t* __restrict__ rwp = (const bf16_t*)p.rms_w;
+    #pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int64_t n = nw + nt * 32 + rg * 8 + half * 4;
+                    if (do_norm && n < N) unpack4(*(const uint2*)(rwp + n), &rw[nt][rg * 4]);
+                    else rw[nt][rg * 4 + 0] = rw[nt][rg * 4 + 1] = rw[nt][rg * 4 + 2] = rw[nt][rg * 4 + 3] = 1.f;
+                }
+        }
+
+        constexpr bool kGeglu = EPI == DWM_EPI_GEGLU;
+        constexpr int CW = kGeglu ? 32 : 64;                   // output columns of this wave's slab
+        const int64_t ncol0 = kGeglu ? (n0 >> 1) + wn * (WCOLS / 2) + ch * 32 : nw;
+        const int64_t Nout = kGeglu ? (N >> 1) : N;
+        // stage-B lane geometry: 8 fp32 (two 16-B chunks) per lane; LPR lanes per row
+        constexpr int LPR = CW / 8;                            // 8 (or 4 for GEGLU)
+        constexpr int RPS = 64 / LPR;                          // rows per step: 8 (16)
+        const int brow = lane / LPR, bc8 = lane % LPR;
+        const int64_t ncol = ncol0 + bc8 * 8;
+        const bool nok = ncol < Nout;
+
+    #pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            // ---- stage A (packed fp32: the epilogue is VALU-issue bound; the activation switch is
+            // taken once per 32-row pass, not per element)
+#define DWM_PAIR(v_, r_) ((f32x2){(v_)[r_], (v_)[(r_) + 1]})
+            if constexpr (EPI == DWM_EPI_RMSHEAD) {
+                f32x2 ss2 = {0.f, 0.f};
+    #pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 x = DWM_PAIR(acc[mt][ch * 2 + nt], r) + DWM_PAIR(bv[nt], r);
+                        acc[mt][ch * 2 + nt][r] = x[0];
+                        acc[mt][ch * 2 + nt][r + 1] = x[1];
+                        ss2 += x * x;
+                    }
+                float ss = ss2[0] + ss2[1];
+                ss += __shfl_xor(ss, 32, 64);                   // other half of the row lives in lane^32
+                const float rinv = do_norm ? rsqrtf(ss * (1.f / 64.f) + p.rms_eps) : 1.f;
+    #pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 x = (DWM_PAIR(acc[mt][ch * 2 + nt], r) * splat2(rinv)) * DWM_PAIR(rw[nt], r);
+                        acc[mt][ch * 2 + nt][r] = x[0];
+                        acc[mt][ch * 2 + nt][r + 1] = x[1];
+                    }
+            } else if constexpr (kGeglu) {
+    #pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 hv = DWM_PAIR(acc[mt][ch * 2], r) + DWM_PAIR(bv[0], r);
+                    const f32x2 x = hv * gelu_erf2(DWM_PAIR(acc[mt][ch * 2 + 1], r) + DWM_PAIR(bv[1], r));
+                    acc[mt][ch * 2][r] = x[0];
+                    acc[mt][ch * 2][r + 1] = x[1];
+                }
+            } else {
+#define DWM_ACT_PASS(FN_)                                                                           \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                     \
+                    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                              \
+                        const f32x2 x = FN_(DWM_PAIR(acc[mt][ch * 2 + nt], r) + DWM_PAIR(bv[nt], r)); \
+                        acc[mt][ch * 2 + nt][r] = x[0];                                              \
+                        acc[mt][ch * 2 + nt][r + 1] = x[1];                                          \
+                    }
+                if (p.act == DWM_ACT_GELU_TANH) { DWM_ACT_PASS(gelu_tanh2) }
+                else if (p.act == DWM_ACT_SILU) { DWM_ACT_PASS(silu2) }
+                else if (p.act == DWM_ACT_RELU) { DWM_ACT_PASS(relu2) }
+                else { DWM_ACT_PASS() }
+#undef DWM_ACT_PASS
+            }
+#undef DWM_PAIR
+            // ---- transpose: row l31, 16-B chunk c = (nt*32 + rg*8 + half*4) / 4, swizzled by the row
+    #pragma unroll
+            for (int nt = 0; nt < (kGeglu ? 1 : 2); ++nt)
+    #pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = nt * 8 + rg * 2 + half;
+                    const float4 v = make_float4(acc[mt][ch * 2 + nt][rg * 4], acc[mt][ch * 2 + nt][rg * 4 + 1],
+                                                 acc[mt][ch * 2 + nt][rg * 4 + 2], acc[mt][ch * 2 + nt][rg * 4 + 3]);
+                    *(float4*)(scr + l31 * (CW * 4) + ((c ^ (l31 & (CW / 4 - 1))) << 4)) = v;
+                }
+            // same-wave LDS ops complete in order; the reads below see the writes above
+            // ---- stage B: all gate / residual / blend loads of the pass are issued before its first
+            // store (the outputs may alias the residual, so the compiler would otherwise serialise
+            // every step's loads behind the previous step's stores)
+            constexpr int NST = 32 / RPS;
+            uint4 gq[NST], rq[NST], bq[NST];
+            float al[NST];
+            if constexpr (EPI == DWM_EPI_RESID) {
+    #pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    int64_t m = m0 + wm * 128 + mt * 32 + st * RPS + brow;
+                    m = m < M ? m : M - 1;
+                    const int64_t nc = nok ? ncol : 0;
+                    if (p.gate) gq[st] = *(const uint4*)((const bf16_t*)p.gate + (int64_t)((uint32_t)m / (uint32_t)p.rows_per_gate) * p.ld_gate + nc);
+                    const int64_t mr = map_row(cp.c, m);
+                    if (p.res) {
+                        const int64_t rr = p.res_mod > 0 ? (int64_t)((uint32_t)m % (uint32_t)p.res_mod) : mr;
+                        rq[st] = *(const uint4*)((const bf16_t*)p.res + rr * p.ld_res + nc);
+                    }
+                    if (p.blend) {
+                        bq[st] = *(const uint4*)((const bf16_t*)p.blend + mr * p.ld_blend + nc);
+                        al[st] = p.alpha[(uint32_t)m / (uint32_t)p.rows_per_alpha];
+                    }
+                }
+            }
+    #pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int r = st * RPS + brow;                 // row inside this 32-row pass
+                const float4 x0 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8) ^ (r & (CW / 4 - 1))) << 4));
+                const float4 x1 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8 + 1) ^ (r & (CW / 4 - 1))) << 4));
+                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const int64_t m = m0 + wm * 128 + mt * 32 + r;
+                const int64_t mrow = map_row(cp.c, m < M ? m : M - 1);
+                if constexpr (EPI == DWM_EPI_RESID) {
+                    float t[8];
+                    if (p.gate) {
+                        unpack8(gq[st], t);
+    #pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const f32x2 y = (f32x2){v[j], v[j + 1]} * (f32x2){t[j], t[j + 1]};
+                            v[j] = y[0]; v[j + 1] = y[1];
+                        }
+                    }
+                    if (p.res) {
+                        unpack8(rq[st], t);
+    #pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const f32x2 y = (f32x2){v[j], v[j + 1]} + (f32x2){t[j], t[j + 1]};
+                            v[j] = y[0]; v[j + 1] = y[1];
+                        }
+                    }
+                    if (p.blend) {
+                        unpack8(bq[st], t);
+                        const f32x2 a2 = splat2(al[st]), b2 = splat2(1.f - al[st]);
+    #pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const f32x2 y = a2 * (f32x2){t[j], t[j + 1]} + b2 * (f32x2){v[j], v[j + 1]};
+                            v[j] = y[0]; v[j + 1] = y[1];
+                        }
+                    }
+                }
+                if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+            }
+        }
+    }
+}
+
+}  // namespace
 
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return DWM_EINVAL;
@@ -48,8 +425,26 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a->lda < kpt) return DWM_EINVAL;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
-    // default: the 8-wave kernel (2 waves per SIMD); reserved bit 10 selects the 4-wave kernel
-    // (one wave per SIMD, AGPR accumulators) - measured slower, kept for experiments
-    const bool w4 = (a->reserved & (1 << 10)) != 0;
-    return w4 ? dwm_gemm_launch_w4(a, cp, ntm, ntn, s) : launch_variant<4>(a, cp, ntm, ntn, s);
+    const dim3 grid((unsigned)(ntm * ntn)), block(512);
+    hipError_t e;
+#define DWM_LAUNCH(EPI)                                                                              \
+    do {                                                                                             \
+        static bool attr_set = false;                                                                \
+        if (!attr_set) {                                                                             \
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,                              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
+            if (e != hipSuccess) return (int)e;                                                      \
+            attr_set = true;                                                                         \
+        }                                                                                            \
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);      \
+    } while (0)
+    switch (a->epilogue) {
+        case DWM_EPI_PLAIN: DWM_LAUNCH(DWM_EPI_PLAIN); break;
+        case DWM_EPI_GEGLU: DWM_LAUNCH(DWM_EPI_GEGLU); break;
+        case DWM_EPI_RESID: DWM_LAUNCH(DWM_EPI_RESID); break;
+        default: DWM_LAUNCH(DWM_EPI_RMSHEAD); break;
+    }
+#undef DWM_LAUNCH
+    e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
 }

@@ -138,25 +138,6 @@ def test_gemm_rmshead(dev, M, heads, K, biased):
     assert rel_err(qk, ref[:, :2 * D]) < TOL_KERNEL
 
 
-def test_gemm_four_wave_variant(dev):
-    """The experimental 4-wave instantiation (128x128 per wave, AGPR accumulators) computes the same
-    thing as the default 8-wave kernel."""
-    from opendwm_amd import ops
-    from opendwm_amd.blocks import geglu_pack
-    W4 = 1 << 10
-    M, N, K = 700, 1536, 256
-    a, w, b = _rand((M, K), dev, 1), _rand((N, K), dev, 2, K ** -0.5), _rand((N,), dev, 3)
-    assert torch.equal(ops.gemm(a, w, b, _debug=W4), ops.gemm(a, w, b))
-    assert torch.equal(ops.gemm(a, geglu_pack(w), geglu_pack(b), epilogue=ops.EPI_GEGLU, _debug=W4),
-                       ops.gemm(a, geglu_pack(w), geglu_pack(b), epilogue=ops.EPI_GEGLU))
-    gate, res = _rand((7, N), dev, 4), _rand((M, N), dev, 5)
-    assert torch.equal(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=100, res=res, _debug=W4),
-                       ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=100, res=res))
-    rms = _rand((1024,), dev, 6) * 0.2 + 1
-    assert torch.equal(ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=1024, rms_eps=1e-6, _debug=W4),
-                       ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=1024, rms_eps=1e-6))
-
-
 def test_gemm_rejects_bad_arguments(dev):
     from opendwm_amd import ops
     a, w = _rand((64, 100), dev, 1), _rand((64, 100), dev, 2)
