@@ -35,6 +35,7 @@ struct ConvParams {
     DevRowMap a, c;
     int steps_per_tap;          // k_per_tap / BK
     FastDiv fd_steps;
+    FastDiv fd_rpg, fd_rmod, fd_rpa;   // RESID: rows_per_gate, res_mod, rows_per_alpha
     int64_t tap_shift[9];
 };
 DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
@@ -312,33 +313,37 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     *(float4*)(scr + l31 * (CW * 4) + ((c ^ (l31 & (CW / 4 - 1))) << 4)) = v;
                 }
             // same-wave LDS ops complete in order; the reads below see the writes above
-            // ---- stage B: all gate / residual / blend loads of the pass are issued before its first
-            // store (the outputs may alias the residual, so the compiler would otherwise serialise
-            // every step's loads behind the previous step's stores)
+            // ---- stage B, two steps at a time: the gate / residual / blend loads of a batch are issued
+            // before its first store (the outputs may alias the residual, so the compiler would
+            // otherwise serialise every step's loads behind the previous step's stores); batches of 2
+            // keep the epilogue's register peak below the main loop's, so nothing of the main loop spills
             constexpr int NST = 32 / RPS;
-            uint4 gq[NST], rq[NST], bq[NST];
-            float al[NST];
+            constexpr int NB = 2;
+    #pragma unroll
+            for (int sb = 0; sb < NST; sb += NB) {
+            uint4 gq[NB], rq[NB], bq[NB];
+            float al[NB];
             if constexpr (EPI == DWM_EPI_RESID) {
     #pragma unroll
-                for (int st = 0; st < NST; ++st) {
-                    int64_t m = m0 + wm * 128 + mt * 32 + st * RPS + brow;
+                for (int st = 0; st < NB; ++st) {
+                    int64_t m = m0 + wm * 128 + mt * 32 + (sb + st) * RPS + brow;
                     m = m < M ? m : M - 1;
                     const int64_t nc = nok ? ncol : 0;
-                    if (p.gate) gq[st] = *(const uint4*)((const bf16_t*)p.gate + (int64_t)((uint32_t)m / (uint32_t)p.rows_per_gate) * p.ld_gate + nc);
+                    if (p.gate) gq[st] = *(const uint4*)((const bf16_t*)p.gate + (int64_t)fdiv((uint32_t)m, cp.fd_rpg) * p.ld_gate + nc);
                     const int64_t mr = map_row(cp.c, m);
                     if (p.res) {
-                        const int64_t rr = p.res_mod > 0 ? (int64_t)((uint32_t)m % (uint32_t)p.res_mod) : mr;
+                        const int64_t rr = p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m, cp.fd_rmod) : mr;
                         rq[st] = *(const uint4*)((const bf16_t*)p.res + rr * p.ld_res + nc);
                     }
                     if (p.blend) {
                         bq[st] = *(const uint4*)((const bf16_t*)p.blend + mr * p.ld_blend + nc);
-                        al[st] = p.alpha[(uint32_t)m / (uint32_t)p.rows_per_alpha];
+                        al[st] = p.alpha[fdiv((uint32_t)m, cp.fd_rpa)];
                     }
                 }
             }
     #pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const int r = st * RPS + brow;                 // row inside this 32-row pass
+            for (int st = 0; st < NB; ++st) {
+                const int r = (sb + st) * RPS + brow;          // row inside this 32-row pass
                 const float4 x0 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8) ^ (r & (CW / 4 - 1))) << 4));
                 const float4 x1 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8 + 1) ^ (r & (CW / 4 - 1))) << 4));
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -373,6 +378,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     }
                 }
                 if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+            }
             }
         }
     }
@@ -421,6 +427,10 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (kpt <= 0 || kpt % BK != 0 || kpt * ntaps != a->K) return DWM_EINVAL;
     cp.steps_per_tap = (int)(kpt / BK);
     cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
+    if (a->rows_per_gate > (1ll << 30) || a->res_mod > (1ll << 30) || a->rows_per_alpha > (1ll << 30)) return DWM_EINVAL;
+    cp.fd_rpg = make_fastdiv((uint32_t)(a->rows_per_gate > 0 ? a->rows_per_gate : 1));
+    cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : 1));
+    cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
     for (int t = 0; t < 9; ++t) cp.tap_shift[t] = (a->ntaps > 0 && t < ntaps) ? a->tap_shift[t] : 0;
     if (a->lda < kpt) return DWM_EINVAL;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
