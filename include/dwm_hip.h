@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 6
+#define DWM_ABI_VERSION 7
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -259,6 +259,84 @@ int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld
 
 /* dst bf16 <- src fp32 (n % 4 == 0) */
 int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Training: backward / optimizer kernels of the CTSD train step
+ * (src/dwm/pipelines/ctsd.py:1195-1437: forward under autocast, loss.backward(), optimizer.step()).
+ * They are the hand-written derivatives of the forward entry points above; reductions accumulate
+ * with fp32 atomics into buffers the caller has zeroed.
+ * ---------------------------------------------------------------------- */
+/* out[c, r] = in[r, c], bf16; out is [cols, ld_out] with columns [rows, rows_pad) zero-filled.
+ * Feeds the weight-gradient GEMM dW = dY^T X (both operands K-major = row-contiguous over tokens)
+ * and the input-gradient GEMM dX = dY W (W^T refreshed once per optimizer step). */
+int dwm_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols,
+                       void* out, int64_t ld_out, int64_t rows_pad, void* stream);
+
+/* out[g, n] += sum over rows r with r / rows_per_group == g of a[r, n] * (b ? b[r, n] : 1)
+ * (bias gradients, AdaLN shift / scale / gate gradients per image, mixer alpha gradient). */
+int dwm_segsum(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int64_t ncols,
+               int64_t rows_per_group, float* out, int64_t ld_out, void* stream);
+
+/* y = act(x) / dx = dy * act'(x); act = DWM_ACT_GELU_TANH | DWM_ACT_SILU; n % 8 == 0 */
+int dwm_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);
+int dwm_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t act, void* stream);
+
+/* diffusers GEGLU on the un-packed projection u [rows, 2*inner] = [value | gate]:
+ * g = value * gelu(gate) (erf form);  du = [dg * gelu(gate) | dg * value * gelu'(gate)] */
+int dwm_geglu_fwd(const void* u, int64_t ldu, int64_t rows, int64_t inner, void* g, int64_t ldg, void* stream);
+int dwm_geglu_bwd(const void* u, int64_t ldu, const void* dg, int64_t lddg, int64_t rows, int64_t inner,
+                  void* du, int64_t lddu, void* stream);
+
+/* out[r, n] = a[r, n] * (gate_a ? gate_a[r / rows_per_gate_a, n] : 1) * (coef_a ? coef_a[r / rows_per_coef_a] : 1)
+ *           + (b ? b[r, n] * (coef_b ? coef_b[r / rows_per_coef_b] : 1) : 0)
+ * = gated residual add (forward), gate * dy (its backward), AlphaBlender forward / backward
+ * (crossview_temporal.py:68-72), plain residual add. */
+typedef struct dwm_rowcombine_args {
+    const void* a; int64_t lda;
+    const void* gate_a; int64_t ld_gate_a; int64_t rows_per_gate_a;
+    const float* coef_a; int64_t rows_per_coef_a;
+    const void* b; int64_t ldb;
+    const float* coef_b; int64_t rows_per_coef_b;
+    void* out; int64_t ldo;
+    int64_t rows; int64_t ncols;
+} dwm_rowcombine_args;
+int dwm_rowcombine(const dwm_rowcombine_args* args, void* stream);
+
+/* Backward of dwm_layernorm.  xhat = normalise(x [+ addvec]); output 1 = xhat * gamma1 + ..,
+ * gamma1 = weight * (1 + scale[g]) (either factor optional), output 2 = xhat * (1 + scale2[g]) + ..
+ *   dx (+)= rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy*gamma1 + dy2*gamma2
+ *   dgamma[gg, :] += sum dy * xhat,  dbeta[gg, :] += sum dy   (gg = g if grad_per_group else 0:
+ *   per-image AdaLN scale / shift gradients vs. LayerNorm weight / bias gradients); same for 2. */
+typedef struct dwm_layernorm_bwd_args {
+    const void* x; int64_t ldx;
+    const void* addvec; int64_t ld_add; int64_t rows_per_add;
+    const void* dy; int64_t lddy;
+    const void* dy2; int64_t lddy2;            /* or NULL */
+    void* dx; int64_t lddx; int32_t accumulate; /* accumulate != 0: dx += */
+    int64_t rows; int32_t D; float eps;
+    const void* weight;                        /* bf16 [D] or NULL */
+    const void* scale; const void* scale2; int64_t ld_mod; int64_t rows_per_mod;
+    float* dgamma; float* dbeta; float* dgamma2; float* dbeta2; int64_t ld_grad; int32_t grad_per_group;
+} dwm_layernorm_bwd_args;
+int dwm_layernorm_bwd(const dwm_layernorm_bwd_args* args, void* stream);
+
+/* dwm_rmsnorm_heads that also returns rinv [rows, ncols/64] (fp32), and its backward, in place on
+ * dy (-> dx): y is the normalised output of the forward (xhat * w; w must be non-zero),
+ * dw[c] += sum_rows dy * xhat. */
+int dwm_rmsnorm_heads_train(void* x, int64_t ldx, int64_t rows, int64_t ncols, const void* w, float eps,
+                            float* rinv, void* stream);
+int dwm_rmsnorm_heads_bwd(const void* y, int64_t ldy, const float* rinv, const void* w, void* dy, int64_t lddy,
+                          int64_t rows, int64_t ncols, float* dw, void* stream);
+
+/* torch.optim.AdamW step on fp32 master parameters (g is multiplied by grad_scale first);
+ * p_bf16 (optional) receives the refreshed bf16 compute copy.  bias_corr{1,2} = 1 - beta^t. */
+int dwm_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+              void* stream);
+
+/* y fp32 [rows, ldy] (+)= x bf16 [rows, ldx] */
+int dwm_cast_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols,
+                         int32_t accumulate, void* stream);
 
 #ifdef __cplusplus
 }

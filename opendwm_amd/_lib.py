@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -57,6 +57,25 @@ class LayerNormArgs(C.Structure):
     ]
 
 
+class RowCombineArgs(C.Structure):
+    _fields_ = [
+        ("a", _vp), ("lda", _i64), ("gate_a", _vp), ("ld_gate_a", _i64), ("rows_per_gate_a", _i64),
+        ("coef_a", _vp), ("rows_per_coef_a", _i64), ("b", _vp), ("ldb", _i64),
+        ("coef_b", _vp), ("rows_per_coef_b", _i64), ("out", _vp), ("ldo", _i64), ("rows", _i64), ("ncols", _i64),
+    ]
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("ldx", _i64), ("addvec", _vp), ("ld_add", _i64), ("rows_per_add", _i64),
+        ("dy", _vp), ("lddy", _i64), ("dy2", _vp), ("lddy2", _i64),
+        ("dx", _vp), ("lddx", _i64), ("accumulate", _i32),
+        ("rows", _i64), ("D", _i32), ("eps", _f32), ("weight", _vp),
+        ("scale", _vp), ("scale2", _vp), ("ld_mod", _i64), ("rows_per_mod", _i64),
+        ("dgamma", _vp), ("dbeta", _vp), ("dgamma2", _vp), ("dbeta2", _vp), ("ld_grad", _i64), ("grad_per_group", _i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/dwm_hip.h declares
 SIGNATURES = {
     "dwm_abi_version": (_i32, []),
@@ -79,6 +98,19 @@ SIGNATURES = {
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dwm_pad_tokens": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(RowMap2D), _vp]),
     "dwm_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
+    # training
+    "dwm_transpose_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "dwm_segsum": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dwm_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "dwm_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "dwm_geglu_fwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dwm_geglu_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dwm_rowcombine": (_i32, [C.POINTER(RowCombineArgs), _vp]),
+    "dwm_layernorm_bwd": (_i32, [C.POINTER(LayerNormBwdArgs), _vp]),
+    "dwm_rmsnorm_heads_train": (_i32, [_vp, _i64, _i64, _i64, _vp, _f32, _vp, _vp]),
+    "dwm_rmsnorm_heads_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "dwm_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "dwm_cast_bf16_to_f32": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
 }
 
 _ERR = {-1: "DWM_EINVAL (bad shape / null pointer)", -2: "DWM_EALIGN (alignment)",

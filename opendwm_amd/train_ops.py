@@ -1,0 +1,195 @@
+"""Thin wrappers over the training entry points of libdwm_hip.so (include/dwm_hip.h, "Training"
+section) plus the two GEMM-shaped composites every linear layer's backward needs.  Same
+conventions as opendwm_amd.ops: bf16 CUDA tensors, current stream, no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from .ops import _p, _stream, ACT_GELU_TANH, ACT_SILU  # noqa: F401
+
+bf16 = torch.bfloat16
+
+
+def _rows2d(t: torch.Tensor, name: str, dtype=bf16) -> None:
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a {dtype} CUDA matrix with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+
+
+def transpose(x: torch.Tensor, rows_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, cols] -> out [cols, rows_pad] (zero-filled beyond `rows`; default: rows rounded up to 64)."""
+    _rows2d(x, "x")
+    rows, cols = x.shape
+    if rows_pad is None:
+        rows_pad = (rows + 63) // 64 * 64
+    if out is None:
+        out = torch.empty((cols, rows_pad), dtype=bf16, device=x.device)
+    _lib.check(_lib.load().dwm_transpose_bf16(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), rows_pad, _stream()),
+               "dwm_transpose_bf16")
+    return out
+
+
+def segsum(a: torch.Tensor, b: Optional[torch.Tensor] = None, rows_per_group: Optional[int] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [groups, ncols]: per-group column sums of a (* b); `out` (if given) is accumulated into."""
+    _rows2d(a, "a")
+    rows, ncols = a.shape
+    rpg = rows if rows_per_group is None else rows_per_group
+    groups = (rows + rpg - 1) // rpg
+    if out is None:
+        out = torch.zeros((groups, ncols), dtype=torch.float32, device=a.device)
+    if b is not None:
+        _rows2d(b, "b")
+    _lib.check(_lib.load().dwm_segsum(_p(a), a.stride(0), _p(b), 0 if b is None else b.stride(0), rows, ncols, rpg,
+                                      _p(out), out.stride(0), _stream()), "dwm_segsum")
+    return out
+
+
+def act_fwd(x: torch.Tensor, act: int) -> torch.Tensor:
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().dwm_act_fwd(_p(x), _p(y), x.numel(), act, _stream()), "dwm_act_fwd")
+    return y
+
+
+def act_bwd(x: torch.Tensor, dy: torch.Tensor, act: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    dx = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().dwm_act_bwd(_p(x), _p(dy), _p(dx), x.numel(), act, _stream()), "dwm_act_bwd")
+    return dx
+
+
+def geglu_fwd(u: torch.Tensor) -> torch.Tensor:
+    _rows2d(u, "u")
+    rows, two = u.shape
+    g = torch.empty((rows, two // 2), dtype=bf16, device=u.device)
+    _lib.check(_lib.load().dwm_geglu_fwd(_p(u), u.stride(0), rows, two // 2, _p(g), g.stride(0), _stream()), "dwm_geglu_fwd")
+    return g
+
+
+def geglu_bwd(u: torch.Tensor, dg: torch.Tensor) -> torch.Tensor:
+    _rows2d(u, "u"); _rows2d(dg, "dg")
+    rows, two = u.shape
+    du = torch.empty_like(u)
+    _lib.check(_lib.load().dwm_geglu_bwd(_p(u), u.stride(0), _p(dg), dg.stride(0), rows, two // 2, _p(du), du.stride(0),
+                                         _stream()), "dwm_geglu_bwd")
+    return du
+
+
+def rowcombine(a: torch.Tensor, *, gate_a: Optional[torch.Tensor] = None, rows_per_gate_a: int = 1,
+               coef_a: Optional[torch.Tensor] = None, rows_per_coef_a: int = 1,
+               b: Optional[torch.Tensor] = None, coef_b: Optional[torch.Tensor] = None, rows_per_coef_b: int = 1,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a * gate_a[row // rpg] * coef_a[row // rpc] + b * coef_b[row // rpc] (see dwm_rowcombine)."""
+    _rows2d(a, "a")
+    if out is None:
+        out = torch.empty((a.shape[0], a.shape[1]), dtype=bf16, device=a.device)
+    r = _lib.RowCombineArgs()
+    r.a, r.lda = _p(a), a.stride(0)
+    if gate_a is not None:
+        _rows2d(gate_a, "gate_a")
+        r.gate_a, r.ld_gate_a, r.rows_per_gate_a = _p(gate_a), gate_a.stride(0), rows_per_gate_a
+    if coef_a is not None:
+        r.coef_a, r.rows_per_coef_a = _p(coef_a), rows_per_coef_a
+    if b is not None:
+        _rows2d(b, "b")
+        r.b, r.ldb = _p(b), b.stride(0)
+        if coef_b is not None:
+            r.coef_b, r.rows_per_coef_b = _p(coef_b), rows_per_coef_b
+    r.out, r.ldo, r.rows, r.ncols = _p(out), out.stride(0), a.shape[0], a.shape[1]
+    _lib.check(_lib.load().dwm_rowcombine(C.byref(r), _stream()), "dwm_rowcombine")
+    return out
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, *, eps: float, dx: Optional[torch.Tensor] = None,
+                  accumulate: bool = False, addvec: Optional[torch.Tensor] = None, rows_per_add: int = 1,
+                  weight: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+                  scale2: Optional[torch.Tensor] = None, rows_per_mod: int = 0, dy2: Optional[torch.Tensor] = None,
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                  dgamma2: Optional[torch.Tensor] = None, dbeta2: Optional[torch.Tensor] = None,
+                  grad_per_group: bool = False) -> torch.Tensor:
+    """Backward of ops.layernorm; dgamma/dbeta[/2] are fp32 [G or 1, D] accumulators (see dwm_layernorm_bwd)."""
+    _rows2d(x, "x"); _rows2d(dy, "dy")
+    rows, D = x.shape
+    if dx is None:
+        dx = torch.empty((rows, D), dtype=bf16, device=x.device)
+        accumulate = False
+    a = _lib.LayerNormBwdArgs()
+    a.x, a.ldx, a.dy, a.lddy, a.dx, a.lddx = _p(x), x.stride(0), _p(dy), dy.stride(0), _p(dx), dx.stride(0)
+    a.accumulate, a.rows, a.D, a.eps = int(accumulate), rows, D, eps
+    if addvec is not None:
+        a.addvec, a.ld_add, a.rows_per_add = _p(addvec), addvec.stride(0), rows_per_add
+    if dy2 is not None:
+        a.dy2, a.lddy2 = _p(dy2), dy2.stride(0)
+    a.weight = _p(weight)
+    mod = scale if scale is not None else scale2
+    if mod is not None:
+        a.scale, a.scale2, a.ld_mod, a.rows_per_mod = _p(scale), _p(scale2), mod.stride(0), rows_per_mod
+    elif grad_per_group:
+        a.rows_per_mod = rows_per_mod
+    g0 = next((g for g in (dgamma, dbeta, dgamma2, dbeta2) if g is not None), None)
+    if g0 is not None:
+        a.dgamma, a.dbeta, a.dgamma2, a.dbeta2 = _p(dgamma), _p(dbeta), _p(dgamma2), _p(dbeta2)
+        a.ld_grad, a.grad_per_group = g0.stride(0), int(grad_per_group)
+    _lib.check(_lib.load().dwm_layernorm_bwd(C.byref(a), _stream()), "dwm_layernorm_bwd")
+    return dx
+
+
+def rmsnorm_heads_train_(x: torch.Tensor, w_expanded: torch.Tensor, eps: float) -> torch.Tensor:
+    """In-place per-head RMSNorm of x [rows, ncols]; returns rinv fp32 [rows, ncols // 64]."""
+    _rows2d(x, "x")
+    rows, ncols = x.shape
+    rinv = torch.empty((rows, ncols // 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dwm_rmsnorm_heads_train(_p(x), x.stride(0), rows, ncols, _p(w_expanded), eps, _p(rinv), _stream()),
+               "dwm_rmsnorm_heads_train")
+    return rinv
+
+
+def rmsnorm_heads_bwd_(y: torch.Tensor, rinv: torch.Tensor, w_expanded: torch.Tensor, dy: torch.Tensor,
+                       dw: torch.Tensor) -> torch.Tensor:
+    """dy -> dx in place; dw fp32 [ncols] accumulated."""
+    _rows2d(y, "y"); _rows2d(dy, "dy")
+    rows, ncols = y.shape
+    _lib.check(_lib.load().dwm_rmsnorm_heads_bwd(_p(y), y.stride(0), _p(rinv), _p(w_expanded), _p(dy), dy.stride(0), rows, ncols,
+                                                 _p(dw), _stream()), "dwm_rmsnorm_heads_bwd")
+    return dy
+
+
+def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, p_bf16: Optional[torch.Tensor], *,
+           lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("adamw_: fp32 contiguous tensors expected")
+    _lib.check(_lib.load().dwm_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                     1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, _stream()), "dwm_adamw")
+
+
+def cast_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """fp32 (+)= bf16 matrix / vector."""
+    x2 = x if x.dim() == 2 else x.reshape(1, -1)
+    _rows2d(x2, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        accumulate = False
+    o2 = out if out.dim() == 2 else out.reshape(1, -1)
+    _lib.check(_lib.load().dwm_cast_bf16_to_f32(_p(x2), x2.stride(0), _p(o2), o2.stride(0), x2.shape[0], x2.shape[1],
+                                                int(accumulate), _stream()), "dwm_cast_bf16_to_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ composites
+def linear_dgrad(dy: torch.Tensor, w_t: torch.Tensor, out: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:
+    """dX [M, K] = dY [M, N] @ W [N, K], with W^T [K, N] given (the GEMM contracts over the columns of
+    both operands).  Extra keyword arguments are GEMM epilogue options (e.g. a fused residual add)."""
+    return ops.gemm(dy, w_t, None, out=out, **epi)
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """dW [N, K] (bf16) = dY^T X and db [N] (fp32) = column sums of dY; dY [M, N], X [M, K].
+    Both operands are transposed so the contraction (over the M tokens) runs along rows."""
+    dyt = transpose(dy)                    # [N, Mp]
+    xt = transpose(x)                      # [K, Mp]
+    dw = ops.gemm(dyt, xt, None)           # [N, K]
+    db = segsum(dy)[0] if want_bias else None
+    return dw, db

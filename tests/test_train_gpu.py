@@ -1,0 +1,200 @@
+"""GPU leg (`-m gpu`): the backward / optimizer kernels of the train step against fp32 torch
+autograd of the same op on the same (bf16-rounded) inputs.  Gradients are bf16 outputs of fp32
+arithmetic, so the per-kernel bound is the same one-rounding tolerance as the forward kernels;
+fp32 reductions (bias / modulation gradients) are held to 1e-3."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.common import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+bf16 = torch.bfloat16
+TOL_KERNEL = 6e-3
+TOL_REDUCE = 2e-3
+
+
+def _log(name, **kv):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "gpu_parity.log"), "a") as f:
+        f.write(json.dumps({"test": name, **kv}) + "\n")
+    print(name, kv)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need a HIP device (torch.cuda.is_available() is False)")
+    from opendwm_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev).to(bf16)
+
+
+def test_transpose_and_segsum(dev):
+    from opendwm_amd import train_ops as T
+    x = _rand((300, 136), dev, 1)
+    xt = T.transpose(x)
+    assert xt.shape == (136, 320)
+    assert torch.equal(xt[:, :300], x.t()) and torch.count_nonzero(xt[:, 300:]) == 0
+    v = _rand((1000, 264), dev, 2)[:, :256]                       # strided view
+    assert torch.equal(T.transpose(v)[:, :1000], v.t())
+    a, b = _rand((1001, 1536), dev, 3), _rand((1001, 1536), dev, 4)
+    s = T.segsum(a)
+    assert rel_err(s[0], a.float().sum(0)) < TOL_REDUCE
+    s2 = T.segsum(a, b, rows_per_group=154)
+    ref = torch.stack([(a.float() * b.float())[i * 154:(i + 1) * 154].sum(0) for i in range(7)])
+    e = rel_err(s2, ref)
+    _log("segsum", rel=e)
+    assert s2.shape == (7, 1536) and e < TOL_REDUCE
+
+
+@pytest.mark.parametrize("act", ["gelu_tanh", "silu"])
+def test_activation_fwd_bwd(dev, act):
+    from opendwm_amd import ops, train_ops as T
+    code = ops.ACT_GELU_TANH if act == "gelu_tanh" else ops.ACT_SILU
+    f = (lambda t: F.gelu(t, approximate="tanh")) if act == "gelu_tanh" else F.silu
+    x, dy = _rand((512, 1024), dev, 1, 2.0), _rand((512, 1024), dev, 2)
+    xr = x.float().requires_grad_(True)
+    y = f(xr)
+    y.backward(dy.float())
+    e1, e2 = rel_err(T.act_fwd(x, code), y), rel_err(T.act_bwd(x, dy, code), xr.grad)
+    _log("act_fwd_bwd", act=act, fwd=e1, bwd=e2)
+    assert e1 < TOL_KERNEL and e2 < TOL_KERNEL
+
+
+def test_geglu_fwd_bwd(dev):
+    from opendwm_amd import train_ops as T
+    u, dg = _rand((300, 2 * 1024), dev, 1, 1.5), _rand((300, 1024), dev, 2)
+    ur = u.float().requires_grad_(True)
+    hv, gt = ur.chunk(2, -1)
+    g = hv * F.gelu(gt)
+    g.backward(dg.float())
+    e1, e2 = rel_err(T.geglu_fwd(u), g), rel_err(T.geglu_bwd(u, dg), ur.grad)
+    _log("geglu_fwd_bwd", fwd=e1, bwd=e2)
+    assert e1 < TOL_KERNEL and e2 < TOL_KERNEL
+
+
+def test_rowcombine(dev):
+    from opendwm_amd import train_ops as T
+    rows, n, rpg = 600, 512, 100
+    a, b, gate = _rand((rows, n), dev, 1), _rand((rows, n), dev, 2), _rand((6, n), dev, 3)
+    ca, cb = torch.rand(3, device=dev), torch.rand(3, device=dev)
+    idx = torch.arange(rows, device=dev)
+    ref = a.float() * gate.float()[idx // rpg] * ca[idx // 200][:, None] + b.float() * cb[idx // 200][:, None]
+    out = T.rowcombine(a, gate_a=gate, rows_per_gate_a=rpg, coef_a=ca, rows_per_coef_a=200, b=b, coef_b=cb, rows_per_coef_b=200)
+    assert rel_err(out, ref) < TOL_KERNEL
+    assert rel_err(T.rowcombine(a, b=b), a.float() + b.float()) < TOL_KERNEL
+    assert rel_err(T.rowcombine(a, gate_a=gate, rows_per_gate_a=rpg), a.float() * gate.float()[idx // rpg]) < TOL_KERNEL
+
+
+@pytest.mark.parametrize("D,mode", [(1536, "mod"), (1536, "mod2"), (1536, "affine"), (1536, "affine_add"), (320, "affine")])
+def test_layernorm_bwd(dev, D, mode):
+    from opendwm_amd import ops, train_ops as T
+    I, N = 5, 77
+    rows = I * N
+    x, dy, dy2 = _rand((rows, D), dev, 1, 1.5), _rand((rows, D), dev, 2), _rand((rows, D), dev, 3)
+    idx = torch.arange(rows, device=dev) // N
+    xr = x.float().requires_grad_(True)
+    if mode in ("mod", "mod2"):
+        sc, sh, sc2, sh2 = (_rand((I, D), dev, s, 0.3) for s in (4, 5, 6, 7))
+        scr, shr, sc2r, sh2r = (t.float().requires_grad_(True) for t in (sc, sh, sc2, sh2))
+        xh = F.layer_norm(xr, (D,), eps=1e-6)
+        y = xh * (1 + scr[idx]) + shr[idx]
+        loss = (y * dy.float()).sum()
+        if mode == "mod2":
+            loss = loss + ((xh * (1 + sc2r[idx]) + sh2r[idx]) * dy2.float()).sum()
+        loss.backward()
+        dg, db = torch.zeros(I, D, device=dev), torch.zeros(I, D, device=dev)
+        dg2, db2 = torch.zeros(I, D, device=dev), torch.zeros(I, D, device=dev)
+        dx = T.layernorm_bwd(x, dy, eps=1e-6, scale=sc, scale2=sc2 if mode == "mod2" else None, rows_per_mod=N,
+                             dy2=dy2 if mode == "mod2" else None, dgamma=dg, dbeta=db,
+                             dgamma2=dg2 if mode == "mod2" else None, dbeta2=db2 if mode == "mod2" else None,
+                             grad_per_group=True)
+        errs = dict(dx=rel_err(dx, xr.grad), dscale=rel_err(dg, scr.grad), dshift=rel_err(db, shr.grad))
+        if mode == "mod2":
+            errs.update(dscale2=rel_err(dg2, sc2r.grad), dshift2=rel_err(db2, sh2r.grad))
+    else:
+        w, b = _rand((D,), dev, 4, 0.2) + 1, _rand((D,), dev, 5, 0.2)
+        wr, br = w.float().requires_grad_(True), b.float().requires_grad_(True)
+        emb = _rand((I, D), dev, 6) if mode == "affine_add" else None
+        xin = xr
+        if emb is not None:
+            embr = emb.float().requires_grad_(True)
+            ssum = xr + embr[idx]
+            xin = ssum.detach().to(bf16).float() + (ssum - ssum.detach())   # forward rounds the sum to bf16 (straight-through)
+        y = F.layer_norm(xin, (D,), wr, br, eps=1e-5)
+        (y * dy.float()).sum().backward()
+        dg, db = torch.zeros(1, D, device=dev), torch.zeros(1, D, device=dev)
+        pre = _rand((rows, D), dev, 8)
+        dx = pre.clone()
+        T.layernorm_bwd(x, dy, eps=1e-5, dx=dx, accumulate=True, weight=w, addvec=emb, rows_per_add=N, dgamma=dg, dbeta=db)
+        errs = dict(dx=rel_err(dx, xr.grad + pre.float()), dw=rel_err(dg[0], wr.grad), db=rel_err(db[0], br.grad))
+        # consistency with the forward kernel's output
+        yk = ops.layernorm(x, eps=1e-5, weight=w, bias=b, addvec=emb, rows_per_add=N,
+                           xsum=torch.empty_like(x) if emb is not None else None)
+        errs["fwd"] = rel_err(yk, y)
+    _log("layernorm_bwd", D=D, mode=mode, **errs)
+    assert all(v < (TOL_REDUCE if k.startswith("ds") or k in ("dw", "db") else TOL_KERNEL) for k, v in errs.items()), errs
+
+
+def test_rmsnorm_heads_fwd_bwd(dev):
+    from opendwm_amd import train_ops as T
+    rows, heads = 333, 24
+    ncols = 2 * heads * 64
+    x, dy = _rand((rows, ncols + 64), dev, 1, 1.3)[:, :ncols], _rand((rows, ncols), dev, 2)
+    wq, wk = _rand((64,), dev, 3, 0.2) + 1, _rand((64,), dev, 4, 0.2) + 1
+    w = torch.cat([wq.repeat(heads), wk.repeat(heads)]).contiguous()
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    xh = xr.view(rows, 2 * heads, 64)
+    y = (xh * torch.rsqrt(xh.pow(2).mean(-1, keepdim=True) + 1e-6)).view(rows, ncols) * wr
+    y.backward(dy.float())
+    xk = x.clone()
+    rinv = T.rmsnorm_heads_train_(xk, w, 1e-6)
+    e_f = rel_err(xk, y)
+    dw = torch.zeros(ncols, device=dev)
+    dx = T.rmsnorm_heads_bwd_(xk, rinv, w, dy.clone(), dw)
+    e_x, e_w = rel_err(dx, xr.grad), rel_err(dw, wr.grad)
+    _log("rmsnorm_heads_bwd", fwd=e_f, dx=e_x, dw=e_w)
+    # dx goes through y / w (bf16 y): one extra rounding in the normalised activations
+    assert e_f < TOL_KERNEL and e_x < 1.5e-2 and e_w < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(896, 1536, 1536), (154 * 3, 4608, 1536), (96, 1536, 256)])
+def test_linear_backward(dev, M, N, K):
+    from opendwm_amd import ops, train_ops as T
+    x, w, b, dy = _rand((M, K), dev, 1), _rand((N, K), dev, 2, K ** -0.5), _rand((N,), dev, 3), _rand((M, N), dev, 4)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    F.linear(xr, wr, br).backward(dy.float())
+    dx = T.linear_dgrad(dy, T.transpose(w, rows_pad=N))
+    dw, db = T.linear_wgrad(dy, x)
+    e = dict(dx=rel_err(dx, xr.grad), dw=rel_err(dw, wr.grad), db=rel_err(db, br.grad))
+    _log("linear_backward", M=M, N=N, K=K, **e)
+    assert e["dx"] < TOL_KERNEL and e["dw"] < TOL_KERNEL and e["db"] < TOL_REDUCE
+
+
+def test_adamw_matches_torch(dev):
+    from opendwm_amd import train_ops as T
+    n = 100_003
+    g0 = torch.Generator(device="cpu").manual_seed(0)
+    p = torch.randn(n, generator=g0).to(dev)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    m, v, pb = torch.zeros_like(p), torch.zeros_like(p), torch.empty(n, dtype=bf16, device=dev)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=g0).to(dev)
+        ref.grad = g.clone()
+        opt.step()
+        T.adamw_(p, g, m, v, pb, lr=3e-4, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.01, step=step)
+    assert rel_err(p, ref.detach()) < 1e-6
+    assert torch.equal(pb, p.to(bf16))
+    out = T.cast_f32(pb)
+    assert torch.equal(out, pb.float())
