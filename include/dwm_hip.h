@@ -144,9 +144,27 @@ typedef struct dwm_attn_args {
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
     int32_t variant;                           /* 0 = auto; tuning knob, see attention.hip    */
     int32_t reserved;
+    float* lse;                                /* optional out fp32 [n_problems, heads, L0+L1]: NEGATIVE
+                                                * log2-domain log-sum-exp of scale*log2(e)*q.k, i.e.
+                                                * P = exp2(scale*log2(e)*q.k + lse) (saved for the backward) */
 } dwm_attn_args;
 
 int dwm_attention_fwd(const dwm_attn_args* args, void* stream);
+
+/* Backward of dwm_attention_fwd (F.scaled_dot_product_attention inside JointAttnProcessor2_0 /
+ * AttnProcessor2_0 under autograd).  `fwd` repeats the forward call: q/k/v, the forward OUTPUTS
+ * o0/o1 (read here), the row map, masks and fwd.lse as written by the forward.  do0/do1 are laid out
+ * like o0/o1 (ldo0/ldo1); dq/dk/dv are addressed like q/k/v through the same row map with leading
+ * dimensions ld_d0/ld_d1 and must satisfy dq1-dq0 == dk1-dk0 == dv1-dv0.  delta = caller scratch,
+ * fp32 [n_problems, heads, L0+L1].  All 16-byte aligned, ldo % 8 == 0. */
+typedef struct dwm_attn_bwd_args {
+    dwm_attn_args fwd;
+    const void *do0, *do1;
+    void *dq0, *dk0, *dv0; int64_t ld_d0;
+    void *dq1, *dk1, *dv1; int64_t ld_d1;
+    float* delta;
+} dwm_attn_bwd_args;
+int dwm_attention_bwd(const dwm_attn_bwd_args* args, void* stream);
 
 /* Diagnostic (tests only): one wave issues ds_read_b64_tr_b16 at LDS byte offset offs[lane]
  * (8-byte aligned, < 8192) of an image with img16[i] = i; out[lane*4 + j] = element j. */

@@ -42,7 +42,15 @@ class AttnArgs(C.Structure):
         ("pdiv", _i64 * 3), ("pmod", _i64 * 3), ("pstride", _i64 * 3),
         ("ldiv", _i64 * 2), ("lstride", _i64 * 3),
         ("mask", _vp), ("mask_G", _i64), ("group_size", _i64), ("p_per_mask", _i64),
-        ("variant", _i32), ("reserved", _i32),
+        ("variant", _i32), ("reserved", _i32), ("lse", _vp),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", AttnArgs), ("do0", _vp), ("do1", _vp),
+        ("dq0", _vp), ("dk0", _vp), ("dv0", _vp), ("ld_d0", _i64),
+        ("dq1", _vp), ("dk1", _vp), ("dv1", _vp), ("ld_d1", _i64), ("delta", _vp),
     ]
 
 
@@ -81,6 +89,7 @@ SIGNATURES = {
     "dwm_abi_version": (_i32, []),
     "dwm_gemm_bf16": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dwm_attention_fwd": (_i32, [C.POINTER(AttnArgs), _vp]),
+    "dwm_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
     "dwm_debug_tr_probe": (_i32, [_vp, _vp, _vp]),
     "dwm_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),
     "dwm_rmsnorm_heads": (_i32, [_vp, _i64, _i64, _i64, _vp, _f32, _vp]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdwm_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "norm.hip", "elementwise.hip", "vae.hip", "train.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "vae.hip", "train.hip"]
 # translation units built without -amdgpu-mfma-vgpr-form (accumulators allowed into AGPRs); none at present
 AGPR_SOURCES: set = set()
 ARCH = "gfx950"
@@ -37,7 +37,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "dwm_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attention_common.h"), os.path.join(INCLUDE, "dwm_hip.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the

@@ -24,86 +24,11 @@
 // which folds the reference's einops rearranges (crossview_temporal_dit.py:307-315,
 // 336-361) into the loads/stores; segment 1 (text context of the joint attention)
 // is dense.  Mask modes: none / [B,G,G] group mask (cross-view) / dense bytes.
-#include "common.h"
-#include "dwm_hip.h"
+#include "attention_common.h"
+
+using namespace dwm_attn;
 
 namespace {
-
-constexpr int KT = 64;                        // keys per tile
-constexpr int K_TILE_BYTES = KT * 128;        // 8192
-constexpr int V_TILE_BYTES = KT * 128;        // 8192
-constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
-constexpr int MAX_LDS_BYTES = 96 * 1024;
-constexpr int NSTAGE = 3;                     // LDS ring depth (tiles t, t+1, t+2 resident or in flight)
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-struct RowMap {
-    FastDiv pdiv[3], pmod[3];
-    int64_t pstride[3];
-    FastDiv ldiv0, ldiv1;
-    int64_t lstride[3];
-};
-
-struct AttnParams {
-    const bf16_t *q0, *k0, *v0, *q1, *k1, *v1;
-    bf16_t *o0, *o1;
-    int64_t ld0, ld1, ldo0, ldo1;
-    int L0, L1, L;
-    int64_t seg1_delta;      // (q1 - q0) == (k1 - k0) == (v1 - v0) in elements
-    int n_problems, heads, nqb;
-    FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;
-    float scale_log2;
-    int mask_mode;
-    const uint8_t* mask;
-    int mask_G, group_size, p_per_mask;
-    float inv_group_size, inv_G;
-    RowMap rm;
-};
-
-DWM_DEVINL int64_t seg0_base(const RowMap& rm, int p) {
-    int64_t b = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) b += (int64_t)fmod_u(fdiv((uint32_t)p, rm.pdiv[i]), rm.pmod[i]) * rm.pstride[i];
-    return b;
-}
-DWM_DEVINL int64_t seg0_row(const RowMap& rm, int64_t base, int l) {
-    const uint32_t q0 = fdiv((uint32_t)l, rm.ldiv0), lo = (uint32_t)l - q0 * rm.ldiv0.d;
-    const uint32_t hi = fdiv(q0, rm.ldiv1), mid = q0 - hi * rm.ldiv1.d;
-    return base + (int64_t)lo * rm.lstride[0] + (int64_t)mid * rm.lstride[1] + (int64_t)hi * rm.lstride[2];
-}
-DWM_DEVINL float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // fmaxf() adds a canonicalising v_max per MFMA output
-    return r;
-}
-// max over the 32 scores a lane holds for one query (two 32-key sub-tiles), combined with the
-// partner lane (lane ^ 32) that holds the other keys of the same query
-DWM_DEVINL float tile_max32(const f32x16& s0, const f32x16& s1) {
-    float mxa = max3f(s0[0], s0[1], s0[2]), mxb = max3f(s0[3], s0[4], s0[5]);
-    float mxc = max3f(s1[0], s1[1], s1[2]), mxd = max3f(s1[3], s1[4], s1[5]);
-#pragma unroll
-    for (int r = 6; r < 14; r += 4) {
-        mxa = max3f(mxa, s0[r], s0[r + 1]);
-        mxb = max3f(mxb, s0[r + 2], s0[r + 3]);
-        mxc = max3f(mxc, s1[r], s1[r + 1]);
-        mxd = max3f(mxd, s1[r + 2], s1[r + 3]);
-    }
-    mxa = max3f(mxa, s0[14], s0[15]);
-    mxc = max3f(mxc, s1[14], s1[15]);
-    const float mx = max3f(max3f(mxa, mxb, mxc), mxd, -INFINITY);
-    return max3f(mx, __shfl_xor(mx, 32, 64), -INFINITY);
-}
-// 8 bf16 * c -> 8 bf16 (folds softmax scale * log2(e) into the Q fragments)
-DWM_DEVINL bf16x8 scale_frag(const bf16x8& v, float c) {
-    const uint4 u = *reinterpret_cast<const uint4*>(&v);
-    float f[8];
-    unpack8(u, f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] *= c;
-    const uint4 o = pack8(f);
-    return *reinterpret_cast<const bf16x8*>(&o);
-}
 
 // MASK: 0 none, 1 group mask, 2 dense byte mask.  NW = 4 waves (256 threads).
 // occupancy target: 3 workgroups (waves per SIMD) for 32 queries/wave, 2 for 64 queries/wave
@@ -113,7 +38,8 @@ attn_fwd_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 4;
     constexpr int QB = NW * QT * 32;          // queries per block
-    // [L] offset (in 16-byte units, relative to the segment-0 base pointer) of every token row of this problem
+    // [L] offset (in 16-byte units) of every token row of this problem inside ITS segment's buffers;
+    // segment 1 rows add seg1_delta (kept 64-bit: the two allocations may be > 32 GiB apart)
     int32_t* __restrict__ rowtab = (int32_t*)(smem + NSTAGE * STAGE_BYTES);
 
     const int tid = threadIdx.x;
@@ -139,7 +65,7 @@ attn_fwd_kernel(const AttnParams P) {
         const int64_t base0 = seg0_base(P.rm, prob);
         for (int l = tid; l < L; l += 256)
             rowtab[l] = (int32_t)((l < L0 ? seg0_row(P.rm, base0, l) * P.ld0
-                                          : P.seg1_delta + ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
+                                          : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
     }
     __syncthreads();
 
@@ -154,7 +80,7 @@ attn_fwd_kernel(const AttnParams P) {
         const int lq = qb * QB + (wave * QT + t) * 32 + l31;
         qok[t] = lq < L;
         const int lqc = qok[t] ? lq : L - 1;
-        const bf16_t* qptr = P.q0 + ((int64_t)rowtab[lqc] << 3) + hoff;      // q, k, v share the offset table
+        const bf16_t* qptr = P.q0 + ((int64_t)rowtab[lqc] << 3) + (lqc < L0 ? 0 : P.seg1_delta) + hoff;      // q, k, v share the offset table
         if (lqc < L0) optr[t] = P.o0 + seg0_row(P.rm, seg0_base(P.rm, prob), lqc) * P.ldo0 + hoff;
         else optr[t] = P.o1 + ((int64_t)prob * P.L1 + (lqc - L0)) * P.ldo1 + hoff;
 #pragma unroll
@@ -186,8 +112,10 @@ attn_fwd_kernel(const AttnParams P) {
 #define DWM_DMA_TILE(kt_, stage_)                                                           \
     do {                                                                                    \
         const int kb_ = (kt_) * KT;                                                         \
-        const int64_t oa_ = (int64_t)rowtab[kb_ + srow0 < L ? kb_ + srow0 : L - 1] << 3;    \
-        const int64_t ob_ = (int64_t)rowtab[kb_ + srow1 < L ? kb_ + srow1 : L - 1] << 3;    \
+        const int ra_ = kb_ + srow0 < L ? kb_ + srow0 : L - 1;                              \
+        const int rb_ = kb_ + srow1 < L ? kb_ + srow1 : L - 1;                              \
+        const int64_t oa_ = ((int64_t)rowtab[ra_] << 3) + (ra_ < L0 ? 0 : P.seg1_delta);    \
+        const int64_t ob_ = ((int64_t)rowtab[rb_] << 3) + (rb_ < L0 ? 0 : P.seg1_delta);    \
         char* kl_ = smem + (stage_) * STAGE_BYTES + sdst;                                   \
         glds16(kg0 + oa_, kl_);                                                             \
         glds16(kg1 + ob_, kl_ + 1024);                                                      \
@@ -368,6 +296,8 @@ attn_fwd_kernel(const AttnParams P) {
     for (int t = 0; t < QT; ++t) {
         const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
         const float inv = __builtin_amdgcn_rcpf(l_tot);
+        if (P.lse != nullptr && qok[t] && half == 0)       // NEGATIVE log2-domain LSE: P = exp2(c q.k + neg_lse)
+            P.lse[((int64_t)prob * P.heads + head) * L + qb * QB + (wave * QT + t) * 32 + l31] = negm[t][0] - __builtin_amdgcn_logf(l_tot);
         if (qok[t]) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -411,48 +341,10 @@ void launch_attn(const AttnParams& P, hipStream_t s) {
 }  // namespace
 
 extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
-    if (a == nullptr || a->q0 == nullptr || a->k0 == nullptr || a->v0 == nullptr || a->o0 == nullptr) return DWM_EINVAL;
-    if (a->head_dim != 64) return DWM_EUNSUPPORTED;
-    if (a->L0 <= 0 || a->L1 < 0 || a->n_problems <= 0 || a->heads <= 0) return DWM_EINVAL;
-    if (a->L1 > 0 && (a->q1 == nullptr || a->k1 == nullptr || a->v1 == nullptr || a->o1 == nullptr)) return DWM_EINVAL;
-    if (a->ld0 % 8 != 0 || a->ldo0 % 4 != 0 || (a->L1 > 0 && (a->ld1 % 8 != 0 || a->ldo1 % 4 != 0))) return DWM_EALIGN;
-    if (!dwm_aligned16(a->q0) || !dwm_aligned16(a->k0) || !dwm_aligned16(a->v0) || (((uintptr_t)a->o0) & 7u)) return DWM_EALIGN;
-    if (a->L1 > 0 && (!dwm_aligned16(a->q1) || !dwm_aligned16(a->k1) || !dwm_aligned16(a->v1) || (((uintptr_t)a->o1) & 7u)))
-        return DWM_EALIGN;
-    if (a->ldiv[0] <= 0 || a->ldiv[1] <= 0) return DWM_EINVAL;
-    if (a->mask_mode < 0 || a->mask_mode > 2) return DWM_EINVAL;
-    if (a->mask_mode != 0 && a->mask == nullptr) return DWM_EINVAL;
-    if (a->mask_mode == 1 && (a->mask_G <= 0 || a->mask_G > 32 || a->group_size <= 0 || a->p_per_mask <= 0)) return DWM_EINVAL;
-    const int64_t L = a->L0 + a->L1;
-    if (L >= (1 << 22) || a->n_problems >= (1ll << 30)) return DWM_EUNSUPPORTED;
-
     AttnParams P;
-    P.q0 = (const bf16_t*)a->q0; P.k0 = (const bf16_t*)a->k0; P.v0 = (const bf16_t*)a->v0;
-    P.q1 = (const bf16_t*)a->q1; P.k1 = (const bf16_t*)a->k1; P.v1 = (const bf16_t*)a->v1;
-    P.o0 = (bf16_t*)a->o0; P.o1 = (bf16_t*)a->o1;
-    P.ld0 = a->ld0; P.ld1 = a->ld1; P.ldo0 = a->ldo0; P.ldo1 = a->ldo1;
-    P.L0 = (int)a->L0; P.L1 = (int)a->L1; P.L = (int)L;
-    P.seg1_delta = 0;
-    if (a->L1 > 0) {
-        // the kernel addresses both segments through one offset table relative to q0/k0/v0
-        const int64_t dq = P.q1 - P.q0, dk = P.k1 - P.k0, dv = P.v1 - P.v0;
-        if (dq != dk || dk != dv) return DWM_EUNSUPPORTED;
-        P.seg1_delta = dq;
-    }
-    P.n_problems = (int)a->n_problems; P.heads = a->heads;
-    P.scale_log2 = a->scale * 1.4426950408889634f;
-    P.mask_mode = a->mask_mode; P.mask = a->mask;
-    P.mask_G = (int)a->mask_G; P.group_size = (int)a->group_size; P.p_per_mask = (int)a->p_per_mask;
-    P.inv_group_size = a->group_size > 0 ? 1.f / (float)a->group_size : 0.f;
-    P.inv_G = a->mask_G > 0 ? 1.f / (float)a->mask_G : 0.f;
-    for (int i = 0; i < 3; ++i) {
-        if (a->pdiv[i] <= 0 || a->pmod[i] <= 0 || a->pdiv[i] > (1ll << 30) || a->pmod[i] > (1ll << 30)) return DWM_EINVAL;
-        P.rm.pdiv[i] = make_fastdiv((uint32_t)a->pdiv[i]); P.rm.pmod[i] = make_fastdiv((uint32_t)a->pmod[i]);
-        P.rm.pstride[i] = a->pstride[i];
-    }
-    if (a->ldiv[0] > (1ll << 30) || a->ldiv[1] > (1ll << 30)) return DWM_EINVAL;
-    P.rm.ldiv0 = make_fastdiv((uint32_t)a->ldiv[0]); P.rm.ldiv1 = make_fastdiv((uint32_t)a->ldiv[1]);
-    for (int i = 0; i < 3; ++i) P.rm.lstride[i] = a->lstride[i];
+    const int rc = fill_params(a, P);
+    if (rc != DWM_OK) return rc;
+    const int64_t L = P.L;
 
     // variant: 0 = auto; 1 / 2 = 32 / 64 queries per wave (128 / 256 per workgroup)
     int qt = a->variant & 15;
@@ -460,10 +352,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     if (qt != 1 && qt != 2) return DWM_EINVAL;
     const int qblock = qt * 128;
     P.nqb = (int)((L + qblock - 1) / qblock);
-    P.fd_nqb = make_fastdiv((uint32_t)P.nqb); P.fd_heads = make_fastdiv((uint32_t)P.heads);
-    P.fd_gs = make_fastdiv((uint32_t)(P.group_size > 0 ? P.group_size : 1));
-    P.fd_G = make_fastdiv((uint32_t)(P.mask_G > 0 ? P.mask_G : 1));
-    P.fd_ppm = make_fastdiv((uint32_t)(P.p_per_mask > 0 ? P.p_per_mask : 1));
+    P.fd_nqb = make_fastdiv((uint32_t)P.nqb);
     if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
     if (NSTAGE * STAGE_BYTES + L * 4 + 16 > MAX_LDS_BYTES) return DWM_EUNSUPPORTED;   // ring + row table must fit the LDS window
     hipStream_t s = (hipStream_t)stream;

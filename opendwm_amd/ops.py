@@ -229,23 +229,12 @@ def rowmap_temporal_pointwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
                   ldiv=(BIG, BIG), lstride=(V * hw, 0, 0))
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
-              rowmap: RowMap, heads: int, *,
-              q1: Optional[torch.Tensor] = None, k1: Optional[torch.Tensor] = None,
-              v1: Optional[torch.Tensor] = None, out1: Optional[torch.Tensor] = None,
-              scale: Optional[float] = None,
-              group_mask: Optional[torch.Tensor] = None, dense_mask: Optional[torch.Tensor] = None,
-              variant: int = 0) -> None:
-    """softmax(QK^T * scale [+mask]) V per (problem, head); q/k/v/out are 2-D [rows, heads*64]
-    views sharing a row stride (e.g. column slices of a fused qkv buffer).  Segment 1
-    (q1/k1/v1/out1: [n_problems*L1, heads*64]) is appended to every problem's key/query
-    sequence (text context of the joint attention).  group_mask: bool/uint8 [Bm, G, G];
-    dense_mask: bool/uint8 [n_problems, L, L]."""
+def _attn_args(a, q, k, v, out, rowmap, heads, q1, k1, v1, out1, scale, group_mask, dense_mask):
+    """fill a dwm_attn_args; returns the uint8 mask tensor that must outlive the launch (or None)"""
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         _chk2d(t, name)
     if not (q.stride(0) == k.stride(0) == v.stride(0)):
         raise RuntimeError("q, k, v must share a row stride")
-    a = _lib.AttnArgs()
     a.q0, a.k0, a.v0, a.ld0 = q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0)
     a.o0, a.ldo0 = out.data_ptr(), out.stride(0)
     a.L0, a.L1, a.n_problems = rowmap.L0, 0, rowmap.n_problems
@@ -274,8 +263,57 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     elif dense_mask is not None:
         keep = dense_mask.to(torch.uint8).contiguous()
         a.mask_mode, a.mask = 2, keep.data_ptr()
+    return keep
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+              rowmap: RowMap, heads: int, *,
+              q1: Optional[torch.Tensor] = None, k1: Optional[torch.Tensor] = None,
+              v1: Optional[torch.Tensor] = None, out1: Optional[torch.Tensor] = None,
+              scale: Optional[float] = None,
+              group_mask: Optional[torch.Tensor] = None, dense_mask: Optional[torch.Tensor] = None,
+              variant: int = 0, lse: Optional[torch.Tensor] = None) -> None:
+    """softmax(QK^T * scale [+mask]) V per (problem, head); q/k/v/out are 2-D [rows, heads*64]
+    views sharing a row stride (e.g. column slices of a fused qkv buffer).  Segment 1
+    (q1/k1/v1/out1: [n_problems*L1, heads*64]) is appended to every problem's key/query
+    sequence (text context of the joint attention).  group_mask: bool/uint8 [Bm, G, G];
+    dense_mask: bool/uint8 [n_problems, L, L].  lse (optional, fp32 [n_problems, heads, L0+L1])
+    receives the negative log2-domain log-sum-exp the backward needs."""
+    a = _lib.AttnArgs()
+    keep = _attn_args(a, q, k, v, out, rowmap, heads, q1, k1, v1, out1, scale, group_mask, dense_mask)
     a.variant = variant
+    if lse is not None:
+        if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != a.n_problems * heads * (a.L0 + a.L1):
+            raise RuntimeError("lse: fp32 contiguous [n_problems, heads, L0+L1] expected")
+        a.lse = lse.data_ptr()
     _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
+    if keep is not None:
+        keep.record_stream(torch.cuda.current_stream())
+
+
+def attention_bwd(q, k, v, out, dout, dq, dk, dv, rowmap: RowMap, heads: int, lse: torch.Tensor, *,
+                  q1=None, k1=None, v1=None, out1=None, dout1=None, dq1=None, dk1=None, dv1=None,
+                  scale: Optional[float] = None, group_mask=None, dense_mask=None) -> None:
+    """Backward of `attention` (same arguments plus the forward outputs, their gradients and lse);
+    writes dq/dk/dv (and dq1/dk1/dv1), which share a row stride per segment."""
+    b = _lib.AttnBwdArgs()
+    keep = _attn_args(b.fwd, q, k, v, out, rowmap, heads, q1, k1, v1, out1, scale, group_mask, dense_mask)
+    b.fwd.lse = lse.data_ptr()
+    for name, t in (("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
+        _chk2d(t, name)
+    if dout.stride(0) != out.stride(0) or not (dq.stride(0) == dk.stride(0) == dv.stride(0)):
+        raise RuntimeError("dout must be laid out like out; dq, dk, dv must share a row stride")
+    b.do0, b.dq0, b.dk0, b.dv0, b.ld_d0 = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0)
+    if q1 is not None:
+        for name, t in (("dout1", dout1), ("dq1", dq1), ("dk1", dk1), ("dv1", dv1)):
+            _chk2d(t, name)
+        if dout1.stride(0) != out1.stride(0):
+            raise RuntimeError("dout1 must be laid out like out1")
+        b.do1, b.dq1, b.dk1, b.dv1, b.ld_d1 = dout1.data_ptr(), dq1.data_ptr(), dk1.data_ptr(), dv1.data_ptr(), dq1.stride(0)
+    delta = torch.empty(lse.numel(), dtype=torch.float32, device=lse.device)
+    b.delta = delta.data_ptr()
+    _lib.check(_lib.load().dwm_attention_bwd(C.byref(b), _stream()), "dwm_attention_bwd")
+    delta.record_stream(torch.cuda.current_stream())
     if keep is not None:
         keep.record_stream(torch.cuda.current_stream())
 

@@ -198,3 +198,92 @@ def test_adamw_matches_torch(dev):
     assert torch.equal(pb, p.to(bf16))
     out = T.cast_f32(pb)
     assert torch.equal(out, pb.float())
+
+
+# ------------------------------------------------------------------------------- attention backward
+def _attn_ref_autograd(qkv, cqkv, rows, heads, do, cdo, mask=None):
+    """fp32 autograd reference: qkv [R, 3D] (+ context cqkv [P*L1, 3D]) -> grads wrt qkv, cqkv."""
+    from oracle import ctsd_oracle as O
+    P, L0 = rows.shape
+    D = heads * 64
+    x = qkv.float().requires_grad_(True)
+    c = cqkv.float().requires_grad_(True) if cqkv is not None else None
+
+    def gather(t, t1):
+        g = t[rows.reshape(-1)].view(P, L0, heads, 64)
+        if t1 is not None:
+            g = torch.cat([g, t1.view(P, -1, heads, 64)], 1)
+        return g.transpose(1, 2)
+    Q = gather(x[:, :D], None if c is None else c[:, :D])
+    K = gather(x[:, D:2 * D], None if c is None else c[:, D:2 * D])
+    V = gather(x[:, 2 * D:], None if c is None else c[:, 2 * D:])
+    o = O.sdpa(Q, K, V, None if mask is None else mask[:, None]).transpose(1, 2).reshape(P, -1, D)
+    o0 = torch.zeros(qkv.shape[0], D, device=qkv.device).index_put((rows.reshape(-1),), o[:, :L0].reshape(-1, D))
+    loss = (o0 * do.float()).sum()
+    if c is not None:
+        loss = loss + (o[:, L0:].reshape(-1, D) * cdo.float()).sum()
+    loss.backward()
+    return o0.detach(), x.grad, (None if c is None else c.grad)
+
+
+@pytest.mark.parametrize("I,N,Lc,heads", [(2, 448, 154, 4), (2, 100, 0, 2), (2, 64, 10, 2), (3, 16, 0, 2), (1, 300, 3, 3)])
+def test_attention_backward_joint(dev, I, N, Lc, heads):
+    from opendwm_amd import ops
+    D = heads * 64
+    qkv, do = _rand((I * N, 3 * D), dev, 1), _rand((I * N, D), dev, 3)
+    cqkv = _rand((I * Lc, 3 * D), dev, 2) if Lc else None
+    cdo = _rand((I * Lc, D), dev, 4) if Lc else None
+    out = torch.zeros((I * N, D), dtype=bf16, device=dev)
+    cout = torch.zeros((I * Lc, D), dtype=bf16, device=dev) if Lc else None
+    rm = ops.rowmap_identity(I, N)
+    lse = torch.empty(I * heads * (N + Lc), dtype=torch.float32, device=dev)
+    kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout) if Lc else {}
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, lse=lse, **kw)
+    dqkv = torch.zeros_like(qkv)
+    dcqkv = torch.zeros_like(cqkv) if Lc else None
+    if Lc:
+        kw.update(dout1=cdo, dq1=dcqkv[:, :D], dk1=dcqkv[:, D:2 * D], dv1=dcqkv[:, 2 * D:])
+    ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, do, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                      rm, heads, lse, **kw)
+    o_ref, g_ref, cg_ref = _attn_ref_autograd(qkv, cqkv, rm.rows().to(dev), heads, do, cdo)
+    e = dict(fwd=rel_err(out, o_ref), dq=rel_err(dqkv[:, :D], g_ref[:, :D]), dk=rel_err(dqkv[:, D:2 * D], g_ref[:, D:2 * D]),
+             dv=rel_err(dqkv[:, 2 * D:], g_ref[:, 2 * D:]))
+    if Lc:
+        e.update(dq1=rel_err(dcqkv[:, :D], cg_ref[:, :D]), dk1=rel_err(dcqkv[:, D:2 * D], cg_ref[:, D:2 * D]),
+                 dv1=rel_err(dcqkv[:, 2 * D:], cg_ref[:, 2 * D:]))
+    _log("attention_bwd_joint", I=I, N=N, Lc=Lc, heads=heads, **e)
+    # P and dS are rounded to bf16 before their second MFMA (as P is in the forward): 1e-2
+    assert all(v < 1e-2 for v in e.values()), e
+
+
+@pytest.mark.parametrize("kind", ["crossview_rowwise", "temporal_rowwise", "temporal_pointwise", "crossview_full"])
+def test_attention_backward_rowmaps_and_masks(dev, kind):
+    from opendwm_amd import ops
+    from oracle import ctsd_oracle as O
+    B, T, V, h, w, heads = 2, 5, 6, 3, 7, 2
+    D = heads * 64
+    rm = getattr(ops, "rowmap_" + kind)(B, T, V, h, w)
+    R = B * T * V * h * w
+    qkv, do = _rand((R, 3 * D), dev, 3), _rand((R, D), dev, 5)
+    out = torch.zeros((R, D), dtype=bf16, device=dev)
+    gmask = ref_mask = None
+    if kind.startswith("crossview"):
+        gmask = O.ring_crossview_mask(B, V).to(dev)
+        gmask[1, 2, 5] = True
+        p = torch.arange(rm.n_problems, device=dev)[:, None, None]
+        l = torch.arange(rm.L0, device=dev)
+        ref_mask = gmask[p // rm.p_per_mask, ((l // rm.group_size) % V)[None, :, None], ((l // rm.group_size) % V)[None, None, :]]
+    lse = torch.empty(rm.n_problems * heads * rm.L0, dtype=torch.float32, device=dev)
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, group_mask=gmask, lse=lse)
+    dqkv = torch.zeros_like(qkv)
+    ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, do, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                      rm, heads, lse, group_mask=gmask)
+    _, g_ref, _ = _attn_ref_autograd(qkv, None, rm.rows().to(dev), heads, do, None, mask=ref_mask)
+    e = rel_err(dqkv, g_ref)
+    _log("attention_bwd_rowmap", kind=kind, rel=e)
+    assert e < 1e-2
+    if ref_mask is not None:                                   # the same through the dense-mask mode
+        d2 = torch.zeros_like(qkv)
+        ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, do, d2[:, :D], d2[:, D:2 * D], d2[:, 2 * D:],
+                          rm, heads, lse, dense_mask=ref_mask)
+        assert rel_err(d2, g_ref) < 1e-2
