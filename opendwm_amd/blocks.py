@@ -21,11 +21,55 @@ from .ops import (ACT_GELU_TANH, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_R
 bf16 = torch.bfloat16
 
 
+class ParamStore:
+    """bf16 compute copies of (fp32 master) parameters, keyed by parameter identity.  A copy is
+    refreshed when the parameter's storage / autograd version changes or after `bump()` (the
+    optimizer step of opendwm_amd.train writes the new bf16 values straight into the shadows and
+    then calls `bump(keep_shadows=True)` so only derived tensors - fused / transposed weights - are
+    rebuilt)."""
+
+    def __init__(self):
+        self.step = 0
+        self._shadow = {}       # id(param) -> (key, bf16 tensor)
+        self._derived = {}      # (id(param), tag) -> (step, tensor)
+
+    def bf(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype == bf16:
+            d = t.detach()
+            return d if d.is_contiguous() else d.contiguous()
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        hit = self._shadow.get(id(t))
+        if hit is None or hit[0] != key:
+            d = t.detach()
+            if d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.numel() % 4 == 0:
+                sh = ops.cast_bf16(d)
+            else:
+                sh = d.to(bf16).contiguous()
+            hit = (key, sh)
+            self._shadow[id(t)] = hit
+        return hit[1]
+
+    def derived(self, t: torch.Tensor, tag: str, make):
+        """cache of a tensor derived from parameter(s) (transpose, fused qkv, ...) valid for one optimizer step"""
+        k = (id(t), tag)
+        hit = self._derived.get(k)
+        if hit is None or hit[0] != (self.step, t.data_ptr(), t._version):
+            hit = ((self.step, t.data_ptr(), t._version), make())
+            self._derived[k] = hit
+        return hit[1]
+
+    def bump(self, keep_shadows: bool = False) -> None:
+        self.step += 1
+        self._derived.clear()
+        if not keep_shadows:
+            self._shadow.clear()
+
+
+STORE = ParamStore()
+
+
 def _bf(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    if t is None:
-        return None
-    t = t.detach()
-    return t if t.dtype == bf16 and t.is_contiguous() else t.to(bf16).contiguous()
+    return None if t is None else STORE.bf(t)
 
 
 def geglu_pack(w: torch.Tensor) -> torch.Tensor:
@@ -134,9 +178,11 @@ class Attention(nn.Module):
                 self.norm_added_q = RMSNorm(dim_head, eps)
                 self.norm_added_k = RMSNorm(dim_head, eps)
         self._pk = None
+        self._pk_step = -1
 
     def packed(self) -> dict:
-        if self._pk is None:
+        if self._pk is None or self._pk_step != STORE.step:
+            self._pk_step = STORE.step
             def fuse(q, k, v):
                 w = torch.cat([_bf(q.weight), _bf(k.weight), _bf(v.weight)], 0).contiguous()
                 b = None if q.bias is None else torch.cat([_bf(q.bias), _bf(k.bias), _bf(v.bias)]).contiguous()
@@ -284,9 +330,11 @@ class VTSelfAttentionBlock(nn.Module):
         self.norm3 = nn.LayerNorm(time_mix_inner_dim)
         self.ff = FeedForward(time_mix_inner_dim, activation_fn="geglu")
         self._pk = None
+        self._pk_step = -1
 
     def packed(self) -> dict:
-        if self._pk is None:
+        if self._pk is None or self._pk_step != STORE.step:
+            self._pk_step = STORE.step
             pk = {}
             for name, ff in (("ff_in", self.ff_in), ("ff", self.ff)):
                 pk[name + "_w"] = geglu_pack(_bf(ff.net[0].proj.weight))

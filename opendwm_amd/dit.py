@@ -76,7 +76,8 @@ class PatchEmbed(nn.Module):
         return self._cache[key]
 
     def packed_weight(self):
-        key = (self.proj.weight.data_ptr(), self.proj.weight._version)
+        from .blocks import STORE
+        key = (self.proj.weight.data_ptr(), self.proj.weight._version, STORE.step)
         if key not in self._wcache:
             w = self.proj.weight.detach().reshape(self.proj.weight.shape[0], -1)
             k = w.shape[1]
@@ -224,6 +225,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
             if hasattr(m, "_wcache"):
                 m._wcache = {}
         self._adapter_cache = (None, None)
+        from .blocks import STORE
+        STORE.bump()
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)

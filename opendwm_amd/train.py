@@ -1,0 +1,648 @@
+"""Training path of the CTSD MMDiT (reference: `train_step`, src/dwm/pipelines/ctsd.py:1195-1437,
+forward under autocast with gradient checkpointing `:497-521`, `loss.backward()` `:1401-1404`,
+optimizer `:1406-1432`; DDP wrap `:1051-1054`).
+
+Design (MI355X-first rather than op-by-op autograd):
+  * one `torch.autograd.Function` per transformer block.  Its forward is the fused inference path
+    (opendwm_amd.blocks.*.run) and keeps only the block inputs - the reference's gradient
+    checkpointing; its backward re-runs the block un-fused (pre-activations are needed) and then
+    walks it backwards with the hand-written HIP kernels of include/dwm_hip.h "Training".
+  * parameters enter the Functions as inputs, so autograd's AccumulateGrad nodes - and with them
+    `DistributedDataParallel`'s bucketed RCCL all-reduce - see every gradient as soon as its block
+    is done; torch only orchestrates, all arithmetic on token-sized tensors is HIP.
+  * master parameters may be fp32; compute copies are bf16 shadows (blocks.STORE) that the AdamW
+    kernel refreshes in the same pass.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from . import train_ops as T
+from .blocks import (STORE, AlphaBlender, JointTransformerBlock, TimestepEmbedding, VTSelfAttentionBlock, _bf)
+from .ops import ACT_GELU_TANH, ACT_SILU
+
+bf16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------ helpers
+class Grads:
+    """fp32 gradient accumulator keyed by parameter (one block's worth)."""
+
+    def __init__(self):
+        self.g: Dict[int, torch.Tensor] = {}
+
+    def add(self, p: Optional[torch.Tensor], g: Optional[torch.Tensor]) -> None:
+        """g: bf16 or fp32, any shape with p.numel() elements"""
+        if p is None or g is None or not p.requires_grad:
+            return
+        cur = self.g.get(id(p))
+        if g.dtype == bf16:
+            g2 = g.reshape(-1, g.shape[-1]) if g.dim() > 1 else g.reshape(1, -1)
+            if cur is None:
+                self.g[id(p)] = T.cast_f32(g2.contiguous()).view(p.shape)
+            else:
+                T.cast_f32(g2.contiguous(), out=cur.view(g2.shape), accumulate=True)
+        else:
+            g = g.reshape(p.shape).to(torch.float32)
+            if cur is None:
+                self.g[id(p)] = g.clone()
+            else:
+                cur.add_(g)
+
+    def take(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        g = self.g.get(id(p))
+        if g is None:
+            return None
+        return g if g.dtype == p.dtype else g.to(p.dtype)
+
+
+def w_t(w: torch.Tensor) -> torch.Tensor:
+    """bf16 W^T [K, N] of a 2-D weight [N, K] (N % 8 == 0), cached for one optimizer step"""
+    return STORE.derived(w, "T", lambda: T.transpose(_bf(w).reshape(w.shape[0], -1), rows_pad=w.shape[0]))
+
+
+def lin_fwd(x: torch.Tensor, lin: torch.nn.Linear, **epi) -> torch.Tensor:
+    return ops.gemm(x, _bf(lin.weight), _bf(lin.bias), **epi)
+
+
+def lin_bwd(G: Grads, lin: torch.nn.Linear, x: torch.Tensor, dy: torch.Tensor, need_dx: bool = True,
+            **epi) -> Optional[torch.Tensor]:
+    """gradients of y = x W^T + b; `epi` = GEMM epilogue of the input-gradient GEMM (e.g. fused residual add)"""
+    want_w = lin.weight.requires_grad
+    want_b = lin.bias is not None and lin.bias.requires_grad
+    if want_w:
+        dw, db = T.linear_wgrad(dy, x, want_bias=want_b)
+        G.add(lin.weight, dw)
+        G.add(lin.bias, db)
+    elif want_b:
+        G.add(lin.bias, T.segsum(dy)[0])
+    return T.linear_dgrad(dy, w_t(lin.weight), **epi) if need_dx else None
+
+
+def _fused_t(attn, added: bool) -> torch.Tensor:
+    """transpose of the fused qkv projection weight [3D, D] -> [D, 3D]"""
+    pk = attn.packed()
+    key = "wadd" if added else "wqkv"
+    anchor = (attn.add_q_proj if added else attn.to_q).weight
+    return STORE.derived(anchor, "fusedT", lambda: T.transpose(pk[key], rows_pad=pk[key].shape[0]))
+
+
+def qkv_bwd(G: Grads, attn, x: torch.Tensor, dqkv: torch.Tensor, added: bool = False) -> torch.Tensor:
+    """backward of the fused q/k/v projection: dqkv [rows, 3D] -> dx, parameter gradients split per projection"""
+    lins = (attn.add_q_proj, attn.add_k_proj, attn.add_v_proj) if added else (attn.to_q, attn.to_k, attn.to_v)
+    D = lins[0].weight.shape[0]
+    if lins[0].weight.requires_grad:
+        want_b = lins[0].bias is not None
+        dw, db = T.linear_wgrad(dqkv, x, want_bias=want_b)
+        for i, l in enumerate(lins):
+            G.add(l.weight, dw[i * D:(i + 1) * D])
+            if want_b:
+                G.add(l.bias, db[i * D:(i + 1) * D])
+    return T.linear_dgrad(dqkv, _fused_t(attn, added))
+
+
+def qk_norm_bwd(G: Grads, attn, qkv: torch.Tensor, rinv: Optional[torch.Tensor], dqkv: torch.Tensor, added: bool = False) -> None:
+    """in place on dqkv[:, :2D]; folds the per-column weight gradient back onto norm_{q,k}.weight [64]"""
+    if rinv is None:
+        return
+    pk = attn.packed()
+    rms = pk["rms_add" if added else "rms"]
+    D2 = rms.numel()
+    dw = torch.zeros(D2, dtype=torch.float32, device=qkv.device)
+    T.rmsnorm_heads_bwd_(qkv[:, :D2], rinv, rms, dqkv[:, :D2], dw)
+    nq, nk = (attn.norm_added_q, attn.norm_added_k) if added else (attn.norm_q, attn.norm_k)
+    dw = dw.view(2, attn.heads, 64).sum(1)
+    G.add(nq.weight, dw[0])
+    G.add(nk.weight, dw[1])
+
+
+def project_qkv_train(attn, x: torch.Tensor, added: bool = False):
+    """fused projection + in-place per-head RMSNorm keeping 1/rms for the backward"""
+    pk = attn.packed()
+    w, b, rms = (pk["wadd"], pk["badd"], pk.get("rms_add")) if added else (pk["wqkv"], pk["bqkv"], pk.get("rms"))
+    qkv = ops.gemm(x, w, b)
+    rinv = T.rmsnorm_heads_train_(qkv[:, :rms.numel()], rms, attn.eps) if rms is not None else None
+    return qkv, rinv
+
+
+def small_mlp_fwd(m: TimestepEmbedding, x: torch.Tensor):
+    u = lin_fwd(x, m.linear_1)
+    a = T.act_fwd(u, ACT_SILU)
+    return lin_fwd(a, m.linear_2), (x, u, a)
+
+
+def small_mlp_bwd(G: Grads, m: TimestepEmbedding, saved, dy: torch.Tensor, need_dx: bool = False):
+    x, u, a = saved
+    da = lin_bwd(G, m.linear_2, a, dy)
+    du = T.act_bwd(u, da, ACT_SILU)
+    return lin_bwd(G, m.linear_1, x, du, need_dx=need_dx)
+
+
+def _params(mod: torch.nn.Module) -> List[torch.nn.Parameter]:
+    return [p for p in mod.parameters()]
+
+
+def _grads_for(G: Grads, params, needs) -> tuple:
+    return tuple((G.take(p) if need else None) for p, need in zip(params, needs))
+
+
+# ------------------------------------------------------------------------------------------ joint block
+def joint_block_backward(blk: JointTransformerBlock, h: torch.Tensor, c: torch.Tensor, st: torch.Tensor, n_img: int,
+                         dh: torch.Tensor, dc: Optional[torch.Tensor], G: Grads):
+    """Recompute + backward of JointTransformerBlock.run (diffusers JointTransformerBlock.forward).
+    h [I*N, D], c [I*Lc, D], st = silu(temb) [I, D]: the block INPUTS; dh / dc: gradients of its outputs.
+    Returns (dh_in, dc_in, dst)."""
+    D = blk.dim
+    N, Lc = h.shape[0] // n_img, c.shape[0] // n_img
+    dual, pre_only = blk.use_dual_attention, blk.context_pre_only
+    sl = lambda m, i: m[:, i * D:(i + 1) * D]
+    id_map = ops.rowmap_identity(n_img, N)
+
+    # ---------------- recompute (un-fused where a pre-activation is needed)
+    mod = lin_fwd(st, blk.norm1.linear)
+    cmod = lin_fwd(st, blk.norm1_context.linear)
+    nh2 = torch.empty_like(h) if dual else None
+    nh = ops.layernorm(h, eps=1e-6, scale=sl(mod, 1), shift=sl(mod, 0), rows_per_mod=N,
+                       scale2=sl(mod, 7) if dual else None, shift2=sl(mod, 6) if dual else None, out2=nh2)
+    cs, cb = (0, 1) if pre_only else (1, 0)           # AdaLayerNormContinuous: scale first
+    nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, cs), shift=sl(cmod, cb), rows_per_mod=Lc)
+    qkv, rinv = project_qkv_train(blk.attn, nh)
+    cqkv, crinv = project_qkv_train(blk.attn, nc, added=True)
+    ao, cao = torch.empty_like(h), torch.empty_like(c)
+    lse = torch.empty(n_img * blk.heads * (N + Lc), dtype=torch.float32, device=h.device)
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, id_map, blk.heads,
+                  q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cao, lse=lse)
+    t_att = lin_fwd(ao, blk.attn.to_out[0])
+    h1 = T.rowcombine(t_att, gate_a=sl(mod, 2), rows_per_gate_a=N, b=h)
+    if dual:
+        qkv2, rinv2 = project_qkv_train(blk.attn2, nh2)
+        ao2 = torch.empty_like(h)
+        lse2 = torch.empty(n_img * blk.heads * N, dtype=torch.float32, device=h.device)
+        ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], ao2, id_map, blk.heads, lse=lse2)
+        t_att2 = lin_fwd(ao2, blk.attn2.to_out[0])
+        h1 = T.rowcombine(t_att2, gate_a=sl(mod, 8), rows_per_gate_a=N, b=h1)
+    nh3 = ops.layernorm(h1, eps=1e-6, scale=sl(mod, 4), shift=sl(mod, 3), rows_per_mod=N)
+    f1, f2 = blk.ff.net[0].proj, blk.ff.net[2]
+    u = lin_fwd(nh3, f1)
+    ffh = T.act_fwd(u, ACT_GELU_TANH)
+    t_ff = lin_fwd(ffh, f2)
+
+    dmod = torch.zeros(mod.shape, dtype=torch.float32, device=h.device)
+    dcmod = torch.zeros(cmod.shape, dtype=torch.float32, device=h.device)
+
+    # ---------------- context stream tail (needed first: the joint attention backward wants d(cao))
+    if not pre_only:
+        t_catt = lin_fwd(cao, blk.attn.to_add_out)
+        c1 = T.rowcombine(t_catt, gate_a=sl(cmod, 2), rows_per_gate_a=Lc, b=c)
+        nc3 = ops.layernorm(c1, eps=1e-6, scale=sl(cmod, 4), shift=sl(cmod, 3), rows_per_mod=Lc)
+        c1f, c2f = blk.ff_context.net[0].proj, blk.ff_context.net[2]
+        cu = lin_fwd(nc3, c1f)
+        cffh = T.act_fwd(cu, ACT_GELU_TANH)
+        t_cff = lin_fwd(cffh, c2f)
+        # c2 = c1 + gate_mlp * t_cff
+        T.segsum(t_cff, dc, rows_per_group=Lc, out=sl(dcmod, 5))
+        dct = T.rowcombine(dc, gate_a=sl(cmod, 5), rows_per_gate_a=Lc)
+        dcffh = lin_bwd(G, c2f, cffh, dct)
+        dcu = T.act_bwd(cu, dcffh, ACT_GELU_TANH)
+        dnc3 = lin_bwd(G, c1f, nc3, dcu)
+        dc1 = dc.clone()
+        T.layernorm_bwd(c1, dnc3, eps=1e-6, dx=dc1, accumulate=True, scale=sl(cmod, 4), rows_per_mod=Lc,
+                        dgamma=sl(dcmod, 4), dbeta=sl(dcmod, 3), grad_per_group=True)
+        # c1 = c + gate_msa * t_catt
+        T.segsum(t_catt, dc1, rows_per_group=Lc, out=sl(dcmod, 2))
+        dct1 = T.rowcombine(dc1, gate_a=sl(cmod, 2), rows_per_gate_a=Lc)
+        dcao = lin_bwd(G, blk.attn.to_add_out, cao, dct1)
+    else:
+        dc1 = torch.zeros_like(c)
+        dcao = torch.zeros_like(c)
+
+    # ---------------- sample stream: h2 = h1 + gate_mlp * t_ff
+    T.segsum(t_ff, dh, rows_per_group=N, out=sl(dmod, 5))
+    dt = T.rowcombine(dh, gate_a=sl(mod, 5), rows_per_gate_a=N)
+    dffh = lin_bwd(G, f2, ffh, dt)
+    du = T.act_bwd(u, dffh, ACT_GELU_TANH)
+    dnh3 = lin_bwd(G, f1, nh3, du)
+    dh1 = dh.clone()
+    T.layernorm_bwd(h1, dnh3, eps=1e-6, dx=dh1, accumulate=True, scale=sl(mod, 4), rows_per_mod=N,
+                    dgamma=sl(dmod, 4), dbeta=sl(dmod, 3), grad_per_group=True)
+    dnh2 = None
+    if dual:       # h1 = h1a + gate2 * t_att2
+        T.segsum(t_att2, dh1, rows_per_group=N, out=sl(dmod, 8))
+        dt2 = T.rowcombine(dh1, gate_a=sl(mod, 8), rows_per_gate_a=N)
+        dao2 = lin_bwd(G, blk.attn2.to_out[0], ao2, dt2)
+        dqkv2 = torch.empty_like(qkv2)
+        ops.attention_bwd(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], ao2, dao2,
+                          dqkv2[:, :D], dqkv2[:, D:2 * D], dqkv2[:, 2 * D:], id_map, blk.heads, lse2)
+        qk_norm_bwd(G, blk.attn2, qkv2, rinv2, dqkv2)
+        dnh2 = qkv_bwd(G, blk.attn2, nh2, dqkv2)
+    # h1a = h + gate_msa * t_att
+    T.segsum(t_att, dh1, rows_per_group=N, out=sl(dmod, 2))
+    dt1 = T.rowcombine(dh1, gate_a=sl(mod, 2), rows_per_gate_a=N)
+    dao = lin_bwd(G, blk.attn.to_out[0], ao, dt1)
+
+    # ---------------- joint attention
+    dqkv, dcqkv = torch.empty_like(qkv), torch.empty_like(cqkv)
+    ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                      id_map, blk.heads, lse, q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cao, dout1=dcao,
+                      dq1=dcqkv[:, :D], dk1=dcqkv[:, D:2 * D], dv1=dcqkv[:, 2 * D:])
+    qk_norm_bwd(G, blk.attn, qkv, rinv, dqkv)
+    qk_norm_bwd(G, blk.attn, cqkv, crinv, dcqkv, added=True)
+    dnh = qkv_bwd(G, blk.attn, nh, dqkv)
+    dnc = qkv_bwd(G, blk.attn, nc, dcqkv, added=True)
+
+    # ---------------- the two AdaLN layers at the block input
+    T.layernorm_bwd(h, dnh, eps=1e-6, dx=dh1, accumulate=True, scale=sl(mod, 1), scale2=sl(mod, 7) if dual else None,
+                    rows_per_mod=N, dy2=dnh2, dgamma=sl(dmod, 1), dbeta=sl(dmod, 0),
+                    dgamma2=sl(dmod, 7) if dual else None, dbeta2=sl(dmod, 6) if dual else None, grad_per_group=True)
+    T.layernorm_bwd(c, dnc, eps=1e-6, dx=dc1, accumulate=True, scale=sl(cmod, cs), rows_per_mod=Lc,
+                    dgamma=sl(dcmod, cs), dbeta=sl(dcmod, cb), grad_per_group=True)
+
+    # ---------------- modulation linears (M = images)
+    dst = lin_bwd(G, blk.norm1.linear, st, dmod.to(bf16))
+    dst2 = lin_bwd(G, blk.norm1_context.linear, st, dcmod.to(bf16))
+    ops.add_(dst, dst2)
+    return dh1, dc1, dst
+
+
+class JointBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, blk, n_img, h, c, st, *params):
+        ctx.blk, ctx.n_img = blk, n_img
+        ctx.save_for_backward(h, c, st)
+        ctx.np = len(params)
+        with torch.no_grad():
+            c_out, h_out = blk.run(h.clone(), c.clone(), st, n_img)
+        if c_out is None:
+            c_out = c.new_zeros(())           # context_pre_only: the context stream ends here
+        return h_out, c_out
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        h, c, st = ctx.saved_tensors
+        blk = ctx.blk
+        G = Grads()
+        if blk.context_pre_only:
+            dc = None
+        dh_in, dc_in, dst = joint_block_backward(blk, h, c, st, ctx.n_img, dh.contiguous(),
+                                                 None if dc is None else dc.contiguous(), G)
+        ps = _params(blk)
+        return (None, None, dh_in, dc_in, dst) + _grads_for(G, ps, ctx.needs_input_grad[5:])
+
+
+def joint_block_train(blk: JointTransformerBlock, h, c, st, n_img: int):
+    return JointBlockFn.apply(blk, n_img, h, c, st, *_params(blk))
+
+
+# ------------------------------------------------------------------------------------------ VT block + mixer
+def vt_block_backward(blk: VTSelfAttentionBlock, h: torch.Tensor, emb: torch.Tensor, rows_per_emb: int, rowmap,
+                      group_mask, dense_mask, alpha: torch.Tensor, rows_per_alpha: int, dy: torch.Tensor, G: Grads):
+    """Recompute + backward of VTSelfAttentionBlock.run followed by the AlphaBlender
+    (crossview_temporal.py:562-582, 68-72; crossview_temporal_dit.py:320-327,363-370).
+    Returns (dh, demb fp32 [G, D], dalpha fp32 [B])."""
+    D = blk.dim
+    ln = lambda x, n, **kw: ops.layernorm(x, eps=1e-5, weight=_bf(n.weight), bias=_bf(n.bias), **kw)
+    # ---------------- recompute
+    xs0 = torch.empty_like(h)
+    y = ln(h, blk.norm_in, addvec=emb, rows_per_add=rows_per_emb, xsum=xs0)          # xs0 = h + emb
+    pi, l2i = blk.ff_in.net[0].proj, blk.ff_in.net[2]
+    u1 = lin_fwd(y, pi)
+    g1 = T.geglu_fwd(u1)
+    xs1 = lin_fwd(g1, l2i, epilogue=ops.EPI_RESID, res=xs0)
+    y1 = ln(xs1, blk.norm1)
+    qkv, rinv = project_qkv_train(blk.attn1, y1)
+    ao = torch.empty_like(h)
+    lse = torch.empty(rowmap.n_problems * blk.heads * rowmap.L0, dtype=torch.float32, device=h.device)
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, rowmap, blk.heads, group_mask=group_mask,
+                  dense_mask=dense_mask, lse=lse)
+    to_out = blk.attn1.to_out[0]
+    xs2 = lin_fwd(ao, to_out, epilogue=ops.EPI_RESID, res=xs1)
+    y3 = ln(xs2, blk.norm3)
+    p3, l23 = blk.ff.net[0].proj, blk.ff.net[2]
+    u3 = lin_fwd(y3, p3)
+    g3 = T.geglu_fwd(u3)
+    out = lin_fwd(g3, l23, epilogue=ops.EPI_RESID, res=xs2)
+
+    # ---------------- mixer: blended = alpha * h + (1 - alpha) * out
+    one_minus = (1.0 - alpha).contiguous()
+    dalpha = (T.segsum(dy, h, rows_per_group=rows_per_alpha).sum(-1) - T.segsum(dy, out, rows_per_group=rows_per_alpha).sum(-1))
+    dout = T.rowcombine(dy, coef_a=one_minus, rows_per_coef_a=rows_per_alpha)
+    del out
+
+    def ln_bwd(x, n, dyy, dx, **kw):
+        dg = torch.zeros(1, D, dtype=torch.float32, device=h.device)
+        db = torch.zeros(1, D, dtype=torch.float32, device=h.device)
+        T.layernorm_bwd(x, dyy, eps=1e-5, dx=dx, accumulate=True, weight=_bf(n.weight), dgamma=dg, dbeta=db, **kw)
+        G.add(n.weight, dg[0])
+        G.add(n.bias, db[0])
+
+    # out = xs2 + ff(norm3(xs2))
+    dxs2 = dout
+    dg3 = lin_bwd(G, l23, g3, dout)
+    du3 = T.geglu_bwd(u3, dg3)
+    dy3 = lin_bwd(G, p3, y3, du3)
+    ln_bwd(xs2, blk.norm3, dy3, dxs2)
+    # xs2 = xs1 + to_out(attn(norm1(xs1)))
+    dao = lin_bwd(G, to_out, ao, dxs2)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, dao, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                      rowmap, blk.heads, lse, group_mask=group_mask, dense_mask=dense_mask)
+    qk_norm_bwd(G, blk.attn1, qkv, rinv, dqkv)
+    dy1 = qkv_bwd(G, blk.attn1, y1, dqkv)
+    dxs1 = dxs2
+    ln_bwd(xs1, blk.norm1, dy1, dxs1)
+    # xs1 = xs0 + ff_in(norm_in(xs0))
+    dg1 = lin_bwd(G, l2i, g1, dxs1)
+    du1 = T.geglu_bwd(u1, dg1)
+    dyin = lin_bwd(G, pi, y, du1)
+    dxs0 = dxs1
+    ln_bwd(h, blk.norm_in, dyin, dxs0, addvec=emb, rows_per_add=rows_per_emb)
+    # xs0 = h + emb[row // rows_per_emb]
+    demb = T.segsum(dxs0, rows_per_group=rows_per_emb)
+    dh = T.rowcombine(dy, coef_a=alpha, rows_per_coef_a=rows_per_alpha, b=dxs0)
+    return dh, demb, dalpha
+
+
+class VTBlockFn(torch.autograd.Function):
+    """h_out = AlphaBlender(h, VTSelfAttentionBlock(h + emb)); inputs that carry gradients: h, emb, alpha."""
+
+    @staticmethod
+    def forward(ctx, blk, rowmap, rows_per_emb, rows_per_alpha, group_mask, dense_mask, h, emb, alpha, *params):
+        ctx.blk, ctx.rowmap, ctx.rpe, ctx.rpa = blk, rowmap, rows_per_emb, rows_per_alpha
+        ctx.gm, ctx.dm = group_mask, dense_mask
+        ctx.save_for_backward(h, emb, alpha)
+        with torch.no_grad():
+            out = h.clone()
+            blk.run(out, rowmap, emb=emb, rows_per_emb=rows_per_emb, group_mask=group_mask, dense_mask=dense_mask,
+                    blend_alpha=alpha, rows_per_alpha=rows_per_alpha, blend_into=out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, emb, alpha = ctx.saved_tensors
+        G = Grads()
+        dh, demb, dalpha = vt_block_backward(ctx.blk, h, emb, ctx.rpe, ctx.rowmap, ctx.gm, ctx.dm, alpha, ctx.rpa,
+                                             dy.contiguous(), G)
+        ps = _params(ctx.blk)
+        return (None, None, None, None, None, None, dh, demb.to(emb.dtype), dalpha.to(alpha.dtype)) + \
+            _grads_for(G, ps, ctx.needs_input_grad[9:])
+
+
+def vt_block_train(blk, h, rowmap, emb, rows_per_emb, alpha, rows_per_alpha, group_mask=None, dense_mask=None):
+    return VTBlockFn.apply(blk, rowmap, rows_per_emb, rows_per_alpha, group_mask, dense_mask, h, emb, alpha, *_params(blk))
+
+
+def alpha_train(mixer: AlphaBlender, image_only_indicator: Optional[torch.Tensor], batch: int) -> torch.Tensor:
+    """AlphaBlender.get_alpha with autograd on mix_factor (one scalar: plain torch)."""
+    mf = mixer.mix_factor.float()
+    if mixer.merge_strategy == "fixed":
+        return mf.expand(batch).contiguous()
+    if mixer.merge_strategy == "learned":
+        return torch.sigmoid(mf).expand(batch).contiguous()
+    flag = image_only_indicator.reshape(batch).to(device=mf.device, dtype=torch.bool)
+    return torch.where(flag, torch.ones((), device=mf.device), torch.sigmoid(mf).expand(batch)).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ small modules
+class MlpFn(torch.autograd.Function):
+    """TimestepEmbedding: linear_2(silu(linear_1(x))) [+ res]; x carries no gradient (sinusoids / pooled text)."""
+
+    @staticmethod
+    def forward(ctx, m, x, res, *params):
+        ctx.m = m
+        with torch.no_grad():
+            y, saved = small_mlp_fwd(m, x)
+            if res is not None:
+                y = T.rowcombine(y, b=res)
+        ctx.saved = saved
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        G = Grads()
+        dy = dy.contiguous()
+        small_mlp_bwd(G, ctx.m, ctx.saved, dy)
+        ps = _params(ctx.m)
+        return (None, None, dy if ctx.has_res else None) + _grads_for(G, ps, ctx.needs_input_grad[3:])
+
+
+def mlp_train(m: TimestepEmbedding, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return MlpFn.apply(m, x, res, *_params(m))
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lin, x, *params):
+        ctx.lin = lin
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return lin_fwd(x, lin)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        G = Grads()
+        dx = lin_bwd(G, ctx.lin, x, dy.contiguous(), need_dx=ctx.needs_input_grad[1])
+        return (None, dx) + _grads_for(G, _params(ctx.lin), ctx.needs_input_grad[2:])
+
+
+def linear_train(lin: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    return LinearFn.apply(lin, x, *_params(lin))
+
+
+class SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return T.act_fwd(x, ACT_SILU)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return T.act_bwd(x, dy.contiguous(), ACT_SILU)
+
+
+class AddFn(torch.autograd.Function):
+    """a + b on bf16 matrices (HIP)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        with torch.no_grad():
+            return T.rowcombine(a, b=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """SD3 PatchEmbed (strided conv as patchify + GEMM, + cropped pos embed); the latents carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, pe, x, *params):
+        ctx.pe = pe
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return pe.run(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pe = ctx.pe
+        G = Grads()
+        if pe.proj.weight.requires_grad:
+            wp = pe.packed_weight()
+            cols = ops.patchify(x, pe.patch_size, wp.shape[1])
+            dw, db = T.linear_wgrad(dy.contiguous(), cols)
+            k = pe.proj.weight[0].numel()
+            G.add(pe.proj.weight, dw[:, :k].contiguous())
+            G.add(pe.proj.bias, db)
+        return (None, None) + _grads_for(G, _params(pe), ctx.needs_input_grad[2:])
+
+
+class OutFn(torch.autograd.Function):
+    """norm_out (AdaLayerNormContinuous) + proj_out + unpatchify"""
+
+    @staticmethod
+    def forward(ctx, model, geom, h, st, *params):
+        ctx.model, ctx.geom = model, geom
+        ctx.save_for_backward(h, st)
+        I, C, hh, ww, p, N, D = geom
+        with torch.no_grad():
+            mod = lin_fwd(st, model.norm_out.linear)
+            nh = ops.layernorm(h, eps=1e-6, scale=mod[:, :D], shift=mod[:, D:], rows_per_mod=N)
+            y = lin_fwd(nh, model.proj_out)
+            return ops.unpatchify(y, I, C, hh, ww, p)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, st = ctx.saved_tensors
+        model = ctx.model
+        I, C, hh, ww, p, N, D = ctx.geom
+        G = Grads()
+        mod = lin_fwd(st, model.norm_out.linear)
+        nh = ops.layernorm(h, eps=1e-6, scale=mod[:, :D], shift=mod[:, D:], rows_per_mod=N)
+        # unpatchify is a permutation: its transpose is the patch gather with (py, px, c) column order
+        do = dout.to(bf16).contiguous().view(I, C, hh, p, ww, p).permute(0, 2, 4, 3, 5, 1).reshape(I * hh * ww, p * p * C).contiguous()
+        dnh = lin_bwd(G, model.proj_out, nh, do)
+        dmod = torch.zeros(mod.shape, dtype=torch.float32, device=h.device)
+        dh = T.layernorm_bwd(h, dnh, eps=1e-6, scale=mod[:, :D], rows_per_mod=N, dgamma=dmod[:, :D], dbeta=dmod[:, D:],
+                             grad_per_group=True)
+        dst = lin_bwd(G, model.norm_out.linear, st, dmod.to(bf16))
+        ps = _params(model.norm_out) + _params(model.proj_out)
+        return (None, None, dh, dst) + _grads_for(G, ps, ctx.needs_input_grad[4:])
+
+
+# ------------------------------------------------------------------------------------------ model forward
+def forward_train(model, sample, timestep, encoder_hidden_states, pooled_projections, disable_crossview=None,
+                  disable_temporal=None, crossview_attention_mask=None, added_time_ids=None):
+    """Autograd-enabled forward of DiTCrossviewTemporalConditionModel (text-conditioned configuration;
+    crossview_temporal_dit.py:372-630).  Returns the prediction [B, T, V, C, H, W] (bf16) with a grad_fn."""
+    if model.condition_image_adapter is not None:
+        raise NotImplementedError("training with the layout ImageAdapter is not implemented (its conv backward is missing)")
+    B, Tn, V, _, H, W = sample.shape
+    p = model._cfg.patch_size
+    height, width = H // p, W // p
+    N, I, D = height * width, B * Tn * V, model.inner_dim
+    dev = sample.device
+
+    def as_bf16(t):
+        return t if t.dtype == bf16 else (ops.cast_bf16(t.contiguous()) if t.dtype == torch.float32 else t.to(bf16))
+
+    x = sample.flatten(0, 2).contiguous()
+    h = PatchEmbedFn.apply(model.pos_embed, x, *_params(model.pos_embed))
+    ehs = as_bf16(encoder_hidden_states.flatten(0, 2))
+    Lc = ehs.shape[1]
+    c = linear_train(model.context_embedder, ehs.reshape(I * Lc, -1))
+    pooled = as_bf16(pooled_projections.flatten(0, 2)).contiguous()
+    tte = model.time_text_embed
+    t_emb = mlp_train(tte.timestep_embedder, ops.timestep_sinusoid(timestep.flatten(), 256))
+    temb = mlp_train(tte.text_embedder, pooled, res=t_emb)
+    st = SiluFn.apply(temb)
+
+    view_cam_emb = None
+    if model.perspective_modeling_type == "implicit":
+        ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256).view(I, -1)
+        view_cam_emb = mlp_train(model.view_embedding, ve)
+    if model.enable_crossview and disable_crossview is None:
+        disable_crossview = torch.zeros(B, dtype=torch.bool, device=dev)
+    if model.enable_temporal and disable_temporal is None:
+        disable_temporal = torch.zeros(B, dtype=torch.bool, device=dev)
+
+    for i, block in enumerate(model.transformer_blocks):
+        h, c = joint_block_train(block, h, c, st, I)
+        if model.enable_temporal and i in model.temporal_block_layers:
+            k = model.temporal_block_layers.index(i)
+            idx = torch.arange(Tn, device=dev).view(1, Tn, 1).expand(B, Tn, V)
+            seq = ops.timestep_sinusoid(idx, D)
+            use_cam = model.enable_crossview and not model.disable_view_emb_on_temporal_module and view_cam_emb is not None
+            seq_emb = mlp_train(model.time_pos_embeds[k], seq, res=view_cam_emb if use_cam else None)
+            tt = model.temporal_attention_type
+            mk = ops.rowmap_temporal_full if tt == "full" else \
+                ops.rowmap_temporal_rowwise if tt == "rowwise" else ops.rowmap_temporal_pointwise
+            alpha = alpha_train(model.time_mixers[k], disable_temporal, B)
+            h = vt_block_train(model.temporal_transformer_blocks[k], h, mk(B, Tn, V, height, width), seq_emb, N,
+                               alpha, Tn * V * N)
+        if model.enable_crossview and i in model.crossview_block_layers:
+            k = model.crossview_block_layers.index(i)
+            idx = torch.arange(V, device=dev).view(1, 1, V).expand(B, Tn, V)
+            vemb = mlp_train(model.view_pos_embeds[k], ops.timestep_sinusoid(idx, D), res=view_cam_emb)
+            ct = model.crossview_attention_type
+            gmask = dmask = None
+            if ct == "rowwise":
+                rm = ops.rowmap_crossview_rowwise(B, Tn, V, height, width)
+                gmask = crossview_attention_mask
+            elif ct == "full":
+                rm = ops.rowmap_crossview_full(B, Tn, V, height, width)
+                dmask = crossview_attention_mask
+            else:
+                raise NotImplementedError(f"Not support {ct}")
+            alpha = alpha_train(model.view_mixers[k], disable_crossview, B)
+            h = vt_block_train(model.crossview_transformer_blocks[k], h, rm, vemb, N, alpha, Tn * V * N,
+                               group_mask=gmask, dense_mask=dmask)
+
+    geom = (I, model.out_channels, height, width, p, N, D)
+    out = OutFn.apply(model, geom, h, st, *(_params(model.norm_out) + _params(model.proj_out)))
+    return out.view(B, Tn, V, model.out_channels, height * p, width * p)
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+class AdamW:
+    """torch.optim.AdamW semantics on the HIP kernel; also refreshes the bf16 shadows of blocks.STORE."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.state = {}
+        self.t = 0
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0):
+        self.t += 1
+        for p in self.params:
+            if p.grad is None:
+                continue
+            if p.dtype != torch.float32:
+                raise RuntimeError("AdamW: fp32 master parameters expected")
+            st = self.state.get(id(p))
+            if st is None:
+                st = (torch.zeros_like(p), torch.zeros_like(p))
+                self.state[id(p)] = st
+            g = p.grad if p.grad.dtype == torch.float32 else p.grad.float()
+            shadow = STORE.bf(p) if (p.is_cuda and p.numel() % 4 == 0 and p.is_contiguous()) else None
+            if shadow is None:
+                STORE._shadow.pop(id(p), None)      # re-cast on next use
+            T.adamw_(p.data, g.contiguous(), st[0], st[1], shadow, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                     eps=self.eps, weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale)
+        STORE.bump(keep_shadows=True)
