@@ -239,8 +239,39 @@ class DiTCrossviewTemporalConditionModel(_Base):
         return out
 
     # ---- forward (crossview_temporal_dit.py:372-630)
+    def forward(self, sample, timestep=None, *args, **kwargs):
+        """Reference signature.  In train() mode with autograd enabled the prediction carries a grad_fn
+        (opendwm_amd.train: checkpointed block Functions with HIP backward kernels); otherwise the fused
+        inference path runs under no_grad."""
+        if self.training and torch.is_grad_enabled():
+            from . import train as _train
+            names = ["frustum_bev_residuals", "encoder_hidden_states", "pooled_projections", "condition_image_tensor",
+                     "disable_crossview", "disable_temporal", "crossview_attention_mask", "crossview_attention_index",
+                     "camera_intrinsics", "camera_transforms", "camera_intrinsics_norm", "camera2referego",
+                     "added_time_ids", "noise", "return_dict"]
+            kw = dict(zip(names, args))
+            kw.update(kwargs)
+            if kw.get("condition_image_tensor") is not None and self.condition_image_adapter is not None:
+                raise NotImplementedError("training with the layout ImageAdapter is not implemented")
+            squeeze = sample.dim() < 6
+            if squeeze:
+                sample, timestep = sample.unsqueeze(2), timestep.unsqueeze(2)
+                for k in ("encoder_hidden_states", "pooled_projections", "disable_temporal"):
+                    if kw.get(k) is not None:
+                        kw[k] = kw[k].unsqueeze(2)
+            out = _train.forward_train(self, sample, timestep, kw.get("encoder_hidden_states"), kw.get("pooled_projections"),
+                                       disable_crossview=kw.get("disable_crossview"), disable_temporal=kw.get("disable_temporal"),
+                                       crossview_attention_mask=kw.get("crossview_attention_mask"),
+                                       added_time_ids=kw.get("added_time_ids"))
+            if squeeze:
+                out = out.squeeze(2)
+            if kw.get("return_dict"):
+                return {"noise_pred": out}
+            return [out], None, None
+        return self._forward_infer(sample, timestep, *args, **kwargs)
+
     @torch.no_grad()
-    def forward(
+    def _forward_infer(
         self,
         sample: torch.FloatTensor,
         timestep: torch.LongTensor = None,

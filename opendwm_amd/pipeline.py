@@ -133,3 +133,90 @@ class CTSDDenoiser:
         for i in range(start, self.inference_steps if stop is None else stop):
             self.step(i)
         return self.result()
+
+
+# ------------------------------------------------------------------------------------------ training
+def flow_match_train_sigmas(num_train_timesteps: int = 1000, shift: float = 3.0) -> torch.Tensor:
+    """sigmas[i] of the *training* FlowMatchEulerDiscreteScheduler (timesteps[i] = 1000 * sigmas[i], descending);
+    ctsd.py:1255-1270 indexes it with floor(u * num_train_timesteps)."""
+    s = torch.linspace(1, num_train_timesteps, num_train_timesteps).flip(0) / num_train_timesteps
+    return (shift * s / (1 + (shift - 1) * s)).float()
+
+
+def sample_timestep_indices(shape, generator: Optional[torch.Generator] = None, weighting_scheme: str = "logit_normal",
+                            num_train_timesteps: int = 1000, logit_mean: float = 0.0, logit_std: float = 1.0) -> torch.Tensor:
+    """sd3_compute_density_for_timestep_sampling + `(u * num_train_timesteps).long()` (ctsd.py:1256-1262)."""
+    if weighting_scheme == "logit_normal":
+        u = torch.sigmoid(torch.randn(shape, generator=generator) * logit_std + logit_mean)
+    elif weighting_scheme in ("none", "uniform"):
+        u = torch.rand(shape, generator=generator)
+    else:
+        raise NotImplementedError(weighting_scheme)
+    return (u * num_train_timesteps).long().clamp_(max=num_train_timesteps - 1)
+
+
+class CTSDTrainer:
+    """The SD 3 branch of CrossviewTemporalSD.train_step (ctsd.py:1195-1437) on latents that are already
+    VAE-encoded and conditions that are already embedded:
+
+        idx ~ logit-normal, sigma = sigmas[idx], t = 1000 sigma           :1255-1266
+        x_t = sigma * noise + (1 - sigma) * x0,  target = x0               :1267-1272
+        pred = model(x_t, t, conditions);  x0_hat = pred * (-sigma) + x_t  :1355-1360
+        loss = mse(x0_hat.float(), x0.float()) * coef                      :1368-1370
+        loss.backward(); [clip_grad_norm_]; optimizer.step(); zero_grad    :1401-1432
+
+    `ddp=True` wraps the model in torch DistributedDataParallel (ctsd.py:1051-1054): the block Functions of
+    opendwm_amd.train hand their parameter gradients to autograd block by block, so the bucketed RCCL
+    all-reduce overlaps the rest of the backward."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 shift: float = 3.0, num_train_timesteps: int = 1000, loss_coef: float = 1.0,
+                 max_grad_norm: Optional[float] = None, weighting_scheme: str = "logit_normal", ddp: bool = False,
+                 ddp_kwargs: Optional[dict] = None):
+        from . import train as _train
+        self.model = model.train()
+        self.wrapper = model
+        if ddp:
+            dev = next(model.parameters()).device
+            kw = dict(device_ids=[dev.index] if dev.type == "cuda" else None, gradient_as_bucket_view=True)
+            kw.update(ddp_kwargs or {})
+            self.wrapper = torch.nn.parallel.DistributedDataParallel(model, **kw)
+        self.optimizer = _train.AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.sigmas = flow_match_train_sigmas(num_train_timesteps, shift)
+        self.num_train_timesteps, self.loss_coef = num_train_timesteps, loss_coef
+        self.max_grad_norm, self.weighting_scheme = max_grad_norm, weighting_scheme
+
+    def make_training_pair(self, latents: torch.Tensor, generator: Optional[torch.Generator] = None,
+                           timestep_indices: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """returns (noisy_latents, timesteps [B,T,V], sigmas [B,1,1,1,1,1], noise); host RNG like the reference (CPU generator)"""
+        B, T, V = latents.shape[:3]
+        if noise is None:
+            noise = torch.randn(latents.shape, generator=generator)
+        if timestep_indices is None:
+            timestep_indices = sample_timestep_indices((B,), generator, self.weighting_scheme, self.num_train_timesteps)
+        sig = self.sigmas[timestep_indices.cpu()]
+        timesteps = (sig * self.num_train_timesteps).view(B, 1, 1).expand(B, T, V).contiguous()
+        dev = latents.device
+        sig_b = sig.view(B, 1, 1, 1, 1, 1).to(dev)
+        noise = noise.to(dev)
+        noisy = sig_b * noise + (1.0 - sig_b) * latents.float()
+        return noisy, timesteps.to(dev), sig_b, noise
+
+    def loss(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
+             timestep_indices=None, noise=None) -> torch.Tensor:
+        noisy, timesteps, sig, _ = self.make_training_pair(latents, generator, timestep_indices, noise)
+        cond = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
+                for k, v in conditions.items()}
+        pred = self.wrapper(noisy.to(bf16), timesteps, **cond)[0][0]
+        x0_hat = pred.float() * (-sig) + noisy
+        return torch.nn.functional.mse_loss(x0_hat, latents.float(), reduction="mean") * self.loss_coef
+
+    def train_step(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
+                   timestep_indices=None, noise=None) -> torch.Tensor:
+        loss = self.loss(latents, conditions, generator, timestep_indices, noise)
+        loss.backward()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach()

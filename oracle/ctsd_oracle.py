@@ -612,6 +612,30 @@ def flow_match_sigmas(num_inference_steps: int, shift: float = 3.0,
     return torch.cat([sig, torch.zeros(1)]).float()
 
 
+def flow_match_train_sigmas(shift: float = 3.0, num_train_timesteps: int = 1000) -> Tensor:
+    """sigmas of the *training* ``FlowMatchEulerDiscreteScheduler`` as its constructor builds them
+    (diffusers 0.31.0): timesteps = linspace(1, n, n)[::-1]; sigma = t/n; shifted; scheduler.timesteps
+    = sigma * n.  ``sd3_get_sigmas`` (ctsd.py:1263-1266) looks sigma up by timestep, i.e. sigmas[idx]."""
+    s = torch.linspace(1, num_train_timesteps, num_train_timesteps).flip(0) / num_train_timesteps
+    return (shift * s / (1 + (shift - 1) * s)).float()
+
+
+def train_loss(sd: SD, cfg: dict, latents: Tensor, conditions: dict, timestep_indices: Tensor, noise: Tensor,
+               shift: float = 3.0, loss_coef: float = 1.0, num_train_timesteps: int = 1000) -> Tensor:
+    """SD 3 branch of ``train_step`` (ctsd.py:1255-1272, 1355-1370) for given noise and timestep indices
+    (the reference draws them from a CPU generator, :1229, :1256-1262):
+    x_t = sigma*eps + (1-sigma)*x0; pred = model(x_t, 1000*sigma); x0_hat = pred*(-sigma) + x_t;
+    loss = mse(x0_hat, x0) * coef.  latents [B,T,V,C,H,W]; timestep_indices [B]."""
+    B, T, V = latents.shape[:3]
+    sig = flow_match_train_sigmas(shift, num_train_timesteps).to(latents.device)[timestep_indices]
+    timesteps = (sig * num_train_timesteps).view(B, 1, 1).expand(B, T, V)
+    sg = sig.view(B, 1, 1, 1, 1, 1)
+    noisy = sg * noise + (1.0 - sg) * latents
+    pred = dit_forward(sd, cfg, noisy, timesteps, **conditions)
+    x0_hat = pred * (-sg) + noisy
+    return torch.nn.functional.mse_loss(x0_hat.float(), latents.float(), reduction="mean") * loss_coef
+
+
 def denoise(sd: SD, cfg: dict, latents: Tensor, conditions: dict, steps: int,
             guidance_scale: float, shift: float = 3.0, stop: Optional[int] = None, start: int = 0,
             image_latents: Optional[Tensor] = None, reference_frame_count: int = 0,

@@ -367,3 +367,28 @@ def test_ctypes_structs_match_header_field_order():
             m = re.search(rf"[\s\*,]{fname}\s*(\[\d+\])?\s*[,;]", body[pos + 1:])
             assert m, (cname, fname)
             pos = pos + 1 + m.start()
+
+
+def test_train_pair_construction_matches_oracle():
+    """Host-side part of the train step (no GPU needed): sigma table, timestep / noisy-latent construction."""
+    from opendwm_amd import pipeline as P
+    sig = P.flow_match_train_sigmas(1000, 3.0)
+    assert torch.equal(sig, O.flow_match_train_sigmas(3.0, 1000))
+    assert sig.shape == (1000,) and sig[0] == 1.0 and abs(sig[-1].item() - 3e-3 / (1 + 2e-3)) < 1e-9
+    assert torch.all(sig[1:] < sig[:-1])
+    g = torch.Generator().manual_seed(3)
+    idx = P.sample_timestep_indices((4096,), g)
+    assert idx.min() >= 0 and idx.max() <= 999 and 400 < idx.float().mean() < 600      # logit-normal(0, 1): centred
+
+    class _M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(4))
+    tr = P.CTSDTrainer.__new__(P.CTSDTrainer)
+    tr.sigmas, tr.num_train_timesteps, tr.weighting_scheme = sig, 1000, "logit_normal"
+    lat = torch.randn(2, 3, 2, 4, 4, 6)
+    idx = torch.tensor([10, 700])
+    noise = torch.randn(lat.shape)
+    noisy, ts, sg, _ = tr.make_training_pair(lat, timestep_indices=idx, noise=noise)
+    assert ts.shape == (2, 3, 2) and torch.allclose(ts[:, 0, 0], sig[idx] * 1000)
+    assert torch.allclose(noisy, sig[idx].view(2, 1, 1, 1, 1, 1) * noise + (1 - sig[idx].view(2, 1, 1, 1, 1, 1)) * lat)

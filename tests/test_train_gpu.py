@@ -382,3 +382,86 @@ def test_adamw_step_updates_shadows(dev):
     from opendwm_amd.blocks import STORE
     w = m.transformer_blocks[0].ff.net[2].weight
     assert torch.equal(STORE.bf(w), w.detach().to(bf16))
+
+
+def test_train_step_loss_and_descent(dev):
+    """CTSDTrainer: the loss of one batch equals the oracle's restatement of train_step, and a few optimizer steps on
+    the same batch reduce it."""
+    from oracle import ctsd_oracle as O
+    from opendwm_amd.pipeline import CTSDTrainer
+    from tests.common import small_config, small_inputs, to_dev
+    cfg = small_config()
+    sd = {k: v.to(bf16).float() for k, v in O.make_state_dict(cfg, 0).items()}
+    inp = small_inputs(cfg, 0)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v) for k, v in inp.items()}
+    lat = inp.pop("sample")
+    inp.pop("timestep")
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(lat.shape, generator=g)
+    idx = torch.tensor([250, 800])
+    ref = O.train_loss(sd, cfg, lat, inp, idx, noise).item()
+    m = _train_model(cfg, sd, dev)
+    tr = CTSDTrainer(m, lr=2e-4, weight_decay=0.0)
+    di = to_dev(inp, dev)
+    l0 = tr.loss(lat.to(dev), di, timestep_indices=idx, noise=noise).item()
+    _log("train_step_loss", ours=l0, oracle=ref)
+    assert abs(l0 - ref) / ref < 2e-2
+    tr.optimizer.zero_grad()
+    losses = [tr.train_step(lat.to(dev), di, timestep_indices=idx, noise=noise).item() for _ in range(4)]
+    _log("train_step_descent", losses=losses)
+    assert losses[-1] < losses[0]
+
+
+def _ddp_worker(rank, world, port, cfg, sd, inp, wgt, path):
+    import torch.distributed as dist
+    from opendwm_amd import train
+    dev = torch.device("cuda:0")                       # both ranks share the one GPU of the test box (gloo moves the buckets)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        m = _train_model(cfg, sd, dev)
+        ddp = torch.nn.parallel.DistributedDataParallel(m)
+        mine = {k: (v[rank:rank + 1].to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+        out, _, _ = ddp(mine.pop("sample"), mine.pop("timestep"), **mine)
+        (out[0].float() * wgt[rank:rank + 1].to(dev)).sum().backward()
+        if rank == 0:
+            torch.save({n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}, path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_average_gradients(dev):
+    """DistributedDataParallel over the block Functions: two ranks (one batch element each, gloo) end up with the
+    mean of their gradients == half the single-process full-batch gradient."""
+    import torch.multiprocessing as mp
+    from oracle import ctsd_oracle as O
+    from tests.common import small_config, small_inputs, to_dev
+    cfg = small_config()
+    sd = {k: v.to(bf16).float() for k, v in O.make_state_dict(cfg, 0).items()}
+    inp = small_inputs(cfg, 0)
+    inp = {k: (v.to(bf16) if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v) for k, v in inp.items()}
+    g = torch.Generator().manual_seed(7)
+    wgt = torch.randn(inp["sample"].shape, generator=g)
+    # single process, full batch
+    m = _train_model(cfg, sd, dev)
+    di = to_dev(inp, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    (out[0].float() * wgt.to(dev)).sum().backward()
+    full = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = 29500 + os.getpid() % 2000
+    path = os.path.join(tempfile.mkdtemp(), "ddp_grads.pt")
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, cfg, sd, inp, wgt, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = torch.load(path)
+    num = sum(float((2 * got[n].double() - full[n].double()).pow(2).sum()) for n in full)
+    den = sum(float(full[n].double().pow(2).sum()) for n in full)
+    e = (num / den) ** 0.5
+    _log("ddp_two_ranks", rel=e, n_params=len(full))
+    assert set(got) == set(full) and e < 5e-3
