@@ -177,6 +177,68 @@ def cpu_baseline(threads: int):
                        f"the {full_flops / 1e12:.1f} TFLOP of one full step")
 
 
+def main_train(args):
+    """Training step (ctsd.py:1195-1437, SD 3 branch) on synthetic latents / conditions: fp32 master weights, bf16
+    compute, checkpointed blocks, HIP backward kernels, HIP AdamW; with N > 1 ranks torch DDP all-reduces the
+    gradients over RCCL (one sample per GPU: weak scaling)."""
+    from opendwm_amd import dist as D
+    rank, local_rank, world = D.env_ranks()
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init("nccl", dev)
+    from opendwm_amd import _lib
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel, model_flops
+    from opendwm_amd.pipeline import CTSDTrainer
+    _lib.load()
+    kwargs = dict(MODEL_KWARGS)
+    if args.layers is not None:
+        n = args.layers
+        kwargs.update(num_layers=n, dual_attention_layers=[i for i in kwargs["dual_attention_layers"] if i < n],
+                      crossview_block_layers=[i for i in kwargs["crossview_block_layers"] if i < n],
+                      temporal_block_layers=[i for i in kwargs["temporal_block_layers"] if i < n])
+    with torch.device(dev):
+        model = DiTCrossviewTemporalConditionModel(**kwargs)          # fp32 master parameters
+    synth_init_(model, 0)                                             # same seed on every rank
+    if args.freeze_base:
+        model.transformer_blocks.requires_grad_(False)
+        model.time_text_embed.requires_grad_(False)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    n_all = sum(p.numel() for p in model.parameters())
+    trainer = CTSDTrainer(model, lr=1e-5, weight_decay=0.01, ddp=world > 1)
+    w = WORKLOAD
+    cond = {k: (v[:w["B"]] if torch.is_tensor(v) else v) for k, v in make_conditions(dev, seed=rank).items()}
+    g = torch.Generator(device="cuda").manual_seed(rank)
+    latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    losses = []
+
+    def step(i):
+        losses.append(trainer.train_step(latents, cond, generator=gen))
+
+    dt = D.timed_steps(step, args.steps, args.warmup, dev)
+    finite = bool(torch.isfinite(torch.stack(losses)).all().item())
+    if rank == 0:
+        fwd = model_flops(kwargs, w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])["total"]
+        step_ms = 1e3 * dt / args.steps
+        mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+        print(json.dumps({
+            "metric": "train-samples/sec (6-view x16f 448x256 per sample), SD-3.5 CTSD train step", "value": world * args.steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 compute, fp32 master weights / grads / AdamW",
+            "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
+            "config": {"workload": "BASELINE config 4: CTSD SD-3.5 MMDiT train step (flow-matching loss, checkpointed blocks: "
+                                   "forward + recompute + backward, AdamW), one [1,16,6,16,32,56] sample per GPU, DDP over RCCL",
+                       "layers": kwargs["num_layers"], "parameters": n_all, "trainable_parameters": n_train,
+                       "frozen_base": bool(args.freeze_base), "forward_flop": fwd,
+                       "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "finite": finite,
+                       "peak_memory_GiB": mem},
+            # forward + recompute + 2x backward GEMMs (input + weight gradients); frozen weights skip their wgrad
+            "approx_mfma_frac": (4.0 * fwd) / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12) if not args.freeze_base else None,
+        }))
+    D.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,7 +250,14 @@ def main():
                     help="text+layout variant (examples/ctsd_35_df16_6views_video_generation_with_layout.json model: "
                          "ImageAdapter + point-wise temporal attention, 13 added time ids)")
     ap.add_argument("--no-adapter-cache", action="store_true", help="with --layout: recompute the adapter every step as the reference does")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 4 instead of the headline metric: one SD-3.5 training step per 'step' "
+                         "(forward + backward + AdamW on one 6-view x 16-frame sample per GPU, DDP gradient all-reduce over RCCL)")
+    ap.add_argument("--freeze-base", action="store_true",
+                    help="with --train: freezing_pattern ^(transformer_blocks|time_text_embed)$ of the reference's warm-up configs")
     args = ap.parse_args()
+    if args.train:
+        return main_train(args)
 
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()
