@@ -21,4 +21,9 @@ echo "== rocprof"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1)
 find /tmp/prof_$TAG -name "*stats*" | head
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv"); do cp $f $OUT/; done
-for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1); do head -25 $f; done
+for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1); do head -12 $f | cut -c1-160; done
+echo "== train bench (BASELINE config 4, one GPU)"
+timeout 900 python bench.py --train --steps 3 --warmup 1 > $OUT/bench_train.log 2>&1; echo "train bench exit $?" | tee -a $OUT/bench_train.log; tail -2 $OUT/bench_train.log | cut -c1-400
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$TAG -o train -- python $GRAFT_REPO_ROOT/bench.py --train --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_train.log 2>&1)
+for f in $(find /tmp/proft_$TAG -name "*kernel_stats*.csv"); do cp $f $OUT/train_kernel_stats.csv; done
+head -12 $OUT/train_kernel_stats.csv | cut -c1-200
