@@ -167,12 +167,14 @@ rowcombine_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __res
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm backward
-// One wave per row (row in registers), RPB rows per wave sequentially; per-lane fp32 partial
-// sums of the parameter / modulation gradients over the wave's rows, flushed with atomics once.
+// One wave per row (row in registers), RB/4 rows per wave sequentially; per-lane fp32 partial
+// sums of the parameter / modulation gradients over the wave's rows, reduced over the 4 waves in
+// LDS and flushed with one atomic per column and workgroup.
+constexpr int LN_BWD_RB = 128;
 template <int NI>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
-    constexpr int RB = 32;                  // rows per block (8 per wave)
+    constexpr int RB = LN_BWD_RB;           // rows per block (a quarter per wave)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = p.D;
     const int64_t rpg = p.rows_per_mod > 0 ? p.rows_per_mod : p.rows;
@@ -299,16 +301,22 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
         }
     }
     // flush: dgamma[gg][c], dbeta[gg][c]; gg = group for modulation gradients, 0 for affine parameters
+    __shared__ float red[4][NI * 512];
+    const int64_t gg = p.grad_per_group ? g : 0;
+    float* const outs[4] = {p.dgamma, p.dbeta, p.dgamma2, p.dbeta2};
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        if (!ok[i] || rbeg >= rend) continue;
-        const int c = (i * 64 + lane) * 8;
+    for (int q = 0; q < 4; ++q) {
+        if (outs[q] == nullptr) continue;               // kernel-argument uniform
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (p.dgamma) atomicAdd(p.dgamma + (p.grad_per_group ? g : 0) * p.ld_grad + c + j, sg[i][j]);
-            if (p.dbeta) atomicAdd(p.dbeta + (p.grad_per_group ? g : 0) * p.ld_grad + c + j, sb[i][j]);
-            if (p.dgamma2) atomicAdd(p.dgamma2 + (p.grad_per_group ? g : 0) * p.ld_grad + c + j, sg2[i][j]);
-            if (p.dbeta2) atomicAdd(p.dbeta2 + (p.grad_per_group ? g : 0) * p.ld_grad + c + j, sb2[i][j]);
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                red[wave][(i * 64 + lane) * 8 + j] = q == 0 ? sg[i][j] : q == 1 ? sb[i][j] : q == 2 ? sg2[i][j] : sb2[i][j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (rbeg < rend) atomicAdd(outs[q] + gg * p.ld_grad + c, v);
         }
     }
 }
@@ -506,7 +514,7 @@ extern "C" int dwm_layernorm_bwd(const dwm_layernorm_bwd_args* a, void* stream) 
     if ((a->dgamma || a->dbeta || a->dgamma2 || a->dbeta2) && a->ld_grad < a->D) return DWM_EINVAL;
     const int64_t rpg = a->rows_per_mod > 0 ? a->rows_per_mod : a->rows;
     const int64_t groups = (a->rows + rpg - 1) / rpg;
-    const int cpg = (int)(((rpg < a->rows ? rpg : a->rows) + 31) / 32);
+    const int cpg = (int)(((rpg < a->rows ? rpg : a->rows) + LN_BWD_RB - 1) / LN_BWD_RB);
     if (groups * cpg >= (1ll << 31)) return DWM_EUNSUPPORTED;
     const dim3 grid((unsigned)(groups * cpg));
     hipStream_t s = (hipStream_t)stream;
