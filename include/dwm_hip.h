@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 7
+#define DWM_ABI_VERSION 8
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -88,7 +88,7 @@ typedef struct dwm_gemm_args {
     int32_t act;                          /* DWM_ACT_* (PLAIN / RESID)                    */
     /* RESID */
     const void* gate; int64_t ld_gate; int64_t rows_per_gate;   /* bf16 gate[row/rows_per_gate][n] or NULL */
-    const void* res;  int64_t ld_res;  int64_t res_mod;         /* bf16 res[res_mod ? row%res_mod : row][n] or NULL */
+    const void* res;  int64_t ld_res;  int64_t res_mod;         /* bf16 res[res_mod > 0 ? row % res_mod : res_mod < 0 ? row / -res_mod : row][n] or NULL */
     const void* blend; int64_t ld_blend;                        /* bf16 blend[row][n] or NULL               */
     const float* alpha; int64_t rows_per_alpha;                 /* fp32 alpha[row/rows_per_alpha]           */
     /* RMSHEAD */
@@ -143,7 +143,9 @@ typedef struct dwm_attn_args {
     int64_t ldiv[2], lstride[3];
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
     int32_t variant;                           /* 0 = auto; tuning knob, see attention.hip    */
-    int32_t reserved;
+    int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
+                                                * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
+                                                * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */
     float* lse;                                /* optional out fp32 [n_problems, heads, L0+L1]: NEGATIVE
                                                 * log2-domain log-sum-exp of scale*log2(e)*q.k, i.e.
                                                 * P = exp2(scale*log2(e)*q.k + lse) (saved for the backward) */
@@ -263,6 +265,16 @@ int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream);
 int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
                        const void* gamma, const void* beta, int32_t silu, float* stats,
                        const dwm_rowmap2d* out_map, void* stream);
+
+/* Same with an (image, pixel) -> row map: image i, pixel p lives in token row
+ * (i / iv) * s_ihi + (i % iv) * s_ilo + (p / pn) * s_phi + p % pn  (iv = 0 / NULL: row = i*P + p).
+ * diffusers TemporalResnetBlock's GroupNorm over [B*V, C, T, H, W] on the [(b t v), (h w), C] layout:
+ * I = B*V, P = T*h*w, iv = V, pn = h*w, s_ihi = T*V*h*w, s_ilo = h*w, s_phi = V*h*w.  out_map then maps the
+ * token row (not the image-local pixel).  C/G == 4 or >= 8. */
+typedef struct dwm_gn_imgmap { int64_t iv, pn, s_ihi, s_ilo, s_phi; } dwm_gn_imgmap;
+int dwm_groupnorm_silu_mapped(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                              const void* gamma, const void* beta, int32_t silu, float* stats,
+                              const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream);
 
 /* F.interpolate(scale_factor=2, mode="nearest") of token-major x [I, h, w, C], written into the
  * padded grid y [I, 2h+2, 2w+2, C] (diffusers Upsample2D before its 3x3 conv). */

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -42,7 +42,7 @@ class AttnArgs(C.Structure):
         ("pdiv", _i64 * 3), ("pmod", _i64 * 3), ("pstride", _i64 * 3),
         ("ldiv", _i64 * 2), ("lstride", _i64 * 3),
         ("mask", _vp), ("mask_G", _i64), ("group_size", _i64), ("p_per_mask", _i64),
-        ("variant", _i32), ("reserved", _i32), ("lse", _vp),
+        ("variant", _i32), ("cross", _i32), ("lse", _vp),
     ]
 
 
@@ -63,6 +63,10 @@ class LayerNormArgs(C.Structure):
         ("scale2", _vp), ("shift2", _vp),
         ("addvec", _vp), ("ld_add", _i64), ("rows_per_add", _i64),
     ]
+
+
+class GnImgMap(C.Structure):
+    _fields_ = [("iv", _i64), ("pn", _i64), ("s_ihi", _i64), ("s_ilo", _i64), ("s_phi", _i64)]
 
 
 class RowCombineArgs(C.Structure):
@@ -104,6 +108,7 @@ SIGNATURES = {
     "dwm_avgpool2_tokens": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dwm_add_inplace": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_groupnorm_silu": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), _vp]),
+    "dwm_groupnorm_silu_mapped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dwm_pad_tokens": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(RowMap2D), _vp]),
     "dwm_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),

@@ -78,8 +78,8 @@ attn_fwd_kernel(const AttnParams P) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int lq = qb * QB + (wave * QT + t) * 32 + l31;
-        qok[t] = lq < L;
-        const int lqc = qok[t] ? lq : L - 1;
+        qok[t] = lq < P.qend;
+        const int lqc = qok[t] ? lq : P.qend - 1;
         const bf16_t* qptr = P.q0 + ((int64_t)rowtab[lqc] << 3) + (lqc < L0 ? 0 : P.seg1_delta) + hoff;      // q, k, v share the offset table
         if (lqc < L0) optr[t] = P.o0 + seg0_row(P.rm, seg0_base(P.rm, prob), lqc) * P.ldo0 + hoff;
         else optr[t] = P.o1 + ((int64_t)prob * P.L1 + (lqc - L0)) * P.ldo1 + hoff;
@@ -101,7 +101,7 @@ attn_fwd_kernel(const AttnParams P) {
     // ---- staging by LDS-DMA: 16 B per lane, LDS destination lane-linear, so wave w's instruction i
     //      fills tile rows 16 w + 8 i + (lane >> 3) and the chunk swizzle is applied on the *source*
     //      column: LDS chunk position (lane & 7) of row r holds global chunk (lane & 7) ^ swz(r).
-    const int nkt = (L + KT - 1) / KT;
+    const int nkt = (L - P.kbeg + KT - 1) / KT;
     const int srow0 = wave * 16 + (lane >> 3), srow1 = srow0 + 8;
     const bf16_t* const kg0 = P.k0 + hoff + (((lane & 7) ^ ((srow0 >> 1) & 7)) << 3);
     const bf16_t* const kg1 = P.k0 + hoff + (((lane & 7) ^ ((srow1 >> 1) & 7)) << 3);
@@ -111,7 +111,7 @@ attn_fwd_kernel(const AttnParams P) {
 
 #define DWM_DMA_TILE(kt_, stage_)                                                           \
     do {                                                                                    \
-        const int kb_ = (kt_) * KT;                                                         \
+        const int kb_ = P.kbeg + (kt_) * KT;                                                \
         const int ra_ = kb_ + srow0 < L ? kb_ + srow0 : L - 1;                              \
         const int rb_ = kb_ + srow1 < L ? kb_ + srow1 : L - 1;                              \
         const int64_t oa_ = ((int64_t)rowtab[ra_] << 3) + (ra_ < L0 ? 0 : P.seg1_delta);    \
@@ -167,7 +167,7 @@ attn_fwd_kernel(const AttnParams P) {
 
     // a wave whose queries all lie past the end of the sequence (last query block) only takes part
     // in the staging and the barriers
-    const bool wave_active = qb * QB + wave * QT * 32 < L;
+    const bool wave_active = qb * QB + wave * QT * 32 < P.qend;
     int stage = 0;                        // ring slot of tile kt
     for (int kt = 0; kt < nkt; ++kt) {
         const char* kl = smem + stage * STAGE_BYTES;
@@ -189,7 +189,7 @@ attn_fwd_kernel(const AttnParams P) {
         __builtin_amdgcn_s_setprio(0);
 
         // ---- masks (raw-score domain), online softmax; P^T fragments stay in registers
-        const int kbase = kt * KT;
+        const int kbase = P.kbeg + kt * KT;
         if (kbase + KT > L) {                       // ragged last tile (wave-uniform)
 #pragma unroll
             for (int t = 0; t < QT; ++t)
@@ -351,7 +351,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     if (qt == 0) qt = 1;   // 32 queries per wave (3 workgroups per CU) measured faster in the full step than 64
     if (qt != 1 && qt != 2) return DWM_EINVAL;
     const int qblock = qt * 128;
-    P.nqb = (int)((L + qblock - 1) / qblock);
+    P.nqb = (int)((P.qend + qblock - 1) / qblock);
     P.fd_nqb = make_fastdiv((uint32_t)P.nqb);
     if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
     if (NSTAGE * STAGE_BYTES + L * 4 + 16 > MAX_LDS_BYTES) return DWM_EUNSUPPORTED;   // ring + row table must fit the LDS window

@@ -436,6 +436,7 @@ int launch_bwd(const AttnParams& P, hipStream_t s) {
 
 extern "C" int dwm_attention_bwd(const dwm_attn_bwd_args* b, void* stream) {
     if (b == nullptr) return DWM_EINVAL;
+    if (b->fwd.cross) return DWM_EUNSUPPORTED;       // cross-attention has no backward yet (the UNet path is inference only)
     AttnParams P;
     const int rc = fill_params(&b->fwd, P);
     if (rc != DWM_OK) return rc;

@@ -28,6 +28,7 @@ struct AttnParams {
     bf16_t *o0, *o1;
     int64_t ld0, ld1, ldo0, ldo1;
     int L0, L1, L;
+    int qend, kbeg;          // queries are tokens [0, qend), keys tokens [kbeg, L): (L, 0), or (L0, L0) for cross-attention
     int64_t seg1_delta;      // (q1 - q0) == (k1 - k0) == (v1 - v0) in elements
     float* lse;              // optional [n_problems, heads, L]: NEGATIVE log2-domain log-sum-exp of scale*log2(e)*q.k
     // backward only
@@ -97,10 +98,11 @@ inline int fill_params(const dwm_attn_args* a, AttnParams& P) {
     if (a == nullptr || a->q0 == nullptr || a->k0 == nullptr || a->v0 == nullptr || a->o0 == nullptr) return DWM_EINVAL;
     if (a->head_dim != 64) return DWM_EUNSUPPORTED;
     if (a->L0 <= 0 || a->L1 < 0 || a->n_problems <= 0 || a->heads <= 0) return DWM_EINVAL;
-    if (a->L1 > 0 && (a->q1 == nullptr || a->k1 == nullptr || a->v1 == nullptr || a->o1 == nullptr)) return DWM_EINVAL;
-    if (a->ld0 % 8 != 0 || a->ldo0 % 4 != 0 || (a->L1 > 0 && (a->ld1 % 8 != 0 || a->ldo1 % 4 != 0))) return DWM_EALIGN;
+    if (a->L1 > 0 && (a->q1 == nullptr || a->k1 == nullptr || a->v1 == nullptr || (a->o1 == nullptr && !a->cross))) return DWM_EINVAL;
+    if (a->cross && a->L1 <= 0) return DWM_EINVAL;
+    if (a->ld0 % 8 != 0 || a->ldo0 % 4 != 0 || (a->L1 > 0 && (a->ld1 % 8 != 0 || (!a->cross && a->ldo1 % 4 != 0)))) return DWM_EALIGN;
     if (!dwm_aligned16(a->q0) || !dwm_aligned16(a->k0) || !dwm_aligned16(a->v0) || (((uintptr_t)a->o0) & 7u)) return DWM_EALIGN;
-    if (a->L1 > 0 && (!dwm_aligned16(a->q1) || !dwm_aligned16(a->k1) || !dwm_aligned16(a->v1) || (((uintptr_t)a->o1) & 7u)))
+    if (a->L1 > 0 && (!dwm_aligned16(a->q1) || !dwm_aligned16(a->k1) || !dwm_aligned16(a->v1) || (!a->cross && (((uintptr_t)a->o1) & 7u))))
         return DWM_EALIGN;
     if (a->ldiv[0] <= 0 || a->ldiv[1] <= 0) return DWM_EINVAL;
     if (a->mask_mode < 0 || a->mask_mode > 2) return DWM_EINVAL;
@@ -115,6 +117,8 @@ inline int fill_params(const dwm_attn_args* a, AttnParams& P) {
     P.o0 = (bf16_t*)a->o0; P.o1 = (bf16_t*)a->o1;
     P.ld0 = a->ld0; P.ld1 = a->ld1; P.ldo0 = a->ldo0; P.ldo1 = a->ldo1;
     P.L0 = (int)a->L0; P.L1 = (int)a->L1; P.L = (int)L;
+    P.qend = a->cross ? P.L0 : P.L;
+    P.kbeg = a->cross ? P.L0 : 0;
     P.seg1_delta = 0;
     P.oseg1_delta = 0;
     if (a->L1 > 0) {
@@ -122,7 +126,7 @@ inline int fill_params(const dwm_attn_args* a, AttnParams& P) {
         const int64_t dq = P.q1 - P.q0, dk = P.k1 - P.k0, dv = P.v1 - P.v0;
         if (dq != dk || dk != dv) return DWM_EUNSUPPORTED;
         P.seg1_delta = dq;
-        P.oseg1_delta = P.o1 - P.o0;
+        P.oseg1_delta = a->cross ? 0 : P.o1 - P.o0;
     }
     P.lse = a->lse;
     P.n_problems = (int)a->n_problems; P.heads = a->heads;

@@ -332,7 +332,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     if (p.gate) gq[st] = *(const uint4*)((const bf16_t*)p.gate + (int64_t)fdiv((uint32_t)m, cp.fd_rpg) * p.ld_gate + nc);
                     const int64_t mr = map_row(cp.c, m);
                     if (p.res) {
-                        const int64_t rr = p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m, cp.fd_rmod) : mr;
+                        const int64_t rr = p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m, cp.fd_rmod) : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m, cp.fd_rmod) : mr;
                         rq[st] = *(const uint4*)((const bf16_t*)p.res + rr * p.ld_res + nc);
                     }
                     if (p.blend) {
@@ -427,9 +427,9 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (kpt <= 0 || kpt % BK != 0 || kpt * ntaps != a->K) return DWM_EINVAL;
     cp.steps_per_tap = (int)(kpt / BK);
     cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
-    if (a->rows_per_gate > (1ll << 30) || a->res_mod > (1ll << 30) || a->rows_per_alpha > (1ll << 30)) return DWM_EINVAL;
+    if (a->rows_per_gate > (1ll << 30) || a->res_mod > (1ll << 30) || a->res_mod < -(1ll << 30) || a->rows_per_alpha > (1ll << 30)) return DWM_EINVAL;
     cp.fd_rpg = make_fastdiv((uint32_t)(a->rows_per_gate > 0 ? a->rows_per_gate : 1));
-    cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : 1));
+    cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : a->res_mod < 0 ? -a->res_mod : 1));
     cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
     for (int t = 0; t < 9; ++t) cp.tap_shift[t] = (a->ntaps > 0 && t < ntaps) ? a->tap_shift[t] : 0;
     if (a->lda < kpt) return DWM_EINVAL;

@@ -7,11 +7,23 @@
 
 namespace {
 
-// ---- GroupNorm statistics: x [I, P, C] token-major, G groups of CG = C/G channels.
-// grid (chunks, I); each block reduces PPB pixels for all groups of image i and atomically adds
-// (sum, sumsq) into stats[i][g][2] (fp32, zeroed by the caller's memset node).
+// ---- optional (image, pixel) -> token-row map: lets one GroupNorm call normalise over a strided set of
+// rows, e.g. the (T, H, W) extent of every (batch, view) pair of a [(b t v), (h w), C] tensor
+// (TemporalResnetBlock's GroupNorm over [B*V, C, T, H, W]).
+struct ImgMap { int enabled; FastDiv iv, pn; int64_t s_ihi, s_ilo, s_phi; };
+DWM_DEVINL int64_t img_row(const ImgMap& m, int64_t i, int64_t p, int64_t P) {
+    if (!m.enabled) return i * P + p;
+    const uint32_t ihi = fdiv((uint32_t)i, m.iv), ilo = (uint32_t)i - ihi * m.iv.d;
+    const uint32_t phi = fdiv((uint32_t)p, m.pn), plo = (uint32_t)p - phi * m.pn.d;
+    return (int64_t)ihi * m.s_ihi + (int64_t)ilo * m.s_ilo + (int64_t)phi * m.s_phi + plo;
+}
+
+// ---- GroupNorm statistics: x token-major [rows, C], G groups of CG = C/G channels (CG == 4 or CG >= 8:
+// the 8 channels of a 16-B chunk then span at most two groups).  grid (chunks, I); each block reduces
+// ppb pixels for all groups of image i and atomically adds (sum, sumsq) into stats[i][g][2] (fp32,
+// zeroed by the entry point's memset).
 __global__ void __launch_bounds__(256)
-gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ stats) {
+gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ stats, ImgMap im) {
     extern __shared__ float red[];            // [2 * G]
     const int i = blockIdx.y;
     const int C8 = C >> 3, CG = C / G;
@@ -19,23 +31,29 @@ gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t p
     const int64_t p1 = p0 + ppb < P ? p0 + ppb : P;
     for (int t = threadIdx.x; t < 2 * G; t += 256) red[t] = 0.f;
     __syncthreads();
-    // thread t owns channel chunk c8 = t % C8 (8 channels) and strides over pixels
-    const int c8 = threadIdx.x % C8;
-    const int prow = threadIdx.x / C8, pstep = 256 / C8;
-    // a thread's 8 channels span one group (CG >= 8) or two (CG == 4): split sums by 4-channel half
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    const int TW = C8 < 256 ? C8 : 256;       // threads across channel chunks
+    const int prow = threadIdx.x / TW, pstep = 256 / TW;
     if (prow < pstep) {
-        for (int64_t p = p0 + prow; p < p1; p += pstep) {
-            float v[8];
-            unpack8(*(const uint4*)(x + ((int64_t)i * P + p) * C + c8 * 8), v);
+        for (int c8 = threadIdx.x % TW; c8 < C8; c8 += TW) {
+            const int g0 = (c8 * 8) / CG;
+            const int bnd = (g0 + 1) * CG - c8 * 8;     // first element of the chunk that belongs to group g0 + 1
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+            for (int64_t p = p0 + prow; p < p1; p += pstep) {
+                float v[8];
+                unpack8(*(const uint4*)(x + img_row(im, i, p, P) * C + c8 * 8), v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s0 += v[j]; q0 += v[j] * v[j]; s1 += v[j + 4]; q1 += v[j + 4] * v[j + 4]; }
+                for (int j = 0; j < 8; ++j) {
+                    if (j < bnd) { s0 += v[j]; q0 += v[j] * v[j]; }
+                    else { s1 += v[j]; q1 += v[j] * v[j]; }
+                }
+            }
+            atomicAdd(&red[2 * g0], s0);
+            atomicAdd(&red[2 * g0 + 1], q0);
+            if (bnd < 8) {
+                atomicAdd(&red[2 * g0 + 2], s1);
+                atomicAdd(&red[2 * g0 + 3], q1);
+            }
         }
-        const int g0 = (c8 * 8) / CG, g1 = (c8 * 8 + 4) / CG;
-        atomicAdd(&red[2 * g0], s0);
-        atomicAdd(&red[2 * g0 + 1], q0);
-        atomicAdd(&red[2 * g1], s1);
-        atomicAdd(&red[2 * g1 + 1], q1);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < 2 * G; t += 256) atomicAdd(&stats[(int64_t)i * 2 * G + t], red[t]);
@@ -51,20 +69,23 @@ DWM_DEVINL int64_t pad_row(const PadMap& m, int64_t r) {
 }
 
 __global__ void __launch_bounds__(256)
-gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int64_t P, int C, int G,
+gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I, int64_t P, int C, int G,
                 const float* __restrict__ stats, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
-                float eps, int silu, PadMap pm) {
+                float eps, int silu, PadMap pm, ImgMap im) {
     const int C8 = C >> 3, CG = C / G;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * C8) return;
+    if (idx >= I * P * C8) return;
     const int c8 = (int)(idx % C8);
-    const int64_t r = idx / C8;
-    const int64_t i = r / P;
+    const int64_t ip = idx / C8;
+    const int64_t i = ip / P, pp = ip - i * P;
+    const int64_t r = img_row(im, i, pp, P);
     const float n = (float)P * (float)CG;
+    const int g0 = (c8 * 8) / CG;
+    const int bnd = (g0 + 1) * CG - c8 * 8;
     float mean[2], rstd[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-        const int g = (c8 * 8 + 4 * hf) / CG;
+        const int g = g0 + hf < G ? g0 + hf : G - 1;
         mean[hf] = stats[(i * G + g) * 2] / n;
         const float var = fmaxf(stats[(i * G + g) * 2 + 1] / n - mean[hf] * mean[hf], 0.f);
         rstd[hf] = rsqrtf(var + eps);
@@ -75,7 +96,8 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t ro
     unpack8(*(const uint4*)(beta + c8 * 8), be);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float t = (v[j] - mean[j >> 2]) * rstd[j >> 2] * ga[j] + be[j];
+        const int hf = j < bnd ? 0 : 1;
+        float t = (v[j] - mean[hf]) * rstd[hf] * ga[j] + be[j];
         v[j] = silu ? silu_f(t) : t;
     }
     *(uint4*)(y + pad_row(pm, r) * C + c8 * 8) = pack8(v);
@@ -154,24 +176,33 @@ inline int finish() {
 
 }  // namespace
 
-extern "C" int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
-                                  const void* gamma, const void* beta, int32_t silu, float* stats,
-                                  const dwm_rowmap2d* out_map, void* stream) {
+extern "C" int dwm_groupnorm_silu_mapped(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                                         const void* gamma, const void* beta, int32_t silu, float* stats,
+                                         const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream) {
     if (x == nullptr || y == nullptr || gamma == nullptr || beta == nullptr || stats == nullptr) return DWM_EINVAL;
     if (I <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G != 0) return DWM_EINVAL;
     const int CG = C / G;
-    if (C % 8 != 0 || CG % 4 != 0 || C / 8 > 256 || 256 % (C / 8) != 0 || I > 65535) return DWM_EUNSUPPORTED;
+    if (C % 8 != 0 || !(CG == 4 || CG >= 8) || I > 65535 || I * P >= (1ll << 31)) return DWM_EUNSUPPORTED;
     if (!dwm_aligned16(x) || !dwm_aligned16(y) || !dwm_aligned16(gamma) || !dwm_aligned16(beta)) return DWM_EALIGN;
+    ImgMap im;
+    im.enabled = img_map != nullptr && img_map->iv > 0;
+    if (im.enabled) {
+        if (img_map->pn <= 0 || img_map->iv >= (1ll << 30) || img_map->pn >= (1ll << 30)) return DWM_EINVAL;
+        im.iv = make_fastdiv((uint32_t)img_map->iv); im.pn = make_fastdiv((uint32_t)img_map->pn);
+        im.s_ihi = img_map->s_ihi; im.s_ilo = img_map->s_ilo; im.s_phi = img_map->s_phi;
+    } else {
+        im.iv = make_fastdiv(1); im.pn = make_fastdiv(1); im.s_ihi = im.s_ilo = im.s_phi = 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * G * I, s);
     if (e != hipSuccess) return (int)e;
     const int64_t ppb = 2048;
     const dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)I);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), sizeof(float) * 2 * G, s, (const bf16_t*)x, P, C, G, ppb, stats);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), sizeof(float) * 2 * G, s, (const bf16_t*)x, P, C, G, ppb, stats, im);
     PadMap pm;
     pm.enabled = out_map != nullptr && out_map->rw > 0;
     if (pm.enabled) {
-        if (out_map->rh <= 0 || out_map->rw * out_map->rh != P) return DWM_EINVAL;
+        if (out_map->rh <= 0 || (!im.enabled && out_map->rw * out_map->rh != P)) return DWM_EINVAL;
         pm.rw = make_fastdiv((uint32_t)out_map->rw); pm.rh = make_fastdiv((uint32_t)out_map->rh);
         pm.rpitch = out_map->rpitch; pm.ipitch = out_map->ipitch; pm.origin = out_map->origin;
     } else {
@@ -179,8 +210,14 @@ extern "C" int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, 
     }
     const int64_t total = I * P * (C / 8);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
-                       (bf16_t*)y, I * P, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm);
+                       (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im);
     return finish();
+}
+
+extern "C" int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                                  const void* gamma, const void* beta, int32_t silu, float* stats,
+                                  const dwm_rowmap2d* out_map, void* stream) {
+    return dwm_groupnorm_silu_mapped(x, y, I, P, C, G, eps, gamma, beta, silu, stats, out_map, nullptr, stream);
 }
 
 extern "C" int dwm_upsample2_padded(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream) {

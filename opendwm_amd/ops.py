@@ -79,12 +79,44 @@ class PaddedGrid:
     def tap_shifts_stride2(self):
         return [dy * (self.w + 2) + dx for dy in range(3) for dx in range(3)]
 
+    def fill_stride2_sym(self, m: "_lib.RowMap2D") -> None:
+        """stride-2 3x3 conv with symmetric padding 1 (diffusers Downsample2D(padding=1), SD 2.1 UNet): output (y, x)
+        reads input rows (2y - 1 + dy, 2x - 1 + dx) = padded rows (2y + dy, 2x + dx): origin 0, same tap shifts."""
+        self.fill_stride2(m)
+        m.origin = 0
+
     def interior_index(self) -> torch.Tensor:
         """[pixels] int64 padded-row index of every compact pixel (host reference of the kernel's map)"""
         i = torch.arange(self.I)[:, None, None]
         y = torch.arange(self.h)[None, :, None]
         x = torch.arange(self.w)[None, None, :]
         return (i * (self.h + 2) * (self.w + 2) + (y + 1) * (self.w + 2) + x + 1).reshape(-1)
+
+
+@dataclass
+class TimeGrid:
+    """Token rows [(b t v), (h w)] with one zero frame before and after every sequence:
+    [B, T + 2, V*N, C] - the input layout of a Conv3d with kernel (3, 1, 1) / padding (1, 0, 0) run as a
+    3-tap implicit GEMM (diffusers TemporalResnetBlock).  `vn` = V * h * w rows per frame."""
+    B: int
+    T: int
+    vn: int
+
+    @property
+    def rows(self) -> int:
+        return self.B * (self.T + 2) * self.vn
+
+    @property
+    def pixels(self) -> int:
+        return self.B * self.T * self.vn
+
+    def fill(self, m: "_lib.RowMap2D") -> None:
+        m.rw, m.rh = self.vn, self.T
+        m.rpitch, m.ipitch = self.vn, (self.T + 2) * self.vn
+        m.origin = self.vn
+
+    def tap_shifts(self):
+        return [-self.vn, 0, self.vn]
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
@@ -94,8 +126,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          blend: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
          rows_per_alpha: int = 1,
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
-         a_grid: Optional[PaddedGrid] = None, conv3x3: bool = False, stride2: bool = False,
-         c_grid: Optional[PaddedGrid] = None,
+         a_grid=None, conv3x3: bool = False, stride2=False, conv_taps: Optional[list] = None,
+         c_grid=None,
          rows: Optional[int] = None, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
     a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
@@ -106,7 +138,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         raise RuntimeError("w must be contiguous [N, K]")
     N, K = w.shape
     if a_grid is not None:
-        if a.shape[0] != a_grid.rows or a.shape[1] * (9 if conv3x3 else 1) != K:
+        ntap_ = 9 if conv3x3 else (len(conv_taps) if conv_taps is not None else 1)
+        if a.shape[0] != a_grid.rows or a.shape[1] * ntap_ != K:
             raise RuntimeError(f"gemm: padded A {tuple(a.shape)} does not match grid / weight {tuple(w.shape)}")
         M = a_grid.pixels // 4 if stride2 else a_grid.pixels
     else:
@@ -143,12 +176,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if stride2:
             if not conv3x3 or a_grid.h % 2 or a_grid.w % 2:
                 raise RuntimeError("gemm: stride2 needs conv3x3 on an even-sized grid")
-            a_grid.fill_stride2(g.a_map)
+            (a_grid.fill_stride2_sym if stride2 == "sym" else a_grid.fill_stride2)(g.a_map)
         else:
             a_grid.fill(g.a_map)
         if conv3x3:
             g.ntaps, g.k_per_tap = 9, a.shape[1]
             for t, sh in enumerate(a_grid.tap_shifts_stride2() if stride2 else a_grid.tap_shifts()):
+                g.tap_shift[t] = sh
+        elif conv_taps is not None:
+            g.ntaps, g.k_per_tap = len(conv_taps), a.shape[1]
+            for t, sh in enumerate(conv_taps):
                 g.tap_shift[t] = sh
     if c_grid is not None:
         c_grid.fill(g.c_map)
@@ -318,6 +355,35 @@ def attention_bwd(q, k, v, out, dout, dq, dk, dv, rowmap: RowMap, heads: int, ls
         keep.record_stream(torch.cuda.current_stream())
 
 
+def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_problems: int, heads: int,
+                    scale: Optional[float] = None) -> None:
+    """Cross-attention (diffusers BasicTransformerBlock.attn2): q/out [n_problems*Lq, heads*64], k/v
+    [n_problems*Lk, heads*64] (column slices of one buffer sharing a row stride); every query attends to all Lk keys of
+    its problem.  Runs dwm_attention_fwd in `cross` mode: queries = segment 0, keys / values = segment 1."""
+    for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        _chk2d(t, name)
+    if k.stride(0) != v.stride(0) or q.shape[0] % n_problems or k.shape[0] % n_problems:
+        raise RuntimeError("cross_attention: k, v must share a row stride; rows must be n_problems * L")
+    a = _lib.AttnArgs()
+    a.q0 = a.q1 = q.data_ptr()
+    a.k0 = a.k1 = k.data_ptr()
+    a.v0 = a.v1 = v.data_ptr()
+    a.ld0, a.ld1 = q.stride(0), k.stride(0)
+    a.o0, a.ldo0 = out.data_ptr(), out.stride(0)
+    a.L0, a.L1, a.n_problems = q.shape[0] // n_problems, k.shape[0] // n_problems, n_problems
+    a.heads, a.head_dim = heads, 64
+    if q.shape[1] != heads * 64:
+        raise RuntimeError("attention: head_dim must be 64")
+    a.scale = float(scale) if scale is not None else 64 ** -0.5
+    rm = rowmap_identity(n_problems, a.L0)
+    for i in range(3):
+        a.pdiv[i], a.pmod[i], a.pstride[i] = rm.pdiv[i], rm.pmod[i], rm.pstride[i]
+        a.lstride[i] = rm.lstride[i]
+    a.ldiv[0], a.ldiv[1] = rm.ldiv
+    a.cross = 1
+    _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
+
+
 # -------------------------------------------------------------------------------- norms
 def layernorm(x: torch.Tensor, *, eps: float, out: Optional[torch.Tensor] = None,
               weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
@@ -466,9 +532,10 @@ def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
                    eps: float, silu: bool = True, out: Optional[torch.Tensor] = None,
-                   out_grid: Optional[PaddedGrid] = None) -> torch.Tensor:
+                   out_grid=None, img_map: Optional[tuple] = None) -> torch.Tensor:
     """GroupNorm(groups) [+ SiLU] of token-major x [I*P, C]; with out_grid the result lands in the
-    interior of a padded grid `out` [out_grid.rows, C] whose border must already be zero."""
+    interior of a padded grid `out` [out_grid.rows, C] whose border must already be zero.  img_map =
+    (iv, pn, s_ihi, s_ilo, s_phi): image i / pixel p -> token row (see dwm_groupnorm_silu_mapped)."""
     _chk2d(x, "x")
     if not x.is_contiguous() or x.shape[0] != I * P:
         raise RuntimeError("groupnorm_silu: x must be contiguous [I*P, C]")
@@ -484,9 +551,12 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
     m = _lib.RowMap2D()
     if out_grid is not None:
         out_grid.fill(m)
-    _lib.check(_lib.load().dwm_groupnorm_silu(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
-                                              beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), _stream()),
-               "dwm_groupnorm_silu")
+    im = _lib.GnImgMap()
+    if img_map is not None:
+        im.iv, im.pn, im.s_ihi, im.s_ilo, im.s_phi = img_map
+    _lib.check(_lib.load().dwm_groupnorm_silu_mapped(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
+                                                     beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
+                                                     _stream()), "dwm_groupnorm_silu_mapped")
     return out
 
 

@@ -1,0 +1,111 @@
+"""GPU leg (`-m gpu`): the SD 2.1 UNet path - kernel extensions it needs and the
+model against the fp32 oracle (oracle/unet_oracle.py)."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.common import rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+bf16 = torch.bfloat16
+TOL_KERNEL = 6e-3
+TOL_MODEL = 2e-2
+
+
+def _log(name, **kv):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "gpu_parity.log"), "a") as f:
+        f.write(json.dumps({"test": name, **kv}) + "\n")
+    print(name, kv)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need a HIP device (torch.cuda.is_available() is False)")
+    from opendwm_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev).to(bf16)
+
+
+@pytest.mark.parametrize("C", [320, 960, 1920, 2560, 64])
+def test_groupnorm_general_channel_counts(dev, C):
+    """32 groups of 10 / 30 / 60 / 80 / 2... channels: chunks of 8 channels straddle group boundaries"""
+    from opendwm_amd import ops
+    I, P, G = 3, 77, 32
+    if C // G < 4:
+        G = 16
+    x = _rand((I * P, C), dev, 1, 1.5) + 0.3
+    ga, be = _rand((C,), dev, 2, 0.2) + 1, _rand((C,), dev, 3, 0.2)
+    y = ops.groupnorm_silu(x, I, P, ga, be, G, 1e-5, silu=True)
+    ref = F.silu(F.group_norm(x.float().view(I, P, C).transpose(1, 2), G, ga.float(), be.float(), 1e-5)).transpose(1, 2).reshape(I * P, C)
+    e = rel_err(y, ref)
+    _log("groupnorm_general", C=C, rel=e)
+    assert e < TOL_KERNEL
+
+
+def test_groupnorm_temporal_map_and_time_grid(dev):
+    """GroupNorm over (T, h, w) per (batch, view) on the [(b t v), (h w), C] layout, written into the T-padded grid, then the
+    Conv3d (3,1,1) as a 3-tap implicit GEMM with a per-(b,t,v) additive vector (time embedding) in the epilogue."""
+    from opendwm_amd import ops
+    B, T, V, N, C, Co = 2, 5, 3, 12, 128, 64
+    x = _rand((B * T * V * N, C), dev, 1, 1.2)
+    ga, be = _rand((C,), dev, 2, 0.2) + 1, _rand((C,), dev, 3, 0.2)
+    tg = ops.TimeGrid(B, T, V * N)
+    pad = torch.zeros((tg.rows, C), dtype=bf16, device=dev)
+    ops.groupnorm_silu(x, B * V, T * N, ga, be, 32, 1e-5, silu=True, out=pad, out_grid=tg,
+                       img_map=(V, N, T * V * N, N, V * N))
+    x5 = x.float().view(B, T, V, N, C).permute(0, 2, 4, 1, 3).reshape(B * V, C, T, N, 1)      # [(b v), C, T, N, 1]
+    ref_n = F.silu(F.group_norm(x5, 32, ga.float(), be.float(), 1e-5))
+    got = pad.view(B, T + 2, V, N, C)
+    assert torch.count_nonzero(got[:, 0]) == 0 and torch.count_nonzero(got[:, -1]) == 0
+    inner = got[:, 1:-1].permute(0, 2, 4, 1, 3).reshape(B * V, C, T, N, 1)
+    e1 = rel_err(inner, ref_n)
+    w = _rand((Co, C, 3, 1, 1), dev, 4, (3 * C) ** -0.5)
+    bias, temb = _rand((Co,), dev, 5, 0.1), _rand((B * T * V, Co), dev, 6)
+    wk = w.view(Co, C, 3).permute(0, 2, 1).reshape(Co, 3 * C).contiguous()                   # tap-major K
+    y = ops.gemm(pad, wk, bias, a_grid=tg, conv_taps=tg.tap_shifts(), epilogue=ops.EPI_RESID, res=temb, res_mod=-N)
+    ref = F.conv3d(ref_n.to(bf16).float(), w.float(), bias.float(), padding=(1, 0, 0))        # [(b v), Co, T, N, 1]
+    ref = ref.view(B, V, Co, T, N).permute(0, 3, 1, 4, 2).reshape(B * T * V * N, Co) + temb.float().repeat_interleave(N, 0)
+    e2 = rel_err(y, ref)
+    _log("temporal_groupnorm_conv", gn=e1, conv=e2)
+    assert e1 < TOL_KERNEL and e2 < TOL_KERNEL
+
+
+def test_conv_stride2_symmetric_padding(dev):
+    from opendwm_amd import ops
+    I, h, w, C, Co = 2, 8, 12, 64, 128
+    x = _rand((I * h * w, C), dev, 1)
+    wt, b = _rand((Co, C, 3, 3), dev, 2, (9 * C) ** -0.5), _rand((Co,), dev, 3, 0.1)
+    g = ops.PaddedGrid(I, h, w)
+    pad = ops.pad_tokens(x, g)
+    y = ops.gemm(pad, wt.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous(), b, a_grid=g, conv3x3=True, stride2="sym")
+    ref = F.conv2d(x.float().view(I, h, w, C).permute(0, 3, 1, 2), wt.float(), b.float(), stride=2, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Co)
+    e = rel_err(y, ref)
+    _log("conv_stride2_sym", rel=e)
+    assert y.shape == ref.shape and e < TOL_KERNEL
+
+
+@pytest.mark.parametrize("I,Lq,Lk,heads", [(3, 448, 77, 5), (2, 100, 10, 2), (4, 28, 77, 20), (1, 1792, 77, 5)])
+def test_cross_attention(dev, I, Lq, Lk, heads):
+    from opendwm_amd import ops
+    from oracle import ctsd_oracle as O
+    D = heads * 64
+    q, kv = _rand((I * Lq, D), dev, 1), _rand((I * Lk, 2 * D), dev, 2)
+    out = torch.zeros((I * Lq, D), dtype=bf16, device=dev)
+    ops.cross_attention(q, kv[:, :D], kv[:, D:], out, I, heads)
+    hd = lambda t, L: t.float().view(I, L, heads, 64).transpose(1, 2)
+    ref = O.sdpa(hd(q, Lq), hd(kv[:, :D], Lk), hd(kv[:, D:], Lk)).transpose(1, 2).reshape(I * Lq, D)
+    e = rel_err(out, ref)
+    _log("cross_attention", I=I, Lq=Lq, Lk=Lk, heads=heads, rel=e)
+    assert e < TOL_KERNEL
