@@ -244,6 +244,15 @@ def rowmap_crossview_full(B: int, T: int, V: int, h: int, w: int) -> RowMap:
                   ldiv=(w, V), lstride=(1, h * w, w), p_per_mask=T, group_size=w)
 
 
+def rowmap_crossview_pointwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
+    """btv hw c -> (bt hw) v c: TemporalBasicTransformerBlock(num_frames=V) of the SD 2.1 UNet without row-wise
+    cross-view attention (crossview_temporal.py:358-361, :228-229)."""
+    hw = h * w
+    return RowMap(L0=V, n_problems=B * T * hw,
+                  pdiv=(hw, 1, 1), pmod=(BIG, hw, 1), pstride=(V * hw, 1, 0),
+                  ldiv=(BIG, BIG), lstride=(hw, 0, 0), p_per_mask=T * hw, group_size=1)
+
+
 def rowmap_temporal_rowwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
     """(b t v) (h w) c -> (b v h) (t w) c   (crossview_temporal_dit.py:345-347)."""
     return RowMap(L0=T * w, n_problems=B * V * h,

@@ -109,3 +109,43 @@ def test_cross_attention(dev, I, Lq, Lk, heads):
     e = rel_err(out, ref)
     _log("cross_attention", I=I, Lq=Lq, Lk=Lk, heads=heads, rel=e)
     assert e < TOL_KERNEL
+
+
+def _small_unet_cfg(**over):
+    from oracle import unet_oracle as U
+    cfg = U.make_unet_config(block_out_channels=(128, 256, 512, 512), num_attention_heads=(2, 4, 8, 8), cross_attention_dim=128,
+                             projection_class_embeddings_input_dim=11 * 256)
+    cfg.update(over)
+    return cfg
+
+
+@pytest.mark.parametrize("rowwise", [True, False])
+def test_unet_forward_vs_oracle(dev, rowwise):
+    """whole SD 2.1 UNet graph (4 levels, cross-attn down / up blocks, mid block, temporal resnets, row-wise or point-wise
+    cross-view / temporal transformer blocks, skip concatenations) at small width against the fp32 oracle"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = _small_unet_cfg(enable_rowwise_crossview=rowwise, enable_rowwise_temporal=rowwise)
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 3, 3, 16, 24, text_len=10)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    if not rowwise:
+        inp["crossview_attention_mask"] = None          # the reference's un-expanded mask only fits T == 1 there
+    ref = U.unet_forward(sd, cfg, **inp)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)
+    assert isinstance(out, tuple) and out[0][0].shape == ref.shape and out[0][0].dtype == bf16
+    e = rel_err(out[0][0], ref)
+    _log("unet_forward", rowwise=rowwise, rel=e)
+    assert e < TOL_MODEL
+    # flags: disable_temporal switches both the resnet and the transformer time mixers to alpha = 1
+    inp2 = dict(inp, disable_temporal=torch.tensor([True, False]), disable_crossview=torch.tensor([False, True]))
+    ref2 = U.unet_forward(sd, cfg, **inp2)
+    di = to_dev(inp2, dev)
+    out2 = m(di.pop("sample"), di.pop("timesteps"), **di)
+    e2 = rel_err(out2[0][0], ref2)
+    _log("unet_forward_flags", rowwise=rowwise, rel=e2)
+    assert e2 < TOL_MODEL and rel_err(ref2, ref) > 1e-2
