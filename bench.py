@@ -177,6 +177,104 @@ def cpu_baseline(threads: int):
                        f"the {full_flops / 1e12:.1f} TFLOP of one full step")
 
 
+UNET_KWARGS = dict(   # examples/ctsd_21_6views_video_generation.json (reference repo)
+    addition_time_embed_dim=256, block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=1024,
+    down_block_types=("CrossAttnDownBlockCrossviewTemporal",) * 3 + ("DownBlockCrossviewTemporal",), in_channels=4,
+    layers_per_block=2, num_attention_heads=(5, 10, 20, 20), out_channels=4, projection_class_embeddings_input_dim=2816,
+    sample_size=96, transformer_layers_per_block=1,
+    up_block_types=("UpBlockCrossviewTemporal",) + ("CrossAttnUpBlockCrossviewTemporal",) * 3, enable_crossview=True,
+    enable_rowwise_crossview=True, enable_temporal=True, enable_rowwise_temporal=True, merge_factor=2)
+UNET_WORKLOAD = dict(B=1, T=6, V=6, C=4, H=32, W=56, text_len=77, guidance_scale=3.0, inference_steps=50)
+
+
+def main_unet(args):
+    """SD 2.1 UNet denoise step (BASELINE configs[1]): UNet forward at the CFG batch + guidance + DPM-Solver++ update."""
+    from opendwm_amd import dist as D
+    rank, local_rank, world = D.env_ranks()
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init("nccl", dev)
+    from opendwm_amd import _lib
+    from opendwm_amd.pipeline import UNetDenoiser
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel, unet_flops
+    _lib.load()
+    timer = KernelTimer().install()
+    import opendwm_amd.unet as unet_mod
+    import opendwm_amd.ops as ops_mod
+    unet_mod.ops = ops_mod
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = UNetCrossviewTemporalConditionModel(**UNET_KWARGS)
+    finally:
+        torch.set_default_dtype(old)
+    model = model.to(device=dev, dtype=torch.bfloat16).eval()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("mix_factor"):
+                p.fill_(2.0)
+            elif p.dim() == 1:
+                p.normal_(0.0, 0.05, generator=g)
+                if name.endswith(".weight"):
+                    p.add_(1.0)
+            else:
+                std = p[0].numel() ** -0.5
+                if ".conv2." in name or name.endswith("proj_out.weight") or ".net.2." in name or ".to_out.0." in name:
+                    std *= 0.5
+                p.normal_(0.0, std, generator=g)
+    w = UNET_WORKLOAD
+    gi = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    B2, T, V = 2 * w["B"], w["T"], w["V"]
+    ring = torch.zeros(V, V, dtype=torch.bool)
+    for i in range(V):
+        for d in (-1, 0, 1):
+            ring[i, (i + d) % V] = True
+    cond = dict(
+        encoder_hidden_states=(torch.randn(B2, T, V, w["text_len"], 1024, device=dev, generator=gi) * 0.5).to(torch.bfloat16),
+        disable_crossview=torch.zeros(B2, dtype=torch.bool, device=dev), disable_temporal=torch.zeros(B2, dtype=torch.bool, device=dev),
+        crossview_attention_mask=ring[None].repeat(B2, 1, 1).to(dev),
+        added_time_ids=torch.rand(B2, T, V, 11, device=dev, generator=gi) * 2 - 1)
+    latents = torch.randn(w["B"], T, V, w["C"], w["H"], w["W"], device=dev, generator=gi)
+    den = UNetDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"]).prepare(latents, cond)
+    ninf = w["inference_steps"]
+
+    def step(i):
+        timer.enabled = i >= args.warmup
+        den.step(i % (ninf - 1))
+
+    dt = D.timed_steps(step, args.steps, args.warmup, dev)
+    timer.enabled = False
+    finite = bool(torch.isfinite(den.latents).all().item())
+    if rank == 0:
+        fl = unet_flops(UNET_KWARGS, B2, T, V, w["H"], w["W"], w["text_len"])
+        ks = timer.summary()
+        step_ms = 1e3 * dt / args.steps
+        gm, at = ks.get("gemm", {}), ks.get("attn", {})
+        print(json.dumps({
+            "metric": "denoise-steps/sec (6-view x6f 448x256), SD-2.1 CTSD UNet", "value": world * args.steps / dt,
+            "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
+            "config": {"workload": "BASELINE configs[1]: CTSD SD-2.1 cross-view temporal UNet (row-wise cross-view + temporal blocks), "
+                                   "6 views x 6 frames x 448x256 px (latents [1,6,6,4,32,56]), CFG g=3 -> model batch 2, 77 text tokens, "
+                                   "DPM-Solver++(2M); one replica per GPU",
+                       "flop_per_step": fl, "finite": finite, "parameters": sum(p.numel() for p in model.parameters())},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (linear + implicit-GEMM conv, all epilogues)",
+                         "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": None, "launches": gm.get("launches"),
+                         "avg_launch_us": gm.get("avg_us"), "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel (self / row-wise)", "achieved": at.get("tflops"),
+                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
+                                   "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
+                                   "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms},
+            "whole_step_mfma_frac": fl / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+        }))
+    D.shutdown()
+
+
 def main_train(args):
     """Training step (ctsd.py:1195-1437, SD 3 branch) on synthetic latents / conditions: fp32 master weights, bf16
     compute, checkpointed blocks, HIP backward kernels, HIP AdamW; with N > 1 ranks torch DDP all-reduces the
@@ -253,11 +351,16 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead of the headline metric: one SD-3.5 training step per 'step' "
                          "(forward + backward + AdamW on one 6-view x 16-frame sample per GPU, DDP gradient all-reduce over RCCL)")
+    ap.add_argument("--unet", action="store_true",
+                    help="BASELINE config 2 instead of the headline metric: SD-2.1 cross-view temporal UNet, 6 views x 6 frames "
+                         "(examples/ctsd_21_6views_video_generation.json: DPM-Solver++ 50 steps, guidance 3)")
     ap.add_argument("--freeze-base", action="store_true",
                     help="with --train: freezing_pattern ^(transformer_blocks|time_text_embed)$ of the reference's warm-up configs")
     args = ap.parse_args()
     if args.train:
         return main_train(args)
+    if args.unet:
+        return main_unet(args)
 
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()

@@ -287,6 +287,14 @@ int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, const dwm_ro
 /* y[r, :L] = softmax(scale * x[r, :L]) (fp32 math, bf16 storage; single-head mid-block attention). */
 int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream);
 
+/* classifier-free guidance + one step of a linear multistep scheduler on fp32 latents (SD 2.1 configs:
+ * diffusers DPMSolverMultistepScheduler, dpmsolver++ / midpoint, called at ctsd.py:1548-1575):
+ *   out = u + g (c - u);  x0 = kx * x + ko * out  (epsilon: kx = 1/alpha_t, ko = -sigma_t/alpha_t; v: kx = alpha_t, ko = -sigma_t)
+ *   x <- A * x + B * x0 + C * x0_prev;  x0_prev <- x0;  model_in (optional, bf16 [2, n]) <- x
+ * The scalar coefficients are the scheduler's per-step constants, computed on the host. */
+int dwm_cfg_multistep(const void* pred, float* latents, float* x0_prev, void* model_in, int64_t n, float guidance,
+                      float kx, float ko, float A, float B, float C, void* stream);
+
 /* dst bf16 <- src fp32 (n % 4 == 0) */
 int dwm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 

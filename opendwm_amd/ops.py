@@ -507,6 +507,20 @@ def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, d
                                               float(guidance), float(dsigma), _stream()), "dwm_cfg_euler_step")
 
 
+def cfg_multistep(pred: torch.Tensor, latents: torch.Tensor, x0_prev: torch.Tensor, guidance: float, kx: float, ko: float,
+                  A: float, B: float, Cc: float, model_in: Optional[torch.Tensor] = None) -> None:
+    """CFG combine + linear multistep scheduler update (see dwm_cfg_multistep); latents / x0_prev fp32 in place."""
+    n = latents.numel()
+    if pred.dtype != bf16 or pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda:
+        raise RuntimeError("cfg_multistep: pred must be contiguous bf16 with 2x the latent elements")
+    for t in (latents, x0_prev):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise RuntimeError("cfg_multistep: latents / x0_prev must be contiguous fp32 of the same size")
+    _lib.check(_lib.load().dwm_cfg_multistep(pred.data_ptr(), latents.data_ptr(), x0_prev.data_ptr(), _p(model_in), n,
+                                             float(guidance), float(kx), float(ko), float(A), float(B), float(Cc), _stream()),
+               "dwm_cfg_multistep")
+
+
 def unshuffle_tokens(x: torch.Tensor, r: int, ldo: Optional[int] = None) -> torch.Tensor:
     """PixelUnshuffle(r): [I, C, H, W] (fp32 / bf16) -> token-major bf16 [I*(H/r)*(W/r), ldo]."""
     if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, bf16):

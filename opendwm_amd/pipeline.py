@@ -220,3 +220,81 @@ class CTSDTrainer:
         self.optimizer.step()
         self.optimizer.zero_grad()
         return loss.detach()
+
+
+# ------------------------------------------------------------------------------------------ SD 2.1 (UNet) denoise loop
+def dpm_solver_tables(num_inference_steps: int, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                      beta_end: float = 0.012):
+    """(timesteps [n], sigmas [n+1]) of diffusers DPMSolverMultistepScheduler.set_timesteps with the SD 2.1 scheduler
+    config (scaled_linear betas, 'linspace' spacing, final sigma 0)."""
+    import numpy as np
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, 0).numpy().astype(np.float64)
+    ts = np.linspace(0, num_train_timesteps - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+    sig = np.interp(ts, np.arange(num_train_timesteps), ((1 - acp) / acp) ** 0.5)
+    return torch.from_numpy(ts), torch.from_numpy(np.concatenate([sig, [0.0]]))
+
+
+def dpm_solver_coefficients(sigmas: torch.Tensor, i: int, prediction_type: str):
+    """(kx, ko, A, B, C) of step i for dwm_cfg_multistep: dpmsolver++ with solver_order 2, midpoint, first order on the
+    first step, x' = x0 on the last (final sigma 0)."""
+    import math
+    n = sigmas.numel() - 1
+
+    def a_s(s):
+        a = 1.0 / math.sqrt(s * s + 1.0)
+        return a, s * a
+    a0, s0 = a_s(float(sigmas[i]))
+    kx, ko = (1.0 / a0, -s0 / a0) if prediction_type == "epsilon" else (a0, -s0)
+    if i == n - 1:
+        return kx, ko, 0.0, 1.0, 0.0
+    at, st = a_s(float(sigmas[i + 1]))
+    lam = lambda a, s: math.log(a) - math.log(s)
+    h = lam(at, st) - lam(a0, s0)
+    e = math.exp(-h) - 1.0
+    A = st / s0
+    if i == 0:
+        return kx, ko, A, -at * e, 0.0
+    a1, s1 = a_s(float(sigmas[i - 1]))
+    r0 = (lam(a0, s0) - lam(a1, s1)) / h
+    return kx, ko, A, -at * e * (1.0 + 0.5 / r0), 0.5 * at * e / r0
+
+
+class UNetDenoiser:
+    """Hot loop of inference_pipeline (ctsd.py:1496-1575) for the SD 2.1 configs
+    (examples/ctsd_21_6views_*_generation.json: DPMSolverMultistepScheduler, guidance 3, 50 steps): UNet forward at the
+    CFG batch + guidance combine + DPM-Solver++(2M) update in one kernel.  latents fp32 [B,T,V,4,H,W]; conditions =
+    CFG-doubled model kwargs (unconditional half first)."""
+
+    def __init__(self, model, guidance_scale: float = 3.0, inference_steps: int = 50, prediction_type: str = "v_prediction"):
+        self.model, self.guidance_scale, self.inference_steps = model, guidance_scale, inference_steps
+        self.prediction_type = prediction_type
+        self.timesteps, self.sigmas = dpm_solver_tables(inference_steps)
+
+    def prepare(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor]):
+        dev = latents.device
+        self.latents = latents.to(torch.float32).contiguous().clone()        # init_noise_sigma = 1
+        self.x0_prev = torch.zeros_like(self.latents)
+        B = latents.shape[0]
+        self.model_in = torch.empty((2 * B, *latents.shape[1:]), dtype=bf16, device=dev)
+        lat16 = ops.cast_bf16(self.latents)
+        self.model_in[:B].copy_(lat16)
+        self.model_in[B:].copy_(lat16)
+        self.conditions = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
+                           for k, v in conditions.items()}
+        self._ts = self.timesteps.to(dev).float()
+        return self
+
+    def step(self, i: int):
+        B, T, V = self.latents.shape[:3]
+        ts = self._ts[i].expand(2 * B, T, V)
+        out = self.model(self.model_in, ts, **self.conditions)
+        pred = out["noise_pred"] if isinstance(out, dict) else out[0][0]
+        kx, ko, A, Bc, Cc = dpm_solver_coefficients(self.sigmas, i, self.prediction_type)
+        ops.cfg_multistep(pred, self.latents, self.x0_prev, self.guidance_scale, kx, ko, A, Bc, Cc, model_in=self.model_in)
+
+    def run(self, latents, conditions, stop: Optional[int] = None):
+        self.prepare(latents, conditions)
+        for i in range(self.inference_steps if stop is None else stop):
+            self.step(i)
+        return self.latents

@@ -502,3 +502,94 @@ class UNetCrossviewTemporalConditionModel(_Base):
         # the reference returns (result, maskgit_up, maskgit_down) whenever those lists are non-empty (:831-833); the
         # intermediate activations are not re-materialised in NCHW here
         return (out,), None, None
+
+
+# ------------------------------------------------------------------------------------------ FLOP model (bench)
+def _block_plan(cfg: dict):
+    """channel bookkeeping of UNetCrossviewTemporalConditionModel.__init__ (crossview_temporal_unet.py:438-560)"""
+    boc = list(cfg["block_out_channels"])
+    n = len(boc)
+    heads = cfg["num_attention_heads"]
+    heads = [heads] * n if isinstance(heads, int) else list(heads)
+    lpb = cfg["layers_per_block"]
+    lpb = [lpb] * n if isinstance(lpb, int) else list(lpb)
+    tl = cfg["transformer_layers_per_block"]
+    tl = [tl] * n if isinstance(tl, int) else list(tl)
+    down = []
+    out_c = boc[0]
+    for i, typ in enumerate(cfg["down_block_types"]):
+        in_c, out_c = out_c, boc[i]
+        down.append(dict(attn=typ.startswith("CrossAttn"), resnets=[(in_c if j == 0 else out_c, out_c) for j in range(lpb[i])],
+                         heads=heads[i], tlayers=tl[i], downsample=i != n - 1, channels=out_c))
+    up = []
+    rboc, rheads, rlpb, rtl = boc[::-1], heads[::-1], lpb[::-1], tl[::-1]
+    out_c = rboc[0]
+    for i, typ in enumerate(cfg["up_block_types"]):
+        prev, out_c = out_c, rboc[i]
+        in_c = rboc[min(i + 1, n - 1)]
+        nl = rlpb[i] + 1
+        res = []
+        for j in range(nl):
+            skip = in_c if j == nl - 1 else out_c
+            rin = prev if j == 0 else out_c
+            res.append((rin + skip, out_c))
+        up.append(dict(attn=typ.startswith("CrossAttn"), resnets=res, heads=rheads[i], tlayers=rtl[i], upsample=i != n - 1,
+                       channels=out_c))
+    return down, dict(channels=boc[-1], heads=heads[-1], tlayers=tl[-1]), up
+
+
+
+def unet_flops(cfg: dict, B: int, T: int, V: int, H: int, W: int, text_len: int = 77) -> float:
+    """2*MAC of every conv / linear + 4*L^2*64 per attention problem-head of one forward"""
+    down, mid, up = _block_plan(cfg)
+    I = B * T * V
+    E = 4 * cfg["block_out_channels"][0]
+    cd = cfg["cross_attention_dim"]
+    total = 0.0
+
+    def resblock(ci, co, h, w):
+        px = I * h * w
+        f = 2.0 * px * co * (9 * ci) + 2.0 * px * co * (9 * co) + (2.0 * px * co * ci if ci != co else 0) + 2.0 * I * E * co
+        if cfg["enable_temporal"]:
+            f += 2 * (2.0 * px * co * 3 * co) + 2.0 * I * E * co
+        return f
+
+    def tbt(c, px, L, nprob):
+        return 2.0 * px * c * (8 * c + 4 * c) * 2 + 2.0 * px * c * 4 * c + 4.0 * nprob * (c // 64) * L * L * 64
+
+    def tmodel(c, nl, h, w):
+        px, N = I * h * w, h * w
+        f = 2 * 2.0 * px * c * c
+        for _ in range(nl):
+            f += 2.0 * px * c * 4 * c + 4.0 * I * (c // 64) * N * N * 64                      # self attention
+            f += 2.0 * px * c * 2 * c + 2 * 2.0 * I * text_len * cd * c + 4.0 * I * (c // 64) * N * text_len * 64
+            f += 2.0 * px * c * 12 * c
+            if cfg["enable_crossview"]:
+                L = V * w if cfg["enable_rowwise_crossview"] else V
+                f += tbt(c, px, L, px // L)
+            if cfg["enable_temporal"]:
+                L = T * w if cfg["enable_rowwise_temporal"] else T
+                f += tbt(c, px, L, px // L)
+        return f
+
+    h, w = H, W
+    total += 2.0 * I * h * w * cfg["block_out_channels"][0] * 9 * cfg["in_channels"]
+    for blk in down:
+        for (ci, co) in blk["resnets"]:
+            total += resblock(ci, co, h, w)
+            if blk["attn"]:
+                total += tmodel(co, blk["tlayers"], h, w)
+        if blk["downsample"]:
+            h, w = h // 2, w // 2
+            total += 2.0 * I * h * w * blk["channels"] * 9 * blk["channels"]
+    total += 2 * resblock(mid["channels"], mid["channels"], h, w) + tmodel(mid["channels"], mid["tlayers"], h, w)
+    for blk in up:
+        for (ci, co) in blk["resnets"]:
+            total += resblock(ci, co, h, w)
+            if blk["attn"]:
+                total += tmodel(co, blk["tlayers"], h, w)
+        if blk["upsample"]:
+            h, w = 2 * h, 2 * w
+            total += 2.0 * I * h * w * blk["channels"] * 9 * blk["channels"]
+    total += 2.0 * I * h * w * cfg["out_channels"] * 9 * cfg["block_out_channels"][0]
+    return total

@@ -17,6 +17,7 @@ HIP model (opendwm_amd/unet.py) and the reference class.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Optional
 
 import torch
@@ -424,3 +425,63 @@ def unet_flops(cfg: dict, B: int, T: int, V: int, H: int, W: int, text_len: int 
             total += 2.0 * I * h * w * blk["channels"] * 9 * blk["channels"]
     total += 2.0 * I * h * w * cfg["out_channels"] * 9 * cfg["block_out_channels"][0]
     return total
+
+
+# ------------------------------------------------------------------------------------------ scheduler / denoise loop
+def dpm_solver_tables(num_inference_steps: int, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                      beta_end: float = 0.012):
+    """diffusers DPMSolverMultistepScheduler.set_timesteps (0.31.0 defaults of the SD 2.1 scheduler config:
+    scaled_linear betas, timestep_spacing 'linspace', final_sigmas_type 'zero'): returns (timesteps [n], sigmas [n+1])."""
+    import numpy as np
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, 0).numpy().astype(np.float64)
+    ts = np.linspace(0, num_train_timesteps - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+    sig = ((1 - acp) / acp) ** 0.5
+    sig = np.interp(ts, np.arange(num_train_timesteps), sig)
+    sig = np.concatenate([sig, [0.0]])
+    return torch.from_numpy(ts), torch.from_numpy(sig)
+
+
+def dpm_solver_coefficients(sigmas: Tensor, i: int, prediction_type: str):
+    """per-step scalars of dpmsolver++ (solver_order 2, midpoint, lower_order_final): x0 = kx*x + ko*out;
+    x' = A*x + B*x0 + C*x0_prev (DPMSolverMultistepScheduler.convert_model_output / dpm_solver_first_order_update /
+    multistep_dpm_solver_second_order_update)."""
+    n = sigmas.numel() - 1
+    def a_s(s):
+        a = 1.0 / math.sqrt(s * s + 1.0)
+        return a, s * a
+    alpha_s0, sigma_s0 = a_s(float(sigmas[i]))
+    kx, ko = (1.0 / alpha_s0, -sigma_s0 / alpha_s0) if prediction_type == "epsilon" else (alpha_s0, -sigma_s0)
+    alpha_t, sigma_t = a_s(float(sigmas[i + 1]))
+    lam = lambda a, s: math.log(a) - math.log(s)
+    if i == n - 1:                                   # final_sigmas_type "zero": x' = x0
+        return kx, ko, 0.0, 1.0, 0.0
+    h = lam(alpha_t, sigma_t) - lam(alpha_s0, sigma_s0)
+    e = math.exp(-h) - 1.0
+    A = sigma_t / sigma_s0
+    if i == 0:                                       # first step: first order
+        return kx, ko, A, -alpha_t * e, 0.0
+    alpha_s1, sigma_s1 = a_s(float(sigmas[i - 1]))
+    r0 = (lam(alpha_s0, sigma_s0) - lam(alpha_s1, sigma_s1)) / h
+    # D0 = m0, D1 = (m0 - m1) / r0:  x' = A x - alpha_t e m0 - 0.5 alpha_t e (m0 - m1) / r0
+    return kx, ko, A, -alpha_t * e * (1.0 + 0.5 / r0), 0.5 * alpha_t * e / r0
+
+
+def unet_denoise(sd: SD, cfg: dict, latents: Tensor, conditions: dict, steps: int, guidance_scale: float,
+                 prediction_type: str = "v_prediction", stop: Optional[int] = None) -> Tensor:
+    """inference_pipeline hot loop (ctsd.py:1496-1575) for the SD 2.1 configs: CFG + DPMSolverMultistepScheduler.
+    conditions: the CFG-doubled tensors ([2B, ...], unconditional first); latents fp32 [B,T,V,C,H,W]."""
+    ts, sig = dpm_solver_tables(steps)
+    x = latents.float().clone() * 1.0            # init_noise_sigma = 1 for DPM-Solver
+    prev = torch.zeros_like(x)
+    B, T, V = x.shape[:3]
+    for i in range(steps if stop is None else stop):
+        t = ts[i].float().expand(2 * B, T, V)
+        out = unet_forward(sd, cfg, torch.cat([x, x]), t, **conditions)
+        u, c = out.chunk(2)
+        o = u + guidance_scale * (c - u)
+        kx, ko, A, Bc, Cc = dpm_solver_coefficients(sig, i, prediction_type)
+        x0 = kx * x + ko * o
+        x = A * x + Bc * x0 + Cc * prev
+        prev = x0
+    return x

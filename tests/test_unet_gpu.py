@@ -149,3 +149,31 @@ def test_unet_forward_vs_oracle(dev, rowwise):
     e2 = rel_err(out2[0][0], ref2)
     _log("unet_forward_flags", rowwise=rowwise, rel=e2)
     assert e2 < TOL_MODEL and rel_err(ref2, ref) > 1e-2
+
+
+def test_unet_denoise_loop_vs_oracle(dev):
+    """CFG + DPM-Solver++(2M) loop (first-order first step, second-order steps, x0 on the last) against the oracle"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.pipeline import UNetDenoiser, dpm_solver_coefficients, dpm_solver_tables
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    ts, sg = dpm_solver_tables(10)
+    ts_o, sg_o = U.dpm_solver_tables(10)
+    assert torch.equal(ts, ts_o) and torch.equal(sg, sg_o)
+    for i in (0, 3, 9):
+        for pt in ("epsilon", "v_prediction"):
+            assert dpm_solver_coefficients(sg, i, pt) == pytest.approx(U.dpm_solver_coefficients(sg_o, i, pt))
+    cfg = _small_unet_cfg()
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 16, 24, text_len=10)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    lat = inp.pop("sample")[:1]
+    inp.pop("timesteps")
+    steps = 4
+    ref = U.unet_denoise(sd, cfg, lat, inp, steps, 3.0)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).to(bf16).eval()
+    out = UNetDenoiser(m, 3.0, steps).run(lat.to(dev), to_dev(inp, dev))
+    e = rel_err(out, ref)
+    _log("unet_denoise_loop", steps=steps, rel=e)
+    assert e < 3e-2
