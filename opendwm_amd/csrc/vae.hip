@@ -196,7 +196,9 @@ extern "C" int dwm_groupnorm_silu_mapped(const void* x, void* y, int64_t I, int6
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * G * I, s);
     if (e != hipSuccess) return (int)e;
-    const int64_t ppb = 2048;
+    // pixels per statistics block: enough blocks to fill the chip even for a dozen images (temporal GroupNorm: I = B*V)
+    int64_t ppb = (I * P + 2047) / 2048;
+    ppb = ppb < 64 ? 64 : ppb > 2048 ? 2048 : ppb;
     const dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)I);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), sizeof(float) * 2 * G, s, (const bf16_t*)x, P, C, G, ppb, stats, im);
     PadMap pm;
