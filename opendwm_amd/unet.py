@@ -382,10 +382,10 @@ class UNetCrossviewTemporalConditionModel(_Base):
     def try_to_convert_state_dict(state_dict: dict):
         """SD 2.1 -> this tree key renaming (crossview_temporal_unet.py:358-373)"""
         import re
-        pat = re.compile(r"resnets.(\\d+).conv")
+        pat = re.compile(r"resnets.(\d+).conv")
         if any(pat.search(k) for k in state_dict):
-            p2 = re.compile(r"resnets.(\\d+)")
-            return {(p2.sub(r"resnets.\\1.spatial_res_block", k) if "resnets" in k else k): v for k, v in state_dict.items()}
+            p2 = re.compile(r"resnets.(\d+)")
+            return {(p2.sub(r"resnets.\1.spatial_res_block", k) if "resnets" in k else k): v for k, v in state_dict.items()}
         return state_dict
 
     def _apply(self, fn, *a, **kw):

@@ -19,6 +19,12 @@ from oracle import ctsd_oracle as O            # noqa: E402
 from tests.common import small_config, small_inputs, GOLDEN   # noqa: E402
 
 
+def unet_small_config():
+    from oracle import unet_oracle as U
+    return U.make_unet_config(block_out_channels=(128, 256, 512, 512), num_attention_heads=(2, 4, 8, 8), cross_attention_dim=128,
+                              projection_class_embeddings_input_dim=11 * 256)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -42,6 +48,15 @@ def main():
         c2 = small_config(temporal_attention_type=tt)
         y2 = O.dit_forward(sd, c2, **inp)
         torch.save({"output": y2.float()}, os.path.join(GOLDEN, f"dit_small_forward_{tt}.pt"))
+    # SD 2.1 UNet (oracle/unet_oracle.py): one forward + two DPM-Solver++ CFG steps at small width
+    from oracle import unet_oracle as U
+    ucfg = unet_small_config()
+    usd = U.make_unet_state_dict(ucfg, 0)
+    uinp = U.make_unet_inputs(ucfg, 2, 2, 3, 8, 16, text_len=10)
+    uy = U.unet_forward(usd, ucfg, **uinp)
+    ucond = {k: v for k, v in uinp.items() if k not in ("sample", "timesteps")}
+    uout = U.unet_denoise(usd, ucfg, uinp["sample"][:1], ucond, steps=4, guidance_scale=3.0, stop=2)
+    torch.save({"output": uy.float(), "denoise_2steps": uout.float()}, os.path.join(GOLDEN, "unet_small.pt"))
     print("written to", GOLDEN)
 
 

@@ -392,3 +392,87 @@ def test_train_pair_construction_matches_oracle():
     noisy, ts, sg, _ = tr.make_training_pair(lat, timestep_indices=idx, noise=noise)
     assert ts.shape == (2, 3, 2) and torch.allclose(ts[:, 0, 0], sig[idx] * 1000)
     assert torch.allclose(noisy, sig[idx].view(2, 1, 1, 1, 1, 1) * noise + (1 - sig[idx].view(2, 1, 1, 1, 1, 1)) * lat)
+
+
+# ------------------------------------------------------------------ SD 2.1 UNet (row a10)
+def _unet_small():
+    from tests.golden.make_golden import unet_small_config
+    return unet_small_config()
+
+
+def test_unet_oracle_matches_golden():
+    from oracle import unet_oracle as U
+    cfg = _unet_small()
+    sd = U.make_unet_state_dict(cfg, 0)
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
+    gold = torch.load(os.path.join(GOLDEN, "unet_small.pt"))
+    y = U.unet_forward(sd, cfg, **inp)
+    assert y.shape == (2, 2, 3, 4, 8, 16) and rel_err(y, gold["output"]) < 1e-5
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timesteps")}
+    out = U.unet_denoise(sd, cfg, inp["sample"][:1], cond, steps=4, guidance_scale=3.0, stop=2)
+    assert rel_err(out, gold["denoise_2steps"]) < 1e-5
+
+
+def test_unet_oracle_pieces_equal_torch_modules():
+    """the restated diffusers blocks against torch.nn modules wired the documented way (same weights)"""
+    from oracle import unet_oracle as U
+    g = torch.Generator().manual_seed(0)
+    C, Co, E = 64, 128, 96
+    x, temb = torch.randn(3, C, 6, 8, generator=g), torch.randn(3, E, generator=g)
+    n1, c1, tp = torch.nn.GroupNorm(32, C, eps=1e-5), torch.nn.Conv2d(C, Co, 3, padding=1), torch.nn.Linear(E, Co)
+    n2, c2, cs = torch.nn.GroupNorm(32, Co, eps=1e-5), torch.nn.Conv2d(Co, Co, 3, padding=1), torch.nn.Conv2d(C, Co, 1)
+    sd = {}
+    for name, m in (("norm1", n1), ("conv1", c1), ("time_emb_proj", tp), ("norm2", n2), ("conv2", c2), ("conv_shortcut", cs)):
+        for k, v in m.state_dict().items():
+            sd[f"r.{name}.{k}"] = v
+    silu = torch.nn.functional.silu
+    h = c1(silu(n1(x))) + tp(silu(temb))[:, :, None, None]
+    ref = cs(x) + c2(silu(n2(h)))
+    assert rel_err(U.resnet_block_2d(sd, "r", x, temb, 1e-5), ref) < 1e-6
+    # temporal resnet: Conv3d (3,1,1) over T, temb [N, T, E]
+    x5, t5 = torch.randn(2, Co, 5, 4, 6, generator=g), torch.randn(2, 5, E, generator=g)
+    m1, k1, tq = torch.nn.GroupNorm(32, Co, eps=1e-5), torch.nn.Conv3d(Co, Co, (3, 1, 1), padding=(1, 0, 0)), torch.nn.Linear(E, Co)
+    m2, k2 = torch.nn.GroupNorm(32, Co, eps=1e-5), torch.nn.Conv3d(Co, Co, (3, 1, 1), padding=(1, 0, 0))
+    sd = {}
+    for name, m in (("norm1", m1), ("conv1", k1), ("time_emb_proj", tq), ("norm2", m2), ("conv2", k2)):
+        for k, v in m.state_dict().items():
+            sd[f"t.{name}.{k}"] = v
+    h = k1(silu(m1(x5))) + tq(silu(t5)).permute(0, 2, 1)[:, :, :, None, None]
+    assert rel_err(U.temporal_resnet_block(sd, "t", x5, t5, 1e-5), x5 + k2(silu(m2(h)))) < 1e-6
+
+
+def test_unet_model_state_dict_keys_equal_oracle_tree():
+    """the HIP model's module tree carries exactly the reference key names / shapes the oracle uses; SD 2.1 checkpoints are
+    renamed the reference's way (crossview_temporal_unet.py:358-373)"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = _unet_small()
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    shapes = U.unet_param_shapes(cfg)
+    sd = m.state_dict()
+    assert set(sd) == set(shapes)
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    conv = UNetCrossviewTemporalConditionModel.try_to_convert_state_dict(
+        {"down_blocks.0.resnets.1.conv1.weight": 1, "down_blocks.0.attentions.0.norm.weight": 2})
+    assert set(conv) == {"down_blocks.0.resnets.1.spatial_res_block.conv1.weight", "down_blocks.0.attentions.0.norm.weight"}
+    full = U.make_unet_config()
+    n = sum(torch.Size(s).numel() for s in U.unet_param_shapes(full).values())
+    assert 1.9e9 < n < 1.95e9
+
+
+def test_dpm_solver_tables_and_last_step():
+    from oracle import unet_oracle as U
+    ts, sig = U.dpm_solver_tables(50)
+    assert ts[0] == 999 and ts[-1] == 20 and sig[-1] == 0 and torch.all(sig[1:] < sig[:-1])
+    kx, ko, A, B, Cc = U.dpm_solver_coefficients(sig, 49, "v_prediction")
+    assert (A, B, Cc) == (0.0, 1.0, 0.0)
+    # a constant x0 prediction is a fixed point of the data-prediction solver: x' - x0 = A (x - x0) for every order
+    for i in (0, 5, 30):
+        kx, ko, A, B, Cc = U.dpm_solver_coefficients(sig, i, "epsilon")
+        a_t = 1.0 / (float(sig[i + 1]) ** 2 + 1) ** 0.5
+        a_s = 1.0 / (float(sig[i]) ** 2 + 1) ** 0.5
+        # exactness for x = alpha x0 + sigma eps with the true (constant) x0: the update lands on the same form at t
+        x0, eps = 0.7, -0.3
+        x = a_s * x0 + float(sig[i]) * a_s * eps
+        xn = A * x + (B + Cc) * x0
+        assert abs(xn - (a_t * x0 + float(sig[i + 1]) * a_t * eps)) < 1e-9
