@@ -177,3 +177,23 @@ def test_unet_denoise_loop_vs_oracle(dev):
     e = rel_err(out, ref)
     _log("unet_denoise_loop", steps=steps, rel=e)
     assert e < 3e-2
+
+
+def test_unet_matches_golden_fixture(dev):
+    """the committed oracle fixture (tests/golden/unet_small.pt) through the HIP path"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    from tests.common import GOLDEN
+    from tests.golden.make_golden import unet_small_config
+    cfg = unet_small_config()
+    sd = U.make_unet_state_dict(cfg, 0)
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
+    gold = torch.load(os.path.join(GOLDEN, "unet_small.pt"))
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    e = rel_err(out, gold["output"])
+    _log("unet_vs_golden", rel=e)
+    assert e < TOL_MODEL
