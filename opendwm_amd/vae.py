@@ -196,10 +196,10 @@ class AutoencoderKL(nn.Module):
                  use_quant_conv: bool = False, use_post_quant_conv: bool = False,
                  mid_block_add_attention: bool = True, **unused):
         super().__init__()
-        if use_post_quant_conv:
-            raise NotImplementedError("post_quant_conv (SD 2.1 VAE) is not built yet")
-        if use_quant_conv:
-            raise NotImplementedError("quant_conv (SD 2.1 VAE) is not built yet")
+        # SD 2.1 VAE (diffusers defaults use_quant_conv = use_post_quant_conv = True there): 1x1 convs on the moments /
+        # the latents, run as GEMMs on the 64-column padded token rows
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1) if use_quant_conv else None
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1) if use_post_quant_conv else None
         self.encoder = Encoder(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups,
                                mid_block_add_attention=mid_block_add_attention)
         self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups,
@@ -285,7 +285,16 @@ class AutoencoderKL(nn.Module):
         h = e.mid_block.resnets[1].run(h, grid, scratch)
         hp = ops.groupnorm_silu(h, I, grid.h * grid.w, _bf(e.conv_norm_out.weight), _bf(e.conv_norm_out.bias), e.groups,
                                 e.eps, out=scratch(grid, h.shape[1]), out_grid=grid)
-        m = ops.gemm(hp, _conv3_w(e.conv_out), _bf(e.conv_out.bias), a_grid=grid, conv3x3=True)      # [I*P, 2*latent]
+        if self.quant_conv is None:
+            m = ops.gemm(hp, _conv3_w(e.conv_out), _bf(e.conv_out.bias), a_grid=grid, conv3x3=True)      # [I*P, 2*latent]
+        else:
+            nm = self.quant_conv.weight.shape[0]
+            kp = 64 * ((nm + 63) // 64)
+            m64 = torch.zeros((I * grid.h * grid.w, kp), dtype=bf16, device=h.device)      # K of the 1x1 conv padded to 64
+            ops.gemm(hp, _conv3_w(e.conv_out), _bf(e.conv_out.bias), a_grid=grid, conv3x3=True, out=m64[:, :nm])
+            wq = torch.zeros((nm, kp), dtype=bf16, device=h.device)
+            wq[:, :nm] = _bf(self.quant_conv.weight).reshape(nm, nm)
+            m = ops.gemm(m64, wq, _bf(self.quant_conv.bias))
         return m.reshape(I, grid.h, grid.w, -1).permute(0, 3, 1, 2).contiguous()
 
     @torch.no_grad()
@@ -309,6 +318,13 @@ class AutoencoderKL(nn.Module):
         grid = PaddedGrid(I, h, w)
         scratch = self._pad_scratch
         tok = ops.unshuffle_tokens(z, 1, 64 * ((lc + 63) // 64))                  # [I*h*w, 64], zero padded channels
+        if self.post_quant_conv is not None:
+            kp = tok.shape[1]
+            wq = torch.zeros((kp, kp), dtype=bf16, device=z.device)               # output keeps the 64-column padding
+            wq[:lc, :lc] = _bf(self.post_quant_conv.weight).reshape(lc, lc)
+            bq = torch.zeros(kp, dtype=bf16, device=z.device)
+            bq[:lc] = _bf(self.post_quant_conv.bias)
+            tok = ops.gemm(tok, wq, bq)
         zp = ops.pad_tokens(tok, grid, out=scratch(grid, tok.shape[1]))
         x = ops.gemm(zp, _conv3_w(d.conv_in, tok.shape[1]), _bf(d.conv_in.bias), a_grid=grid, conv3x3=True)
         x = d.mid_block.resnets[0].run(x, grid, scratch)

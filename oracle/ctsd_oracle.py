@@ -477,6 +477,8 @@ def vae_decode(sd: SD, vcfg: dict, z: Tensor) -> Tensor:
     conv_in -> mid (resnet, attention, resnet) -> 4 up blocks (3 resnets [+ nearest-2x + conv]) ->
     GroupNorm -> SiLU -> conv_out."""
     g, eps = vcfg.get("norm_num_groups", 32), 1e-6
+    if "post_quant_conv.weight" in sd:         # SD 2.1 VAE: AutoencoderKL.decode applies post_quant_conv (1x1) first
+        z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
     x = F.conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
     x = _vae_resnet(sd, "decoder.mid_block.resnets.0", x, g, eps)
     if vcfg.get("mid_block_add_attention", True):
@@ -514,7 +516,10 @@ def vae_encode_moments(sd: SD, vcfg: dict, x: Tensor) -> Tensor:
         h = _vae_attention(sd, "encoder.mid_block.attentions.0", h, g, eps)
     h = _vae_resnet(sd, "encoder.mid_block.resnets.1", h, g, eps)
     h = F.silu(F.group_norm(h, g, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], eps))
-    return F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    m = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    if "quant_conv.weight" in sd:              # SD 2.1 VAE: 1x1 quant_conv on the moments
+        m = F.conv2d(m, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    return m
 
 
 def vae_decoder_shapes(vcfg: dict) -> Dict[str, tuple]:
@@ -572,6 +577,10 @@ def vae_decoder_shapes(vcfg: dict) -> Dict[str, tuple]:
             S[f"{a}.{nm}.bias"] = (ch[-1],)
     norm("encoder.conv_norm_out", ch[-1])
     conv("encoder.conv_out", ch[-1], 2 * lc, 3)
+    if vcfg.get("use_quant_conv", False):
+        conv("quant_conv", 2 * lc, 2 * lc, 1)
+    if vcfg.get("use_post_quant_conv", False):
+        conv("post_quant_conv", lc, lc, 1)
     return S
 
 

@@ -644,3 +644,25 @@ def test_full_width_block_stack_vs_oracle_on_device(dev):
     e = rel_err(out[0], ref)
     _log("full_width_6layers", rel=e)
     assert torch.isfinite(out[0].float()).all() and e < TOL_MODEL
+
+
+def test_vae_sd21_quant_convs(dev):
+    """SD 2.1 VAE: 4 latent channels, quant_conv on the moments, post_quant_conv before the decoder (diffusers AutoencoderKL
+    with use_quant_conv / use_post_quant_conv, scaling 0.18215)"""
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=4,
+                use_quant_conv=True, use_post_quant_conv=True, scaling_factor=0.18215, shift_factor=None)
+    sd = _bf16_round_sd(O.make_vae_state_dict(vcfg, 0))
+    vae = AutoencoderKL(**vcfg)
+    missing, unexpected = vae.load_state_dict(sd)
+    assert not missing and not unexpected
+    vae = vae.to(dev).to(bf16).eval()
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).to(bf16).float()
+    ref = O.vae_encode_moments(sd, vcfg, x)
+    dist = vae.encode(x.to(dev)).latent_dist
+    e1 = rel_err(dist.parameters, ref)
+    z = torch.randn(2, 4, 8, 8, generator=g).to(bf16).float()
+    e2 = rel_err(vae.decode(z.to(dev))[0], O.vae_decode(sd, vcfg, z))
+    _log("vae_sd21", encode=e1, decode=e2)
+    assert dist.parameters.shape == (2, 8, 8, 8) and e1 < TOL_MODEL and e2 < TOL_MODEL
