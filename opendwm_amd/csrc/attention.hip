@@ -50,14 +50,20 @@ attn_fwd_kernel(const AttnParams P) {
 
     // block -> (problem, head, query block); query block fastest so the blocks that
     // share one (problem, head)'s K/V are neighbours on one XCD.
-    uint32_t id = (uint32_t)xcd_remap(blockIdx.x, P.n_problems * P.heads * P.nqb);
+    uint32_t id = (uint32_t)xcd_remap(blockIdx.x, P.n_problems * (P.heads / P.hpb) * P.nqb);
     const uint32_t id1 = fdiv(id, P.fd_nqb);
     const int qb = (int)(id - id1 * P.fd_nqb.d);
+    // a workgroup handles `hpb` consecutive heads of its (problem, query block) back to back: the K/V tile
+    // stream simply continues into the next head (its first tiles are already in flight during the current
+    // head's last ones), the row table is built once, and the next head's Q rows are fetched a head ahead -
+    // the fixed cost per (problem, head, query block) is what limits short sequences
     const int prob = (int)fdiv(id1, P.fd_heads);
-    const int head = (int)(id1 - (uint32_t)prob * P.fd_heads.d);
+    const int hgrp = (int)(id1 - (uint32_t)prob * P.fd_heads.d);
+    const int hpb = P.hpb;
+    const int head0 = hgrp * hpb;
 
     const int L = P.L, L0 = P.L0;
-    const int64_t hoff = (int64_t)head * 64;
+    const int64_t hoff = (int64_t)head0 * 64;
 
     // ---- row table: token l -> row index in its segment's buffers (one div/mod chain per token
     //      per block instead of one per staged 16-B chunk)
@@ -71,6 +77,7 @@ attn_fwd_kernel(const AttnParams P) {
 
     // ---- this lane's queries
     bf16x8 qf[QT][4];
+    const bf16_t* qbase[QT];
     bf16_t* optr[QT];
     bool qok[QT];
     uint32_t gbits[QT];
@@ -81,6 +88,7 @@ attn_fwd_kernel(const AttnParams P) {
         qok[t] = lq < P.qend;
         const int lqc = qok[t] ? lq : P.qend - 1;
         const bf16_t* qptr = P.q0 + ((int64_t)rowtab[lqc] << 3) + (lqc < L0 ? 0 : P.seg1_delta) + hoff;      // q, k, v share the offset table
+        qbase[t] = qptr;
         if (lqc < L0) optr[t] = P.o0 + seg0_row(P.rm, seg0_base(P.rm, prob), lqc) * P.ldo0 + hoff;
         else optr[t] = P.o1 + ((int64_t)prob * P.L1 + (lqc - L0)) * P.ldo1 + hoff;
 #pragma unroll
@@ -109,7 +117,13 @@ attn_fwd_kernel(const AttnParams P) {
     const bf16_t* const vg1 = P.v0 + hoff + (((lane & 7) ^ (((srow1 >> 1) & 1) << 2)) << 3);
     const int sdst = wave * 2048;                     // wave-uniform byte offset of this wave's rows in a tile image
 
-#define DWM_DMA_TILE(kt_, stage_)                                                           \
+    int dma_h = 0, dma_kt = 0;            // (head, key tile) of the next tile to request
+#define DWM_DMA_NEXT(stage_)                                                                \
+    do {                                                                                    \
+        DWM_DMA_TILE(dma_kt, stage_, dma_h * 64);                                           \
+        if (++dma_kt == nkt) { dma_kt = 0; ++dma_h; }                                       \
+    } while (0)
+#define DWM_DMA_TILE(kt_, stage_, ho_)                                                      \
     do {                                                                                    \
         const int kb_ = P.kbeg + (kt_) * KT;                                                \
         const int ra_ = kb_ + srow0 < L ? kb_ + srow0 : L - 1;                              \
@@ -117,10 +131,10 @@ attn_fwd_kernel(const AttnParams P) {
         const int64_t oa_ = ((int64_t)rowtab[ra_] << 3) + (ra_ < L0 ? 0 : P.seg1_delta);    \
         const int64_t ob_ = ((int64_t)rowtab[rb_] << 3) + (rb_ < L0 ? 0 : P.seg1_delta);    \
         char* kl_ = smem + (stage_) * STAGE_BYTES + sdst;                                   \
-        glds16(kg0 + oa_, kl_);                                                             \
-        glds16(kg1 + ob_, kl_ + 1024);                                                      \
-        glds16(vg0 + oa_, kl_ + K_TILE_BYTES);                                              \
-        glds16(vg1 + ob_, kl_ + K_TILE_BYTES + 1024);                                       \
+        glds16(kg0 + oa_ + (ho_), kl_);                                                     \
+        glds16(kg1 + ob_ + (ho_), kl_ + 1024);                                              \
+        glds16(vg0 + oa_ + (ho_), kl_ + K_TILE_BYTES);                                      \
+        glds16(vg1 + ob_ + (ho_), kl_ + K_TILE_BYTES + 1024);                               \
     } while (0)
 
     // Softmax bookkeeping in the exponent domain: Q is pre-multiplied by scale*log2(e) and the S MFMAs
@@ -157,21 +171,26 @@ attn_fwd_kernel(const AttnParams P) {
 
     // prologue: tiles 0, 1, 2 requested (4 DMA instructions per wave and tile; the Q fragment loads
     // were issued before them, so "vmcnt(8)" also covers Q)
-    DWM_DMA_TILE(0, 0);
-    if (nkt > 1) DWM_DMA_TILE(1, 1);
-    if (NSTAGE > 2 && nkt > 2) DWM_DMA_TILE(2, NSTAGE > 2 ? 2 : 0);
-    if (NSTAGE > 2 && nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int NT = hpb * nkt;             // tiles of this workgroup's stream
+    DWM_DMA_NEXT(0);
+    if (NT > 1) DWM_DMA_NEXT(1);
+    if (NSTAGE > 2 && NT > 2) DWM_DMA_NEXT(2);
+    if (NSTAGE > 2 && NT > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // a wave whose queries all lie past the end of the sequence (last query block) only takes part
     // in the staging and the barriers
     const bool wave_active = qb * QB + wave * QT * 32 < P.qend;
-    int stage = 0;                        // ring slot of tile kt
-    for (int kt = 0; kt < nkt; ++kt) {
+    int stage = 0;                        // ring slot of the current tile
+    int hh = 0, kt = 0;                   // (head, key tile) of the current tile
+    for (int sidx = 0; sidx < NT; ++sidx) {
         const char* kl = smem + stage * STAGE_BYTES;
         const char* vl = kl + K_TILE_BYTES;
+        // the last tile of a head: its S MFMAs are the last readers of this head's Q fragments, so the next head's
+        // (raw) Q rows are loaded straight into the same registers and scaled at the head switch below
+        const bool fetch_q = kt == nkt - 1 && hh + 1 < hpb && wave_active;
         if (wave_active) {
 
         // ---- S^T = K Q^T for two 32-key sub-tiles (K fragments shared by the QT query tiles)
@@ -187,6 +206,12 @@ attn_fwd_kernel(const AttnParams P) {
                     st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], ks == 0 ? negm[t] : st[t][j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
+        if (fetch_q) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *(const bf16x8*)(qbase[t] + (hh + 1) * 64 + ks * 16 + half * 8);
+        }
 
         // ---- masks (raw-score domain), online softmax; P^T fragments stay in registers
         const int kbase = P.kbeg + kt * KT;
@@ -281,35 +306,72 @@ attn_fwd_kernel(const AttnParams P) {
         __builtin_amdgcn_s_setprio(0);
         }
 
-        // tile kt+1 landed (tile kt+2 may stay in flight), everyone is done with tile kt's slot,
-        // which then receives tile kt+3
-        if (NSTAGE > 2 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile s+1 landed (tile s+2 may stay in flight), everyone is done with this tile's slot, which then
+        // receives tile s+3 (loads return in order: the Q loads of this iteration are younger than tile s+2's DMA)
+        if (NSTAGE > 2 && sidx + 2 < NT) {
+            if (fetch_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * QT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + NSTAGE < nkt) DWM_DMA_TILE(kt + NSTAGE, stage);
-        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-    }
-#undef DWM_DMA_TILE
 
-    // ---- finalize and store: lane (q, half) reg r of ot[dt] -> d = dt*32 + (r&3) + 8(r>>2) + 4 half
+        // ---- end of a head: normalise and store its output, reset the running state, switch Q.
+        // The 32 x 64 bf16 output tile of a wave is transposed through the 4 KiB of the just-retired stage that
+        // this wave's own DMA will refill next (rows 16 w .. 16 w + 15 of its K and V images), so that every
+        // store instruction writes 8 full 128-byte rows (lane-per-query stores would be 8-byte pieces).
+        if (kt == nkt - 1) {
+            const int head = head0 + hh;
+            char* const sc = smem + stage * STAGE_BYTES + sdst;     // + K_TILE_BYTES for rows 16..31
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(l_tot);
-        if (P.lse != nullptr && qok[t] && half == 0)       // NEGATIVE log2-domain LSE: P = exp2(c q.k + neg_lse)
-            P.lse[((int64_t)prob * P.heads + head) * L + qb * QB + (wave * QT + t) * 32 + l31] = negm[t][0] - __builtin_amdgcn_logf(l_tot);
-        if (qok[t]) {
+            for (int t = 0; t < QT; ++t) {
+                // lane (q, half) reg r of ot[dt] -> d = dt*32 + (r&3) + 8(r>>2) + 4 half
+                const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+                const float inv = __builtin_amdgcn_rcpf(l_tot);
+                if (P.lse != nullptr && qok[t] && half == 0)       // NEGATIVE log2-domain LSE: P = exp2(c q.k + neg_lse)
+                    P.lse[((int64_t)prob * P.heads + head) * L + qb * QB + (wave * QT + t) * 32 + l31] = negm[t][0] - __builtin_amdgcn_logf(l_tot);
+                if (wave_active && !P.dbg_nostore) {
+                    char* const myrow = sc + (l31 >> 4) * K_TILE_BYTES + (l31 & 15) * 128;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    float v[4];
+                        for (int rg = 0; rg < 4; ++rg) {
+                            float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = ot[t][dt][rg * 4 + j] * inv;
-                    *(uint2*)(optr[t] + dt * 32 + rg * 8 + half * 4) = pack4(v);
+                            for (int j = 0; j < 4; ++j) v[j] = ot[t][dt][rg * 4 + j] * inv;
+                            const int chunk = (dt * 4 + rg) ^ (l31 & 7);            // 16-B chunk, swizzled by the row
+                            *(uint2*)(myrow + (chunk << 4) + half * 8) = pack4(v);
+                        }
+                    // same-wave LDS ops complete in order: the reads below see the writes above
+                    const int64_t orow = (int64_t)optr[t];
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int r = pass * 8 + (lane >> 3), c = lane & 7;       // 8 lanes per output row
+                        const uint4 val = *(const uint4*)(sc + (r >> 4) * K_TILE_BYTES + (r & 15) * 128 + ((c ^ (r & 7)) << 4));
+                        const int64_t rp = __shfl(orow, r, 64);                  // row pointer held by the lane that owns query r
+                        const bool ok = qb * QB + (wave * QT + t) * 32 + r < P.qend;
+                        if (ok) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+                    }
                 }
+                l_run[t] = 0.f;
+                mvalid[t] = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[t][r] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
+                if (hh + 1 < hpb) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qf[t][ks] = scale_frag(qf[t][ks], P.scale_log2);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // scratch reads done before this wave's DMA refills it
         }
+        if (sidx + NSTAGE < NT) DWM_DMA_NEXT(stage);
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        if (++kt == nkt) { kt = 0; ++hh; }
     }
+#undef DWM_DMA_NEXT
+#undef DWM_DMA_TILE
 }
 
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
@@ -328,7 +390,7 @@ tr_probe_kernel(const int* __restrict__ offs, short* __restrict__ out) {
 
 template <int QT, int MASK>
 void launch_attn(const AttnParams& P, hipStream_t s) {
-    const int64_t nblk = (int64_t)P.n_problems * P.heads * P.nqb;
+    const int64_t nblk = (int64_t)P.n_problems * (P.heads / P.hpb) * P.nqb;
     const size_t lds = NSTAGE * STAGE_BYTES + (size_t)((P.L + 3) & ~3) * sizeof(int32_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -352,8 +414,19 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     if (qt != 1 && qt != 2) return DWM_EINVAL;
     const int qblock = qt * 128;
     P.nqb = (int)((P.qend + qblock - 1) / qblock);
+    // heads per workgroup: amortises the per-workgroup fixed cost (variant bits 8..11 override: 1..15).
+    // Measured on the step's shapes (L = 168 .. 602): 2 ~ 3 > 1; single-tile problems (L <= 64) take more.
+    P.dbg_nostore = (a->variant >> 4) & 1;
+    int hpb = (a->variant >> 8) & 15;
+    if (hpb == 0) {
+        if (L - P.kbeg <= KT) { for (hpb = 6; P.heads % hpb != 0; --hpb) {} }
+        else hpb = P.heads % 2 == 0 ? 2 : P.heads % 3 == 0 ? 3 : 1;
+    }
+    if (P.heads % hpb != 0) return DWM_EINVAL;
+    P.hpb = hpb;
+    P.fd_heads = make_fastdiv((uint32_t)(P.heads / hpb));
     P.fd_nqb = make_fastdiv((uint32_t)P.nqb);
-    if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
+    if ((int64_t)P.n_problems * (P.heads / P.hpb) * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
     if (NSTAGE * STAGE_BYTES + L * 4 + 16 > MAX_LDS_BYTES) return DWM_EUNSUPPORTED;   // ring + row table must fit the LDS window
     hipStream_t s = (hipStream_t)stream;
 #define DWM_ATTN(QT_)                                              \

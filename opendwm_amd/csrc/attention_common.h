@@ -39,6 +39,8 @@ struct AttnParams {
     float* delta;                        // [n_problems, heads, L] -rowsum(dO * O)
     float scale;
     int n_problems, heads, nqb;
+    int dbg_nostore;         // benchmark knob: skip the output stores
+    int hpb;                 // heads per workgroup (forward); fd_heads then divides by heads / hpb
     FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;
     float scale_log2;
     int mask_mode;
@@ -100,9 +102,9 @@ inline int fill_params(const dwm_attn_args* a, AttnParams& P) {
     if (a->L0 <= 0 || a->L1 < 0 || a->n_problems <= 0 || a->heads <= 0) return DWM_EINVAL;
     if (a->L1 > 0 && (a->q1 == nullptr || a->k1 == nullptr || a->v1 == nullptr || (a->o1 == nullptr && !a->cross))) return DWM_EINVAL;
     if (a->cross && a->L1 <= 0) return DWM_EINVAL;
-    if (a->ld0 % 8 != 0 || a->ldo0 % 4 != 0 || (a->L1 > 0 && (a->ld1 % 8 != 0 || (!a->cross && a->ldo1 % 4 != 0)))) return DWM_EALIGN;
-    if (!dwm_aligned16(a->q0) || !dwm_aligned16(a->k0) || !dwm_aligned16(a->v0) || (((uintptr_t)a->o0) & 7u)) return DWM_EALIGN;
-    if (a->L1 > 0 && (!dwm_aligned16(a->q1) || !dwm_aligned16(a->k1) || !dwm_aligned16(a->v1) || (!a->cross && (((uintptr_t)a->o1) & 7u))))
+    if (a->ld0 % 8 != 0 || a->ldo0 % 8 != 0 || (a->L1 > 0 && (a->ld1 % 8 != 0 || (!a->cross && a->ldo1 % 8 != 0)))) return DWM_EALIGN;
+    if (!dwm_aligned16(a->q0) || !dwm_aligned16(a->k0) || !dwm_aligned16(a->v0) || !dwm_aligned16(a->o0)) return DWM_EALIGN;
+    if (a->L1 > 0 && (!dwm_aligned16(a->q1) || !dwm_aligned16(a->k1) || !dwm_aligned16(a->v1) || (!a->cross && !dwm_aligned16(a->o1))))
         return DWM_EALIGN;
     if (a->ldiv[0] <= 0 || a->ldiv[1] <= 0) return DWM_EINVAL;
     if (a->mask_mode < 0 || a->mask_mode > 2) return DWM_EINVAL;
