@@ -94,6 +94,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []           # (kind, flops, start_event, end_event)
+        self.shapes = []            # per GEMM record: (M, N, K, epilogue, implicit conv)
         self.enabled = False
 
     def install(self):
@@ -109,7 +110,10 @@ class KernelTimer:
             s.record(st)
             out = gemm0(a, w, *args, **kw)
             e.record(st)
-            timer.records.append(("gemm", 2.0 * a.shape[0] * w.shape[0] * a.shape[1], s, e))
+            grid = kw.get("a_grid")
+            M = (grid.pixels // 4 if kw.get("stride2") else grid.pixels) if grid is not None else (kw.get("rows") or a.shape[0])
+            timer.records.append(("gemm", 2.0 * M * w.shape[0] * w.shape[1], s, e))
+            timer.shapes.append((M, w.shape[0], w.shape[1], kw.get("epilogue", 0), a.shape[1] != w.shape[1]))
             return out
 
         def attention(q, k, v, out, rowmap, heads, **kw):
@@ -129,6 +133,19 @@ class KernelTimer:
         for mod in (blocks, dit):
             mod.ops = ops
         return self
+
+    def shape_table(self, top=25):
+        """per-shape totals of the recorded GEMM launches, slowest first (diagnostics: `--gemm-shapes`)"""
+        agg = {}
+        gemms = [(f, s.elapsed_time(e)) for k, f, s, e in self.records if k == "gemm"]
+        for key, (f, ms) in zip(self.shapes, gemms):
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += f
+            a[2] += ms
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][2])[:top]
+        return [dict(M=k[0], N=k[1], K=k[2], epilogue=k[3], conv=bool(k[4]), launches=v[0], ms=round(v[2], 3),
+                     tflops=round(v[1] / v[2] / 1e9, 1)) for k, v in rows]
 
     def summary(self):
         out = {}
@@ -251,6 +268,9 @@ def main_unet(args):
     if rank == 0:
         fl = unet_flops(UNET_KWARGS, B2, T, V, w["H"], w["W"], w["text_len"])
         ks = timer.summary()
+        if args.gemm_shapes:
+            for row in timer.shape_table():
+                print(json.dumps(row), file=sys.stderr)
         step_ms = 1e3 * dt / args.steps
         gm, at = ks.get("gemm", {}), ks.get("attn", {})
         print(json.dumps({
@@ -343,6 +363,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="diagnostics: per-shape GEMM totals on stderr")
     ap.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a bench line)")
     ap.add_argument("--layout", action="store_true",
                     help="text+layout variant (examples/ctsd_35_df16_6views_video_generation_with_layout.json model: "
@@ -411,6 +432,9 @@ def main():
     if rank == 0:
         fl = model_flops(kwargs, 2 * w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])
         ks = timer.summary()
+        if args.gemm_shapes:
+            for row in timer.shape_table():
+                print(json.dumps(row), file=sys.stderr)
         step_ms = 1e3 * dt / args.steps
         gm, at = ks.get("gemm", {}), ks.get("attn", {})
         line = {

@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 8
+#define DWM_ABI_VERSION 9
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -100,6 +100,12 @@ typedef struct dwm_gemm_args {
     dwm_rowmap2d c_map;                                         /* C, res and blend rows                     */
     int32_t ntaps; int32_t k_per_tap;
     int64_t tap_shift[9];                                       /* in rows                                   */
+    /* split-K (PLAIN / RESID epilogues): when the tile grid fills less than half of the GPU and K is long, the K
+     * axis is cut into ranges (one workgroup each), fp32 partial tiles go to `workspace` and a second kernel reduces
+     * them in a fixed order and applies the epilogue.  workspace: 16-byte aligned device scratch of workspace_bytes
+     * (>= 2 * M * N * 4 to be usable), owned by the caller, one per stream; NULL = never split.
+     * split_k: 0 = automatic, 1 = never, > 1 = exactly this many ranges (DWM_EUNSUPPORTED if impossible). */
+    void* workspace; int64_t workspace_bytes; int32_t split_k;
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);

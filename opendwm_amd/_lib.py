@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("rms_w", _vp), ("rms_ncols", _i64), ("rms_eps", _f32), ("reserved", _i32),
         ("a_map", RowMap2D), ("c_map", RowMap2D), ("ntaps", _i32), ("k_per_tap", _i32),
         ("tap_shift", _i64 * 9),
+        ("workspace", _vp), ("workspace_bytes", _i64), ("split_k", _i32),
     ]
 
 

@@ -37,7 +37,13 @@ struct ConvParams {
     FastDiv fd_steps;
     FastDiv fd_rpg, fd_rmod, fd_rpa;   // RESID: rows_per_gate, res_mod, rows_per_alpha
     int64_t tap_shift[9];
+    // split-K: the K steps are cut into `ksplit` contiguous ranges, one workgroup per (tile, range); range s
+    // writes its fp32 partial tile to ws + s * ws_slice ([M, N] row-major) and splitk_finish_kernel reduces
+    int ksplit;
+    float* ws;
+    int64_t ws_slice;
 };
+constexpr int EPI_SPLITK = 100;     // internal epilogue id: fp32 partials to the workspace
 DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     if (!rm.enabled) return m;
     const uint32_t q = fdiv((uint32_t)m, rm.rw), x = (uint32_t)m - q * rm.rw.d;
@@ -66,7 +72,12 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // XCD-contiguous ids, then grouped rasterisation: consecutive ids walk GM row-tiles down a
     // column before moving to the next column, so the ~32 tiles resident on one XCD at a time form
     // a compact GM x (32/GM) block that shares A and W panels in that XCD's L2.
-    const int id = xcd_remap(blockIdx.x, ntm * ntn);
+    int id = xcd_remap(blockIdx.x, ntm * ntn * (EPI == EPI_SPLITK ? cp.ksplit : 1));
+    int slice = 0;
+    if constexpr (EPI == EPI_SPLITK) {          // slice-major: consecutive ids stay tile neighbours of one K range
+        slice = id / (ntm * ntn);
+        id -= slice * (ntm * ntn);
+    }
     int gm_ = (p.reserved >> 4) & 31;
     if (gm_ == 0) gm_ = 8;
     const int per_group = gm_ * ntn;
@@ -94,7 +105,11 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // K step kt covers tap t = kt / steps_per_tap and channels (kt % steps_per_tap)*64.. of it; the A
     // source moves by tap_shift[t] rows (0 for a plain GEMM), the W source is simply contiguous in K
     const int64_t lda_bytes = p.lda * 2;
+    const int nk_all = (int)(K / BK);
+    const int kt0 = EPI == EPI_SPLITK ? (int)((int64_t)slice * nk_all / cp.ksplit) : 0;
+    const int nk = EPI == EPI_SPLITK ? (int)((int64_t)(slice + 1) * nk_all / cp.ksplit) - kt0 : nk_all;
     auto tile_offsets = [&](int kt, int64_t& aoff, int64_t& koff) {
+        kt += kt0;
         koff = (int64_t)kt * (BK * 2);
         const uint32_t tap = fdiv((uint32_t)kt, cp.fd_steps);
         aoff = cp.tap_shift[tap] * lda_bytes + (int64_t)(kt - tap * cp.steps_per_tap) * (BK * 2);
@@ -116,7 +131,6 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + half) ^ swz) << 4;
 
-    const int nk = (int)(K / BK);
 
     // ---- main loop.  Per K tile: 4 sub-steps x 8 chunks of { NTW/2 MFMAs, one fragment read for the
     // next sub-step, a share of the DMA issue }, fenced with sched_barrier so LDS reads and DMA
@@ -202,7 +216,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         if (sink == 123.456f) ((float*)p.C)[0] = sink;
         return;
     }
-    const bf16_t* __restrict__ bias = (const bf16_t*)p.bias;
+    const bf16_t* __restrict__ bias = EPI == EPI_SPLITK ? nullptr : (const bf16_t*)p.bias;
     bf16_t* __restrict__ Cp = (bf16_t*)p.C;
 
     __syncthreads();                                       // every wave is done with the operand tiles
@@ -287,6 +301,8 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     acc[mt][ch * 2][r] = x[0];
                     acc[mt][ch * 2][r + 1] = x[1];
                 }
+            } else if constexpr (EPI == EPI_SPLITK) {
+                // raw fp32 partial sums: bias / activation / residual are applied by the finishing kernel
             } else {
 #define DWM_ACT_PASS(FN_)                                                                           \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                     \
@@ -377,11 +393,71 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         }
                     }
                 }
-                if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+                if constexpr (EPI == EPI_SPLITK) {
+                    if (m < M && nok) {
+                        float* wp = cp.ws + slice * cp.ws_slice + m * N + ncol;
+                        *(float4*)wp = x0;
+                        *(float4*)(wp + 4) = x1;
+                    }
+                } else {
+                    if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+                }
             }
             }
         }
     }
+}
+
+// Split-K finish: out[m][n..n+8) = epilogue(sum_s ws[s][m][n..n+8)) for the PLAIN and RESID epilogues (one thread per
+// 8 columns; fixed summation order, so the result does not depend on scheduling).
+__global__ void __launch_bounds__(256)
+splitk_finish_kernel(const dwm_gemm_args p, const ConvParams cp) {
+    const int64_t n8 = p.N >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.M * n8) return;
+    const int64_t m = i / n8, n = (i - m * n8) << 3;
+    const float* w = cp.ws + m * p.N + n;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < cp.ksplit; ++s) {
+        const float4 a = *(const float4*)(w + s * cp.ws_slice), b = *(const float4*)(w + s * cp.ws_slice + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    float t[8];
+    if (p.bias) {
+        unpack8(*(const uint4*)((const bf16_t*)p.bias + n), t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += t[j];
+    }
+    if (p.act != DWM_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 x = {v[j], v[j + 1]};
+            const f32x2 y = p.act == DWM_ACT_GELU_TANH ? gelu_tanh2(x) : p.act == DWM_ACT_SILU ? silu2(x) : relu2(x);
+            v[j] = y[0]; v[j + 1] = y[1];
+        }
+    }
+    const int64_t mr = map_row(cp.c, m);
+    if (p.epilogue == DWM_EPI_RESID) {
+        if (p.gate) {
+            unpack8(*(const uint4*)((const bf16_t*)p.gate + (int64_t)fdiv((uint32_t)m, cp.fd_rpg) * p.ld_gate + n), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= t[j];
+        }
+        if (p.res) {
+            const int64_t rr = p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m, cp.fd_rmod) : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m, cp.fd_rmod) : mr;
+            unpack8(*(const uint4*)((const bf16_t*)p.res + rr * p.ld_res + n), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += t[j];
+        }
+        if (p.blend) {
+            unpack8(*(const uint4*)((const bf16_t*)p.blend + mr * p.ld_blend + n), t);
+            const float al = p.alpha[fdiv((uint32_t)m, cp.fd_rpa)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = al * t[j] + (1.f - al) * v[j];
+        }
+    }
+    *(uint4*)((bf16_t*)p.C + mr * p.ldc + n) = pack8(v);
 }
 
 }  // namespace
@@ -435,8 +511,48 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a->lda < kpt) return DWM_EINVAL;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)(ntm * ntn)), block(512);
     hipError_t e;
+    // ---- split-K: a grid that fills less than half of the 256 CUs and a long K.  One K range per workgroup,
+    // fp32 partials in the caller's workspace, deterministic reduction + epilogue in splitk_finish_kernel.
+    int ksplit = 1;
+    {
+        const int64_t tiles = (int64_t)ntm * ntn, nk = a->K / BK;
+        const bool can = (a->epilogue == DWM_EPI_PLAIN || a->epilogue == DWM_EPI_RESID) && a->workspace != nullptr &&
+                         dwm_aligned16(a->workspace) && !(a->reserved & 3);
+        if (a->split_k > 1) {
+            if (!can) return DWM_EUNSUPPORTED;
+            ksplit = a->split_k;
+        } else if (a->split_k == 0 && can && tiles <= 128 && nk >= 16) {
+            ksplit = (int)(256 / tiles);
+        }
+        if (ksplit > 1) {
+            const int64_t slice_bytes = a->M * a->N * 4;
+            if (ksplit > nk / 8) ksplit = (int)(nk / 8);
+            if (ksplit > 32) ksplit = 32;
+            if ((int64_t)ksplit * slice_bytes > a->workspace_bytes) ksplit = (int)(a->workspace_bytes / slice_bytes);
+            if (ksplit < 2) {
+                if (a->split_k > 1) return DWM_EUNSUPPORTED;
+                ksplit = 1;
+            }
+        }
+    }
+    cp.ksplit = ksplit;
+    cp.ws = (float*)a->workspace;
+    cp.ws_slice = a->M * a->N;
+    if (ksplit > 1) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_SPLITK>, dim3((unsigned)(ntm * ntn * ksplit)), dim3(512), LDS_BYTES, s, *a, cp, ntm, ntn);
+        const int64_t nthr = a->M * (a->N >> 3);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, *a, cp);
+        e = hipGetLastError();
+        return e == hipSuccess ? DWM_OK : (int)e;
+    }
+    const dim3 grid((unsigned)(ntm * ntn)), block(512);
 #define DWM_LAUNCH(EPI)                                                                              \
     do {                                                                                             \
         static bool attr_set = false;                                                                \

@@ -128,10 +128,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
          a_grid=None, conv3x3: bool = False, stride2=False, conv_taps: Optional[list] = None,
          c_grid=None,
-         rows: Optional[int] = None, _debug: int = 0) -> torch.Tensor:
+         rows: Optional[int] = None, split_k: int = 0, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
     a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
-    axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids."""
+    axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids.
+    split_k: 0 = the kernel's rule (small tile grid + long K -> K ranges, fp32 partials, ordered reduction),
+    1 = never, n > 1 = exactly n ranges."""
     _chk2d(a, "a")
     _chk2d(w, "w")
     if not w.is_contiguous():
@@ -193,8 +195,27 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             if t is not None and t.shape[0] != c_grid.rows:
                 raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
+    g.split_k = split_k
+    # split-K scratch (fp32 partial tiles): only handed over when the kernel's own rule can take it
+    if split_k != 1 and epilogue in (EPI_PLAIN, EPI_RESID) and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and K >= 1024:
+        ws = _gemm_workspace(a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
     return out
+
+
+_WORKSPACES: dict = {}
+GEMM_WORKSPACE_BYTES = 256 << 20
+
+
+def _gemm_workspace(device: torch.device) -> torch.Tensor:
+    """fp32 scratch of the split-K GEMM path, one per (device, stream): partial tiles live there only between the
+    two kernels of one dwm_gemm_bf16 call, so calls on one stream share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.empty(GEMM_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
 
 
 # ---------------------------------------------------------------------------- attention

@@ -78,6 +78,26 @@ class _Geom:
         return _Geom(self.B, self.T, self.V, h, w, self.scratch)
 
 
+class _TimeProj:
+    """`time_emb_proj(silu(emb))` of every residual block (ResnetBlock2D / TemporalResnetBlock) in ONE GEMM: they
+    all read the same [images, temb_channels] input, so their weights are stacked once per weight version and each
+    block takes its column slice of the [images, sum C_out] result (41 skinny launches -> 1)."""
+
+    def __init__(self, layers, silu_emb: torch.Tensor):
+        anchor = layers[0].weight
+        wcat = STORE.derived(anchor, "tproj_w", lambda: torch.cat([_bf(l.weight) for l in layers], 0).contiguous())
+        bcat = STORE.derived(anchor, "tproj_b", lambda: torch.cat([_bf(l.bias) for l in layers], 0).contiguous())
+        self.all = ops.gemm(silu_emb, wcat, bcat)
+        self.slices, off = {}, 0
+        for l in layers:
+            self.slices[id(l)] = (off, l.weight.shape[0])
+            off += l.weight.shape[0]
+
+    def of(self, layer) -> torch.Tensor:
+        off, n = self.slices[id(layer)]
+        return self.all[:, off:off + n]
+
+
 class ResnetBlock2D(nn.Module):
     """diffusers ResnetBlock2D(in, out, temb_channels, eps, groups=32)"""
 
@@ -91,13 +111,13 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
-    def run(self, x: torch.Tensor, silu_emb: torch.Tensor, g: _Geom) -> torch.Tensor:
+    def run(self, x: torch.Tensor, tproj: "_TimeProj", g: _Geom) -> torch.Tensor:
         grid = PaddedGrid(g.I, g.h, g.w)
         w1 = STORE.derived(self.conv1.weight, "c3", lambda: _conv3_w(self.conv1.weight))
         w2 = STORE.derived(self.conv2.weight, "c3", lambda: _conv3_w(self.conv2.weight))
         p1 = ops.groupnorm_silu(x, g.I, g.N, _bf(self.norm1.weight), _bf(self.norm1.bias), 32, self.eps,
                                 out=g.scratch.get("s1", grid.rows, x.shape[1], x.device), out_grid=grid)
-        tp = ops.gemm(silu_emb, _bf(self.time_emb_proj.weight), _bf(self.time_emb_proj.bias))
+        tp = tproj.of(self.time_emb_proj)
         h1 = ops.gemm(p1, w1, _bf(self.conv1.bias), a_grid=grid, conv3x3=True, epilogue=EPI_RESID, res=tp, res_mod=-g.N)
         p2 = ops.groupnorm_silu(h1, g.I, g.N, _bf(self.norm2.weight), _bf(self.norm2.bias), 32, self.eps,
                                 out=g.scratch.get("s2", grid.rows, h1.shape[1], x.device), out_grid=grid)
@@ -119,7 +139,7 @@ class TemporalResnetBlock(nn.Module):
         self.norm2 = nn.GroupNorm(32, channels, eps=eps)
         self.conv2 = nn.Conv3d(channels, channels, (3, 1, 1), padding=(1, 0, 0))
 
-    def run(self, s: torch.Tensor, silu_emb: torch.Tensor, g: _Geom, alpha: torch.Tensor) -> torch.Tensor:
+    def run(self, s: torch.Tensor, tproj: "_TimeProj", g: _Geom, alpha: torch.Tensor) -> torch.Tensor:
         """returns AlphaBlender(s, s + temporal_resnet(s)) (crossview_temporal.py:146-162)"""
         tg = TimeGrid(g.B, g.T, g.V * g.N)
         imap = (g.V, g.N, g.T * g.V * g.N, g.N, g.V * g.N)
@@ -128,7 +148,7 @@ class TemporalResnetBlock(nn.Module):
         w2 = STORE.derived(self.conv2.weight, "c3d", lambda: _conv3d_w(self.conv2.weight))
         t1 = ops.groupnorm_silu(s, g.B * g.V, g.T * g.N, _bf(self.norm1.weight), _bf(self.norm1.bias), 32, self.eps,
                                 out=g.scratch.get("t1", tg.rows, Cc, s.device), out_grid=tg, img_map=imap)
-        tp = ops.gemm(silu_emb, _bf(self.time_emb_proj.weight), _bf(self.time_emb_proj.bias))
+        tp = tproj.of(self.time_emb_proj)
         u1 = ops.gemm(t1, w1, _bf(self.conv1.bias), a_grid=tg, conv_taps=tg.tap_shifts(), epilogue=EPI_RESID, res=tp, res_mod=-g.N)
         t2 = ops.groupnorm_silu(u1, g.B * g.V, g.T * g.N, _bf(self.norm2.weight), _bf(self.norm2.bias), 32, self.eps,
                                 out=g.scratch.get("t2", tg.rows, Cc, s.device), out_grid=tg, img_map=imap)
@@ -149,12 +169,12 @@ class ResBlock(nn.Module):
         else:
             self.temporal_res_block = None
 
-    def run(self, x, silu_emb, g: _Geom, disable_temporal):
-        s = self.spatial_res_block.run(x, silu_emb, g)
+    def run(self, x, tproj: "_TimeProj", g: _Geom, disable_temporal):
+        s = self.spatial_res_block.run(x, tproj, g)
         if self.temporal_res_block is None:
             return s
         alpha = self.time_mixer.get_alpha(disable_temporal, g.B)
-        return self.temporal_res_block.run(s, silu_emb, g, alpha)
+        return self.temporal_res_block.run(s, tproj, g, alpha)
 
 
 class _CrossAttention(nn.Module):
@@ -172,6 +192,31 @@ class _CrossAttention(nn.Module):
         return STORE.derived(self.to_k.weight, "kv", lambda: torch.cat([_bf(self.to_k.weight), _bf(self.to_v.weight)], 0).contiguous())
 
 
+class _TextContext:
+    """Text tokens [images * L, cross_attention_dim] of one `encoder_hidden_states` tensor and the K/V projections of
+    every text cross-attention layer on them.  Both are functions of the text embeddings and the weights only, so the
+    UNet keeps one instance across denoise steps while the caller passes the same (unmodified) tensor."""
+
+    def __init__(self, encoder_hidden_states: torch.Tensor):
+        self.source = encoder_hidden_states                  # held: its storage cannot be recycled under the cache key
+        self.key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
+                    encoder_hidden_states.dtype, STORE.step)
+        ehs = encoder_hidden_states.flatten(0, -3)
+        ehs = ehs if ehs.dtype == bf16 else ehs.to(bf16)
+        self.rows = ehs.reshape(ehs.shape[0] * ehs.shape[1], -1).contiguous()
+        self._kv = {}
+
+    def matches(self, encoder_hidden_states: torch.Tensor) -> bool:
+        t = encoder_hidden_states
+        return t is self.source and self.key == (t.data_ptr(), t._version, tuple(t.shape), t.dtype, STORE.step)
+
+    def kv(self, attn: "_CrossAttention") -> torch.Tensor:
+        out = self._kv.get(id(attn))
+        if out is None:
+            out = self._kv[id(attn)] = ops.gemm(self.rows, attn.wkv())
+        return out
+
+
 class BasicTransformerBlock(nn.Module):
     """diffusers BasicTransformerBlock(dim, heads, head_dim, cross_attention_dim): LayerNorm, GEGLU FF"""
 
@@ -187,7 +232,7 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim, activation_fn="geglu")
 
-    def run(self, h: torch.Tensor, ctx: torch.Tensor, n_img: int) -> torch.Tensor:
+    def run(self, h: torch.Tensor, ctx: "_TextContext", n_img: int) -> torch.Tensor:
         D = self.dim
         N = h.shape[0] // n_img
         ln = lambda x, n, **kw: ops.layernorm(x, eps=1e-5, weight=_bf(n.weight), bias=_bf(n.bias), **kw)
@@ -199,7 +244,7 @@ class BasicTransformerBlock(nn.Module):
         ops.gemm(ao, _bf(o1.weight), _bf(o1.bias), epilogue=EPI_RESID, res=h, out=h)
         y = ln(h, self.norm2, out=y)
         q = ops.gemm(y, _bf(self.attn2.to_q.weight))
-        kv = ops.gemm(ctx, self.attn2.wkv())
+        kv = ctx.kv(self.attn2)
         ops.cross_attention(q, kv[:, :D], kv[:, D:], ao, n_img, self.heads)
         o2 = self.attn2.to_out[0]
         ops.gemm(ao, _bf(o2.weight), _bf(o2.bias), epilogue=EPI_RESID, res=h, out=h)
@@ -244,19 +289,28 @@ class TransformerModel(nn.Module):
         else:
             self.time_pos_embed = None
         self.proj_out = nn.Linear(inner, in_channels)
+        self._emb_cache = (None, None, None)
 
-    def run(self, x: torch.Tensor, ctx: torch.Tensor, g: _Geom, disable_crossview, disable_temporal, mask) -> torch.Tensor:
+    def run(self, x: torch.Tensor, ctx: "_TextContext", g: _Geom, disable_crossview, disable_temporal, mask) -> torch.Tensor:
         B, Tn, V, C = g.B, g.T, g.V, self.in_channels
         dev = x.device
         hn = ops.groupnorm_silu(x, g.I, g.N, _bf(self.norm.weight), _bf(self.norm.bias), 32, 1e-6, silu=False)
         h = ops.gemm(hn, _bf(self.proj_in.weight), _bf(self.proj_in.bias))
+        # view / frame index embeddings depend on (B, T, V) and the weights only: kept across denoise steps
+        key = (STORE.step, B, Tn, V, str(dev))
+        if self._emb_cache[0] != key:
+            view_emb = seq_emb = None
+            if self.view_pos_embed is not None:
+                idx = torch.arange(V, device=dev).view(1, 1, V).expand(B, Tn, V)
+                view_emb = self.view_pos_embed.run(ops.timestep_sinusoid(idx, C))
+            if self.time_pos_embed is not None:
+                idx = torch.arange(Tn, device=dev).view(1, Tn, 1).expand(B, Tn, V)
+                seq_emb = self.time_pos_embed.run(ops.timestep_sinusoid(idx, C))
+            self._emb_cache = (key, view_emb, seq_emb)
+        _, view_emb, seq_emb = self._emb_cache
         if self.view_pos_embed is not None:
-            idx = torch.arange(V, device=dev).view(1, 1, V).expand(B, Tn, V)
-            view_emb = self.view_pos_embed.run(ops.timestep_sinusoid(idx, C))
             alpha_v = self.view_mixer.get_alpha(disable_crossview, B)
         if self.time_pos_embed is not None:
-            idx = torch.arange(Tn, device=dev).view(1, Tn, 1).expand(B, Tn, V)
-            seq_emb = self.time_pos_embed.run(ops.timestep_sinusoid(idx, C))
             alpha_t = self.time_mixer.get_alpha(disable_temporal, B)
         for l, blk in enumerate(self.transformer_blocks):
             h = blk.run(h, ctx, g.I)
@@ -377,6 +431,14 @@ class UNetCrossviewTemporalConditionModel(_Base):
         self.depth_net = None
         self.depth_frustum_range = depth_frustum_range
         self._scratch = _Scratch()
+        self._text_ctx = None
+        self._tproj_layers = None
+
+    def _time_proj_layers(self):
+        """every residual block's `time_emb_proj`, in module order (the column layout of the stacked projection)"""
+        if self._tproj_layers is None:
+            self._tproj_layers = [m.time_emb_proj for m in self.modules() if isinstance(m, (ResnetBlock2D, TemporalResnetBlock))]
+        return self._tproj_layers
 
     @staticmethod
     def try_to_convert_state_dict(state_dict: dict):
@@ -392,6 +454,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
         out = super()._apply(fn, *a, **kw)
         STORE.bump()
         self._scratch = _Scratch()
+        self._text_ctx = None
         return out
 
     def load_state_dict(self, state_dict, *a, **kw):
@@ -430,10 +493,10 @@ class UNetCrossviewTemporalConditionModel(_Base):
         if added_time_ids is not None and self.add_embedding is not None:
             aug = ops.timestep_sinusoid(added_time_ids.flatten(), self.addition_time_embed_dim).view(I, -1)
             emb = self.add_embedding.run(aug, res=emb)
-        silu_emb = ops.silu(emb)
-        ehs = encoder_hidden_states.flatten(0, 2)
-        ehs = ehs if ehs.dtype == bf16 else ehs.to(bf16)
-        ctx = ehs.reshape(I * ehs.shape[1], -1).contiguous()
+        silu_emb = _TimeProj(self._time_proj_layers(), ops.silu(emb))
+        if self._text_ctx is None or not self._text_ctx.matches(encoder_hidden_states):
+            self._text_ctx = _TextContext(encoder_hidden_states)
+        ctx = self._text_ctx
 
         # 2. conv_in: NCHW -> token-major rows with the channels zero-padded to 64, 3x3 implicit GEMM
         xin = sample.flatten(0, 2).contiguous()

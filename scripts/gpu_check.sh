@@ -27,3 +27,8 @@ timeout 900 python bench.py --train --steps 3 --warmup 1 > $OUT/bench_train.log 
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$TAG -o train -- python $GRAFT_REPO_ROOT/bench.py --train --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_train.log 2>&1)
 for f in $(find /tmp/proft_$TAG -name "*kernel_stats*.csv"); do cp $f $OUT/train_kernel_stats.csv; done
 head -12 $OUT/train_kernel_stats.csv | cut -c1-200
+echo "== unet bench (BASELINE config 2, one GPU)"
+timeout 600 python bench.py --unet > $OUT/bench_unet.log 2>&1; echo "unet bench exit $?" | tee -a $OUT/bench_unet.log; tail -2 $OUT/bench_unet.log | cut -c1-400
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profu_$TAG -o unet -- python $GRAFT_REPO_ROOT/bench.py --unet --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_unet.log 2>&1)
+for f in $(find /tmp/profu_$TAG -name "*kernel_stats*.csv"); do cp $f $OUT/unet_kernel_stats.csv; done
+head -25 $OUT/unet_kernel_stats.csv | cut -c1-200

@@ -1,0 +1,102 @@
+"""Autoregressive / streaming generation on the GPU (opendwm_amd.drivers over pipeline.CTSDDenoiser and the HIP
+model) against the restated reference drivers over the fp32 oracle model (oracle/drivers_oracle.py over
+ctsd_oracle.denoise).  Tolerance: bf16 compute vs fp32, relative Frobenius error < TOL_MODEL on the emitted
+frames and on the carried latents (BASELINE.json: 2e-2 bf16); identical host random streams by construction."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ctsd_oracle as O          # noqa: E402
+from oracle import drivers_oracle as DO      # noqa: E402
+from tests.common import rel_err, small_inputs, to_dev   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+TOL_MODEL = 2e-2
+G = 4.0
+NON_TEMPORAL = ["disable_crossview", "disable_temporal", "crossview_attention_mask"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need a HIP device (torch.cuda.is_available() is False)")
+    from opendwm_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model_and_sd(dev, small_cfg):
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    sd = {k: (v.to(bf16).float() if v.is_floating_point() else v) for k, v in O.make_state_dict(small_cfg, 0).items()}
+    m = DiTCrossviewTemporalConditionModel(**small_cfg)
+    m.load_state_dict(sd)
+    return m.to(dev).to(bf16).eval(), sd
+
+
+def conditions(cfg, frames):
+    inp = small_inputs(cfg, 3, T=frames)
+    return {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+
+
+def _log(name, **kw):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/gpu_parity.log", "a") as f:
+        f.write(name + " " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items()) + "\n")
+
+
+def oracle_window(sd, cfg, steps, df):
+    def window(latent_shape, cond, il, ref, start, stop, take_time, noise):
+        lat0 = noise if noise is not None else torch.zeros(tuple(latent_shape))
+        lat = O.denoise(sd, cfg, lat0, cond, steps, G, stop=stop, start=start, image_latents=il, reference_frame_count=ref,
+                        diffusion_forcing=df, take_time=take_time)
+        return {"latents": lat, "images": lat[:, take_time].flatten(0, 1) if df else lat.flatten(0, 2)}
+    return window
+
+
+@pytest.mark.parametrize("df", [False, True])
+def test_autoregressive_vs_oracle(dev, small_cfg, model_and_sd, df):
+    from opendwm_amd.drivers import AutoregressiveDriver
+    from opendwm_amd.pipeline import CTSDDenoiser
+    m, sd = model_and_sd
+    T, V, total, steps = 3, 3, 5, 3
+    shape = (1, T, V, 16, 8, 12)
+    cond = conditions(small_cfg, total)
+    cfg = dict(inference_steps=steps, sequence_length_per_iteration=T, reference_frame_count=2 if df else 1,
+               autoregression_data_exception_for_take_sequence=NON_TEMPORAL)
+    want = DO.autoregressive(oracle_window(sd, small_cfg, steps, df), shape, cond, total, cfg, df, torch.Generator().manual_seed(21))
+    den = CTSDDenoiser(m, guidance_scale=G, inference_steps=steps)
+    got = AutoregressiveDriver(den, cfg, diffusion_forcing=df, generator=torch.Generator().manual_seed(21)).run(
+        shape, to_dev(cond, dev), total, dev)
+    assert got["images"].shape == want["images"].shape
+    e_img, e_lat = rel_err(got["images"], want["images"]), rel_err(got["latents"], want["latents"])
+    _log("autoregressive", diffusion_forcing=df, frames=got["images"].shape[0] // V, rel_images=e_img, rel_latents=e_lat)
+    assert e_img < TOL_MODEL and e_lat < TOL_MODEL
+
+
+def test_streaming_fifo_vs_oracle(dev, small_cfg, model_and_sd):
+    from opendwm_amd.drivers import StreamingDriver
+    from opendwm_amd.pipeline import CTSDDenoiser
+    m, sd = model_and_sd
+    T, V, total, steps = 3, 3, 5, 3
+    shape = (1, T, V, 16, 8, 12)
+    cond = conditions(small_cfg, total)
+    cfg = dict(inference_steps=steps, sequence_length_per_iteration=T,
+               autoregression_data_exception_for_take_sequence=NON_TEMPORAL,
+               autoregression_condition_exception_for_take_sequence=NON_TEMPORAL)
+
+    def window(latent_shape, conditions_, latents, start, stop, take_time):
+        lat = O.denoise(sd, small_cfg, latents, conditions_, steps, G, stop=stop, start=start, image_latents=latents,
+                        diffusion_forcing=True, take_time=take_time)
+        return lat, (lat[:, take_time].flatten(0, 1) if stop >= steps else None)
+    want = DO.Streaming(window, cfg, torch.Generator().manual_seed(22)).fifo(shape, cond, total)
+    den = CTSDDenoiser(m, guidance_scale=G, inference_steps=steps)
+    got = StreamingDriver(den, cfg, generator=torch.Generator().manual_seed(22)).fifo(shape, to_dev(cond, dev), total, dev)
+    assert got.shape == want.shape and got.shape[0] == total * V
+    e = rel_err(got, want)
+    _log("streaming_fifo", frames=total, rel=e)
+    assert e < TOL_MODEL

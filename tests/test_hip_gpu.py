@@ -138,6 +138,69 @@ def test_gemm_rmshead(dev, M, heads, K, biased):
     assert rel_err(qk, ref[:, :2 * D]) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("M,N,K,split", [(300, 1280, 4096, 0), (72, 1280, 5120, 0), (512, 512, 2048, 5), (1536, 1536, 8192, 0),
+                                         (77, 8, 1024, 2)])
+def test_gemm_split_k(dev, M, N, K, split):
+    """Split-K path (small tile grid, long K): fp32 partial tiles + ordered reduction + epilogue in the finishing
+    kernel.  Same references as the single-pass path, every RESID form incl. the in-place ones, and the result must
+    not depend on scheduling (bit-equal across runs)."""
+    from opendwm_amd import ops
+    a, w, b = _rand((M, K), dev, 1), _rand((N, K), dev, 2, K ** -0.5), _rand((N,), dev, 3)
+    y = a.float() @ w.float().T + b.float()
+    out = ops.gemm(a, w, b, split_k=split)
+    one = ops.gemm(a, w, b, split_k=1)
+    e, e1 = rel_err(out, y), rel_err(one, y)
+    assert e < TOL_KERNEL and e1 < TOL_KERNEL
+    assert torch.equal(out, ops.gemm(a, w, b, split_k=split))
+    assert rel_err(ops.gemm(a, w, b, act=ops.ACT_GELU_TANH, split_k=split), F.gelu(y, approximate="tanh")) < TOL_KERNEL
+    rpg = 100
+    groups = (M + rpg - 1) // rpg
+    gate, res, blend = _rand((groups, N), dev, 4), _rand((M, N), dev, 5), _rand((M, N), dev, 6)
+    alpha = torch.rand(groups, device=dev)
+    rows = torch.arange(M, device=dev) // rpg
+    al = alpha[rows][:, None]
+    r2 = res.clone()
+    ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=rpg, res=r2, out=r2, split_k=split)
+    e2 = rel_err(r2, res.float() + gate.float()[rows] * y)
+    bl = blend.clone()
+    ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=res, blend=bl, alpha=alpha, rows_per_alpha=rpg, out=bl, split_k=split)
+    e3 = rel_err(bl, al * blend.float() + (1 - al) * (res.float() + y))
+    per = _rand((groups, N), dev, 7)
+    e4 = rel_err(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=per, res_mod=-rpg, split_k=split), y + per.float()[rows])
+    _log("gemm_split_k", M=M, N=N, K=K, split=split, rel=e, rel_single_pass=e1, rel_gate=e2, rel_blend=e3, rel_per_image=e4)
+    assert e2 < TOL_KERNEL and e3 < TOL_KERNEL and e4 < TOL_KERNEL
+    if split > 1:
+        from opendwm_amd.blocks import geglu_pack
+        with pytest.raises(RuntimeError):
+            ops.gemm(a, geglu_pack(w) if N % 64 == 0 else w, None, epilogue=ops.EPI_GEGLU if N % 64 == 0 else ops.EPI_RMSHEAD,
+                     split_k=split)
+
+
+def test_gemm_split_k_implicit_conv(dev):
+    """the lowest UNet level: few pixels, K = 9 taps x C; padded output grid with an in-place residual"""
+    from opendwm_amd import ops
+    I, h, w, C, N = 4, 4, 7, 1280, 256
+    grid = ops.PaddedGrid(I, h, w)
+    x = _rand((I, C, h, w), dev, 1)
+    wt, b = _rand((N, C, 3, 3), dev, 2, (9 * C) ** -0.5), _rand((N,), dev, 3)
+    ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, N)
+    idx = grid.interior_index().to(dev)
+    xp = torch.zeros((grid.rows, C), dtype=bf16, device=dev)
+    xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    wp = wt.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    outs = [ops.gemm(xp, wp, b, a_grid=grid, conv3x3=True, split_k=sk) for sk in (1, 0, 6)]
+    errs = [rel_err(o, ref) for o in outs]
+    res = torch.zeros((grid.rows, N), dtype=bf16, device=dev)
+    res[idx] = _rand((I * h * w, N), dev, 4)
+    want = res[idx].float() + ref
+    ops.gemm(xp, wp, b, a_grid=grid, conv3x3=True, epilogue=ops.EPI_RESID, res=res, out=res, c_grid=grid, split_k=6)
+    border = torch.ones(grid.rows, dtype=torch.bool, device=dev)
+    border[idx] = False
+    e2 = rel_err(res[idx], want)
+    _log("gemm_split_k_conv", rel_single=errs[0], rel_auto=errs[1], rel_6=errs[2], rel_padded_out=e2)
+    assert max(errs) < TOL_KERNEL and e2 < TOL_KERNEL and torch.count_nonzero(res[border]) == 0
+
+
 def test_gemm_rejects_bad_arguments(dev):
     from opendwm_amd import ops
     a, w = _rand((64, 100), dev, 1), _rand((64, 100), dev, 2)
