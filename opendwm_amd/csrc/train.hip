@@ -28,6 +28,35 @@ transpose_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int64_t rows, int
     }
 }
 
+// Vector form (cols % 8 == 0, rows_pad % 8 == 0, 16-byte aligned rows on both sides): a thread owns an 8 x 8 block -
+// eight 16-byte row loads, a register transpose (v_perm_b32), eight 16-byte stores - so no LDS round trip and every
+// store instruction of a wave writes 4 output rows x 256 contiguous bytes.  Workgroup = 128 rows x 128 cols.
+__global__ void __launch_bounds__(256)
+transpose8_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int64_t rows, int64_t cols,
+                  bf16_t* __restrict__ out, int64_t ld_out, int64_t rows_pad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 128 + wave * 32 + (lane & 3) * 8;
+    const int64_t r = (int64_t)blockIdx.y * 128 + (lane >> 2) * 8;
+    if (c >= cols || r >= rows_pad) return;
+    uint32_t v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (r + i < rows) q = *(const uint4*)(in + (r + i) * ld_in + c);
+        v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        const uint32_t sel = (cc & 1) ? 0x07060302u : 0x05040100u;     // high / low halves of the two source dwords
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(v[1][cc >> 1], v[0][cc >> 1], sel);
+        o.y = __builtin_amdgcn_perm(v[3][cc >> 1], v[2][cc >> 1], sel);
+        o.z = __builtin_amdgcn_perm(v[5][cc >> 1], v[4][cc >> 1], sel);
+        o.w = __builtin_amdgcn_perm(v[7][cc >> 1], v[6][cc >> 1], sel);
+        *(uint4*)(out + (c + cc) * ld_out + r) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------- segmented sums
 // out[g][n] += sum_{r in group g} a[r][n] * (b ? b[r][n] : 1).  Block = 256 threads = 32 column
 // chunks (8 columns each) x 8 row lanes; a block covers 256 columns x up to RB rows of ONE group.
@@ -437,6 +466,12 @@ inline unsigned grid_for(int64_t work_items) {
 extern "C" int dwm_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols, void* out,
                                   int64_t ld_out, int64_t rows_pad, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0 || rows_pad < rows || ld_in < cols || ld_out < rows_pad) return DWM_EINVAL;
+    if (cols % 8 == 0 && rows_pad % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && dwm_aligned16(in) && dwm_aligned16(out)) {
+        const dim3 grid8((unsigned)((cols + 127) / 128), (unsigned)((rows_pad + 127) / 128));
+        hipLaunchKernelGGL(transpose8_kernel, grid8, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, rows, cols,
+                           (bf16_t*)out, ld_out, rows_pad);
+        DWM_RET();
+    }
     const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows_pad + 63) / 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, rows, cols,
                        (bf16_t*)out, ld_out, rows_pad);

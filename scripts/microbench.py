@@ -55,6 +55,15 @@ def bench_attn(variants):
             print(json.dumps({"kernel": "attn", "case": name, "variant": var, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
 
 
+def bench_transpose():
+    from opendwm_amd import train_ops as T
+    for rows, cols in ((86016, 1536), (86016, 6144), (29568, 1536)):
+        x = rnd(rows, cols)
+        ms = timeit(lambda: T.transpose(x))
+        print(json.dumps({"kernel": "transpose", "rows": rows, "cols": cols, "ms": round(ms, 4),
+                          "TB_per_s": round(4.0 * rows * cols / ms / 1e9, 2)}), flush=True)
+
+
 def bench_gemm(dbg_list=(0, 1)):
     from opendwm_amd.blocks import geglu_pack
     shapes = [("qkv rmshead", 86016, 4608, 1536, "rms"), ("out-proj resid", 86016, 1536, 1536, "resid"),
@@ -102,6 +111,8 @@ def bench_ln():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["attn", "gemm", "ln"]
     print(torch.cuda.get_device_name(0))
+    if "tr" in what:
+        bench_transpose()
     if "attn" in what:
         bench_attn([1])
     if "gemm" in what:

@@ -47,6 +47,10 @@ def test_transpose_and_segsum(dev):
     assert torch.equal(xt[:, :300], x.t()) and torch.count_nonzero(xt[:, 300:]) == 0
     v = _rand((1000, 264), dev, 2)[:, :256]                       # strided view
     assert torch.equal(T.transpose(v)[:, :1000], v.t())
+    for shape in ((1003, 1544), (77, 8), (129, 4096), (640, 100)):  # vector path (cols % 8 == 0) and the scalar fallback
+        t = _rand(shape, dev, 5)
+        tt = T.transpose(t)
+        assert torch.equal(tt[:, :shape[0]], t.t()) and torch.count_nonzero(tt[:, shape[0]:]) == 0
     a, b = _rand((1001, 1536), dev, 3), _rand((1001, 1536), dev, 4)
     s = T.segsum(a)
     assert rel_err(s[0], a.float().sum(0)) < TOL_REDUCE
