@@ -364,6 +364,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="diagnostics: per-shape GEMM totals on stderr")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one HIP graph (CTSDDenoiser.enable_graph); the per-kernel HIP-event "
+                         "roofline cannot be taken inside a graph, so the roofline fields are empty in this mode")
     ap.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a bench line)")
     ap.add_argument("--layout", action="store_true",
                     help="text+layout variant (examples/ctsd_35_df16_6views_video_generation_with_layout.json model: "
@@ -416,11 +419,13 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(rank)
     latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
     den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"]).prepare(latents, cond)
+    if args.graph:
+        den.enable_graph()
 
     ninf = w["inference_steps"]
 
     def step(i):
-        timer.enabled = i >= args.warmup
+        timer.enabled = i >= args.warmup and not args.graph
         if args.no_adapter_cache:
             model._adapter_cache = (None, None)
         den.step(i % ninf)

@@ -56,11 +56,15 @@ class CTSDDenoiser:
         self.schedule = FlowMatchEulerSchedule(shift=shift).set_timesteps(inference_steps)
         self.inference_steps = inference_steps
         self._ts_dev = None
+        self.use_graph = False
+        self._graph = None
+        self._side = None
 
     def prepare(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor],
                 image_latents: Optional[torch.Tensor] = None, reference_frame_count: int = 0,
                 diffusion_forcing: bool = False, take_time: int = 0, clear_reference_frame_count: int = 0):
         dev = latents.device
+        self._graph = None                                             # buffers below are re-created: capture again
         self.diffusion_forcing = diffusion_forcing
         self.take_time = take_time
         if diffusion_forcing and image_latents is not None:
@@ -96,8 +100,8 @@ class CTSDDenoiser:
             self.model_in[:B, :self.ref].copy_(r16)
             self.model_in[B:, :self.ref].copy_(r16)
 
-    def step(self, i: int):
-        """One denoise step = model forward at the CFG batch + guidance combine + scheduler update."""
+    def _step_inputs(self, i: int):
+        """(timesteps [2B,T,V] device fp32, sigma step: host float or device fp32 [B,T,V]) of step i"""
         B, T, V = self.latents.shape[:3]
         if self.diffusion_forcing:
             j = torch.arange(T)
@@ -106,13 +110,14 @@ class CTSDDenoiser:
             ts = self._ts_dev[idx].view(1, T, 1).expand(2 * B, T, V)
             in_range = (i - j * self.spi >= 0).to(self._sig_dev.device)
             dsig = torch.where(in_range, self._sig_dev[idx + 1] - self._sig_dev[idx], torch.zeros((), device=idx.device))
-            dsig = dsig.view(1, T, 1).expand(B, T, V).contiguous().float()
-        else:
-            ts = self._ts_dev[i].expand(2 * B, T, V)
-            if self.ref > 0:
-                ts = ts.clone()
-                ts[:, :self.ref] = 0
-            dsig = float(self.schedule.sigmas[i + 1] - self.schedule.sigmas[i])
+            return ts, dsig.view(1, T, 1).expand(B, T, V).contiguous().float()
+        ts = self._ts_dev[i].expand(2 * B, T, V)
+        if self.ref > 0:
+            ts = ts.clone()
+            ts[:, :self.ref] = 0
+        return ts, float(self.schedule.sigmas[i + 1] - self.schedule.sigmas[i])
+
+    def _step_body(self, ts: torch.Tensor, dsig):
         out, _, _ = self.model(self.model_in, ts, **self.conditions)
         pred = out[0]
         if torch.is_tensor(dsig):
@@ -121,6 +126,48 @@ class CTSDDenoiser:
         else:
             ops.cfg_euler_step(pred, self.latents, self.guidance_scale, dsig, model_in=self.model_in)
         self._inject_reference()
+
+    def step(self, i: int):
+        """One denoise step = model forward at the CFG batch + guidance combine + scheduler update."""
+        ts, dsig = self._step_inputs(i)
+        if self.use_graph:
+            self._graph_step(ts, dsig)
+        else:
+            self._step_body(ts, dsig)
+
+    # ---- whole-step HIP graph (SURVEY.md §8f-2): the ~600 launches of one step (model forward, CFG combine, scheduler
+    # update, reference re-injection) are captured once per prepare() and replayed; per-step inputs (timesteps, sigma
+    # steps) live in static device buffers that are refreshed before each replay.
+    def enable_graph(self, on: bool = True):
+        self.use_graph = on
+        self._graph = None
+        return self
+
+    def _graph_step(self, ts: torch.Tensor, dsig):
+        B, T, V = self.latents.shape[:3]
+        if not torch.is_tensor(dsig):
+            dsig = torch.full((B, T, V), dsig, dtype=torch.float32, device=self.latents.device)
+        if self._graph is None:
+            self._g_ts = ts.to(torch.float32).contiguous().clone()
+            self._g_dsig = dsig.clone()
+            # one eager pass on a side stream fills every cache the forward keeps (packed weights, adapter residuals,
+            # scratch buffers) and warms the allocator; the state it touched is restored before the capture
+            keep_lat, keep_in = self.latents.clone(), self.model_in.clone()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.latents.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._step_body(self._g_ts, self._g_dsig)
+            torch.cuda.current_stream().wait_stream(side)
+            self.latents.copy_(keep_lat)
+            self.model_in.copy_(keep_in)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._step_body(self._g_ts, self._g_dsig)
+        self._g_ts.copy_(ts)
+        self._g_dsig.copy_(dsig)
+        self._graph.replay()
 
     def result(self) -> torch.Tensor:
         if self.ref > 0:                                              # ctsd.py:1623-1627

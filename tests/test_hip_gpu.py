@@ -685,6 +685,31 @@ def test_denoise_modes_vs_oracle(dev, small_cfg, mode):
         assert torch.equal(out[:, :1].cpu(), img[:, :1])
 
 
+@pytest.mark.parametrize("mode", ["full", "reference_frames", "diffusion_forcing"])
+def test_denoise_step_graph_replay_equals_eager(dev, small_cfg, mode):
+    """Whole-step HIP graph (CTSDDenoiser.enable_graph): captured once, replayed per step with refreshed timestep /
+    sigma-step buffers - bit-identical latents to launching the same kernels eagerly."""
+    from opendwm_amd.pipeline import CTSDDenoiser
+    sd = _bf16_round_sd(O.make_state_dict(small_cfg, 0))
+    m = _hip_model(small_cfg, sd, dev)
+    inp = small_inputs(small_cfg, 0)
+    cond = to_dev({k: v for k, v in inp.items() if k not in ("sample", "timestep")}, dev)
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn(1, 3, 3, 16, 8, 12, generator=g).to(dev)
+    img = torch.randn(1, 3, 3, 16, 8, 12, generator=g).to(dev)
+    kw = {"full": {}, "reference_frames": dict(image_latents=img, reference_frame_count=1),
+          "diffusion_forcing": dict(image_latents=img, diffusion_forcing=True, take_time=0)}[mode]
+    steps = 6
+    eager = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=steps).run(lat, cond, stop=4, **kw)
+    den = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=steps).enable_graph()
+    graphed = den.run(lat, cond, stop=4, **kw)
+    assert den._graph is not None
+    _log("denoise_graph", mode=mode, equal=bool(torch.equal(eager, graphed)), rel=rel_err(graphed, eager))
+    assert torch.equal(eager, graphed)
+    again = den.run(lat, cond, stop=4, **kw)                     # a second prepare() re-captures on fresh buffers
+    assert torch.equal(again, eager)
+
+
 def test_full_width_block_stack_vs_oracle_on_device(dev):
     """BASELINE config-3 token geometry (6 views x 16 frames x 32x56 latents, CFG batch 2,
     d = 1536, 24 heads, 154 text tokens) with the first 6 layers of the schedule (dual blocks,
