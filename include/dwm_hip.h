@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 9
+#define DWM_ABI_VERSION 10
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -99,7 +99,7 @@ typedef struct dwm_gemm_args {
     dwm_rowmap2d a_map;                                         /* A rows                                    */
     dwm_rowmap2d c_map;                                         /* C, res and blend rows                     */
     int32_t ntaps; int32_t k_per_tap;
-    int64_t tap_shift[9];                                       /* in rows                                   */
+    int64_t tap_shift[27];                                      /* in rows; up to 3x3x3 taps (causal Conv3d) */
     /* split-K (PLAIN / RESID epilogues): when the tile grid fills less than half of the GPU and K is long, the K
      * axis is cut into ranges (one workgroup each), fp32 partial tiles go to `workspace` and a second kernel reduces
      * them in a fixed order and applies the epilogue.  workspace: 16-byte aligned device scratch of workspace_bytes
@@ -281,6 +281,26 @@ typedef struct dwm_gn_imgmap { int64_t iv, pn, s_ihi, s_ilo, s_phi; } dwm_gn_img
 int dwm_groupnorm_silu_mapped(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
                               const void* gamma, const void* beta, int32_t silu, float* stats,
                               const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream);
+
+/* CogVideoXSpatialNorm3D (diffusers autoencoder_kl_cogvideox; decoder norms of AutoencoderKLCogVideoX, selected by
+ * src/dwm/pipelines/ctsd.py:953-964):  y = silu?( GroupNorm(f) * conv_y(zq) + conv_b(zq) ) with zq nearest-resized to f.
+ * f rows are ordered (frame t, video b, y, x), I = videos, P = frames*h*w; the 1x1x1 convolutions are evaluated at
+ * latent resolution by the caller (one GEMM, N = 2C) and gathered here: f pixel (t, b, y, x) reads mod row
+ * ((zt[t]*videos + b)*hz + (y >> shift))*wz + (x >> shift), columns [0, C) = conv_y, [C, 2C) = conv_b. */
+typedef struct dwm_gn_zmap {
+    const void* mod; int64_t ld_mod;
+    int32_t frames, videos, h, w, shift;
+    int32_t zt[32];                 /* f frame -> zq frame (nearest, incl. the separate first frame of odd clips) */
+} dwm_gn_zmap;
+int dwm_groupnorm_spatial(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                          const void* gamma, const void* beta, int32_t silu, float* stats,
+                          const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap, void* stream);
+
+/* out frame j = w0[j] * x[f0[j]] + w1[j] * x[f1[j]] on frames of `frame_elems` contiguous bf16 elements: the temporal
+ * average pooling of CogVideoXDownsample3D (0.5 / 0.5, first frame of an odd clip kept) and the temporal nearest
+ * upsampling of CogVideoXUpsample3D (1 / 0 with repeated sources).  n_out <= 64. */
+typedef struct dwm_frame_mix { int32_t n_out; int32_t f0[64], f1[64]; float w0[64], w1[64]; } dwm_frame_mix;
+int dwm_frame_mix_bf16(const void* x, void* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream);
 
 /* F.interpolate(scale_factor=2, mode="nearest") of token-major x [I, h, w, C], written into the
  * padded grid y [I, 2h+2, 2w+2, C] (diffusers Upsample2D before its 3x3 conv). */

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
         ("blend", _vp), ("ld_blend", _i64), ("alpha", _vp), ("rows_per_alpha", _i64),
         ("rms_w", _vp), ("rms_ncols", _i64), ("rms_eps", _f32), ("reserved", _i32),
         ("a_map", RowMap2D), ("c_map", RowMap2D), ("ntaps", _i32), ("k_per_tap", _i32),
-        ("tap_shift", _i64 * 9),
+        ("tap_shift", _i64 * 27),
         ("workspace", _vp), ("workspace_bytes", _i64), ("split_k", _i32),
     ]
 
@@ -68,6 +68,15 @@ class LayerNormArgs(C.Structure):
 
 class GnImgMap(C.Structure):
     _fields_ = [("iv", _i64), ("pn", _i64), ("s_ihi", _i64), ("s_ilo", _i64), ("s_phi", _i64)]
+
+
+class GnZMap(C.Structure):
+    _fields_ = [("mod", _vp), ("ld_mod", _i64), ("frames", _i32), ("videos", _i32), ("h", _i32), ("w", _i32),
+                ("shift", _i32), ("zt", _i32 * 32)]
+
+
+class FrameMix(C.Structure):
+    _fields_ = [("n_out", _i32), ("f0", _i32 * 64), ("f1", _i32 * 64), ("w0", _f32 * 64), ("w1", _f32 * 64)]
 
 
 class RowCombineArgs(C.Structure):
@@ -113,6 +122,9 @@ SIGNATURES = {
     "dwm_groupnorm_silu_mapped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dwm_pad_tokens": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(RowMap2D), _vp]),
+    "dwm_groupnorm_spatial": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D),
+                                     C.POINTER(GnImgMap), C.POINTER(GnZMap), _vp]),
+    "dwm_frame_mix_bf16": (_i32, [_vp, _vp, _i64, C.POINTER(FrameMix), _vp]),
     "dwm_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
     # training
     "dwm_transpose_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),

@@ -36,7 +36,7 @@ struct ConvParams {
     int steps_per_tap;          // k_per_tap / BK
     FastDiv fd_steps;
     FastDiv fd_rpg, fd_rmod, fd_rpa;   // RESID: rows_per_gate, res_mod, rows_per_alpha
-    int64_t tap_shift[9];
+    int64_t tap_shift[27];
     // split-K: the K steps are cut into `ksplit` contiguous ranges, one workgroup per (tile, range); range s
     // writes its fp32 partial tile to ws + s * ws_slice ([M, N] row-major) and splitk_finish_kernel reduces
     int ksplit;
@@ -498,7 +498,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     };
     if (!mk(a->a_map, cp.a) || !mk(a->c_map, cp.c)) return DWM_EINVAL;
     const int ntaps = a->ntaps > 0 ? a->ntaps : 1;
-    if (ntaps > 9) return DWM_EINVAL;
+    if (ntaps > 27) return DWM_EINVAL;
     const int64_t kpt = a->ntaps > 0 ? a->k_per_tap : a->K;
     if (kpt <= 0 || kpt % BK != 0 || kpt * ntaps != a->K) return DWM_EINVAL;
     cp.steps_per_tap = (int)(kpt / BK);
@@ -507,7 +507,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     cp.fd_rpg = make_fastdiv((uint32_t)(a->rows_per_gate > 0 ? a->rows_per_gate : 1));
     cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : a->res_mod < 0 ? -a->res_mod : 1));
     cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
-    for (int t = 0; t < 9; ++t) cp.tap_shift[t] = (a->ntaps > 0 && t < ntaps) ? a->tap_shift[t] : 0;
+    for (int t = 0; t < 27; ++t) cp.tap_shift[t] = (a->ntaps > 0 && t < ntaps) ? a->tap_shift[t] : 0;
     if (a->lda < kpt) return DWM_EINVAL;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;

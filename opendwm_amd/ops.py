@@ -119,6 +119,41 @@ class TimeGrid:
         return [-self.vn, 0, self.vn]
 
 
+@dataclass
+class Grid3D:
+    """Input layout of a causal 3x3x3 convolution (CogVideoXCausalConv3d) run as a 27-tap implicit GEMM: token rows
+    ordered (frame t, video b, y, x) - a frame of all videos is one contiguous slab - with two context frames in
+    front of the clip and a zero spatial border: [T + 2, B, h + 2, w + 2, C].  Compact pixel m = ((t*B + b)*h + y)*w + x
+    lives at row ((t + 2)*B + b)*(h+2)(w+2) + (y+1)(w+2) + x + 1.  The context frames hold the previous chunk's last
+    two input frames (or the first frame twice); there is no trailing padding (causal)."""
+    T: int
+    B: int
+    h: int
+    w: int
+
+    @property
+    def frame_rows(self) -> int:          # rows of one padded frame slab (all videos)
+        return self.B * (self.h + 2) * (self.w + 2)
+
+    @property
+    def rows(self) -> int:
+        return (self.T + 2) * self.frame_rows
+
+    @property
+    def pixels(self) -> int:
+        return self.T * self.B * self.h * self.w
+
+    def fill(self, m: "_lib.RowMap2D") -> None:
+        m.rw, m.rh = self.w, self.h
+        m.rpitch, m.ipitch = self.w + 2, (self.h + 2) * (self.w + 2)
+        m.origin = 2 * self.frame_rows + self.w + 2 + 1
+
+    def tap_shifts(self):
+        """row shift of tap (dt, dy, dx) in the order of a [N, 3, 3, 3, C] weight; dt = 2 is the current frame"""
+        return [(dt - 2) * self.frame_rows + (dy - 1) * (self.w + 2) + (dx - 1)
+                for dt in range(3) for dy in range(3) for dx in range(3)]
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, epilogue: int = EPI_PLAIN, act: int = ACT_NONE,
          gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
@@ -576,10 +611,11 @@ def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
                    eps: float, silu: bool = True, out: Optional[torch.Tensor] = None,
-                   out_grid=None, img_map: Optional[tuple] = None) -> torch.Tensor:
+                   out_grid=None, img_map: Optional[tuple] = None, zmap: Optional[dict] = None) -> torch.Tensor:
     """GroupNorm(groups) [+ SiLU] of token-major x [I*P, C]; with out_grid the result lands in the
     interior of a padded grid `out` [out_grid.rows, C] whose border must already be zero.  img_map =
-    (iv, pn, s_ihi, s_ilo, s_phi): image i / pixel p -> token row (see dwm_groupnorm_silu_mapped)."""
+    (iv, pn, s_ihi, s_ilo, s_phi): image i / pixel p -> token row (see dwm_groupnorm_silu_mapped).
+    zmap = dict(mod [z rows, 2C], frames, videos, h, w, shift, zt): CogVideoXSpatialNorm3D (dwm_groupnorm_spatial)."""
     _chk2d(x, "x")
     if not x.is_contiguous() or x.shape[0] != I * P:
         raise RuntimeError("groupnorm_silu: x must be contiguous [I*P, C]")
@@ -598,9 +634,45 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
     im = _lib.GnImgMap()
     if img_map is not None:
         im.iv, im.pn, im.s_ihi, im.s_ilo, im.s_phi = img_map
+    if zmap is not None:
+        mod = zmap["mod"]
+        _chk2d(mod, "zmap.mod")
+        zm = _lib.GnZMap()
+        zm.mod, zm.ld_mod = mod.data_ptr(), mod.stride(0)
+        zm.frames, zm.videos, zm.h, zm.w, zm.shift = zmap["frames"], zmap["videos"], zmap["h"], zmap["w"], zmap["shift"]
+        for t, z in enumerate(zmap["zt"]):
+            zm.zt[t] = z
+        need = ((max(zmap["zt"]) + 1) * zmap["videos"]) * (zmap["h"] >> zmap["shift"]) * (zmap["w"] >> zmap["shift"])
+        if mod.shape[0] < need or mod.shape[1] < 2 * Cc:
+            raise RuntimeError("groupnorm_silu: zmap.mod is smaller than the latent grid it is indexed with")
+        _lib.check(_lib.load().dwm_groupnorm_spatial(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
+                                                     beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
+                                                     C.byref(zm), _stream()), "dwm_groupnorm_spatial")
+        return out
     _lib.check(_lib.load().dwm_groupnorm_silu_mapped(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
                                                      beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
                                                      _stream()), "dwm_groupnorm_silu_mapped")
+    return out
+
+
+def frame_mix(x: torch.Tensor, frame_elems: int, f0, f1, w0, w1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out frame j = w0[j] * x[f0[j]] + w1[j] * x[f1[j]] over frames of `frame_elems` contiguous bf16 elements of the
+    flat tensor x (temporal average pooling / temporal nearest upsampling of the CogVideoX VAE)."""
+    n = len(f0)
+    if x.dtype != bf16 or not x.is_cuda or not x.is_contiguous() or x.numel() % frame_elems != 0:
+        raise RuntimeError("frame_mix: x must be a contiguous bf16 device tensor of whole frames")
+    nin = x.numel() // frame_elems
+    if not (len(f1) == len(w0) == len(w1) == n) or n == 0 or n > 64 or max(max(f0), max(f1)) >= nin:
+        raise RuntimeError("frame_mix: bad frame tables")
+    if out is None:
+        out = torch.empty(n * frame_elems, dtype=bf16, device=x.device)
+    if out.numel() != n * frame_elems or out.dtype != bf16 or not out.is_contiguous():
+        raise RuntimeError("frame_mix: bad out")
+    fm = _lib.FrameMix()
+    fm.n_out = n
+    for j in range(n):
+        fm.f0[j], fm.f1[j], fm.w0[j], fm.w1[j] = f0[j], f1[j], w0[j], w1[j]
+    _lib.check(_lib.load().dwm_frame_mix_bf16(x.data_ptr(), out.data_ptr(), frame_elems, C.byref(fm), _stream()), "dwm_frame_mix_bf16")
     return out
 
 
