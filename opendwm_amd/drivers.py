@@ -44,6 +44,45 @@ def latent_sequence_length(frames: int, vae_pre: int = 0, vae_stride: int = 1) -
     return (frames - vae_pre) // vae_stride + (1 if vae_pre > 0 else 0)
 
 
+class LatentDecoder:
+    """latents [B, t, V, C, h, w] -> images [(b t v), 3, H, W], the decode tail of inference_pipeline (ctsd.py:1606-1647):
+    `vae.decode(latents / scaling_factor + shift_factor)` through memory_efficient_split_call chunks, then
+    VaeImageProcessor.postprocess(output_type="pt") = (x / 2 + 0.5).clamp(0, 1).
+
+    2-D VAE (opendwm_amd.vae.AutoencoderKL): frames are independent images "(b t v) c h w".  Temporal VAE
+    (opendwm_amd.vae_cogvideox.AutoencoderKLCogVideoX): clips "(b v) c t h w"; in diffusion-forcing mode a single
+    latent frame is decoded as [frame, zeros] and the first half of the 8 output frames is kept (:1611-1622)."""
+
+    def __init__(self, vae, memory_efficient_batch: int = -1, postprocess: bool = True):
+        from .vae_cogvideox import AutoencoderKLCogVideoX
+        self.vae, self.batch, self.postprocess = vae, memory_efficient_batch, postprocess
+        self.is_temporal_vae = isinstance(vae, AutoencoderKLCogVideoX)
+
+    def _split_call(self, x: torch.Tensor) -> torch.Tensor:
+        """dwm.functional.memory_efficient_split_call, src/dwm/functional.py:184-193"""
+        if self.batch == -1:
+            return self.vae.decode(x, return_dict=False)[0]
+        return torch.cat([self.vae.decode(c, return_dict=False)[0] for c in x.split(self.batch)])
+
+    def __call__(self, latents: torch.Tensor, diffusion_forcing: bool = False) -> torch.Tensor:
+        B, t, V = latents.shape[:3]
+        cfgv = self.vae.config
+        shift = cfgv.shift_factor if cfgv.shift_factor is not None else 0
+        x = latents.to(self.vae.dtype) / cfgv.scaling_factor + shift
+        if self.is_temporal_vae:
+            clips = x.permute(0, 2, 3, 1, 4, 5).flatten(0, 1)                   # b t v c h w -> (b v) c t h w
+            if diffusion_forcing:
+                if t != 1:
+                    raise ValueError("diffusion forcing decodes one queue slot at a time")
+                img = self.vae.decode(torch.cat([clips, clips * 0], 2), return_dict=False)[0].chunk(2, dim=2)[0]
+            else:
+                img = self._split_call(clips)
+            img = img.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5).flatten(0, 2)   # (b v) c t h w -> (b t v) c h w
+        else:
+            img = self._split_call(x.flatten(0, 2)) if not diffusion_forcing else self.vae.decode(x.flatten(0, 2), return_dict=False)[0]
+        return (img.float() / 2 + 0.5).clamp(0, 1) if self.postprocess else img
+
+
 @dataclass
 class Window:
     """One call of the per-window denoise loop."""
@@ -62,15 +101,16 @@ class Window:
 class AutoregressiveDriver:
     """denoiser: pipeline.CTSDDenoiser-like object with run(latents, conditions, stop=, start=, image_latents=,
     reference_frame_count=, diffusion_forcing=, take_time=, clear_reference_frame_count=) -> latents.
-    decode(latents [B, t, V, C, H, W]) -> images with dim 0 = (b t v); defaults to returning the latents
-    flattened the same way, so the driver is usable (and testable) without a VAE."""
+    decode(latents [B, t, V, C, H, W], diffusion_forcing=bool) -> images with dim 0 = (b t v), e.g. a LatentDecoder;
+    defaults to returning the latents flattened the same way, so the driver is usable (and testable) without a VAE."""
 
     def __init__(self, denoiser, inference_config: dict, diffusion_forcing: bool = False,
                  decode: Optional[Callable] = None, generator: Optional[torch.Generator] = None,
                  init_noise_sigma: float = 1.0, is_temporal_vae: bool = False):
         self.denoiser, self.cfg, self.df = denoiser, dict(inference_config), diffusion_forcing
-        self.decode = decode if decode is not None else (lambda lat: lat.flatten(0, 2))
-        self.generator, self.init_noise_sigma, self.is_temporal_vae = generator, init_noise_sigma, is_temporal_vae
+        self.decode = decode if decode is not None else (lambda lat, diffusion_forcing=False: lat.flatten(0, 2))
+        self.generator, self.init_noise_sigma = generator, init_noise_sigma
+        self.is_temporal_vae = is_temporal_vae or bool(getattr(decode, "is_temporal_vae", False))
 
     # ---------------------------------------------------------------- planning (pure host logic)
     def plan(self, latent_frames: int, total_frame_count: int, have_reference: bool) -> List[Window]:
@@ -135,7 +175,7 @@ class AutoregressiveDriver:
                 if w.carry == "all":
                     carried = lat
                     continue
-                img = self.decode(lat[:, w.take_time:w.take_time + 1])
+                img = self.decode(lat[:, w.take_time:w.take_time + 1], diffusion_forcing=True)
                 images.append(img.chunk(4)[-1] if w.quarter else img)
                 keep = (torch.arange(T, device=lat.device) <= w.take_time).view(1, T, 1, 1, 1, 1)
                 carried = torch.where(keep, carried, lat)
@@ -163,7 +203,7 @@ class StreamingDriver:
     def __init__(self, denoiser, inference_config: dict, decode: Optional[Callable] = None,
                  generator: Optional[torch.Generator] = None, init_noise_sigma: float = 1.0):
         self.denoiser, self.cfg = denoiser, dict(inference_config)
-        self.decode = decode if decode is not None else (lambda lat: lat.flatten(0, 2))
+        self.decode = decode if decode is not None else (lambda lat, diffusion_forcing=False: lat.flatten(0, 2))
         self.generator, self.init_noise_sigma = generator, init_noise_sigma
         self.latent_shape = None
 
@@ -185,7 +225,7 @@ class StreamingDriver:
         lat = self.denoiser.run(self.latents, self.conditions, stop=stop, start=start, image_latents=self.latents,
                                 diffusion_forcing=True, take_time=take_time)
         if stop >= self.cfg["inference_steps"]:                                   # :2092-2101
-            self.frames.append(self.decode(lat[:, take_time:take_time + 1]))
+            self.frames.append(self.decode(lat[:, take_time:take_time + 1], diffusion_forcing=True))
         return lat
 
     def _queue(self, frame_conditions: Dict, slide: bool):

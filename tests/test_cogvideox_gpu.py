@@ -186,3 +186,30 @@ def test_rejects_cpu_and_bad_rank(dev):
         m.decode(torch.zeros(1, 16, 1, 4, 6))
     with pytest.raises(ValueError):
         m.decode(torch.zeros(1, 16, 4, 6, device=dev))
+
+
+def test_latent_decoder_layouts(dev):
+    """drivers.LatentDecoder: "(b v) c t h w" clips for the temporal VAE, the [frame, zeros] trick of the
+    diffusion-forcing decode (ctsd.py:1606-1622), scaling / shift, postprocess to [0, 1]"""
+    from opendwm_amd.drivers import LatentDecoder
+    cfg = small_cfg()
+    sd = _bf_sd(CV.make_state_dict(cfg, 1))
+    m = _model(cfg, sd, dev)
+    dec = LatentDecoder(m)
+    assert dec.is_temporal_vae
+    B, T, V = 1, 3, 2
+    lat = torch.randn(B, T, V, 16, 4, 6, generator=torch.Generator().manual_seed(6)).to(bf16).float()
+    z = (lat / cfg["scaling_factor"]).to(bf16).float().permute(0, 2, 3, 1, 4, 5).flatten(0, 1)
+    ref = CV.decode(sd, cfg, z)                                               # (b v) c t h w
+    want = (ref.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5).flatten(0, 2) / 2 + 0.5).clamp(0, 1)
+    got = dec(lat.to(dev))
+    e = rel_err(got, want)
+    assert got.shape == (B * 9 * V, 3, 32, 48) and e < TOL_MODEL
+    one = lat[:, 1:2]
+    z1 = (one / cfg["scaling_factor"]).to(bf16).float().permute(0, 2, 3, 1, 4, 5).flatten(0, 1)
+    ref1 = CV.decode(sd, cfg, torch.cat([z1, z1 * 0], 2)).chunk(2, dim=2)[0]
+    want1 = (ref1.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5).flatten(0, 2) / 2 + 0.5).clamp(0, 1)
+    got1 = dec(one.to(dev), diffusion_forcing=True)
+    e1 = rel_err(got1, want1)
+    _log("latent_decoder_tvae", rel_clip=e, rel_df_frame=e1)
+    assert got1.shape == (B * 4 * V, 3, 32, 48) and e1 < TOL_MODEL
