@@ -125,8 +125,9 @@ act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* 
         if (BWD) unpack8(*(const uint4*)(dy + i * 8), d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (!BWD) v[j] = ACT == DWM_ACT_GELU_TANH ? gelu_tanh_f(v[j]) : silu_f(v[j]);
-            else v[j] = d[j] * (ACT == DWM_ACT_GELU_TANH ? gelu_tanh_grad(v[j]) : silu_grad(v[j]));
+            if (!BWD) v[j] = ACT == DWM_ACT_GELU_TANH ? gelu_tanh_f(v[j]) : ACT == DWM_ACT_RELU ? fmaxf(v[j], 0.f) : silu_f(v[j]);
+            else v[j] = ACT == DWM_ACT_RELU ? (v[j] > 0.f ? d[j] : 0.f)          // x may be the pre- or the post-activation
+                                            : d[j] * (ACT == DWM_ACT_GELU_TANH ? gelu_tanh_grad(v[j]) : silu_grad(v[j]));
         }
         *(uint4*)(out + i * 8) = pack8(v);
     }
@@ -498,6 +499,7 @@ extern "C" int dwm_act_fwd(const void* x, void* y, int64_t n, int32_t act, void*
     hipStream_t s = (hipStream_t)stream;
     if (act == DWM_ACT_GELU_TANH) hipLaunchKernelGGL((act_kernel<DWM_ACT_GELU_TANH, false>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, nullptr, (bf16_t*)y, n / 8);
     else if (act == DWM_ACT_SILU) hipLaunchKernelGGL((act_kernel<DWM_ACT_SILU, false>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, nullptr, (bf16_t*)y, n / 8);
+    else if (act == DWM_ACT_RELU) hipLaunchKernelGGL((act_kernel<DWM_ACT_RELU, false>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, nullptr, (bf16_t*)y, n / 8);
     else return DWM_EINVAL;
     DWM_RET();
 }
@@ -508,6 +510,7 @@ extern "C" int dwm_act_bwd(const void* x, const void* dy, void* dx, int64_t n, i
     hipStream_t s = (hipStream_t)stream;
     if (act == DWM_ACT_GELU_TANH) hipLaunchKernelGGL((act_kernel<DWM_ACT_GELU_TANH, true>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
     else if (act == DWM_ACT_SILU) hipLaunchKernelGGL((act_kernel<DWM_ACT_SILU, true>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+    else if (act == DWM_ACT_RELU) hipLaunchKernelGGL((act_kernel<DWM_ACT_RELU, true>), dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
     else return DWM_EINVAL;
     DWM_RET();
 }

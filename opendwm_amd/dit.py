@@ -251,8 +251,6 @@ class DiTCrossviewTemporalConditionModel(_Base):
                      "added_time_ids", "noise", "return_dict"]
             kw = dict(zip(names, args))
             kw.update(kwargs)
-            if kw.get("condition_image_tensor") is not None and self.condition_image_adapter is not None:
-                raise NotImplementedError("training with the layout ImageAdapter is not implemented")
             squeeze = sample.dim() < 6
             if squeeze:
                 sample, timestep = sample.unsqueeze(2), timestep.unsqueeze(2)
@@ -262,7 +260,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
             out = _train.forward_train(self, sample, timestep, kw.get("encoder_hidden_states"), kw.get("pooled_projections"),
                                        disable_crossview=kw.get("disable_crossview"), disable_temporal=kw.get("disable_temporal"),
                                        crossview_attention_mask=kw.get("crossview_attention_mask"),
-                                       added_time_ids=kw.get("added_time_ids"))
+                                       added_time_ids=kw.get("added_time_ids"),
+                                       condition_image_tensor=kw.get("condition_image_tensor"))
             if squeeze:
                 out = out.squeeze(2)
             if kw.get("return_dict"):

@@ -537,13 +537,142 @@ class OutFn(torch.autograd.Function):
         return (None, None, dh, dst) + _grads_for(G, ps, ctx.needs_input_grad[4:])
 
 
+# ------------------------------------------------------------------------------------------ layout ImageAdapter
+def _conv3_wgrad(dh: torch.Tensor, x_pad: torch.Tensor, grid, idx: torch.Tensor) -> torch.Tensor:
+    """dW [N, 9*C] (tap-major, bf16) of h = conv3x3(x): dW[n, t, c] = sum_pixels dh[pixel, n] * x_pad[row(pixel) + shift_t, c].
+    One weight-gradient GEMM per tap; its activation operand is the tap-shifted gather of the padded grid, transposed so
+    that the pixel contraction runs along rows (as in train_ops.linear_wgrad)."""
+    N, Cc = dh.shape[1], x_pad.shape[1]
+    dw = torch.empty((N, 9 * Cc), dtype=bf16, device=dh.device)
+    dht = T.transpose(dh)                                              # [N, Pp]
+    for t, sh in enumerate(grid.tap_shifts()):
+        xt = T.transpose(x_pad[idx + sh])                              # [C, Pp]: rows of tap t for every pixel
+        ops.gemm(dht, xt, None, out=dw[:, t * Cc:(t + 1) * Cc])
+    return dw
+
+
+def _conv3_flip(w: torch.Tensor) -> torch.Tensor:
+    """weight of the input-gradient convolution: [N, C, 3, 3] -> tap-major [C, 9*N] with the taps mirrored"""
+    return STORE.derived(w, "c3flip", lambda: _bf(w).flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous())
+
+
+class AdapterFn(torch.autograd.Function):
+    """dwm.models.adapters.ImageAdapter (src/dwm/models/adapters.py:40-60) with a hand-written backward.  Forward =
+    the inference path (opendwm_amd.adapters.ImageAdapter.run) keeping only the condition images (the reference wraps
+    the adapter body in gradient checkpointing, adapters.py:44-52); backward recomputes the body level by level, keeping
+    each resnet's input grid and ReLU output, then walks it in reverse: 1x1 convolutions as GEMMs, the 3x3 input gradient
+    as the implicit GEMM with mirrored taps, the 3x3 weight gradient as nine tap-shifted GEMMs."""
+
+    @staticmethod
+    def forward(ctx, adapter, x, *params):
+        ctx.adapter = adapter
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return tuple(adapter.run(x))
+
+    @staticmethod
+    def backward(ctx, *dfeats):
+        from .ops import ACT_RELU, EPI_RESID, PaddedGrid
+        (x,) = ctx.saved_tensors
+        ad = ctx.adapter
+        G = Grads()
+        x = x.flatten(0, -4).contiguous()
+        if x.dtype not in (torch.float32, bf16):
+            x = x.to(bf16)
+        I, _, H, W = x.shape
+        r = ad.downscale_factor
+        h, w = H // r, W // r
+        # ---- recompute, keeping what the backward needs
+        cur = ops.unshuffle_tokens(x, r)
+        levels = []
+        xp, grid, idx = None, None, None
+        for bi, (blk, zc) in enumerate(zip(ad.body, ad.zero_convs)):
+            if blk.downsample is not None:
+                if bi != 0:
+                    raise NotImplementedError("adapter backward: AvgPool2d only in the first block (every shipped DiT layout config)")
+                cur = ops.avgpool2_tokens(cur, I, h, w)
+                h, w = h // 2, w // 2
+            if grid is None:
+                grid = PaddedGrid(I, h, w)
+                idx = grid.interior_index().to(x.device)
+            lv = {"blk": blk, "zc": zc, "in": None, "res": []}
+            if xp is None:
+                if blk.in_conv is None:
+                    raise NotImplementedError("adapter backward: the first block needs an in_conv")
+                wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1)
+                if wi.shape[1] != cur.shape[1]:
+                    wpad = torch.zeros((wi.shape[0], cur.shape[1]), dtype=bf16, device=wi.device)
+                    wpad[:, :wi.shape[1]] = wi
+                    wi = wpad
+                xp = ops.gemm(cur, wi.contiguous(), _bf(blk.in_conv.bias), c_grid=grid)
+                lv["in"] = ("first", cur)
+            elif blk.in_conv is not None:
+                wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1).contiguous()
+                lv["in"] = ("grid", xp)
+                xp = ops.gemm(xp, wi, _bf(blk.in_conv.bias), a_grid=grid, c_grid=grid)
+            for res in blk.resnets:
+                pk = res.packed()
+                h1 = ops.gemm(xp, pk["w3"], _bf(res.block1.bias), act=ACT_RELU, a_grid=grid, conv3x3=True)
+                xn = ops.gemm(h1, pk["w1"], _bf(res.block2.bias), epilogue=EPI_RESID, res=xp, c_grid=grid)
+                lv["res"].append((res, xp, h1))
+                xp = xn
+            lv["out"] = xp
+            levels.append(lv)
+        # ---- backward, last level first; dx: gradient w.r.t. the level's output grid (padded rows, zero border)
+        dx = None
+        for lv, df in zip(reversed(levels), reversed(dfeats)):
+            if df is not None:
+                df = df.to(bf16).contiguous()
+                zc = lv["zc"]
+                if zc is not None:
+                    xc = lv["out"][idx]                                           # compact rows of the level output
+                    dwz, dbz = T.linear_wgrad(df, xc, want_bias=True)
+                    G.add(zc.weight, dwz)
+                    G.add(zc.bias, dbz)
+                    wz_t = w_t(zc.weight)
+                    dx = ops.gemm(df, wz_t, None, c_grid=grid) if dx is None else \
+                        ops.gemm(df, wz_t, None, epilogue=EPI_RESID, res=dx, out=dx, c_grid=grid)
+                else:
+                    dpad = ops.pad_tokens(df, grid)
+                    dx = dpad if dx is None else T.rowcombine(dx, b=dpad)
+            if dx is None:
+                continue
+            for res, xin, h1 in reversed(lv["res"]):
+                dyc = dx[idx]                                                     # compact gradient of the block output
+                dw1, db1 = T.linear_wgrad(dyc, h1, want_bias=True)
+                G.add(res.block2.weight, dw1)
+                G.add(res.block2.bias, db1)
+                dh1 = T.linear_dgrad(dyc, w_t(res.block2.weight))
+                T.act_bwd(h1, dh1, ACT_RELU, out=dh1)
+                G.add(res.block1.bias, T.segsum(dh1)[0])
+                G.add(res.block1.weight, _conv3_wgrad(dh1, xin, grid, idx).view(dh1.shape[1], 3, 3, -1).permute(0, 3, 1, 2))
+                dhp = ops.pad_tokens(dh1, grid)
+                ops.gemm(dhp, _conv3_flip(res.block1.weight), None, a_grid=grid, conv3x3=True, epilogue=EPI_RESID, res=dx,
+                         out=dx, c_grid=grid)                                     # dx += conv3x3^T(dh1), in place
+            kind = lv["in"]
+            if kind is not None:
+                blk = lv["blk"]
+                dxc = dx[idx]
+                if kind[0] == "first":
+                    dwi, dbi = T.linear_wgrad(dxc, kind[1], want_bias=True)
+                    ci = blk.in_conv.weight.shape[1]
+                    G.add(blk.in_conv.weight, dwi[:, :ci].contiguous())
+                    G.add(blk.in_conv.bias, dbi)
+                    dx = None                                                     # the condition images carry no gradient
+                else:
+                    dwi, dbi = T.linear_wgrad(dxc, kind[1][idx], want_bias=True)
+                    G.add(blk.in_conv.weight, dwi)
+                    G.add(blk.in_conv.bias, dbi)
+                    dx = ops.gemm(dxc, w_t(blk.in_conv.weight), None, c_grid=grid)
+        ps = _params(ad)
+        return (None, None) + _grads_for(G, ps, ctx.needs_input_grad[2:])
+
+
 # ------------------------------------------------------------------------------------------ model forward
 def forward_train(model, sample, timestep, encoder_hidden_states, pooled_projections, disable_crossview=None,
-                  disable_temporal=None, crossview_attention_mask=None, added_time_ids=None):
+                  disable_temporal=None, crossview_attention_mask=None, added_time_ids=None, condition_image_tensor=None):
     """Autograd-enabled forward of DiTCrossviewTemporalConditionModel (text-conditioned configuration;
     crossview_temporal_dit.py:372-630).  Returns the prediction [B, T, V, C, H, W] (bf16) with a grad_fn."""
-    if model.condition_image_adapter is not None:
-        raise NotImplementedError("training with the layout ImageAdapter is not implemented (its conv backward is missing)")
     B, Tn, V, _, H, W = sample.shape
     p = model._cfg.patch_size
     height, width = H // p, W // p
@@ -573,7 +702,17 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
     if model.enable_temporal and disable_temporal is None:
         disable_temporal = torch.zeros(B, dtype=torch.bool, device=dev)
 
+    residuals: List[torch.Tensor] = []
+    if model.condition_image_adapter is not None and condition_image_tensor is not None:            # :459-462
+        ad = model.condition_image_adapter
+        residuals = list(AdapterFn.apply(ad, condition_image_tensor, *_params(ad)))
+        for f in residuals:
+            if f.shape != h.shape:
+                raise RuntimeError(f"condition residual {tuple(f.shape)} does not match hidden states {tuple(h.shape)}")
+
     for i, block in enumerate(model.transformer_blocks):
+        if residuals:
+            h = AddFn.apply(h, residuals.pop(0))                                                   # :491-494
         h, c = joint_block_train(block, h, c, st, I)
         if model.enable_temporal and i in model.temporal_block_layers:
             k = model.temporal_block_layers.index(i)
