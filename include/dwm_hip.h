@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 10
+#define DWM_ABI_VERSION 11
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -265,7 +265,7 @@ int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream);
  * on token-major activations x [I, P, C] (P = pixels per image).
  * ---------------------------------------------------------------------- */
 /* torch.nn.GroupNorm(G, C, eps) [+ SiLU]: statistics over (P, C/G) per image and group (fp32,
- * `stats` = caller scratch of 2*G*I floats), y = (x - mean) * rstd * gamma + beta [then x*sigmoid(x)].
+ * `stats` = caller scratch of dwm_groupnorm_stats_floats(I, P, G) floats), y = (x - mean) * rstd * gamma + beta [then x*sigmoid(x)].
  * If out_map (rw > 0) is given, y is written into the zero-padded token grid that feeds a 3x3
  * implicit-GEMM convolution (borders must have been zeroed once by the caller).  C/G % 4 == 0. */
 int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
@@ -278,6 +278,10 @@ int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, 
  * I = B*V, P = T*h*w, iv = V, pn = h*w, s_ihi = T*V*h*w, s_ilo = h*w, s_phi = V*h*w.  out_map then maps the
  * token row (not the image-local pixel).  C/G == 4 or >= 8. */
 typedef struct dwm_gn_imgmap { int64_t iv, pn, s_ihi, s_ilo, s_phi; } dwm_gn_imgmap;
+/* fp32 elements the `stats` scratch of the dwm_groupnorm_* entry points needs for I images of P pixels and G groups: the
+ * final (sum, sumsq) per image and group plus the per-chunk partial sums that are added in a fixed order (the
+ * statistics, and with them every GroupNorm output, are bit-reproducible from run to run). */
+int64_t dwm_groupnorm_stats_floats(int64_t I, int64_t P, int32_t G);
 int dwm_groupnorm_silu_mapped(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
                               const void* gamma, const void* beta, int32_t silu, float* stats,
                               const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream);

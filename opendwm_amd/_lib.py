@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -122,6 +122,7 @@ SIGNATURES = {
     "dwm_groupnorm_silu_mapped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dwm_pad_tokens": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(RowMap2D), _vp]),
+    "dwm_groupnorm_stats_floats": (_i64, [_i64, _i64, _i32]),
     "dwm_groupnorm_spatial": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D),
                                      C.POINTER(GnImgMap), C.POINTER(GnZMap), _vp]),
     "dwm_frame_mix_bf16": (_i32, [_vp, _vp, _i64, C.POINTER(FrameMix), _vp]),

@@ -20,17 +20,16 @@ DWM_DEVINL int64_t img_row(const ImgMap& m, int64_t i, int64_t p, int64_t P) {
 
 // ---- GroupNorm statistics: x token-major [rows, C], G groups of CG = C/G channels (CG == 4 or CG >= 8:
 // the 8 channels of a 16-B chunk then span at most two groups).  grid (chunks, I); each block reduces
-// ppb pixels for all groups of image i and atomically adds (sum, sumsq) into stats[i][g][2] (fp32,
-// zeroed by the entry point's memset).
+// ppb pixels for all groups of image i into part[i][chunk][2G]; gn_finalize_kernel adds the chunks.  Every sum runs
+// in a fixed order (per-thread partials -> LDS -> one thread per group -> one thread per statistic): the result does
+// not depend on scheduling, so the whole UNet / VAE is bit-reproducible from run to run.
 __global__ void __launch_bounds__(256)
-gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ stats, ImgMap im) {
-    extern __shared__ float red[];            // [2 * G]
+gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ part, ImgMap im) {
+    extern __shared__ float red[];            // [pstep][C8][4]: (sum, sumsq) of the two groups a chunk can touch
     const int i = blockIdx.y;
     const int C8 = C >> 3, CG = C / G;
     const int64_t p0 = (int64_t)blockIdx.x * ppb;
     const int64_t p1 = p0 + ppb < P ? p0 + ppb : P;
-    for (int t = threadIdx.x; t < 2 * G; t += 256) red[t] = 0.f;
-    __syncthreads();
     const int TW = C8 < 256 ? C8 : 256;       // threads across channel chunks
     const int prow = threadIdx.x / TW, pstep = 256 / TW;
     if (prow < pstep) {
@@ -47,16 +46,35 @@ gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t p
                     else { s1 += v[j]; q1 += v[j] * v[j]; }
                 }
             }
-            atomicAdd(&red[2 * g0], s0);
-            atomicAdd(&red[2 * g0 + 1], q0);
-            if (bnd < 8) {
-                atomicAdd(&red[2 * g0 + 2], s1);
-                atomicAdd(&red[2 * g0 + 3], q1);
-            }
+            float* r = red + ((size_t)prow * C8 + c8) * 4;
+            r[0] = s0; r[1] = q0; r[2] = s1; r[3] = q1;
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * G; t += 256) atomicAdd(&stats[(int64_t)i * 2 * G + t], red[t]);
+    // group g collects chunks [g*CG/8, ((g+1)*CG - 1)/8]: first slot of a chunk if the chunk starts in g, else second
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float s = 0.f, q = 0.f;
+        const int c_lo = (g * CG) >> 3, c_hi = ((g + 1) * CG - 1) >> 3;
+        for (int c8 = c_lo; c8 <= c_hi; ++c8) {
+            const int slot = ((c8 * 8) / CG == g) ? 0 : 2;
+            for (int pr = 0; pr < pstep; ++pr) {
+                const float* r = red + ((size_t)pr * C8 + c8) * 4 + slot;
+                s += r[0]; q += r[1];
+            }
+        }
+        float* o = part + (((int64_t)i * gridDim.x + blockIdx.x) * G + g) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nchunks, int G2) {
+    const int i = blockIdx.x;
+    for (int t = threadIdx.x; t < G2; t += 64) {
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c) s += part[((int64_t)i * nchunks + c) * G2 + t];
+        stats[(int64_t)i * G2 + t] = s;
+    }
 }
 
 // ---- y = silu?( (x - mean) * rstd * gamma + beta ), written compact or into a padded grid.
@@ -246,6 +264,17 @@ inline int finish() {
 
 }  // namespace
 
+static int64_t gn_pixels_per_block(int64_t I, int64_t P) {
+    int64_t ppb = (I * P + 2047) / 2048;
+    return ppb < 64 ? 64 : ppb > 2048 ? 2048 : ppb;
+}
+
+extern "C" int64_t dwm_groupnorm_stats_floats(int64_t I, int64_t P, int32_t G) {
+    if (I <= 0 || P <= 0 || G <= 0) return 0;
+    const int64_t ppb = gn_pixels_per_block(I, P);
+    return 2 * (int64_t)G * I * (1 + (P + ppb - 1) / ppb);
+}
+
 static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
                           const void* gamma, const void* beta, int32_t silu, float* stats,
                           const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap, void* stream) {
@@ -264,13 +293,16 @@ static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t 
         im.iv = make_fastdiv(1); im.pn = make_fastdiv(1); im.s_ihi = im.s_ilo = im.s_phi = 0;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * G * I, s);
-    if (e != hipSuccess) return (int)e;
     // pixels per statistics block: enough blocks to fill the chip even for a dozen images (temporal GroupNorm: I = B*V)
-    int64_t ppb = (I * P + 2047) / 2048;
-    ppb = ppb < 64 ? 64 : ppb > 2048 ? 2048 : ppb;
-    const dim3 grid((unsigned)((P + ppb - 1) / ppb), (unsigned)I);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), sizeof(float) * 2 * G, s, (const bf16_t*)x, P, C, G, ppb, stats, im);
+    const int64_t ppb = gn_pixels_per_block(I, P);
+    const int nchunks = (int)((P + ppb - 1) / ppb);
+    const int C8 = C / 8, TW = C8 < 256 ? C8 : 256;
+    const size_t lds = sizeof(float) * 4 * (size_t)(256 / TW) * C8;
+    if (lds > 64 * 1024) return DWM_EUNSUPPORTED;
+    float* part = stats + 2 * (int64_t)G * I;             // [I][nchunks][2G] behind the final statistics
+    const dim3 grid((unsigned)nchunks, (unsigned)I);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds, s, (const bf16_t*)x, P, C, G, ppb, part, im);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)I), dim3(64), 0, s, (const float*)part, stats, nchunks, 2 * G);
     PadMap pm;
     pm.enabled = out_map != nullptr && out_map->rw > 0;
     if (pm.enabled) {

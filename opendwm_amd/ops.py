@@ -627,7 +627,7 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
         out = (torch.zeros if out_grid is not None else torch.empty)((rows, Cc), dtype=bf16, device=x.device)
     if out.shape != (rows, Cc) or not out.is_contiguous() or out.dtype != bf16:
         raise RuntimeError("groupnorm_silu: bad out")
-    stats = torch.empty(2 * groups * I, dtype=torch.float32, device=x.device)
+    stats = torch.empty(_lib.load().dwm_groupnorm_stats_floats(I, P, groups), dtype=torch.float32, device=x.device)
     m = _lib.RowMap2D()
     if out_grid is not None:
         out_grid.fill(m)

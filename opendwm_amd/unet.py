@@ -368,8 +368,8 @@ class UNetCrossviewTemporalConditionModel(_Base):
                  condition_image_adapter_config=None, depth_net_config=None, depth_frustum_range=None,
                  enforce_align_projection=None):
         nn.Module.__init__(self)
-        if condition_image_adapter_config is not None or depth_net_config is not None or enforce_align_projection is not None:
-            raise NotImplementedError("UNet: condition_image_adapter / depth_net / align projection are not built")
+        if depth_net_config is not None or enforce_align_projection is not None:
+            raise NotImplementedError("UNet: depth_net / align projection are not built")
         n = len(block_out_channels)
         as_list = lambda v: [v] * n if isinstance(v, int) else list(v)
         heads, lpb, tl = as_list(num_attention_heads), as_list(layers_per_block), as_list(transformer_layers_per_block)
@@ -428,6 +428,10 @@ class UNetCrossviewTemporalConditionModel(_Base):
         self.conv_norm_out = nn.GroupNorm(32, c0, eps=1e-5)
         self.conv_out = nn.Conv2d(c0, out_channels, 3, padding=1)
         self.condition_image_adapter = None
+        if condition_image_adapter_config is not None:                  # crossview_temporal_unet.py: layout ImageAdapter
+            from .adapters import ImageAdapter
+            self.condition_image_adapter = ImageAdapter(**condition_image_adapter_config)
+        self._adapter_cache = (None, None)
         self.depth_net = None
         self.depth_frustum_range = depth_frustum_range
         self._scratch = _Scratch()
@@ -455,6 +459,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
         STORE.bump()
         self._scratch = _Scratch()
         self._text_ctx = None
+        self._adapter_cache = (None, None)
         return out
 
     def load_state_dict(self, state_dict, *a, **kw):
@@ -507,6 +512,22 @@ class UNetCrossviewTemporalConditionModel(_Base):
         pin = ops.pad_tokens(tok, grid, out=self._scratch.get("in", grid.rows, 64, dev))
         wci = STORE.derived(self.conv_in.weight, "c3", lambda: _conv3_w(self.conv_in.weight, c_pad=64))
         x = ops.gemm(pin, wci, _bf(self.conv_in.bias), a_grid=grid, conv3x3=True)
+        # layout residuals (:717-729, 748-750): one after conv_in, one after every down block - added in place, so the
+        # block's last skip connection carries the sum as in the reference.  Step-invariant: cached on the tensor identity.
+        residuals = []
+        if self.condition_image_adapter is not None and condition_image_tensor is not None:
+            key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape), STORE.step)
+            if self._adapter_cache[0] != key:
+                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor), condition_image_tensor)
+            residuals = list(self._adapter_cache[1])
+
+        def add_residual(t):
+            if residuals:
+                f = residuals.pop(0)
+                if f.shape != t.shape:
+                    raise RuntimeError(f"UNet: layout residual {tuple(f.shape)} does not match the feature map {tuple(t.shape)}")
+                ops.add_(t, f)
+        add_residual(x)
 
         # 3. down
         skips = [(x, H, W)]
@@ -526,6 +547,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
                 x = ops.gemm(pad, wd, _bf(conv.bias), a_grid=gr, conv3x3=True, stride2="sym")
                 h_, w_ = h_ // 2, w_ // 2
                 skips.append((x, h_, w_))
+            add_residual(x)
         # 4. mid
         g = g0.at(h_, w_)
         x = self.mid_block.resnets[0].run(x, silu_emb, g, disable_temporal)

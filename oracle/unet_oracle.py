@@ -197,9 +197,12 @@ def _block_plan(cfg: dict):
 
 def unet_forward(sd: SD, cfg: dict, sample: Tensor, timesteps: Tensor, encoder_hidden_states: Tensor,
                  added_time_ids: Optional[Tensor] = None, disable_crossview: Optional[Tensor] = None,
-                 disable_temporal: Optional[Tensor] = None, crossview_attention_mask: Optional[Tensor] = None) -> Tensor:
-    """UNetCrossviewTemporalConditionModel.forward (crossview_temporal_unet.py:648-835) without adapter / depth net;
-    sample [B,T,V,C,H,W] -> noise prediction of the same shape."""
+                 disable_temporal: Optional[Tensor] = None, crossview_attention_mask: Optional[Tensor] = None,
+                 condition_image_tensor: Optional[Tensor] = None) -> Tensor:
+    """UNetCrossviewTemporalConditionModel.forward (crossview_temporal_unet.py:648-835) without depth net;
+    sample [B,T,V,C,H,W] -> noise prediction of the same shape.  With cfg["condition_image_adapter_config"] and a
+    condition_image_tensor the layout ImageAdapter residuals are added after conv_in and after every down block
+    (:717-755; the last skip of the block is the sum)."""
     B, T, V, _, H, W = sample.shape
     eps = cfg["norm_eps"]
     down, mid, up = _block_plan(cfg)
@@ -213,7 +216,13 @@ def unet_forward(sd: SD, cfg: dict, sample: Tensor, timesteps: Tensor, encoder_h
     if disable_temporal is None:
         disable_temporal = torch.zeros(B, dtype=torch.bool, device=sample.device)
 
+    residuals = []
+    if cfg.get("condition_image_adapter_config") is not None and condition_image_tensor is not None:
+        from .ctsd_oracle import image_adapter
+        residuals = list(image_adapter(sd, cfg, condition_image_tensor))
     x = conv2d(sd, "conv_in", sample.flatten(0, 2)).unflatten(0, (B, T, V))
+    if residuals:
+        x = x + residuals.pop(0)
     skips = [x]
 
     def tm(p, heads, nl, h):
@@ -229,6 +238,9 @@ def unet_forward(sd: SD, cfg: dict, sample: Tensor, timesteps: Tensor, encoder_h
         if blk["downsample"]:
             x = conv2d(sd, f"down_blocks.{i}.downsamplers.0.conv", x.flatten(0, 2), stride=2).unflatten(0, (B, T, V))
             skips.append(x)
+        if residuals:
+            x = x + residuals.pop(0)
+            skips[-1] = x
     x = res_block(sd, "mid_block.resnets.0", x, emb, disable_temporal, eps)
     x = tm("mid_block.attentions.0", mid["heads"], mid["tlayers"], x)
     x = res_block(sd, "mid_block.resnets.1", x, emb, disable_temporal, eps)
@@ -331,6 +343,20 @@ def unet_param_shapes(cfg: dict) -> Dict[str, tuple]:
             conv(f"up_blocks.{i}.upsamplers.0.conv", blk["channels"], blk["channels"])
     norm("conv_norm_out", c0)
     conv("conv_out", c0, cfg["out_channels"])
+    ac = cfg.get("condition_image_adapter_config")
+    if ac is not None:                                   # dwm.models.adapters.ImageAdapter (adapters.py:6-38)
+        cin = ac.get("in_channels", 3) * ac.get("downscale_factor", 8) ** 2
+        for i, ch in enumerate(ac["channels"]):
+            b = f"condition_image_adapter.body.{i}"
+            prev = cin if i == 0 else ac["channels"][i - 1]
+            if prev != ch:
+                S[b + ".in_conv.weight"], S[b + ".in_conv.bias"] = (ch, prev, 1, 1), (ch,)
+            for j in range(ac.get("num_res_blocks", 2)):
+                S[f"{b}.resnets.{j}.block1.weight"], S[f"{b}.resnets.{j}.block1.bias"] = (ch, ch, 3, 3), (ch,)
+                S[f"{b}.resnets.{j}.block2.weight"], S[f"{b}.resnets.{j}.block2.bias"] = (ch, ch, 1, 1), (ch,)
+            if ac.get("use_zero_convs", False):
+                S[f"condition_image_adapter.zero_convs.{i}.weight"] = (ch, ch, 1, 1)
+                S[f"condition_image_adapter.zero_convs.{i}.bias"] = (ch,)
     return S
 
 
@@ -352,6 +378,8 @@ def make_unet_state_dict(cfg: dict, seed: int = 0) -> SD:
                 fan_in *= s
             std = fan_in ** -0.5
             if ".conv2." in name or name.endswith("proj_out.weight") or ".net.2." in name or ".to_out.0." in name:
+                std *= 0.5
+            if name.startswith("condition_image_adapter.") and (".block2." in name or ".zero_convs." in name):
                 std *= 0.5
             sd[name] = torch.randn(*shape, generator=g) * std
     return sd

@@ -197,3 +197,30 @@ def test_unet_matches_golden_fixture(dev):
     e = rel_err(out, gold["output"])
     _log("unet_vs_golden", rel=e)
     assert e < TOL_MODEL
+
+
+def test_unet_with_layout_adapter_vs_oracle(dev):
+    """condition_image_tensor -> ImageAdapter -> residuals after conv_in and after every down block
+    (crossview_temporal_unet.py:717-755): forward against the oracle, and the step-invariant adapter cache"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    acfg = dict(in_channels=3, channels=[128, 128, 256, 512, 512], is_downblocks=[False, True, True, True, False],
+                num_res_blocks=1, downscale_factor=8, use_zero_convs=True)
+    cfg = _small_unet_cfg(condition_image_adapter_config=acfg)
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
+    inp["condition_image_tensor"] = torch.rand(2, 2, 3, 3, 64, 128, generator=torch.Generator().manual_seed(7))
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    ref = U.unet_forward(sd, cfg, **inp)
+    plain = U.unet_forward(sd, cfg, **{k: v for k, v in inp.items() if k != "condition_image_tensor"})
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    e = rel_err(out, ref)
+    _log("unet_layout_adapter", rel=e, effect=rel_err(ref, plain))
+    assert e < TOL_MODEL and rel_err(ref, plain) > 5e-2
+    kw = dict(di)
+    again = m(to_dev(inp, dev)["sample"], to_dev(inp, dev)["timesteps"], **kw)[0][0]      # same tensor object: cached residuals
+    assert torch.equal(again, out) and m._adapter_cache[0] is not None          # also: GroupNorm statistics are order-fixed
