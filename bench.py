@@ -364,6 +364,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="diagnostics: per-shape GEMM totals on stderr")
+    ap.add_argument("--cfg-split", action="store_true",
+                    help="pairs of ranks share one sample: CFG halves on two GPUs, one all-gather per step (per-sample latency "
+                         "mode; the default is one replica per GPU)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one HIP graph (CTSDDenoiser.enable_graph); the per-kernel HIP-event "
                          "roofline cannot be taken inside a graph, so the roofline fields are empty in this mode")
@@ -412,13 +415,22 @@ def main():
     timer = KernelTimer().install()
     model = build_model(kwargs, dev, seed=0)
     w = WORKLOAD
-    cond = make_conditions(dev, seed=rank, n_time_ids=13 if args.layout else 11)
+    # --cfg-split: ranks (2k, 2k+1) share ONE sample (unconditional / conditional half each, one all-gather of the
+    # prediction per step): N GPUs = N/2 samples in flight at about twice the per-sample speed
+    cfg_group, sample_id, n_samples = None, rank, world
+    if args.cfg_split:
+        import torch.distributed as dist
+        assert world % 2 == 0, "--cfg-split needs an even number of ranks"
+        groups = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
+        cfg_group, sample_id, n_samples = groups[rank // 2], rank // 2, world // 2
+    cond = make_conditions(dev, seed=sample_id, n_time_ids=13 if args.layout else 11)
     if args.layout:
-        gl = torch.Generator(device="cuda").manual_seed(77 + rank)
+        gl = torch.Generator(device="cuda").manual_seed(77 + sample_id)
         cond["condition_image_tensor"] = torch.rand(2 * w["B"], w["T"], w["V"], 6, 256, 448, device=dev, generator=gl).to(torch.bfloat16)
-    g = torch.Generator(device="cuda").manual_seed(rank)
+    g = torch.Generator(device="cuda").manual_seed(sample_id)
     latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
-    den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"]).prepare(latents, cond)
+    den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"],
+                       cfg_group=cfg_group).prepare(latents, cond)
     if args.graph:
         den.enable_graph()
 
@@ -444,13 +456,14 @@ def main():
         gm, at = ks.get("gemm", {}), ks.get("attn", {})
         line = {
             "metric": "denoise-steps/sec (6-view x16f 448x256), SD-3.5 CTSD",
-            "value": world * args.steps / dt, "unit": "denoise-steps/s", "n_gpus": world,
+            "value": n_samples * args.steps / dt, "unit": "denoise-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
             "config": {"workload": "CTSD SD-3.5 MMDiT (24 joint blocks, 13 dual, 6 cross-view + 12 temporal VT blocks, "
                                    "rowwise), 6 views x 16 frames x 448x256 px (latents [1,16,6,16,32,56]), CFG g=4 -> "
-                                   "model batch 2, 154 text tokens, FlowMatch-Euler; one replica per GPU",
+                                   "model batch 2, 154 text tokens, FlowMatch-Euler; " +
+                                   ("CFG halves of one sample on two GPUs" if args.cfg_split else "one replica per GPU"),
                        "layers": kwargs["num_layers"], "flop_per_step": fl["total"], "finite": finite,
                        "variant": ("text+layout (ImageAdapter, pointwise temporal)" + ("" if not args.no_adapter_cache else ", adapter recomputed every step")) if args.layout else "text (rowwise temporal)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",

@@ -50,8 +50,21 @@ class CTSDDenoiser:
       * diffusion forcing: per-frame timestep indices min(i - take_time*spi, max(0, i - j*spi)), per-frame
         scheduler step, frames outside the schedule range left untouched (:1498-1507, :1554-1572)."""
 
-    def __init__(self, model, guidance_scale: float = 4.0, inference_steps: int = 40, shift: float = 3.0):
+    def __init__(self, model, guidance_scale: float = 4.0, inference_steps: int = 40, shift: float = 3.0,
+                 cfg_group=None):
+        """cfg_group: a torch.distributed process group of size 2 -> classifier-free-guidance split: the
+        two halves of the CFG batch are independent inside the model, so rank 0 of the group runs the unconditional
+        half and rank 1 the conditional half of ONE sample, the halves of the prediction are exchanged with one
+        all-gather per step (2.2 MB at config 3; RCCL over xGMI) and both ranks apply the same guidance + scheduler
+        update, keeping bit-identical latents.  Halves the per-sample latency; throughput scaling stays with replicas."""
         self.model = model
+        self.cfg_group = cfg_group
+        self.cfg_rank = 0
+        if cfg_group is not None:
+            import torch.distributed as dist
+            if dist.get_world_size(cfg_group) != 2:
+                raise ValueError("the CFG split needs a process group of exactly two ranks")
+            self.cfg_rank = dist.get_rank(cfg_group)
         self.guidance_scale = guidance_scale
         self.schedule = FlowMatchEulerSchedule(shift=shift).set_timesteps(inference_steps)
         self.inference_steps = inference_steps
@@ -82,6 +95,11 @@ class CTSDDenoiser:
         self._refresh_model_in()
         self.conditions = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
                            for k, v in conditions.items()}
+        if self.cfg_group is not None:                                 # this rank's half of every CFG-doubled condition
+            r = self.cfg_rank
+            self.conditions = {k: (v[r * B:(r + 1) * B].contiguous() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == 2 * B else v)
+                               for k, v in self.conditions.items()}
+            self._pred_full = torch.empty((2 * B, *latents.shape[1:]), dtype=bf16, device=dev)
         self._ts_dev = self.schedule.timesteps.to(dev)
         self._sig_dev = self.schedule.sigmas.to(dev)
         return self
@@ -118,8 +136,15 @@ class CTSDDenoiser:
         return ts, float(self.schedule.sigmas[i + 1] - self.schedule.sigmas[i])
 
     def _step_body(self, ts: torch.Tensor, dsig):
-        out, _, _ = self.model(self.model_in, ts, **self.conditions)
-        pred = out[0]
+        if self.cfg_group is None:
+            out, _, _ = self.model(self.model_in, ts, **self.conditions)
+            pred = out[0]
+        else:
+            import torch.distributed as dist
+            B, r = self.latents.shape[0], self.cfg_rank
+            out, _, _ = self.model(self.model_in[r * B:(r + 1) * B], ts[r * B:(r + 1) * B], **self.conditions)
+            dist.all_gather(list(self._pred_full.split(B)), out[0].contiguous(), group=self.cfg_group)
+            pred = self._pred_full
         if torch.is_tensor(dsig):
             ops.cfg_euler_step(pred, self.latents, self.guidance_scale, dsig, model_in=self.model_in,
                                group_elems=self.latents[0, 0, 0].numel())

@@ -710,6 +710,48 @@ def test_denoise_step_graph_replay_equals_eager(dev, small_cfg, mode):
     assert torch.equal(again, eager)
 
 
+def _cfg_split_worker(rank, world, port, cfg, sd, lat, cond, path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opendwm_amd.pipeline import CTSDDenoiser
+    dev = torch.device("cuda:0")
+    m = _hip_model(cfg, sd, dev)
+    den = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=4, cfg_group=dist.group.WORLD)
+    out = den.run(lat.to(dev), to_dev(cond, dev), stop=3)
+    torch.save(out.cpu(), f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_split_two_ranks(dev, small_cfg):
+    """Classifier-free-guidance split: two ranks run the unconditional / conditional half of one sample
+    and exchange the prediction halves with one all-gather per step (gloo here, both ranks on the one GPU; RCCL in
+    production).  Both ranks hold bit-identical latents, equal to the single-process run up to bf16 round-off (the
+    half-size batch picks other GEMM tile grids)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from opendwm_amd.pipeline import CTSDDenoiser
+    sd = _bf16_round_sd(O.make_state_dict(small_cfg, 0))
+    inp = small_inputs(small_cfg, 0)
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    lat = torch.randn(1, 3, 3, 16, 8, 12, generator=torch.Generator().manual_seed(13))
+    single = CTSDDenoiser(_hip_model(small_cfg, sd, dev), guidance_scale=4.0, inference_steps=4).run(lat.to(dev), to_dev(cond, dev), stop=3).cpu()
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() + 7) % 2000
+    path = os.path.join(tempfile.mkdtemp(), "cfg_split")
+    procs = [ctx.Process(target=_cfg_split_worker, args=(r, 2, port, small_cfg, sd, lat, cond, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    a, b = torch.load(path + ".0"), torch.load(path + ".1")
+    e = rel_err(a, single)
+    _log("cfg_split", ranks_equal=bool(torch.equal(a, b)), rel_vs_single=e)
+    assert torch.equal(a, b) and e < 5e-3
+
+
 def test_full_width_block_stack_vs_oracle_on_device(dev):
     """BASELINE config-3 token geometry (6 views x 16 frames x 32x56 latents, CFG batch 2,
     d = 1536, 24 heads, 154 text tokens) with the first 6 layers of the schedule (dual blocks,
