@@ -339,7 +339,7 @@ def test_oracle_vae_round_trip_shapes():
 # ---------------------------------------------------------------------------- C ABI
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*int\s+(dwm_[a-z0-9_]+)\s*\(", hdr, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t)\s+(dwm_[a-z0-9_]+)\s*\(", hdr, flags=re.M)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
