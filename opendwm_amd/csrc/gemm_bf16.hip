@@ -14,8 +14,10 @@
 // image of a tile is [256 rows][8 x 16-B chunks] with chunk XOR-swizzled by
 // ((row >> 1) & 7); the swizzle is applied on the per-lane SOURCE address (the DMA
 // destination is lane-linear) and again on the ds_read_b128 fragment reads, which
-// makes those reads bank-conflict free.  Two LDS stages (128 KiB), one barrier per
-// K step: tile k+1 streams in while tile k is on the matrix cores.
+// makes those reads bank-conflict free.  The whole 160 KiB LDS of the CU is the operand ring: three
+// stages for the activation tile (requested two K steps ahead: it is the operand that streams from HBM
+// when K is long) and two for the weight tile (one step ahead, L2-resident); one barrier per K step with a
+// counted vmcnt that leaves the newest activation requests in flight.
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -23,8 +25,9 @@ namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;            // 32 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A + W
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // double buffered = 128 KiB
+constexpr int A_STAGES = 3, W_STAGES = 2;          // the activation operand is requested two K steps ahead, the weights one
+constexpr int W_BASE = A_STAGES * TILE_BYTES;
+constexpr int LDS_BYTES = (A_STAGES + W_STAGES) * TILE_BYTES;   // 160 KiB: the whole LDS of a CU
 
 struct DevRowMap {
     FastDiv rw, rh;
@@ -78,8 +81,10 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         slice = id / (ntm * ntn);
         id -= slice * (ntm * ntn);
     }
+    // group height: 8 row tiles share a W panel in the XCD's L2 for K ~ 1.5 k; a long K (FF2: 6144) makes the A panel of
+    // 8 rows (25 MB) stream through it, 4 rows measured 3 % faster there
     int gm_ = (p.reserved >> 4) & 31;
-    if (gm_ == 0) gm_ = 8;
+    if (gm_ == 0) gm_ = p.K >= 4096 ? 4 : 8;
     const int per_group = gm_ * ntn;
     const int grp_id = id / per_group, in_grp = id - grp_id * per_group;
     const int first_m = grp_id * gm_;
@@ -135,40 +140,47 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // ---- main loop.  Per K tile: 4 sub-steps x 8 chunks of { NTW/2 MFMAs, one fragment read for the
     // next sub-step, a share of the DMA issue }, fenced with sched_barrier so LDS reads and DMA
     // issues sit in the shadow of the MFMAs.  The single barrier of a tile sits at the START of its
-    // last sub-step: by then every wave holds its last fragments of tile kt in registers (buffer
-    // kt&1 is free for tile kt+2) and its share of tile kt+1 has landed, so the fragment reads of
-    // tile kt+1's first sub-step and the barrier skew hide under the MFMAs of sub-step 3.  DMA of
-    // tile kt+2 is issued right after that barrier and in sub-step 0 of the next tile, i.e. it is
-    // > 2 sub-steps old when its vmcnt(0) comes.
-    auto stage_round = [&](int buf, int64_t aoff, int64_t koff, int j) {
-        const int r0 = (wave * NJ + j) * 8;
-        glds16(a_src[j] + aoff, smem + buf * STAGE_BYTES + r0 * 128);
-        glds16(w_src[j] + koff, smem + buf * STAGE_BYTES + TILE_BYTES + r0 * 128);
+    // last sub-step: by then every wave holds its last fragments of tile kt in registers (the weight slot
+    // kt&1 is free for tile kt+2) and its shares of tile kt+1 have landed, so the fragment reads of
+    // tile kt+1's first sub-step and the barrier skew hide under the MFMAs of sub-step 3.
+    auto stage_a = [&](int buf, int64_t aoff, int j) {
+        glds16(a_src[j] + aoff, smem + buf * TILE_BYTES + ((wave * NJ + j) * 8) * 128);
+    };
+    auto stage_w = [&](int buf, int64_t koff, int j) {
+        glds16(w_src[j] + koff, smem + W_BASE + buf * TILE_BYTES + ((wave * NJ + j) * 8) * 128);
     };
     constexpr int MPC = NTW / 2;                       // MFMAs per chunk
     constexpr int NDS = 4 + NTW;                       // fragment reads per sub-step
     bf16x8 af[2][4], wf[2][NTW];
-    int64_t aoff1, koff1;                              // offsets of the tile whose second half is staged in sub-step 0
+    // Request order per wave (loads return in order, so the barrier's counted wait follows it):
+    //   ... A(kt+1) [sub-step 0 of step kt-1], W(kt+1) [sub-step 3 of step kt-1], A(kt+2) [sub-step 0 of step kt] ...
+    // The barrier of step kt needs A(kt+1) and W(kt+1): vmcnt(NJ) leaves exactly the NJ requests of A(kt+2) in flight,
+    // which therefore have almost two K steps to arrive (the activation panel is the operand that streams from HBM);
+    // the weights have one step (they are shared by every row tile and sit in L2).
+    int sa = 0;                                        // A stage of tile kt (kt % 3)
     {
         int64_t aoff, koff;
         tile_offsets(0, aoff, koff);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) stage_round(0, aoff, koff, j);
+        for (int j = 0; j < NJ; ++j) { stage_a(0, aoff, j); stage_w(0, koff, j); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        tile_offsets(nk > 1 ? 1 : 0, aoff1, koff1);
+        tile_offsets(nk > 1 ? 1 : 0, aoff, koff);
 #pragma unroll
-        for (int j = 0; j < NJ / 2; ++j) stage_round(1, aoff1, koff1, j);
+        for (int j = 0; j < NJ; ++j) stage_a(1, aoff, j);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) stage_w(1, koff, j);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * 128) + coff[0]);
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + TILE_BYTES + w_row_off + nt * (32 * 128) + coff[0]);
+        for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + W_BASE + w_row_off + nt * (32 * 128) + coff[0]);
     }
     for (int kt = 0; kt < nk; ++kt) {
-        const char* la = smem + (kt & 1) * STAGE_BYTES;
-        const char* lb = la + TILE_BYTES;
-        const char* lan = smem + ((kt + 1) & 1) * STAGE_BYTES;     // tile kt+1
-        const char* lbn = lan + TILE_BYTES;
+        const int sa1 = sa == A_STAGES - 1 ? 0 : sa + 1, sa2 = sa1 == A_STAGES - 1 ? 0 : sa1 + 1;
+        const char* la = smem + sa * TILE_BYTES;
+        const char* lb = smem + W_BASE + (kt & 1) * TILE_BYTES;
+        const char* lan = smem + sa1 * TILE_BYTES;                  // tile kt+1
+        const char* lbn = smem + W_BASE + ((kt + 1) & 1) * TILE_BYTES;
         int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
         tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
 #pragma unroll
@@ -176,8 +188,8 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (ks == 3 && c == 0) {
-                    // own last fragments read, own share of tile kt+1 landed -> barrier
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    // own last fragments read; own shares of A(kt+1) and W(kt+1) landed (A(kt+2) may stay in flight)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
                     __syncthreads();
                 }
 #pragma unroll
@@ -192,13 +204,12 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     if (c < 4) af[(ks + 1) & 1][c] = *(const bf16x8*)(fa + a_row_off + c * (32 * 128) + coff[kn]);
                     else wf[(ks + 1) & 1][c - 4] = *(const bf16x8*)(fb + w_row_off + (c - 4) * (32 * 128) + coff[kn]);
                 }
-                if (ks == 0 && c < NJ / 2) stage_round((kt + 1) & 1, aoff1, koff1, NJ / 2 + c);       // 2nd half of tile kt+1
-                if (ks == 3 && c >= 1 && c <= NJ / 2) stage_round(kt & 1, aoff2, koff2, c - 1);       // 1st half of tile kt+2
+                if (ks == 0 && c < NJ) stage_a(sa2, aoff2, c);                       // A(kt+2): the slot tile kt-1 left
+                if (ks == 3 && c >= 1 && c <= NJ) stage_w(kt & 1, koff2, c - 1);     // W(kt+2): the slot of this tile
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        aoff1 = aoff2;
-        koff1 = koff2;
+        sa = sa1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant last DMA must not land in the epilogue scratch
 
