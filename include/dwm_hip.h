@@ -89,7 +89,7 @@ typedef struct dwm_gemm_args {
     /* RESID */
     const void* gate; int64_t ld_gate; int64_t rows_per_gate;   /* bf16 gate[row/rows_per_gate][n] or NULL */
     const void* res;  int64_t ld_res;  int64_t res_mod;         /* bf16 res[res_mod > 0 ? row % res_mod : res_mod < 0 ? row / -res_mod : row][n] or NULL */
-    const void* blend; int64_t ld_blend;                        /* bf16 blend[row][n] or NULL               */
+    const void* blend; int64_t ld_blend;                        /* bf16 blend[row][n] or NULL (not together with gate) */
     const float* alpha; int64_t rows_per_alpha;                 /* fp32 alpha[row/rows_per_alpha]           */
     /* RMSHEAD */
     const void* rms_w; int64_t rms_ncols; float rms_eps;        /* bf16 rms_w[rms_ncols]                    */

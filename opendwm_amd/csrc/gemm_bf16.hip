@@ -227,7 +227,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         if (sink == 123.456f) ((float*)p.C)[0] = sink;
         return;
     }
-    const bf16_t* __restrict__ bias = EPI == EPI_SPLITK ? nullptr : (const bf16_t*)p.bias;
+    const bf16_t* __restrict__ bias = (EPI == EPI_SPLITK || EPI == DWM_EPI_RESID) ? nullptr : (const bf16_t*)p.bias;
     bf16_t* __restrict__ Cp = (bf16_t*)p.C;
 
     __syncthreads();                                       // every wave is done with the operand tiles
@@ -277,6 +277,42 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         const int64_t ncol = ncol0 + bc8 * 8;
         const bool nok = ncol < Nout;
 
+        // RESID operand rows of one 32-row pass: gate (or, without a gate, blend), residual, alpha.  One register set,
+        // refilled in place: as soon as step st of pass mt has consumed its rows, the rows of step st of pass mt + 1 are
+        // requested into the same registers, so four steps' worth of loads are always in flight behind the math and
+        // the stores.  (Plain arrays + a macro: a second set, or structs behind lambda references, end up in scratch.)
+        constexpr int NSTEP = 32 / RPS;
+        uint4 gbA[NSTEP], rA[NSTEP];
+        float alA[NSTEP];
+        // branch-free: always two 16-byte loads and one alpha load per step (absent operands read a valid dummy row of C),
+        // so the compiler's counted waits stay exact and never degrade to "everything outstanding, stores included"
+        const bf16_t* const gb_ptr = p.gate ? (const bf16_t*)p.gate : p.blend ? (const bf16_t*)p.blend : (const bf16_t*)p.C;
+        const int64_t gb_ld = p.gate ? p.ld_gate : p.blend ? p.ld_blend : p.ldc;
+        const bf16_t* const r_ptr = p.res ? (const bf16_t*)p.res : (const bf16_t*)p.C;
+        const int64_t r_ld = p.res ? p.ld_res : p.ldc;
+        const float* const al_ptr = p.blend ? p.alpha : (const float*)p.C;
+        float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // RESID: bias of this lane's 8 output columns
+        if constexpr (EPI == DWM_EPI_RESID) {
+            if (p.bias != nullptr && nok) unpack8(*(const uint4*)((const bf16_t*)p.bias + ncol), b8);
+        }
+#define DWM_ISSUE_RESID(MT_, ST_)                                                                                 \
+        {                                                                                                         \
+            int64_t m_ = m0 + wm * 128 + (MT_) * 32 + (ST_) * RPS + brow;                                         \
+            m_ = m_ < M ? m_ : M - 1;                                                                             \
+            const int64_t nc_ = nok ? ncol : 0;                                                                   \
+            const int64_t mr_ = map_row(cp.c, m_);                                                                \
+            const int64_t grow_ = p.gate ? (int64_t)fdiv((uint32_t)m_, cp.fd_rpg) : mr_;                          \
+            const int64_t rr_ = !p.res ? mr_ : p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m_, cp.fd_rmod)          \
+                                             : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m_, cp.fd_rmod) : mr_;     \
+            gbA[ST_] = *(const uint4*)(gb_ptr + grow_ * gb_ld + nc_);                                             \
+            rA[ST_] = *(const uint4*)(r_ptr + rr_ * r_ld + nc_);                                                  \
+            alA[ST_] = al_ptr[p.blend ? (int64_t)fdiv((uint32_t)m_, cp.fd_rpa) : 0];                              \
+        }
+        if constexpr (EPI == DWM_EPI_RESID) {
+    #pragma unroll
+            for (int st = 0; st < NSTEP; ++st) DWM_ISSUE_RESID(0, st)
+        }
+
     #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             // ---- stage A (packed fp32: the epilogue is VALU-issue bound; the activation switch is
@@ -314,6 +350,9 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                 }
             } else if constexpr (EPI == EPI_SPLITK) {
                 // raw fp32 partial sums: bias / activation / residual are applied by the finishing kernel
+            } else if constexpr (EPI == DWM_EPI_RESID) {
+                // bias + activation are applied after the transpose: a row-major lane owns 8 fixed columns, i.e. 8 bias
+                // registers instead of the 32 of the MFMA layout - the registers the residual pipeline needs
             } else {
 #define DWM_ACT_PASS(FN_)                                                                           \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                     \
@@ -340,37 +379,11 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     *(float4*)(scr + l31 * (CW * 4) + ((c ^ (l31 & (CW / 4 - 1))) << 4)) = v;
                 }
             // same-wave LDS ops complete in order; the reads below see the writes above
-            // ---- stage B, two steps at a time: the gate / residual / blend loads of a batch are issued
-            // before its first store (the outputs may alias the residual, so the compiler would
-            // otherwise serialise every step's loads behind the previous step's stores); batches of 2
-            // keep the epilogue's register peak below the main loop's, so nothing of the main loop spills
+            // ---- stage B.  RESID: the gate / residual / blend rows were requested one pass ahead (see above)
             constexpr int NST = 32 / RPS;
-            constexpr int NB = 2;
     #pragma unroll
-            for (int sb = 0; sb < NST; sb += NB) {
-            uint4 gq[NB], rq[NB], bq[NB];
-            float al[NB];
-            if constexpr (EPI == DWM_EPI_RESID) {
-    #pragma unroll
-                for (int st = 0; st < NB; ++st) {
-                    int64_t m = m0 + wm * 128 + mt * 32 + (sb + st) * RPS + brow;
-                    m = m < M ? m : M - 1;
-                    const int64_t nc = nok ? ncol : 0;
-                    if (p.gate) gq[st] = *(const uint4*)((const bf16_t*)p.gate + (int64_t)fdiv((uint32_t)m, cp.fd_rpg) * p.ld_gate + nc);
-                    const int64_t mr = map_row(cp.c, m);
-                    if (p.res) {
-                        const int64_t rr = p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m, cp.fd_rmod) : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m, cp.fd_rmod) : mr;
-                        rq[st] = *(const uint4*)((const bf16_t*)p.res + rr * p.ld_res + nc);
-                    }
-                    if (p.blend) {
-                        bq[st] = *(const uint4*)((const bf16_t*)p.blend + mr * p.ld_blend + nc);
-                        al[st] = p.alpha[fdiv((uint32_t)m, cp.fd_rpa)];
-                    }
-                }
-            }
-    #pragma unroll
-            for (int st = 0; st < NB; ++st) {
-                const int r = (sb + st) * RPS + brow;          // row inside this 32-row pass
+            for (int st = 0; st < NST; ++st) {
+                const int r = st * RPS + brow;                 // row inside this 32-row pass
                 const float4 x0 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8) ^ (r & (CW / 4 - 1))) << 4));
                 const float4 x1 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8 + 1) ^ (r & (CW / 4 - 1))) << 4));
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -378,8 +391,14 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                 const int64_t mrow = map_row(cp.c, m < M ? m : M - 1);
                 if constexpr (EPI == DWM_EPI_RESID) {
                     float t[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        f32x2 y = (f32x2){v[j], v[j + 1]} + (f32x2){b8[j], b8[j + 1]};
+                        if (p.act != DWM_ACT_NONE) y = p.act == DWM_ACT_GELU_TANH ? gelu_tanh2(y) : p.act == DWM_ACT_SILU ? silu2(y) : relu2(y);
+                        v[j] = y[0]; v[j + 1] = y[1];
+                    }
                     if (p.gate) {
-                        unpack8(gq[st], t);
+                        unpack8(gbA[st], t);
     #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
                             const f32x2 y = (f32x2){v[j], v[j + 1]} * (f32x2){t[j], t[j + 1]};
@@ -387,7 +406,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         }
                     }
                     if (p.res) {
-                        unpack8(rq[st], t);
+                        unpack8(rA[st], t);
     #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
                             const f32x2 y = (f32x2){v[j], v[j + 1]} + (f32x2){t[j], t[j + 1]};
@@ -395,8 +414,9 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         }
                     }
                     if (p.blend) {
-                        unpack8(bq[st], t);
-                        const f32x2 a2 = splat2(al[st]), b2 = splat2(1.f - al[st]);
+                        unpack8(gbA[st], t);             // (gate and blend together are rejected by the entry point)
+                        const float al = alA[st];
+                        const f32x2 a2 = splat2(al), b2 = splat2(1.f - al);
     #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
                             const f32x2 y = a2 * (f32x2){t[j], t[j + 1]} + b2 * (f32x2){v[j], v[j + 1]};
@@ -413,9 +433,12 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                 } else {
                     if (m < M && nok && !((p.reserved & 2) && m >= 0)) *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
                 }
-            }
+                if constexpr (EPI == DWM_EPI_RESID) {
+                    if (mt + 1 < 4) DWM_ISSUE_RESID(mt + 1, st)
+                }
             }
         }
+#undef DWM_ISSUE_RESID
     }
 }
 
@@ -491,6 +514,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
             if (a->gate && (a->rows_per_gate <= 0 || a->ld_gate % 8 != 0 || !dwm_aligned16(a->gate))) return DWM_EINVAL;
             if (a->res && (a->ld_res % 8 != 0 || !dwm_aligned16(a->res))) return DWM_EALIGN;
             if (a->blend && (a->alpha == nullptr || a->rows_per_alpha <= 0 || a->ld_blend % 8 != 0 || !dwm_aligned16(a->blend))) return DWM_EINVAL;
+            if (a->gate && a->blend) return DWM_EUNSUPPORTED;      // one register set carries the gate OR the blend rows
             break;
         case DWM_EPI_RMSHEAD:
             if (a->rms_w == nullptr || a->rms_ncols % 64 != 0 || a->N % 64 != 0) return DWM_EINVAL;
