@@ -1,0 +1,90 @@
+"""End-to-end generation on synthetic weights (reduced-width models, seconds on one MI355X): the pieces a CTSD user
+touches, wired together the way src/dwm/pipelines/ctsd.py wires them -
+
+    VAE.encode(reference frames).latent_dist.mode()        ctsd.py:1677-1703
+    autoregressive windows over the denoise loop           ctsd.py:1656-1833  (opendwm_amd.drivers.AutoregressiveDriver)
+      model forward at the CFG batch + guidance + scheduler ctsd.py:1496-1575  (opendwm_amd.pipeline.CTSDDenoiser, HIP graph)
+    VAE.decode(latents / scaling + shift), postprocess     ctsd.py:1606-1647  (opendwm_amd.drivers.LatentDecoder)
+
+usage: python scripts/e2e_demo.py [--temporal-vae] [--frames 7] [--out /tmp/frames.pt]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import cogvideox_vae_oracle as CV   # synthetic weights only (state-dict generators); no oracle compute here
+from oracle import ctsd_oracle as O
+from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder
+from opendwm_amd.pipeline import CTSDDenoiser
+from opendwm_amd.vae import AutoencoderKL
+from opendwm_amd.vae_cogvideox import AutoencoderKLCogVideoX
+from tests.common import small_config
+
+bf16 = torch.bfloat16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--temporal-vae", action="store_true")
+    ap.add_argument("--frames", type=int, default=7)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = small_config()
+    model = DiTCrossviewTemporalConditionModel(**cfg)
+    model.load_state_dict(O.make_state_dict(cfg, 0))
+    model = model.to(dev).to(bf16).eval()
+    if a.temporal_vae:
+        vcfg = CV.make_cogvideox_config(block_out_channels=(64, 64, 128, 128), layers_per_block=1, norm_num_groups=8)
+        vae = AutoencoderKLCogVideoX(**{k: vcfg[k] for k in ("block_out_channels", "layers_per_block", "norm_num_groups", "latent_channels")})
+        vae.load_state_dict(CV.make_state_dict(vcfg, 0))
+    else:
+        vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
+        vae = AutoencoderKL(**vcfg)
+        vae.load_state_dict(O.make_vae_state_dict(vcfg, 0))
+    vae = vae.to(dev).to(bf16).eval()
+
+    B, T, V, H, W = 1, 3, 3, 8, 16                         # latent window [B, T, V, 16, H, W]; pixels 8x
+    # (the drivers slice per-frame conditions by latent frame; with the temporal VAE one window = 3 latent frames
+    #  = 9 pixel frames is generated - the reference maps pixel-frame clips to latent windows in its dataset glue)
+    total = T if a.temporal_vae else a.frames
+    inp = O.make_inputs(cfg, 2 * B, total, V, H, W, seed=0, text_len=10)
+    cond = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items() if k not in ("sample", "timestep")}
+    gen = torch.Generator().manual_seed(0)
+    # reference frame -> latents
+    ref_px = torch.rand(B, 1, V, 3, 8 * H, 8 * W, generator=gen) * 2 - 1
+    sf, sh = vae.config.scaling_factor, vae.config.shift_factor or 0
+    if a.temporal_vae:
+        x = ref_px.permute(0, 2, 3, 1, 4, 5).flatten(0, 1).to(dev)                       # (b v) c t h w
+        lat = (vae.encode(x).latent_dist.mode() - sh) * sf
+        image_latents = lat.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5).contiguous()     # b t v c h w
+    else:
+        lat = (vae.encode(ref_px.flatten(0, 2).to(dev)).latent_dist.mode() - sh) * sf
+        image_latents = lat.unflatten(0, (B, 1, V))
+    den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=a.steps).enable_graph()
+    drv = AutoregressiveDriver(den, dict(inference_steps=a.steps, sequence_length_per_iteration=T, reference_frame_count=1,
+                                         autoregression_data_exception_for_take_sequence=["disable_crossview", "disable_temporal",
+                                                                                          "crossview_attention_mask"]),
+                               decode=LatentDecoder(vae), generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = drv.run((B, T, V, 16, H, W), cond, total, dev, image_latents=image_latents)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    img = out["images"]
+    print(json.dumps({"frames_x_views": int(img.shape[0]), "image_shape": list(img.shape[1:]), "seconds": round(dt, 3),
+                      "min": float(img.min()), "max": float(img.max()), "finite": bool(torch.isfinite(img).all()),
+                      "windows": len(drv.plan(T, total, True)), "vae": type(vae).__name__}))
+    if a.out:
+        torch.save(img.cpu(), a.out)
+
+
+if __name__ == "__main__":
+    main()
