@@ -4,9 +4,17 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``opendwm_amd/`` may import this
 module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py`` do, and there only as the checker / reported baseline.
 
-PARITY UNPINNED: the reference (SenseTime-FVG/OpenDWM @ 2025-07-04) ships no
-tests, golden tensors or fixtures for this path and cannot
-be imported in this container (``diffusers==0.31.0`` is absent).  This file is
+PARITY UNPINNED for the diffusers arithmetic, pinned for the reference's own
+logic: the reference (SenseTime-FVG/OpenDWM @ 2025-07-04) ships no tests, golden
+tensors or fixtures for this path and its model classes cannot
+be built in this container (``diffusers==0.31.0`` is absent).  What can be
+executed is: AlphaBlender, the cross-view / temporal rearrange + mask + mix
+methods, the inference / autoregressive / streaming control flow and
+``step_by_indices`` (imported behind import-only stubs;
+tests/golden/make_reference_fixtures.py, make_reference_driver_fixtures.py) -
+``alpha_blender``, ``crossview_block_and_mix``, ``temporal_block_and_mix`` and
+``denoise`` below are checked against those vectors
+(tests/test_reference_fixtures_cpu.py).  This file is
 a plain-PyTorch fp32 *restatement* of
 
 * the reference-owned arithmetic

@@ -4,8 +4,10 @@
   * StreamingCrossviewTemporalSD (reset_streaming / send_frame_condition / receive_frame /
     fifo_inference_pipeline)                                   src/dwm/pipelines/ctsd.py:2009-2248
 
-Only tests/ may import this file.  **Parity unpinned**: the reference has no tests or golden vectors for
-these drivers; the restatement follows the reference control flow statement by statement, with the model +
+Only tests/ may import this file.  **Pinned** against vectors produced by executing the reference methods
+themselves (tests/golden/make_reference_driver_fixtures.py -> reference_drivers.pt; tests/test_reference_fixtures_cpu.py):
+emitted frames, final queue latents and the per-window (start, stop, take_time) agree.  The reference ships no tests
+of its own; the restatement follows the reference control flow statement by statement, with the model +
 scheduler loop (`inference_pipeline`, :1439-1654 / :2032-2103) abstracted into a `window` callable so the
 same driver runs over the fp32 oracle model (ctsd_oracle.denoise) or over a recording stub.
 
