@@ -262,10 +262,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
                                        crossview_attention_mask=kw.get("crossview_attention_mask"),
                                        added_time_ids=kw.get("added_time_ids"),
                                        condition_image_tensor=kw.get("condition_image_tensor"))
-            if squeeze:
-                out = out.squeeze(2)
-            if kw.get("return_dict"):
-                return {"noise_pred": out}
+            if kw.get("return_dict"):                       # crossview_temporal_dit.py:620-630: only the dict form is squeezed
+                return {"noise_pred": out.squeeze(2) if squeeze else out}
             return [out], None, None
         return self._forward_infer(sample, timestep, *args, **kwargs)
 

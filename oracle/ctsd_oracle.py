@@ -247,6 +247,20 @@ def joint_transformer_block(sd: SD, p: str, cfg: dict, i: int, h: Tensor,
 # reference-owned blocks
 # --------------------------------------------------------------------------
 
+def vt_attention(sd: SD, p: str, heads: int, y: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """``VTSelfAttentionBlock.attn1``: diffusers Attention(bias=False, out_bias=True, qk_norm rms eps 1e-5) with
+    AttnProcessor2_0 as self-attention; mask bool [Bp, Lq, Lk] (True = attend).  The leaf the reference block calls
+    at crossview_temporal.py:572-574."""
+    q = _heads(linear(sd, p + ".to_q", y), heads)
+    k = _heads(linear(sd, p + ".to_k", y), heads)
+    v = _heads(linear(sd, p + ".to_v", y), heads)
+    if (p + ".norm_q.weight") in sd:
+        q = rms_norm(q, sd[p + ".norm_q.weight"], 1e-5)
+        k = rms_norm(k, sd[p + ".norm_k.weight"], 1e-5)
+    m = None if mask is None else mask[:, None]
+    return linear(sd, p + ".to_out.0", _unheads(sdpa(q, k, v, m)))
+
+
 def vt_self_attention_block(sd: SD, p: str, heads: int, x: Tensor,
                             mask: Optional[Tensor] = None) -> Tensor:
     """``VTSelfAttentionBlock.forward`` (crossview_temporal.py:562-582);
@@ -258,14 +272,7 @@ def vt_self_attention_block(sd: SD, p: str, heads: int, x: Tensor,
     x = feed_forward(sd, p + ".ff_in", y, "geglu") + res
 
     y = F.layer_norm(x, (d,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
-    q = _heads(linear(sd, p + ".attn1.to_q", y), heads)
-    k = _heads(linear(sd, p + ".attn1.to_k", y), heads)
-    v = _heads(linear(sd, p + ".attn1.to_v", y), heads)
-    if (p + ".attn1.norm_q.weight") in sd:
-        q = rms_norm(q, sd[p + ".attn1.norm_q.weight"], 1e-5)
-        k = rms_norm(k, sd[p + ".attn1.norm_k.weight"], 1e-5)
-    m = None if mask is None else mask[:, None]
-    a = linear(sd, p + ".attn1.to_out.0", _unheads(sdpa(q, k, v, m)))
+    a = vt_attention(sd, p + ".attn1", heads, y, mask)
     x = a + x
 
     y = F.layer_norm(x, (d,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)

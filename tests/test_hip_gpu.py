@@ -792,6 +792,32 @@ def test_attention_rowmaps_and_mixer_vs_reference_fixture(dev, name):
     assert e < TOL_KERNEL * 2 and drift < 1e-2
 
 
+def test_model_forward_vs_reference_forward_fixture(dev, small_cfg):
+    """tests/golden/reference_forward.pt: the REAL DiTCrossviewTemporalConditionModel.forward / VTSelfAttentionBlock.forward
+    run with oracle leaf modules (make_reference_forward_fixture.py).  6-D inputs with a disable_temporal flag, and the
+    5-D form [B, T, C, H, W]: the reference returns it with the inserted view axis still in place (tuple form)."""
+    fxf = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))
+    sd = _bf16_round_sd(O.make_state_dict(small_cfg, 0))
+    m = _hip_model(small_cfg, sd, dev)
+    inp = small_inputs(small_cfg, 0)
+    inp["disable_temporal"] = fxf["rowwise"]["disable_temporal"]
+    di = to_dev(inp, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e6 = rel_err(out[0], fxf["rowwise"]["output"])
+    inp1 = small_inputs(small_cfg, 0, V=1)
+    five = {k: (v.squeeze(2) if torch.is_tensor(v) and v.dim() >= 3 and k != "crossview_attention_mask" else v) for k, v in inp1.items()}
+    five["disable_temporal"] = torch.zeros(2, 1, dtype=torch.bool)
+    d5 = to_dev(five, dev)
+    out5, _, _ = m(d5.pop("sample"), d5.pop("timestep"), **d5)
+    e5 = rel_err(out5[0], fxf["five_dim"]["output"])
+    d5 = to_dev(five, dev)
+    as_dict = m(d5.pop("sample"), d5.pop("timestep"), return_dict=True, **d5)
+    _log("reference_forward_fixture", rel_6d=e6, rel_5d=e5, shape_5d=list(out5[0].shape))
+    # fixture weights are fp32, the model holds them rounded to bf16: the bound is the usual bf16 one
+    assert e6 < TOL_MODEL and e5 < TOL_MODEL
+    assert out5[0].dim() == 6 and out5[0].shape[2] == 1 and as_dict["noise_pred"].dim() == 5
+
+
 def test_full_width_block_stack_vs_oracle_on_device(dev):
     """BASELINE config-3 token geometry (6 views x 16 frames x 32x56 latents, CFG batch 2,
     d = 1536, 24 heads, 154 text tokens) with the first 6 layers of the schedule (dual blocks,

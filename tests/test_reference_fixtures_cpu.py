@@ -222,3 +222,25 @@ def test_streaming_drivers_equal_reference(dfx, fake_model, name):
     got = drv.fifo(d["shape"], cond, d["total"], "cpu")
     assert torch.allclose(got, d["images"], atol=1e-6)
     assert torch.allclose(drv.latents, d["final_latents"], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# model forward composition: fixture from the REAL DiTCrossviewTemporalConditionModel.forward / VTSelfAttentionBlock.forward
+# with oracle leaves (tests/golden/make_reference_forward_fixture.py)
+@pytest.mark.parametrize("tt", ["rowwise", "pointwise", "full"])
+def test_oracle_forward_composition_equals_reference_forward(tt):
+    from tests.common import small_config, small_inputs
+    fxf = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))
+    cfg = small_config(temporal_attention_type=tt)
+    sd = O.make_state_dict(small_config(), 0)
+    inp = small_inputs(cfg, 0)
+    inp["disable_temporal"] = fxf[tt]["disable_temporal"]
+    out = O.dit_forward(sd, cfg, **inp)
+    assert torch.allclose(out, fxf[tt]["output"], atol=1e-6)
+
+
+def test_reference_keeps_the_view_axis_for_5d_inputs():
+    """`result = [output]` is built before the squeeze (crossview_temporal_dit.py:620-630): 5-D inputs come back 6-D in the
+    tuple form; the product mirrors that (opendwm_amd/dit.py) - checked on the GPU in test_hip_gpu.py"""
+    fxf = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))
+    assert fxf["five_dim"]["output"].dim() == 6 and fxf["five_dim"]["output"].shape[2] == 1
