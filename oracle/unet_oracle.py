@@ -1,7 +1,11 @@
 """CPU oracle for the CTSD SD-2.1 UNet denoiser.
 
-TEST INFRASTRUCTURE ONLY (same rules as ctsd_oracle.py).  PARITY UNPINNED: the reference ships no
-tests / golden tensors for this path and diffusers 0.31.0 cannot be imported here.
+TEST INFRASTRUCTURE ONLY (same rules as ctsd_oracle.py).  PARITY: the reference ships no tests / golden tensors
+for this path and diffusers 0.31.0 cannot be imported here, so the diffusers leaf arithmetic below is UNPINNED; the
+composition the reference owns IS pinned: tests/golden/make_reference_unet_fixture.py executes the real
+UNetCrossviewTemporalConditionModel.forward with the real block / ResBlock / TransformerModel /
+TemporalBasicTransformerBlock classes over this file's leaf functions and reproduces `unet_forward` to 4e-6
+(tests/test_reference_fixtures_cpu.py).
 
 Plain-PyTorch fp32 restatement of
   * src/dwm/models/crossview_temporal_unet.py:648-835  UNetCrossviewTemporalConditionModel.forward

@@ -244,3 +244,21 @@ def test_reference_keeps_the_view_axis_for_5d_inputs():
     tuple form; the product mirrors that (opendwm_amd/dit.py) - checked on the GPU in test_hip_gpu.py"""
     fxf = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))
     assert fxf["five_dim"]["output"].dim() == 6 and fxf["five_dim"]["output"].shape[2] == 1
+
+
+@pytest.mark.parametrize("name", ["rowwise", "pointwise"])
+def test_oracle_unet_composition_equals_reference_forward(name):
+    """tests/golden/reference_unet_forward.pt: the REAL UNetCrossviewTemporalConditionModel.forward with the real down / mid /
+    up block, ResBlock, TransformerModel and TemporalBasicTransformerBlock classes over oracle leaf modules
+    (make_reference_unet_fixture.py)"""
+    from oracle import unet_oracle as U
+    from tests.golden.make_golden import unet_small_config
+    fxu = torch.load(os.path.join(GOLDEN, "reference_unet_forward.pt"))[name]
+    cfg = dict(unet_small_config(), **fxu["over"])
+    sd = U.make_unet_state_dict(cfg, 0)
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
+    inp["disable_crossview"], inp["disable_temporal"] = fxu["flags"]
+    if name == "pointwise":
+        inp["crossview_attention_mask"] = None
+    out = U.unet_forward(sd, cfg, **inp)
+    assert torch.allclose(out, fxu["output"], atol=5e-5)

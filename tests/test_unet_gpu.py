@@ -224,3 +224,26 @@ def test_unet_with_layout_adapter_vs_oracle(dev):
     kw = dict(di)
     again = m(to_dev(inp, dev)["sample"], to_dev(inp, dev)["timesteps"], **kw)[0][0]      # same tensor object: cached residuals
     assert torch.equal(again, out) and m._adapter_cache[0] is not None          # also: GroupNorm statistics are order-fixed
+
+
+@pytest.mark.parametrize("name", ["rowwise", "pointwise"])
+def test_unet_forward_vs_reference_forward_fixture(dev, name):
+    """against the vector produced by the REFERENCE's own UNet composition (tests/golden/reference_unet_forward.pt)"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    from tests.golden.make_golden import unet_small_config
+    fxu = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_unet_forward.pt"))[name]
+    cfg = dict(unet_small_config(), **fxu["over"])
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
+    inp["disable_crossview"], inp["disable_temporal"] = fxu["flags"]
+    if name == "pointwise":
+        inp["crossview_attention_mask"] = None
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    e = rel_err(out, fxu["output"])
+    _log("unet_reference_forward_fixture", case=name, rel=e)
+    assert e < TOL_MODEL
