@@ -1,0 +1,87 @@
+"""Golden vector from EXECUTING the reference training step - runs only where /root/reference exists.
+
+The REAL CrossviewTemporalSD.train_step (src/dwm/pipelines/ctsd.py:1195-1437, SD 3 branch: logit-normal timestep draw
+:1255-1262 via sd3_compute_density_for_timestep_sampling :807-831, sigma lookup sd3_get_sigmas :833-843, flow-matching
+pair :1267-1272, try_make_input_for_prediction :619-741, x0 prediction + MSE :1355-1370, backward, optimizer step) is
+called on a hand-built instance (ctsd.py imported behind import-only stubs, see make_reference_driver_fixtures.py).
+Faked: the VAE (a fixed average pooling as `latent_dist.sample()`), the image processor (x -> 2x - 1), get_conditions,
+the denoiser (one learnable scale on a cheap function of its inputs; records what it is called with), the training
+scheduler's tables (diffusers FlowMatchEulerDiscreteScheduler constructor, restated in oracle.flow_match_train_sigmas).
+
+usage: python tests/golden/make_reference_train_fixture.py  ->  tests/golden/reference_train_step.pt
+"""
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import ctsd_oracle as O                                      # noqa: E402
+from tests.golden.make_reference_driver_fixtures import _Finder          # noqa: E402
+
+
+def main():
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, "/root/reference/src")
+    import diffusers
+    import dwm.pipelines.ctsd as C
+
+    class FakeSD3(diffusers.SD3Transformer2DModel):
+        depth_net = None
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(0.3))
+            self.seen = []
+
+        def forward(self, x, ts, c=None, **kw):
+            self.seen.append((x.detach().clone(), ts.detach().clone()))
+            return [self.w * (x + 1e-3 * ts[..., None, None, None] + 0.05 * c[..., None, None, None])], None, None
+
+    def get_conditions(model, te, tok, common_config, latent_shape, batch, device, dtype, *a, **kw):
+        return {"c": batch["c"]}
+    C.CrossviewTemporalSD.get_conditions = staticmethod(get_conditions)
+
+    class FakeVae:
+        config = types.SimpleNamespace(shift_factor=0.1, scaling_factor=1.5)
+
+        def encode(self, x):
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: torch.nn.functional.avg_pool2d(x, 8)))
+
+    out = {}
+    for name, tcfg in (("plain", {}), ("loss_coef", {"loss_coef_dict": {"sd": 0.5}, "max_norm_for_grad_clip": 0.01})):
+        p = object.__new__(C.CrossviewTemporalSD)
+        p.model = FakeSD3()
+        p.model_wrapper = p.model
+        p.vae = FakeVae()
+        p.is_temporal_vae = False
+        p.image_processor = types.SimpleNamespace(preprocess=lambda x: x * 2 - 1)
+        p.common_config, p.training_config, p.inference_config = {}, dict(tcfg), {}
+        p.device, p.model_dtype = torch.device("cpu"), torch.float32
+        p.generator = torch.Generator().manual_seed(5)
+        sig = O.flow_match_train_sigmas()
+        p.train_scheduler = types.SimpleNamespace(config=types.SimpleNamespace(num_train_timesteps=1000), timesteps=sig * 1000, sigmas=sig)
+        p.text_encoders = p.tokenizers = p.text_encoder = p.tokenizer = None
+        p.loss_report_list = []
+        p.optimizer = torch.optim.SGD(p.model.parameters(), lr=0.1)
+        p.lr_scheduler = None
+        p.step_duration = 0.0
+        p.distribution_framework = "ddp"
+        B, T, V = 2, 3, 2
+        g = torch.Generator().manual_seed(9)
+        batch = {"vae_images": torch.rand(B, T, V, 3, 32, 48, generator=g), "c": torch.randn(B, T, V, generator=g)}
+        torch.manual_seed(1234)                     # sd3_compute_density_for_timestep_sampling draws from the global generator
+        C.CrossviewTemporalSD.train_step(p, batch, 0)
+        x_t, ts = p.model.seen[0]
+        out[name] = dict(batch=batch, training_config=dict(tcfg), generator_seed=5, global_seed=1234, noisy_latents=x_t, timesteps=ts,
+                         loss=torch.tensor(p.loss_report_list[0]["loss"]), w_before=torch.tensor(0.3), w_after=p.model.w.detach().clone(), lr=0.1)
+        print(name, "loss", p.loss_report_list[0]["loss"], "w", float(p.model.w), "timesteps", ts[:, 0, 0].tolist())
+    torch.save(out, os.path.join(HERE, "reference_train_step.pt"))
+    print("wrote reference_train_step.pt")
+
+
+if __name__ == "__main__":
+    main()

@@ -262,3 +262,39 @@ def test_oracle_unet_composition_equals_reference_forward(name):
         inp["crossview_attention_mask"] = None
     out = U.unet_forward(sd, cfg, **inp)
     assert torch.allclose(out, fxu["output"], atol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training step: fixture from the REAL CrossviewTemporalSD.train_step (tests/golden/make_reference_train_fixture.py)
+@pytest.mark.parametrize("name", ["plain", "loss_coef"])
+def test_training_pair_and_loss_equal_reference_train_step(name, monkeypatch):
+    from opendwm_amd.pipeline import CTSDTrainer, flow_match_train_sigmas, sample_timestep_indices
+    d = torch.load(os.path.join(GOLDEN, "reference_train_step.pt"))[name]
+    img = d["batch"]["vae_images"]
+    B, T, V = img.shape[:3]
+    lat = ((torch.nn.functional.avg_pool2d(img.flatten(0, 2) * 2 - 1, 8) - 0.1) * 1.5).unflatten(0, (B, T, V))
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(d["generator_seed"]))
+    torch.manual_seed(d["global_seed"])
+    idx = sample_timestep_indices((B,))                                # global generator, like the reference's torch.normal
+    sig = flow_match_train_sigmas()
+    assert torch.allclose(sig[idx] * 1000, d["timesteps"][:, 0, 0], atol=1e-4)
+    # product: the flow-matching pair
+    tr = CTSDTrainer.__new__(CTSDTrainer)
+    tr.sigmas, tr.num_train_timesteps, tr.weighting_scheme = sig, 1000, "logit_normal"
+    noisy, ts, sg, _ = tr.make_training_pair(lat, timestep_indices=idx, noise=noise)
+    assert torch.allclose(noisy, d["noisy_latents"], atol=1e-6) and torch.allclose(ts, d["timesteps"], atol=1e-4)
+    # oracle: loss and its gradient w.r.t. the stand-in model's scale
+    w = torch.tensor(0.3, requires_grad=True)
+
+    def fwd(sd, cfg, sample, timestep, c=None, **kw):
+        return w * (sample + 1e-3 * timestep[..., None, None, None] + 0.05 * c[..., None, None, None])
+    monkeypatch.setattr(O, "dit_forward", fwd)
+    coef = d["training_config"].get("loss_coef_dict", {}).get("sd", 1.0)
+    loss = O.train_loss(None, None, lat, {"c": d["batch"]["c"]}, idx, noise, loss_coef=coef)
+    assert abs(loss.item() - d["loss"].item()) < 1e-6
+    loss.backward()
+    g = w.grad
+    clip = d["training_config"].get("max_norm_for_grad_clip")
+    if clip is not None:
+        g = g * min(1.0, clip / (g.abs().item() + 1e-6))
+    assert abs((0.3 - d["lr"] * g).item() - d["w_after"].item()) < 1e-6
