@@ -347,25 +347,32 @@ def temporal_block_and_mix(sd: SD, cfg: dict, k: int, h: Tensor, seq_emb: Tensor
                          disable_temporal).flatten(0, 1)
 
 
+def adapter_block(sd: SD, cfg: dict, i: int, x: Tensor, prefix: str = "condition_image_adapter") -> Tensor:
+    """diffusers T2I ``AdapterBlock`` i (the leaf ``ImageAdapter.forward`` loops over, adapters.py:44-50):
+    [AvgPool2d(2, ceil_mode) if down] -> [Conv1x1 if in != out] -> num_res_blocks x AdapterResnetBlock
+    (x + Conv1x1(ReLU(Conv3x3(x))))."""
+    ac = cfg["condition_image_adapter_config"]
+    b = f"{prefix}.body.{i}"
+    if ac["is_downblocks"][i]:
+        x = F.avg_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
+    if (b + ".in_conv.weight") in sd:
+        x = F.conv2d(x, sd[b + ".in_conv.weight"], sd[b + ".in_conv.bias"])
+    for j in range(ac.get("num_res_blocks", 2)):
+        r = f"{b}.resnets.{j}"
+        hh = F.relu(F.conv2d(x, sd[r + ".block1.weight"], sd[r + ".block1.bias"], padding=1))
+        x = x + F.conv2d(hh, sd[r + ".block2.weight"], sd[r + ".block2.bias"])
+    return x
+
+
 def image_adapter(sd: SD, cfg: dict, x: Tensor, prefix: str = "condition_image_adapter") -> List[Tensor]:
-    """``ImageAdapter.forward`` (src/dwm/models/adapters.py:40-60) with diffusers T2I
-    ``AdapterBlock`` = [AvgPool2d(2, ceil_mode) if down] -> [Conv1x1 if in != out] ->
-    num_res_blocks x AdapterResnetBlock (x + Conv1x1(ReLU(Conv3x3(x)))); optional zero 1x1 convs.
-    x [..., C, H, W]; returns features [*base_shape, C_i, h_i, w_i]."""
+    """``ImageAdapter.forward`` (src/dwm/models/adapters.py:40-60): PixelUnshuffle, the AdapterBlocks, optional zero
+    1x1 convs.  x [..., C, H, W]; returns features [*base_shape, C_i, h_i, w_i]."""
     ac = cfg["condition_image_adapter_config"]
     base_shape = x.shape[:-3]
     x = F.pixel_unshuffle(x.flatten(0, -4), ac.get("downscale_factor", 8))
     feats = []
-    for i, down in enumerate(ac["is_downblocks"]):
-        b = f"{prefix}.body.{i}"
-        if down:
-            x = F.avg_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
-        if (b + ".in_conv.weight") in sd:
-            x = F.conv2d(x, sd[b + ".in_conv.weight"], sd[b + ".in_conv.bias"])
-        for j in range(ac.get("num_res_blocks", 2)):
-            r = f"{b}.resnets.{j}"
-            hh = F.relu(F.conv2d(x, sd[r + ".block1.weight"], sd[r + ".block1.bias"], padding=1))
-            x = x + F.conv2d(hh, sd[r + ".block2.weight"], sd[r + ".block2.bias"])
+    for i in range(len(ac["is_downblocks"])):
+        x = adapter_block(sd, cfg, i, x, prefix)
         x_out = x
         if ac.get("use_zero_convs", False):
             x_out = F.conv2d(x, sd[f"{prefix}.zero_convs.{i}.weight"], sd[f"{prefix}.zero_convs.{i}.bias"])

@@ -28,6 +28,25 @@ from tests.common import small_config, small_inputs                      # noqa:
 from tests.golden.make_reference_fixtures import install_stub            # noqa: E402
 
 
+def build_adapter(RefAdapter, cfg, sd):
+    """the REAL ImageAdapter.forward (adapters.py:40-60) over oracle AdapterBlock leaves; zero convs are real Conv2d"""
+    ac = cfg["condition_image_adapter_config"]
+    a = object.__new__(RefAdapter)
+    torch.nn.Module.__init__(a)
+    a.eval()
+    a.gradient_checkpointing = False
+    a.unshuffle = torch.nn.PixelUnshuffle(ac["downscale_factor"])
+    a.body = [(lambda x, i=i: O.adapter_block(sd, cfg, i, x)) for i in range(len(ac["channels"]))]
+    a.zero_convs = []
+    for i, ch in enumerate(ac["channels"]):
+        z = torch.nn.Conv2d(ch, ch, 1)
+        z.weight.data.copy_(sd[f"condition_image_adapter.zero_convs.{i}.weight"])
+        z.bias.data.copy_(sd[f"condition_image_adapter.zero_convs.{i}.bias"])
+        a.zero_convs.append(z)
+    a.zero_gates = None
+    return a
+
+
 def build(RefDiT, VT, AlphaBlender, cfg, sd):
     D = cfg["num_attention_heads"] * cfg["attention_head_dim"]
     heads = cfg["num_attention_heads"]
@@ -105,7 +124,21 @@ def main():
             mine = O.dit_forward(sd, cfg, **inp)
             print(tt, "reference forward vs oracle forward: max abs diff", float((res[0] - mine).abs().max()))
             out[tt] = dict(output=res[0].clone(), disable_temporal=inp["disable_temporal"])
+        # layout branch: the REAL ImageAdapter.forward feeding the residual insertion of the REAL model forward (:459-462, :491-494)
+        from dwm.models.adapters import ImageAdapter as RefAdapter
+        acfg = dict(in_channels=6, channels=[128, 128, 128], is_downblocks=[True, False, False], num_res_blocks=2,
+                    downscale_factor=8, use_zero_convs=True)
+        cfg = small_config(condition_image_adapter_config=acfg)
+        sd = O.make_state_dict(cfg, 0)
+        inp = small_inputs(cfg, 0)
+        inp["condition_image_tensor"] = torch.rand(2, 3, 3, 6, 64, 96, generator=torch.Generator().manual_seed(5))
+        m = build(RefDiT, VTSelfAttentionBlock, AlphaBlender, cfg, sd)
+        m.condition_image_adapter = build_adapter(RefAdapter, cfg, sd)
+        res, _, _ = RefDiT.forward(m, **inp)
+        print("layout: reference forward vs oracle forward: max abs diff", float((res[0] - O.dit_forward(sd, cfg, **inp)).abs().max()))
+        out["layout"] = dict(output=res[0].clone(), adapter_config=acfg)
         # 5-D inputs [B, T, C, H, W] (no view axis): the should_add_dim branch inserts V = 1
+        sd = O.make_state_dict(small_config(), 0)
         cfg = small_config()
         inp = small_inputs(cfg, 0, V=1)
         five = {k: (v.squeeze(2) if torch.is_tensor(v) and v.dim() >= 3 and k != "crossview_attention_mask" else v) for k, v in inp.items()}

@@ -298,3 +298,14 @@ def test_training_pair_and_loss_equal_reference_train_step(name, monkeypatch):
     if clip is not None:
         g = g * min(1.0, clip / (g.abs().item() + 1e-6))
     assert abs((0.3 - d["lr"] * g).item() - d["w_after"].item()) < 1e-6
+
+
+def test_oracle_layout_branch_equals_reference_forward():
+    """the REAL ImageAdapter.forward (adapters.py:40-60) feeding the REAL model forward's residual insertion"""
+    from tests.common import small_config, small_inputs
+    fxf = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))["layout"]
+    cfg = small_config(condition_image_adapter_config=fxf["adapter_config"])
+    sd = O.make_state_dict(cfg, 0)
+    inp = small_inputs(cfg, 0)
+    inp["condition_image_tensor"] = torch.rand(2, 3, 3, 6, 64, 96, generator=torch.Generator().manual_seed(5))
+    assert torch.allclose(O.dit_forward(sd, cfg, **inp), fxf["output"], atol=1e-6)
