@@ -247,3 +247,48 @@ def test_unet_forward_vs_reference_forward_fixture(dev, name):
     e = rel_err(out, fxu["output"])
     _log("unet_reference_forward_fixture", case=name, rel=e)
     assert e < TOL_MODEL
+
+
+def test_unet_single_frame_six_views(dev):
+    """BASELINE.json configs[0] geometry (examples/ctsd_21_6views_image_generation.json: one frame, six views, the
+    temporal modules still built): T = 1 makes every temporal attention / Conv3d (3,1,1) see a single frame"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = _small_unet_cfg()
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 1, 6, 8, 8, text_len=10)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    ref = U.unet_forward(sd, cfg, **inp)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    e = rel_err(out, ref)
+    _log("unet_single_frame", rel=e)
+    assert out.shape == (2, 1, 6, 4, 8, 8) and e < TOL_MODEL
+
+
+def test_unet_full_width_config0_vs_oracle_on_device(dev):
+    """BASELINE.json configs[0] at FULL width (SD 2.1: 320 / 640 / 1280 / 1280 channels, 5 / 10 / 20 / 20 heads, 1.92 B
+    parameters), six views x one frame x 256x256 px (latents [1,1,6,4,32,32], CFG batch 2, 77 text tokens): the HIP bf16
+    forward against the fp32 oracle evaluated on the same device (the CPU oracle needs minutes for this)."""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = U.make_unet_config()
+    sd = {k: v.to(bf16) for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 1, 6, 32, 32, text_len=77)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    del m
+    torch.cuda.empty_cache()
+    sd_dev = {k: v.to(dev).float() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = U.unet_forward(sd_dev, cfg, **to_dev(inp, dev))
+    e = rel_err(out, ref)
+    _log("unet_full_width_config0", rel=e, finite=bool(torch.isfinite(out.float()).all()))
+    assert out.shape == (2, 1, 6, 4, 32, 32) and e < TOL_MODEL
