@@ -215,6 +215,8 @@ def main_unet(args):
     from opendwm_amd import _lib
     from opendwm_amd.pipeline import UNetDenoiser
     from opendwm_amd.unet import UNetCrossviewTemporalConditionModel, unet_flops
+    from opendwm_amd.build import ensure_built
+    ensure_built()                  # no-op when the in-tree libdwm_hip.so travelled with the snapshot
     _lib.load()
     timer = KernelTimer().install()
     import opendwm_amd.unet as unet_mod
@@ -308,6 +310,8 @@ def main_train(args):
     from opendwm_amd import _lib
     from opendwm_amd.dit import DiTCrossviewTemporalConditionModel, model_flops
     from opendwm_amd.pipeline import CTSDTrainer
+    from opendwm_amd.build import ensure_built
+    ensure_built()                  # no-op when the in-tree libdwm_hip.so travelled with the snapshot
     _lib.load()
     kwargs = dict(MODEL_KWARGS)
     if args.layers is not None:
@@ -399,6 +403,8 @@ def main():
     from opendwm_amd import _lib
     from opendwm_amd.dit import model_flops
     from opendwm_amd.pipeline import CTSDDenoiser
+    from opendwm_amd.build import ensure_built
+    ensure_built()                  # no-op when the in-tree libdwm_hip.so travelled with the snapshot
     _lib.load()
 
     kwargs = dict(MODEL_KWARGS)

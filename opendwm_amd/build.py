@@ -74,5 +74,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def ensure_built() -> str:
+    """Build the library if it is missing (sources newer than the .so do NOT trigger a rebuild here: a snapshot copy may
+    reorder mtimes).  Serialised with a file lock so the ranks of one node do not compile concurrently."""
+    if os.path.exists(LIB):
+        return LIB
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB):
+                build()
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    return LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

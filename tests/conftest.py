@@ -16,3 +16,13 @@ def pytest_configure(config):
 def small_cfg():
     from tests.common import small_config
     return small_config()
+
+
+def pytest_collection_modifyitems(config, items):
+    """the GPU leg calls through the C ABI of the in-tree libdwm_hip.so: build it once if the snapshot came without it"""
+    if any("gpu" in item.keywords for item in items) and config.getoption("-m") != "not gpu":
+        try:
+            from opendwm_amd.build import ensure_built
+            ensure_built()
+        except Exception as e:                          # the tests themselves then fail loudly in _lib.load()
+            print(f"[conftest] libdwm_hip.so could not be built: {e}", file=sys.stderr)
