@@ -100,6 +100,7 @@ class KernelTimer:
     def install(self):
         from opendwm_amd import ops
         gemm0, attn0 = ops.gemm, ops.attention
+        self._orig = (gemm0, attn0)
         timer = self
 
         def gemm(a, w, *args, **kw):
@@ -133,6 +134,10 @@ class KernelTimer:
         for mod in (blocks, dit):
             mod.ops = ops
         return self
+
+    def uninstall(self):
+        from opendwm_amd import ops
+        ops.gemm, ops.attention = self._orig
 
     def shape_table(self, top=25):
         """per-shape totals of the recorded GEMM launches, slowest first (diagnostics: `--gemm-shapes`)"""
@@ -375,10 +380,17 @@ def main():
                     help="replay the whole step as one HIP graph (CTSDDenoiser.enable_graph); the per-kernel HIP-event "
                          "roofline cannot be taken inside a graph, so the roofline fields are empty in this mode")
     ap.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a bench line)")
-    ap.add_argument("--layout", action="store_true",
-                    help="text+layout variant (examples/ctsd_35_df16_6views_video_generation_with_layout.json model: "
-                         "ImageAdapter + point-wise temporal attention, 13 added time ids)")
-    ap.add_argument("--no-adapter-cache", action="store_true", help="with --layout: recompute the adapter every step as the reference does")
+    ap.add_argument("--text-only", action="store_true",
+                    help="the text-conditioned variant (examples/ctsd_35_6views_video_generation.json: row-wise temporal "
+                         "attention, no ImageAdapter) instead of the default text+layout variant BASELINE.json configs[2] names "
+                         "(examples/ctsd_35_df16_6views_video_generation_with_layout.json model: ImageAdapter + point-wise "
+                         "temporal attention, 13 added time ids)")
+    ap.add_argument("--layout", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--no-text-only-leg", action="store_true",
+                    help="skip the secondary leg that times the text-only variant after the headline (reported as 'text_only')")
+    ap.add_argument("--adapter-cache", action="store_true",
+                    help="keep the ImageAdapter residuals across denoise steps (its input does not change from step to step); "
+                         "the default recomputes the adapter inside every step as the reference's forward does")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead of the headline metric: one SD-3.5 training step per 'step' "
                          "(forward + backward + AdamW on one 6-view x 16-frame sample per GPU, DDP gradient all-reduce over RCCL)")
@@ -407,19 +419,7 @@ def main():
     ensure_built()                  # no-op when the in-tree libdwm_hip.so travelled with the snapshot
     _lib.load()
 
-    kwargs = dict(MODEL_KWARGS)
-    if args.layout:
-        kwargs.update(temporal_attention_type="pointwise", projection_class_embeddings_input_dim=3328,
-                      condition_image_adapter_config=dict(in_channels=6, channels=[1536] * 6,
-                                                          is_downblocks=[True] + [False] * 5, num_res_blocks=2,
-                                                          downscale_factor=8, use_zero_convs=True))
-    if args.layers is not None:
-        n = args.layers
-        kwargs.update(num_layers=n, dual_attention_layers=[i for i in kwargs["dual_attention_layers"] if i < n],
-                      crossview_block_layers=[i for i in kwargs["crossview_block_layers"] if i < n],
-                      temporal_block_layers=[i for i in kwargs["temporal_block_layers"] if i < n])
-    timer = KernelTimer().install()
-    model = build_model(kwargs, dev, seed=0)
+    args.layout = not args.text_only
     w = WORKLOAD
     # --cfg-split: ranks (2k, 2k+1) share ONE sample (unconditional / conditional half each, one all-gather of the
     # prediction per step): N GPUs = N/2 samples in flight at about twice the per-sample speed
@@ -429,31 +429,65 @@ def main():
         assert world % 2 == 0, "--cfg-split needs an even number of ranks"
         groups = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
         cfg_group, sample_id, n_samples = groups[rank // 2], rank // 2, world // 2
-    cond = make_conditions(dev, seed=sample_id, n_time_ids=13 if args.layout else 11)
-    if args.layout:
-        gl = torch.Generator(device="cuda").manual_seed(77 + sample_id)
-        cond["condition_image_tensor"] = torch.rand(2 * w["B"], w["T"], w["V"], 6, 256, 448, device=dev, generator=gl).to(torch.bfloat16)
-    g = torch.Generator(device="cuda").manual_seed(sample_id)
-    latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
-    den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=w["inference_steps"],
-                       cfg_group=cfg_group).prepare(latents, cond)
-    if args.graph:
-        den.enable_graph()
-
     ninf = w["inference_steps"]
 
-    def step(i):
-        timer.enabled = i >= args.warmup and not args.graph
-        if args.no_adapter_cache:
-            model._adapter_cache = (None, None)
-        den.step(i % ninf)
+    def run_variant(layout: bool, steps: int, warmup: int):
+        """build the model of one variant, W untimed + K timed denoise steps; -> (kwargs, seconds, KernelTimer, finite)"""
+        kwargs = dict(MODEL_KWARGS)
+        if layout:
+            kwargs.update(temporal_attention_type="pointwise", projection_class_embeddings_input_dim=3328,
+                          condition_image_adapter_config=dict(in_channels=6, channels=[1536] * 6,
+                                                              is_downblocks=[True] + [False] * 5, num_res_blocks=2,
+                                                              downscale_factor=8, use_zero_convs=True))
+        if args.layers is not None:
+            n = args.layers
+            kwargs.update(num_layers=n, dual_attention_layers=[i for i in kwargs["dual_attention_layers"] if i < n],
+                          crossview_block_layers=[i for i in kwargs["crossview_block_layers"] if i < n],
+                          temporal_block_layers=[i for i in kwargs["temporal_block_layers"] if i < n])
+        timer = KernelTimer().install()
+        try:
+            model = build_model(kwargs, dev, seed=0)
+            cond = make_conditions(dev, seed=sample_id, n_time_ids=13 if layout else 11)
+            if layout:
+                gl = torch.Generator(device="cuda").manual_seed(77 + sample_id)
+                cond["condition_image_tensor"] = torch.rand(2 * w["B"], w["T"], w["V"], 6, 256, 448, device=dev,
+                                                            generator=gl).to(torch.bfloat16)
+            g = torch.Generator(device="cuda").manual_seed(sample_id)
+            latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
+            den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=ninf,
+                               cfg_group=cfg_group).prepare(latents, cond)
+            if args.graph:
+                den.enable_graph()
 
-    dt = D.timed_steps(step, args.steps, args.warmup, dev)
-    timer.enabled = False
-    finite = bool(torch.isfinite(den.latents).all().item())
+            def step(i):
+                timer.enabled = i >= warmup and not args.graph
+                if not args.adapter_cache:
+                    model._adapter_cache = (None, None)
+                den.step(i % ninf)
+
+            dt = D.timed_steps(step, steps, warmup, dev)
+            timer.enabled = False
+            finite = bool(torch.isfinite(den.latents).all().item())
+        finally:
+            timer.uninstall()
+        del den, model, cond, latents
+        torch.cuda.empty_cache()
+        return kwargs, dt, timer, finite
+
+    kwargs, dt, timer, finite = run_variant(args.layout, args.steps, args.warmup)
+    # the other example of BASELINE config 3 (SURVEY.md s8d: examples/ctsd_35_6views_video_generation.json, text only,
+    # row-wise temporal attention, 398.98 TFLOP/step) - reported beside the headline, outside its timed region, at N=1 only
+    other = None
+    if world == 1 and args.layout and not args.no_text_only_leg and not args.graph and args.layers is None:
+        try:
+            k2, dt2, t2, fin2 = run_variant(False, args.steps, args.warmup)
+            other = (k2, dt2, t2, fin2)
+        except Exception as e:          # never lose the headline line to the secondary leg
+            print(f"text-only leg failed: {e!r}", file=sys.stderr)
 
     if rank == 0:
         fl = model_flops(kwargs, 2 * w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])
+        step_flop = fl["total"] + (fl["adapter"] if args.layout and not args.adapter_cache else 0)
         ks = timer.summary()
         if args.gemm_shapes:
             for row in timer.shape_table():
@@ -467,11 +501,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
             "config": {"workload": "CTSD SD-3.5 MMDiT (24 joint blocks, 13 dual, 6 cross-view + 12 temporal VT blocks, "
-                                   "rowwise), 6 views x 16 frames x 448x256 px (latents [1,16,6,16,32,56]), CFG g=4 -> "
+                                   "" + ("point-wise temporal + ImageAdapter" if args.layout else "row-wise temporal") + "), 6 views x 16 frames x 448x256 px (latents [1,16,6,16,32,56]), CFG g=4 -> "
                                    "model batch 2, 154 text tokens, FlowMatch-Euler; " +
                                    ("CFG halves of one sample on two GPUs" if args.cfg_split else "one replica per GPU"),
-                       "layers": kwargs["num_layers"], "flop_per_step": fl["total"], "finite": finite,
-                       "variant": ("text+layout (ImageAdapter, pointwise temporal)" + ("" if not args.no_adapter_cache else ", adapter recomputed every step")) if args.layout else "text (rowwise temporal)"},
+                       "layers": kwargs["num_layers"], "flop_per_step": step_flop, "flop_model": fl["total"], "flop_adapter": fl["adapter"],
+                       "baseline_config": "BASELINE.json configs[2]", "finite": finite,
+                       "variant": ("text+layout (ImageAdapter recomputed every step, pointwise temporal)" if not args.adapter_cache else
+                                   "text+layout (ImageAdapter residuals cached across steps, pointwise temporal)")
+                       if args.layout else "text only (rowwise temporal, no adapter)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_bf16_kernel"),
@@ -484,8 +521,19 @@ def main():
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
                                    "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms},
-            "whole_step_mfma_frac": fl["total"] / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+            "whole_step_mfma_frac": step_flop / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
         }
+        if other is not None:
+            k2, dt2, t2, fin2 = other
+            fl2, ks2 = model_flops(k2, 2 * w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"]), t2.summary()
+            ms2 = 1e3 * dt2 / args.steps
+            line["text_only"] = {
+                "variant": "text only (examples/ctsd_35_6views_video_generation.json: row-wise temporal, no adapter), same "
+                           "latents / CFG / scheduler, timed after the headline with the same --steps / --warmup",
+                "value": n_samples * args.steps / dt2, "unit": "denoise-steps/s", "ms_per_step": ms2,
+                "flop_per_step": fl2["total"], "finite": fin2,
+                "gemm_tflops": ks2.get("gemm", {}).get("tflops"), "attention_tflops": ks2.get("attn", {}).get("tflops"),
+                "whole_step_mfma_frac": fl2["total"] / (ms2 * 1e-3) / (PEAK_BF16_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))))
         print(json.dumps(line))

@@ -17,8 +17,9 @@ echo "== smoke"
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -5 $OUT/smoke.log
 echo "== bench"
 timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/bench.log; tail -5 $OUT/bench.log
+timeout 600 python bench.py --no-cpu-baseline --no-text-only-leg --adapter-cache > $OUT/bench_adapter_cache.log 2>&1; tail -1 $OUT/bench_adapter_cache.log | cut -c1-300
 echo "== rocprof"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-text-only-leg > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1)
 find /tmp/prof_$TAG -name "*stats*" | head
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv"); do cp $f $OUT/; done
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1); do head -12 $f | cut -c1-160; done

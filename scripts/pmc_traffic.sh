@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmct_${TAG}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmct_${TAG}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-text-only-leg > $OUT/pmc_$C.log 2>&1
 done
 python - "$OUT" /tmp/pmct_${TAG}_FETCH_SIZE /tmp/pmct_${TAG}_WRITE_SIZE <<'PY'
 import csv, glob, json, sys, collections

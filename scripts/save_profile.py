@@ -17,12 +17,13 @@ for ks, dst in ((os.path.join(src, "bench_kernel_stats.csv"), f"profiles/{name}_
             n = r["Name"]
             n = n if len(n) <= 110 else n[:107] + "..."
             w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-for fn, out in (("bench.log", f"{name}_bench.json"), ("bench_train.log", f"{name}_bench_train.json"), ("bench_unet.log", f"{name}_bench_unet.json"), ("gpu_parity.log", f"{name}_gpu_parity.log"),
+for fn, out in (("bench.log", f"{name}_bench.json"), ("bench_train.log", f"{name}_bench_train.json"), ("bench_unet.log", f"{name}_bench_unet.json"),
+                ("bench_adapter_cache.log", f"{name}_bench_adapter_cache.json"), ("gpu_parity.log", f"{name}_gpu_parity.log"),
                 ("pytest.log", None), ("smoke.log", f"{name}_smoke.log")):
     p = os.path.join(src, fn)
     if not os.path.exists(p):
         continue
-    if fn in ("bench.log", "bench_train.log", "bench_unet.log"):
+    if fn.startswith("bench"):
         lines = [l for l in open(p) if l.startswith("{")]
         if lines:
             open(f"profiles/{out}", "w").write(json.dumps(json.loads(lines[-1]), indent=1) + "\n")
