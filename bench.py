@@ -376,6 +376,10 @@ def main():
     ap.add_argument("--cfg-split", action="store_true",
                     help="pairs of ranks share one sample: CFG halves on two GPUs, one all-gather per step (per-sample latency "
                          "mode; the default is one replica per GPU)")
+    ap.add_argument("--frame-shard", action="store_true",
+                    help="all ranks share ONE sample, T/N frames each (opendwm_amd.sharding: an all-to-all before and after "
+                         "every temporal block); per-sample latency mode, reported as strong scaling.  With --cfg-split: "
+                         "2 CFG halves x N/2 frame shards")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one HIP graph (CTSDDenoiser.enable_graph); the per-kernel HIP-event "
                          "roofline cannot be taken inside a graph, so the roofline fields are empty in this mode")
@@ -429,6 +433,15 @@ def main():
         assert world % 2 == 0, "--cfg-split needs an even number of ranks"
         groups = [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
         cfg_group, sample_id, n_samples = groups[rank // 2], rank // 2, world // 2
+    frame_group = None
+    if args.frame_shard and world > 1:
+        import torch.distributed as dist
+        if args.cfg_split:              # ranks of equal parity hold the same CFG half: they split the frames
+            fgroups = [dist.new_group(list(range(c, world, 2))) for c in range(2)]
+            frame_group = fgroups[rank % 2]
+        else:
+            frame_group = dist.group.WORLD
+        sample_id, n_samples = 0, 1
     ninf = w["inference_steps"]
 
     def run_variant(layout: bool, steps: int, warmup: int):
@@ -455,7 +468,7 @@ def main():
             g = torch.Generator(device="cuda").manual_seed(sample_id)
             latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
             den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=ninf,
-                               cfg_group=cfg_group).prepare(latents, cond)
+                               cfg_group=cfg_group, frame_group=frame_group).prepare(latents, cond)
             if args.graph:
                 den.enable_graph()
 
@@ -498,12 +511,14 @@ def main():
             "metric": "denoise-steps/sec (6-view x16f 448x256), SD-3.5 CTSD",
             "value": n_samples * args.steps / dt, "unit": "denoise-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "strong" if frame_group is not None else "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
             "config": {"workload": "CTSD SD-3.5 MMDiT (24 joint blocks, 13 dual, 6 cross-view + 12 temporal VT blocks, "
                                    "" + ("point-wise temporal + ImageAdapter" if args.layout else "row-wise temporal") + "), 6 views x 16 frames x 448x256 px (latents [1,16,6,16,32,56]), CFG g=4 -> "
                                    "model batch 2, 154 text tokens, FlowMatch-Euler; " +
-                                   ("CFG halves of one sample on two GPUs" if args.cfg_split else "one replica per GPU"),
+                                   ("one sample over all GPUs: " + ("2 CFG halves x " if args.cfg_split else "") + "frame shards, all-to-all around temporal blocks"
+                                    if frame_group is not None else
+                                    "CFG halves of one sample on two GPUs" if args.cfg_split else "one replica per GPU"),
                        "layers": kwargs["num_layers"], "flop_per_step": step_flop, "flop_model": fl["total"], "flop_adapter": fl["adapter"],
                        "baseline_config": "BASELINE.json configs[2]", "finite": finite,
                        "variant": ("text+layout (ImageAdapter recomputed every step, pointwise temporal)" if not args.adapter_cache else

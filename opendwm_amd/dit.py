@@ -175,6 +175,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
         else:
             self.condition_image_adapter = None
         self._adapter_cache = (None, None)
+        self.frame_shard = None             # set by CTSDDenoiser(frame_group=...): opendwm_amd.sharding.FrameShard
         self.perspective_modeling_type = perspective_modeling_type
         if perspective_modeling_type == "implicit":
             self.view_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, inner_dim)
@@ -306,6 +307,12 @@ class DiTCrossviewTemporalConditionModel(_Base):
         height, width = H // p, W // p
         N, I, D = height * width, B * T * V, self.inner_dim
         self.view_count, self.width = V, width
+        # frame_shard (opendwm_amd.sharding.FrameShard): `sample` and the per-frame conditions hold only this rank's
+        # frames of the sample; T is the local frame count, Tg the sample's
+        fs, cam_all = self.frame_shard, None
+        Tg = T if fs is None else T * fs.size
+        if fs is not None and self.enable_temporal:
+            fs.check(height, self.temporal_attention_type)
 
         def as_bf16(t):
             return t if t.dtype == bf16 else (ops.cast_bf16(t.contiguous()) if t.dtype == torch.float32 else t.to(bf16))
@@ -350,18 +357,29 @@ class DiTCrossviewTemporalConditionModel(_Base):
 
             if self.enable_temporal and i in self.temporal_block_layers:
                 k = self.temporal_block_layers.index(i)
-                idx = torch.arange(T, device=h.device).view(1, T, 1).expand(B, T, V)
+                idx = torch.arange(Tg, device=h.device).view(1, Tg, 1).expand(B, Tg, V)
                 seq = ops.timestep_sinusoid(idx, D)
                 use_cam = self.enable_crossview and not self.disable_view_emb_on_temporal_module \
                     and view_cam_emb is not None
-                seq_emb = self.time_pos_embeds[k].run(seq, res=view_cam_emb if use_cam else None)
+                if use_cam and fs is not None and cam_all is None:
+                    cam_all = fs.gather_frames(view_cam_emb.view(B, T, V, D), 1).view(-1, D)
+                seq_emb = self.time_pos_embeds[k].run(seq, res=(view_cam_emb if fs is None else cam_all) if use_cam else None)
                 tt = self.temporal_attention_type
                 mk = ops.rowmap_temporal_full if tt == "full" else \
                     ops.rowmap_temporal_rowwise if tt == "rowwise" else ops.rowmap_temporal_pointwise
                 alpha = self.time_mixers[k].get_alpha(disable_temporal, B)
-                self.temporal_transformer_blocks[k].run(
-                    h, mk(B, T, V, height, width), emb=seq_emb, rows_per_emb=N,
-                    blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
+                if fs is None:
+                    self.temporal_transformer_blocks[k].run(
+                        h, mk(B, T, V, height, width), emb=seq_emb, rows_per_emb=N,
+                        blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
+                else:
+                    # frames of this sample live on other ranks: all frames of MY token rows, block + mixer, and back
+                    hl = height // fs.size
+                    hx = fs.frames_to_rows(h, B, T, V, height, width)
+                    self.temporal_transformer_blocks[k].run(
+                        hx, mk(B, Tg, V, hl, width), emb=seq_emb, rows_per_emb=hl * width,
+                        blend_alpha=alpha, rows_per_alpha=Tg * V * hl * width, blend_into=hx)
+                    fs.rows_to_frames(hx, B, T, V, height, width, out=h)
 
             if self.enable_crossview and i in self.crossview_block_layers:
                 k = self.crossview_block_layers.index(i)

@@ -51,8 +51,12 @@ class CTSDDenoiser:
         scheduler step, frames outside the schedule range left untouched (:1498-1507, :1554-1572)."""
 
     def __init__(self, model, guidance_scale: float = 4.0, inference_steps: int = 40, shift: float = 3.0,
-                 cfg_group=None):
-        """cfg_group: a torch.distributed process group of size 2 -> classifier-free-guidance split: the
+                 cfg_group=None, frame_group=None):
+        """frame_group: a torch.distributed process group whose R ranks hold T/R frames each of ONE sample
+        (opendwm_amd.sharding: one all-to-all before and after every temporal block; everything else is local).  Every
+        rank passes the same full latents / conditions to prepare() and gets the full result() back.
+
+        cfg_group: a torch.distributed process group of size 2 -> classifier-free-guidance split: the
         two halves of the CFG batch are independent inside the model, so rank 0 of the group runs the unconditional
         half and rank 1 the conditional half of ONE sample, the halves of the prediction are exchanged with one
         all-gather per step (2.2 MB at config 3; RCCL over xGMI) and both ranks apply the same guidance + scheduler
@@ -60,6 +64,10 @@ class CTSDDenoiser:
         self.model = model
         self.cfg_group = cfg_group
         self.cfg_rank = 0
+        self.frame_shard = None
+        if frame_group is not None:
+            from .sharding import FrameShard
+            self.frame_shard = FrameShard(frame_group)
         if cfg_group is not None:
             import torch.distributed as dist
             if dist.get_world_size(cfg_group) != 2:
@@ -83,14 +91,30 @@ class CTSDDenoiser:
         if diffusion_forcing and image_latents is not None:
             latents = image_latents                                   # ctsd.py:1470-1471
             image_latents = None
-        self.latents = latents.to(torch.float32).contiguous().clone()
         B, T = latents.shape[:2]
+        self.total_frames, self.t0 = T, 0
         self.ref = reference_frame_count if image_latents is not None else 0
-        self.image_latents = None if image_latents is None else image_latents.to(torch.float32).to(dev)
         if diffusion_forcing:
             if self.inference_steps % (T - clear_reference_frame_count) != 0:
                 raise ValueError("inference_steps must be a multiple of the frame count in diffusion-forcing mode")
             self.spi = self.inference_steps // (T - clear_reference_frame_count)
+        if hasattr(self.model, "frame_shard"):
+            self.model.frame_shard = self.frame_shard
+        elif self.frame_shard is not None:
+            raise ValueError("this model has no frame-sharded forward")
+        if self.frame_shard is not None:                               # keep this rank's frames of everything per-frame
+            if self.use_graph:
+                raise NotImplementedError("frame sharding is not captured into a HIP graph")
+            t0, t1 = self.frame_shard.frame_range(T)
+            self.t0 = t0
+            latents = latents[:, t0:t1]
+            if image_latents is not None:
+                image_latents = image_latents[:, t0:t1]
+            self.ref = min(max(self.ref - t0, 0), t1 - t0)
+            conditions = {k: (v[:, t0:t1] if torch.is_tensor(v) and k not in self.NO_FRAME_AXIS and v.dim() >= 2 and v.shape[1] == T
+                              else v) for k, v in conditions.items()}
+        self.latents = latents.to(torch.float32).contiguous().clone()
+        self.image_latents = None if image_latents is None else image_latents.to(torch.float32).to(dev)
         self.model_in = torch.empty((2 * B, *latents.shape[1:]), dtype=bf16, device=dev)
         self._refresh_model_in()
         self.conditions = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
@@ -103,6 +127,9 @@ class CTSDDenoiser:
         self._ts_dev = self.schedule.timesteps.to(dev)
         self._sig_dev = self.schedule.sigmas.to(dev)
         return self
+
+    # conditions without a frame axis at dim 1 (crossview_temporal_dit.py:372-391)
+    NO_FRAME_AXIS = ("disable_crossview", "disable_temporal", "crossview_attention_mask", "crossview_attention_index")
 
     def _refresh_model_in(self):
         B = self.latents.shape[0]
@@ -122,7 +149,7 @@ class CTSDDenoiser:
         """(timesteps [2B,T,V] device fp32, sigma step: host float or device fp32 [B,T,V]) of step i"""
         B, T, V = self.latents.shape[:3]
         if self.diffusion_forcing:
-            j = torch.arange(T)
+            j = self.t0 + torch.arange(T)                              # this rank's frames of the sample
             idx = torch.minimum(torch.full((T,), i - self.take_time * self.spi), torch.clamp(i - j * self.spi, min=0))
             idx = idx.to(self._ts_dev.device)
             ts = self._ts_dev[idx].view(1, T, 1).expand(2 * B, T, V)
@@ -195,9 +222,12 @@ class CTSDDenoiser:
         self._graph.replay()
 
     def result(self) -> torch.Tensor:
+        out = self.latents
         if self.ref > 0:                                              # ctsd.py:1623-1627
-            return torch.cat([self.image_latents[:, :self.ref], self.latents[:, self.ref:]], 1)
-        return self.latents
+            out = torch.cat([self.image_latents[:, :self.ref], self.latents[:, self.ref:]], 1)
+        if self.frame_shard is not None:
+            out = self.frame_shard.gather_frames(out, 1)               # every rank returns the whole sample
+        return out
 
     def run(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], stop: Optional[int] = None,
             start: int = 0, **prepare_kw):

@@ -74,3 +74,69 @@ def test_shard_samples_properties():
             flat = [i for p in parts for i in p]
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ---------------------------------------------------------------- intra-sample (frame) sharding, opendwm_amd.sharding
+def _frame_shard_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    D.init("gloo")
+    from opendwm_amd.sharding import FrameShard
+    from oracle import ctsd_oracle as O
+    from tests.common import small_config
+    fs = FrameShard()
+    B, T, V, height, width = 2, 4, 2, 4, 3
+    res = {}
+    # 1. the exchange itself: rank r must end up with rows [r*hl, (r+1)*hl) of EVERY frame, and back
+    Dm = 5
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(B, T, V, height, width, Dm, generator=g)
+    t0, t1 = fs.frame_range(T)
+    hl = height // world
+    mine = full[:, t0:t1].reshape(-1, Dm).contiguous()
+    hx = fs.frames_to_rows(mine, B, t1 - t0, V, height, width)
+    res["rows_ok"] = bool(torch.equal(hx.view(B, T, V, hl, width, Dm), full[:, :, :, rank * hl:(rank + 1) * hl]))
+    back = fs.rows_to_frames(hx, B, t1 - t0, V, height, width)
+    res["round_trip"] = bool(torch.equal(back, mine))
+    res["gather"] = bool(torch.equal(fs.gather_frames(full[:, t0:t1].contiguous(), 1), full))
+    # 2. a temporal block + mixer on the re-sharded rows == the same block on the whole sample (oracle as the row compute)
+    for typ in ("rowwise", "pointwise"):
+        cfg = small_config(temporal_attention_type=typ)
+        sd = O.make_state_dict(cfg, 0)
+        C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+        h = torch.randn(B * T * V, height * width, C, generator=g)
+        emb = torch.randn(B * T * V, 1, C, generator=g) * 0.3
+        dis = torch.tensor([False, True])
+        whole = O.temporal_block_and_mix(sd, cfg, 0, h, emb, B, T, V, width, dis).view(B, T, V, height * width, C)
+        loc = h.view(B, T, V, height * width, C)[:, t0:t1].reshape(-1, C).contiguous()
+        hx = fs.frames_to_rows(loc, B, t1 - t0, V, height, width)
+        y = O.temporal_block_and_mix(sd, cfg, 0, hx.view(B * T * V, hl * width, C), emb, B, T, V, width, dis)
+        out = fs.rows_to_frames(y.reshape(-1, C).contiguous(), B, t1 - t0, V, height, width)
+        res[typ] = float((out.view(B, t1 - t0, V, height * width, C) - whole[:, t0:t1]).abs().max())
+    try:
+        fs.check(height, "full")
+        res["full_rejected"] = False
+    except NotImplementedError:
+        res["full_rejected"] = True
+    q.put((rank, res))
+    D.shutdown()
+
+
+def test_frame_shard_exchange_and_temporal_block_gloo():
+    """frames of one sample on two ranks.  The all-to-all re-shard (my frames, all token rows) <->
+    (all frames, my token rows) is exact, and a temporal block + mixer run on the re-sharded rows reproduces the
+    unsharded block (fp32 oracle compute; 1e-5 abs: only the summation order inside torch kernels may differ)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frame_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r]["rows_ok"] and res[r]["round_trip"] and res[r]["gather"] and res[r]["full_rejected"], res[r]
+        assert res[r]["rowwise"] < 1e-5 and res[r]["pointwise"] < 1e-5, res[r]

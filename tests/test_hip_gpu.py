@@ -752,6 +752,54 @@ def test_cfg_split_two_ranks(dev, small_cfg):
     assert torch.equal(a, b) and e < 5e-3
 
 
+def _frame_shard_worker(rank, world, port, cfg, sd, lat, cond, kw, path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opendwm_amd.pipeline import CTSDDenoiser
+    dev = torch.device("cuda:0")
+    m = _hip_model(cfg, sd, dev)
+    den = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=4, frame_group=dist.group.WORLD)
+    out = den.run(lat.to(dev), to_dev(cond, dev), stop=3, **{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()})
+    torch.save(out.cpu(), f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("temporal,mode", [("rowwise", "full"), ("pointwise", "diffusion_forcing"), ("rowwise", "reference_frames")])
+def test_frame_shard_two_ranks(dev, small_cfg, temporal, mode):
+    """Intra-sample sharding (opendwm_amd.sharding): the 4 frames of one sample on two ranks, one
+    all-to-all before and after every temporal block (gloo here, both ranks on the one GPU; RCCL in production), per-frame
+    timesteps / reference frames / scheduler update on the rank that owns the frame.  Every rank returns the whole
+    sample, equal to the single-process run up to bf16 round-off (half-size GEMM grids; 5e-3 rel)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from opendwm_amd.pipeline import CTSDDenoiser
+    cfg = dict(small_cfg, temporal_attention_type=temporal)
+    sd = _bf16_round_sd(O.make_state_dict(cfg, 0))
+    inp = small_inputs(cfg, 0, T=4)
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    lat = torch.randn(1, 4, 3, 16, 8, 12, generator=torch.Generator().manual_seed(13))
+    img = torch.randn(1, 4, 3, 16, 8, 12, generator=torch.Generator().manual_seed(14))
+    kw = {"full": {}, "reference_frames": dict(image_latents=img, reference_frame_count=1),
+          "diffusion_forcing": dict(image_latents=img, diffusion_forcing=True, take_time=0)}[mode]
+    single = CTSDDenoiser(_hip_model(cfg, sd, dev), guidance_scale=4.0, inference_steps=4).run(
+        lat.to(dev), to_dev(cond, dev), stop=3, **{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}).cpu()
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() + 11) % 2000
+    path = os.path.join(tempfile.mkdtemp(), "frame_shard")
+    procs = [ctx.Process(target=_frame_shard_worker, args=(r, 2, port, cfg, sd, lat, cond, kw, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    a, b = torch.load(path + ".0"), torch.load(path + ".1")
+    e = rel_err(a, single)
+    _log("frame_shard", temporal=temporal, mode=mode, ranks_equal=bool(torch.equal(a, b)), rel_vs_single=e)
+    assert a.shape == single.shape and torch.equal(a, b) and e < 5e-3
+
+
 @pytest.mark.parametrize("name", ["crossview_rowwise_0", "crossview_rowwise_1", "crossview_full_0", "temporal_full", "temporal_rowwise", "temporal_pointwise"])
 def test_attention_rowmaps_and_mixer_vs_reference_fixture(dev, name):
     """Golden vectors produced by the REFERENCE's own forward_crossview / forward_temporal_block_and_mix_result code
