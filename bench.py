@@ -71,7 +71,29 @@ def build_model(kwargs, dev, seed=0):
     return model.eval()
 
 
-def make_conditions(dev, seed, w=WORKLOAD, n_time_ids=11):
+def variant_kwargs(layout: bool) -> dict:
+    """constructor kwargs of the two models of BASELINE config 3: text+layout (ImageAdapter + point-wise temporal
+    attention, 13 added time ids; examples/ctsd_35_df16_6views_video_generation_with_layout.json) or text only"""
+    kwargs = dict(MODEL_KWARGS)
+    if layout:
+        kwargs.update(temporal_attention_type="pointwise", projection_class_embeddings_input_dim=3328,
+                      condition_image_adapter_config=dict(in_channels=6, channels=[1536] * 6,
+                                                          is_downblocks=[True] + [False] * 5, num_res_blocks=2,
+                                                          downscale_factor=8, use_zero_convs=True))
+    return kwargs
+
+
+def make_conditions(dev, seed, w=WORKLOAD, n_time_ids=None, layout=False):
+    n_time_ids = n_time_ids or (13 if layout else 11)
+    cond = _make_conditions(dev, seed, w, n_time_ids)
+    if layout:          # 3dbox + hdmap condition images (6 channels) at pixel resolution, CFG-doubled like the rest
+        gl = torch.Generator(device="cuda").manual_seed(77 + seed)
+        cond["condition_image_tensor"] = torch.rand(2 * w["B"], w["T"], w["V"], 6, 8 * w["H"], 8 * w["W"], device=dev,
+                                                    generator=gl).to(torch.bfloat16)
+    return cond
+
+
+def _make_conditions(dev, seed, w, n_time_ids):
     g = torch.Generator(device="cuda").manual_seed(1000 + seed)
     B2, T, V = 2 * w["B"], w["T"], w["V"]
     ring = torch.zeros(V, V, dtype=torch.bool)
@@ -446,12 +468,7 @@ def main():
 
     def run_variant(layout: bool, steps: int, warmup: int):
         """build the model of one variant, W untimed + K timed denoise steps; -> (kwargs, seconds, KernelTimer, finite)"""
-        kwargs = dict(MODEL_KWARGS)
-        if layout:
-            kwargs.update(temporal_attention_type="pointwise", projection_class_embeddings_input_dim=3328,
-                          condition_image_adapter_config=dict(in_channels=6, channels=[1536] * 6,
-                                                              is_downblocks=[True] + [False] * 5, num_res_blocks=2,
-                                                              downscale_factor=8, use_zero_convs=True))
+        kwargs = variant_kwargs(layout)
         if args.layers is not None:
             n = args.layers
             kwargs.update(num_layers=n, dual_attention_layers=[i for i in kwargs["dual_attention_layers"] if i < n],
@@ -460,11 +477,7 @@ def main():
         timer = KernelTimer().install()
         try:
             model = build_model(kwargs, dev, seed=0)
-            cond = make_conditions(dev, seed=sample_id, n_time_ids=13 if layout else 11)
-            if layout:
-                gl = torch.Generator(device="cuda").manual_seed(77 + sample_id)
-                cond["condition_image_tensor"] = torch.rand(2 * w["B"], w["T"], w["V"], 6, 256, 448, device=dev,
-                                                            generator=gl).to(torch.bfloat16)
+            cond = make_conditions(dev, seed=sample_id, layout=layout)
             g = torch.Generator(device="cuda").manual_seed(sample_id)
             latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
             den = CTSDDenoiser(model, guidance_scale=w["guidance_scale"], inference_steps=ninf,
