@@ -196,9 +196,9 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def cpu_baseline(threads: int):
+def cpu_baseline(threads: int, full_flops: float = None):
     """The fp32 CPU oracle (the restated reference path) on the host cores, on a bounded sample of
-    the same workload; reported in denoise-steps/s by FLOP ratio."""
+    the same workload; reported in denoise-steps/s by FLOP ratio (`full_flops` = the timed step's FLOPs)."""
     from oracle import ctsd_oracle as O
     from opendwm_amd.dit import model_flops
     torch.set_num_threads(threads)
@@ -213,7 +213,8 @@ def cpu_baseline(threads: int):
         O.dit_forward(sd, cfg, **inp)
         dt = time.perf_counter() - t0
     sample_flops = model_flops(cfg, 2, T, 6, 32, 56)["total"]
-    full_flops = model_flops(MODEL_KWARGS, 2, WORKLOAD["T"], WORKLOAD["V"], WORKLOAD["H"], WORKLOAD["W"])["total"]
+    if full_flops is None:
+        full_flops = model_flops(MODEL_KWARGS, 2, WORKLOAD["T"], WORKLOAD["V"], WORKLOAD["H"], WORKLOAD["W"])["total"]
     return dict(value=(sample_flops / dt) / full_flops, unit="denoise-steps/s", cores=threads, kind="port",
                 sample=f"fp32 PyTorch-CPU oracle, CFG forward of 6 views x {T} frames x 32x56 latents, first 3 layers "
                        f"(dual joint blocks + 1 cross-view + 1 temporal VT block) at full width d=1536: "
@@ -563,7 +564,7 @@ def main():
                 "gemm_tflops": ks2.get("gemm", {}).get("tflops"), "attention_tflops": ks2.get("attn", {}).get("tflops"),
                 "whole_step_mfma_frac": fl2["total"] / (ms2 * 1e-3) / (PEAK_BF16_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))))
+            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))), step_flop)
         print(json.dumps(line))
     D.shutdown()
 
