@@ -7,10 +7,10 @@ TAG=${1:-r1}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmct_${TAG}_$C -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-text-only-leg > $OUT/pmc_$C.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmct_${TAG}_${C%% *} -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-text-only-leg > $OUT/pmc_${C%% *}.log 2>&1
 done
-python - "$OUT" /tmp/pmct_${TAG}_FETCH_SIZE /tmp/pmct_${TAG}_WRITE_SIZE <<'PY'
+python - "$OUT" /tmp/pmct_${TAG}_FETCH_SIZE /tmp/pmct_${TAG}_WRITE_SIZE /tmp/pmct_${TAG}_SQ_VALU_MFMA_BUSY_CYCLES <<'PY'
 import csv, glob, json, sys, collections
 out, dirs = sys.argv[1], sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
@@ -28,6 +28,16 @@ for k, d in agg.items():
     rd, wr = d.get("FETCH_SIZE", 0) * 1024 * 2, d.get("WRITE_SIZE", 0) * 1024
     res[k] = {"launches": n, "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
               "hbm_bytes_per_launch": (rd + wr) / n, "note": "FETCH_SIZE KiB*1024*2 (gfx950 wide-load correction) + WRITE_SIZE KiB*1024; 2 bench steps (1 warmup + 1)"}
+# MFMA utilisation (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts pipe cycles summed over the 1024 SIMDs,
+# GRBM_GUI_ACTIVE is summed over the 8 XCDs): util = busy / (1024 * gui_active / 8)
+for k, d in agg.items():
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE"):
+        n = max(calls[k], 1)
+        res[k]["mfma"] = {"insts_mfma_per_launch": d.get("SQ_INSTS_MFMA", 0) / n,
+                          "mfma_busy_cycles_per_launch": d["SQ_VALU_MFMA_BUSY_CYCLES"] / n,
+                          "gui_active_cycles_per_xcd_per_launch": d["GRBM_GUI_ACTIVE"] / 8 / n,
+                          "mfma_pipe_utilisation": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * d["GRBM_GUI_ACTIVE"] / 8),
+                          "note": "one rocprofv3 --pmc pass of its own; busy cycles / (1024 SIMDs x kernel cycles)"}
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
