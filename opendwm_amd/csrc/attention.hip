@@ -374,6 +374,143 @@ attn_fwd_kernel(const AttnParams P) {
 #undef DWM_DMA_TILE
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (L <= 32, one segment, no mask): the point-wise temporal attention, L = frame count
+// (crossview_temporal_dit.py:352-361; 5376 x 24 problems of L = 16 at BASELINE config 3).  The tiled kernel above
+// spends a 128-query workgroup and a 64-key tile on 16 tokens; this one packs 32 / SL problems (SL = 8, 16 or 32
+// token slots) into ONE 32 x 32 MFMA tile per wave - block-diagonal validity mask - so that all 64 lanes carry a
+// token, and is bound by the q/k/v/o bytes (1.06 GB at config 3).  No LDS ring and no barrier: Q and K fragments
+// are the lanes' own rows straight from global memory (the A / B operand layouts of v_mfma_f32_32x32x16_bf16 are
+// row-per-lane), V goes through 4 KiB of wave-private LDS for the transposing read, and the output tile returns
+// through the same 4 KiB so that every store instruction writes whole 128-byte rows.
+template <int SL>
+__global__ void __launch_bounds__(256, 4)
+attn_small_kernel(const AttnParams P) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 4096];
+    constexpr int PP = 32 / SL;                      // problems per tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    char* const sc = smem + wave * 4096;
+
+    // block -> (4 consecutive problem groups, head group); head group fastest: the blocks in flight together read the
+    // same token rows
+    const uint32_t quad = fdiv(blockIdx.x, P.fd_heads);
+    const int hgrp = (int)(blockIdx.x - quad * P.fd_heads.d);
+    const int grp = (int)quad * 4 + wave;
+    if (grp * PP >= P.n_problems) return;            // wave-uniform; no block-level barrier anywhere below
+    const int hpb = P.hpb;
+    const int64_t hoff = (int64_t)hgrp * hpb * 64;
+
+    const int slot = l31 / SL, tok = l31 % SL;
+    int prob = grp * PP + slot;
+    const bool pvalid = prob < P.n_problems;
+    if (!pvalid) prob = P.n_problems - 1;
+    const bool ok = pvalid && tok < P.L;
+    const int64_t row = seg0_row(P.rm, seg0_base(P.rm, prob), tok < P.L ? tok : P.L - 1);
+    const bf16_t* const qp = P.q0 + row * P.ld0 + hoff + half * 8;
+    const bf16_t* const kp = P.k0 + row * P.ld0 + hoff + half * 8;
+    const bf16_t* const vp = P.v0 + row * P.ld0 + hoff + half * 8;
+    const int64_t orow = (int64_t)(P.o0 + row * P.ldo0 + hoff);
+
+    // keys this lane's 16 score registers stand for: (r & 3) + 8 (r >> 2) + 4 half; valid = same slot, token < L
+    uint32_t kmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key / SL == slot && key % SL < P.L) kmask |= 1u << r;
+    }
+    // tr-read geometry of the V^T fragments (see attn_fwd_kernel)
+    const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+    int vra[2], vrb[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+        const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+        vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+    }
+    const int vswz = ((l31 >> 1) & 1) << 2;
+    char* const myrow = sc + l31 * 128;
+
+    for (int hh = 0; hh < hpb; ++hh) {
+        bf16x8 qf[4], kf[4];
+        uint4 vv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *(const bf16x8*)(qp + hh * 64 + ks * 16);
+            kf[ks] = *(const bf16x8*)(kp + hh * 64 + ks * 16);
+            vv[ks] = *(const uint4*)(vp + hh * 64 + ks * 16);
+        }
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], scale_frag(qf[ks], P.scale_log2), st, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) *(uint4*)(myrow + (((2 * ks + half) ^ vswz) << 4)) = vv[ks];
+
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!((kmask >> r) & 1u)) st[r] = -INFINITY;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // every slot holds >= 1 valid key: finite
+        float pv[16], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(st[r] - mx);
+            sum += pv[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        bf16x8 pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint4 pk = pack8(pv + 8 * s);
+            pf[s] = *reinterpret_cast<const bf16x8*>(&pk);
+        }
+        f32x16 ot[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sc + vra[dt] + s * (16 * 128)));
+                const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sc + vrb[dt] + s * (16 * 128)));
+                const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], ot[dt], 0, 0, 0);
+            }
+        // normalise; transpose the 32 x 64 output tile through the wave's LDS (same-wave LDS ops complete in order)
+        const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ot[dt][rg * 4 + j] * inv;
+                *(uint2*)(myrow + (((dt * 4 + rg) ^ (l31 & 7)) << 4) + half * 8) = pack4(v);
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (lane >> 3), c = lane & 7;
+            const uint4 val = *(const uint4*)(sc + r * 128 + ((c ^ (r & 7)) << 4));
+            const int64_t rp = __shfl(orow, r, 64);
+            const int okr = __shfl((int)ok, r, 64);
+            if (okr && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+        }
+    }
+}
+
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
 __global__ void __launch_bounds__(64)
@@ -429,6 +566,24 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     if ((int64_t)P.n_problems * (P.heads / P.hpb) * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
     if (NSTAGE * STAGE_BYTES + L * 4 + 16 > MAX_LDS_BYTES) return DWM_EUNSUPPORTED;   // ring + row table must fit the LDS window
     hipStream_t s = (hipStream_t)stream;
+    // short single-segment sequences without a mask (point-wise temporal attention): the packed small-L kernel;
+    // variant bit 5 keeps the tiled kernel (A/B measurements, tests)
+    if (L <= 32 && P.L1 == 0 && P.mask_mode == 0 && P.lse == nullptr && !((a->variant >> 5) & 1)) {
+        int hs = (a->variant >> 8) & 15;
+        if (hs == 0) { for (hs = 8; P.heads % hs != 0; --hs) {} }
+        if (P.heads % hs != 0) return DWM_EINVAL;
+        P.hpb = hs;
+        P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
+        const int sl = L <= 8 ? 8 : L <= 16 ? 16 : 32;
+        const int64_t ngrp = ((int64_t)P.n_problems + 32 / sl - 1) / (32 / sl);
+        const int64_t nblk = ((ngrp + 3) / 4) * (P.heads / hs);
+        if (nblk >= (1ll << 31)) return DWM_EUNSUPPORTED;
+        if (sl == 8) hipLaunchKernelGGL((attn_small_kernel<8>), dim3((unsigned)nblk), dim3(256), 0, s, P);
+        else if (sl == 16) hipLaunchKernelGGL((attn_small_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((attn_small_kernel<32>), dim3((unsigned)nblk), dim3(256), 0, s, P);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? DWM_OK : (int)e;
+    }
 #define DWM_ATTN(QT_)                                              \
     do {                                                           \
         if (P.mask_mode == 0) launch_attn<QT_, 0>(P, s);           \

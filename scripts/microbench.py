@@ -55,6 +55,22 @@ def bench_attn(variants):
             print(json.dumps({"kernel": "attn", "case": name, "variant": var, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
 
 
+def bench_pointwise():
+    """point-wise temporal attention (L = 16): packed small-L kernel (heads per wave 8 / 4 / 12 / 2) vs the tiled kernel"""
+    H, D = 24, 1536
+    B, T, V, h, w = 2, 16, 6, 16, 28
+    R = B * T * V * h * w
+    qkv = rnd(R, 3 * D)
+    out = torch.empty(R, D, device=dev, dtype=bf16)
+    rm = ops.rowmap_temporal_pointwise(B, T, V, h, w)
+    gb = 4 * R * D * 2 / 1e9
+    timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H), iters=300)
+    for name, var in (("packed hs=8", 0), ("packed hs=4", 4 << 8), ("packed hs=12", 12 << 8), ("packed hs=2", 2 << 8),
+                      ("packed hs=8 nostore", 16), ("tiled", 32), ("packed hs=8", 0)):
+        ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var))
+        print(json.dumps({"kernel": "attn-pointwise", "case": name, "ms": round(ms, 4), "GBps": round(gb / ms * 1e3, 1)}), flush=True)
+
+
 def bench_transpose():
     from opendwm_amd import train_ops as T
     for rows, cols in ((86016, 1536), (86016, 6144), (29568, 1536)):
@@ -113,6 +129,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     if "tr" in what:
         bench_transpose()
+    if "pw" in what:
+        bench_pointwise()
     if "attn" in what:
         bench_attn([1])
     if "gemm" in what:

@@ -310,6 +310,47 @@ def test_attention_rowmaps_and_masks(dev, variant, kind):
         assert rel_err(out2, r0) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("L", [1, 3, 6, 8, 9, 16, 17, 31, 32])
+@pytest.mark.parametrize("P,heads", [(13, 2), (7, 24), (50, 5)])
+def test_attention_short_sequences_packed_kernel(dev, L, P, heads):
+    """L <= 32, one segment, no mask -> `attn_small_kernel`: 32 / SL problems share one 32 x 32 MFMA tile (SL = 8, 16, 32
+    token slots) behind a block-diagonal validity mask.  Problem counts that leave the last tile / last workgroup partly
+    empty, every slot size and its ragged fill, three heads-per-wave splits; against fp32 SDPA and against the tiled
+    kernel (variant bit 5) on the same inputs."""
+    from opendwm_amd import ops
+    D = heads * 64
+    qkv = _rand((P * L, 3 * D), dev, 100 + L)
+    rm = ops.rowmap_identity(P, L)
+    out = torch.zeros((P * L, D), dtype=bf16, device=dev)
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads)
+    tiled = torch.zeros_like(out)
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], tiled, rm, heads, variant=32)
+    f = qkv.float()
+    r0, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads)
+    e, et = rel_err(out, r0), rel_err(tiled, r0)
+    _log("attention_short", L=L, P=P, heads=heads, rel=e, rel_tiled=et)
+    assert e < TOL_KERNEL and et < TOL_KERNEL
+
+
+def test_attention_pointwise_temporal_packed_kernel_rowmap(dev):
+    """the point-wise temporal row map (tokens of one (b, v, h, w) across frames, crossview_temporal_dit.py:352-361) at
+    T = 16 through the packed kernel: rows of one problem are V*N apart, two problems per tile, q/k/v as column slices of
+    one fused [rows, 3D] buffer."""
+    from opendwm_amd import ops
+    B, T, V, h, w, heads = 2, 16, 3, 3, 5, 24
+    D = heads * 64
+    rm = ops.rowmap_temporal_pointwise(B, T, V, h, w)
+    R = B * T * V * h * w
+    qkv = _rand((R, 3 * D), dev, 7)
+    out = torch.zeros((R, D), dtype=bf16, device=dev)
+    ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads)
+    f = qkv.float()
+    r0, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads)
+    e = rel_err(out, r0)
+    _log("attention_pointwise_packed", rel=e)
+    assert e < TOL_KERNEL
+
+
 def test_attention_online_softmax_spike(dev):
     """Force the running-max rescale: one key in a LATE tile dominates one query (cdna guide
     §5.4 rule 26), and large-magnitude scores."""
