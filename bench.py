@@ -545,7 +545,7 @@ def main():
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
-            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": at.get("tflops"),
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel + attn_small_kernel (all attention launches)", "achieved": at.get("tflops"),
                                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
