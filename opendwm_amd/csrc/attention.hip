@@ -17,8 +17,10 @@
 // K/V tiles go global -> LDS by LDS-DMA (global_load_lds, no staging registers, no ds_write)
 // into a ring of 3 stages: tile t+3 is requested right after the barrier that retires
 // tile t, so two tiles are always in flight behind the one being consumed (first-touch HBM
-// latency of a (problem, head)'s K/V is ~2 tile times) and the per-tile wait is a counted
-// vmcnt, never a drain.
+// latency of a (problem, head)'s K/V is ~2 tile times) and the per-tile wait at the barrier is a counted
+// vmcnt.  (The compiler still puts a vmcnt(0) in front of the transposing V reads, which it cannot tell apart from
+// the pending LDS-DMA writes; issuing the DMA from inline asm removes it and changes nothing measurable - by then
+// the tiles requested one and two iterations earlier have landed.)
 //
 // Addressing: q/k/v/o rows of segment 0 go through the row map of dwm_attn_args,
 // which folds the reference's einops rearranges (crossview_temporal_dit.py:307-315,
@@ -207,10 +209,16 @@ attn_fwd_kernel(const AttnParams P) {
             }
         __builtin_amdgcn_s_setprio(0);
         if (fetch_q) {
+            // issued as inline asm: a compiler-visible load that is still pending on the loop's back edge makes the
+            // compiler put "s_waitcnt vmcnt(0)" in front of the S MFMAs of EVERY tile - which also drains the K/V
+            // LDS-DMA of the two tiles that are meant to stay in flight.  The wait for these loads is the explicit one
+            // at the head switch below.
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *(const bf16x8*)(qbase[t] + (hh + 1) * 64 + ks * 16 + half * 8);
+                for (int ks = 0; ks < 4; ++ks)
+                    asm volatile("global_load_dwordx4 %0, %1, off"
+                                 : "=v"(qf[t][ks]) : "v"(qbase[t] + (hh + 1) * 64 + ks * 16 + half * 8) : "memory");
         }
 
         // ---- masks (raw-score domain), online softmax; P^T fragments stay in registers
@@ -360,6 +368,10 @@ attn_fwd_kernel(const AttnParams P) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
                 if (hh + 1 < hpb) {
+                    // the next head's raw Q rows (asm loads of this head's last tile) have landed after this wait; the
+                    // fragments are operands of the asm so that the scaling cannot be scheduled above it
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(qf[t][0]), "+v"(qf[t][1]), "+v"(qf[t][2]), "+v"(qf[t][3]) :: "memory");
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) qf[t][ks] = scale_frag(qf[t][ks], P.scale_log2);
                 }

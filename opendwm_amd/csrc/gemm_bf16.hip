@@ -189,8 +189,12 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             for (int c = 0; c < 8; ++c) {
                 if (ks == 3 && c == 0) {
                     // own last fragments read; own shares of A(kt+1) and W(kt+1) landed (A(kt+2) may stay in flight)
+                    // bare s_barrier, not __syncthreads(): the workgroup-scope release fence of __syncthreads() makes the
+                    // compiler append "s_waitcnt vmcnt(0)" (LDS-DMA writes LDS and is tracked by vmcnt), which drains
+                    // A(kt+2) at every K step; the counted wait above is the ordering this barrier needs
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
-                    __syncthreads();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
                 }
 #pragma unroll
                 for (int u = 0; u < MPC; ++u) {
