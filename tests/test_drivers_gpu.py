@@ -102,3 +102,65 @@ def test_streaming_fifo_vs_oracle(dev, small_cfg, model_and_sd):
     e = rel_err(got, want)
     _log("streaming_fifo", frames=total, rel=e)
     assert e < TOL_CHAIN
+
+
+# ---------------------------------------------------------------- the same drivers over a frame-sharded denoiser
+def _sharded_driver_worker(rank, world, port, cfg_model, sd, kind, cond, path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opendwm_amd import _lib
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    from opendwm_amd.pipeline import CTSDDenoiser
+    _lib.load()
+    dev = torch.device("cuda:0")
+    m = DiTCrossviewTemporalConditionModel(**cfg_model)
+    m.load_state_dict(sd)
+    m = m.to(dev).to(bf16).eval()
+    den = CTSDDenoiser(m, guidance_scale=G, inference_steps=4, frame_group=dist.group.WORLD)
+    out = _run_driver(kind, den, cond, dev)
+    torch.save(out.cpu(), f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_driver(kind, den, cond, dev):
+    from opendwm_amd.drivers import AutoregressiveDriver, StreamingDriver
+    T, V, total = 4, 3, 7
+    shape = (1, T, V, 16, 8, 12)
+    if kind == "streaming":
+        cfg = dict(inference_steps=4, sequence_length_per_iteration=T, autoregression_data_exception_for_take_sequence=NON_TEMPORAL,
+                   autoregression_condition_exception_for_take_sequence=NON_TEMPORAL)
+        return StreamingDriver(den, cfg, generator=torch.Generator().manual_seed(31)).fifo(shape, to_dev(cond, dev), total, dev)
+    df = kind == "autoregressive_df"
+    cfg = dict(inference_steps=4, sequence_length_per_iteration=T, reference_frame_count=3 if df else 1,
+               autoregression_data_exception_for_take_sequence=NON_TEMPORAL)
+    return AutoregressiveDriver(den, cfg, diffusion_forcing=df, generator=torch.Generator().manual_seed(31)).run(
+        shape, to_dev(cond, dev), total, dev)["images"]
+
+
+@pytest.mark.parametrize("kind", ["autoregressive", "autoregressive_df", "streaming"])
+def test_window_drivers_over_frame_sharded_denoiser(dev, small_cfg, model_and_sd, kind):
+    """The window drivers only see `CTSDDenoiser.run()` (full latents / conditions in, whole sample out), so they run
+    unchanged on every rank of a frame group (opendwm_amd.sharding; identical host random streams on all ranks): the 4
+    frames of each window on two ranks (gloo, both on the one GPU) must reproduce the single-process frames - reference
+    frames, diffusion-forcing queue and FIFO included (5e-3: bf16 round-off of half-size GEMM grids; measured 0)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from opendwm_amd.pipeline import CTSDDenoiser
+    m, sd = model_and_sd
+    cond = conditions(small_cfg, 7)
+    single = _run_driver(kind, CTSDDenoiser(m, guidance_scale=G, inference_steps=4), cond, dev).cpu()
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() + 37) % 2000
+    path = os.path.join(tempfile.mkdtemp(), "sharded_driver")
+    procs = [ctx.Process(target=_sharded_driver_worker, args=(r, 2, port, small_cfg, sd, kind, cond, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    a, b = torch.load(path + ".0"), torch.load(path + ".1")
+    e = rel_err(a, single)
+    _log("sharded_driver", kind=kind, ranks_equal=bool(torch.equal(a, b)), rel_vs_single=e)
+    assert a.shape == single.shape and torch.equal(a, b) and e < 5e-3
