@@ -53,10 +53,28 @@ class LatentDecoder:
     (opendwm_amd.vae_cogvideox.AutoencoderKLCogVideoX): clips "(b v) c t h w"; in diffusion-forcing mode a single
     latent frame is decoded as [frame, zeros] and the first half of the 8 output frames is kept (:1611-1622)."""
 
-    def __init__(self, vae, memory_efficient_batch: int = -1, postprocess: bool = True):
+    def __init__(self, vae, memory_efficient_batch: int = -1, postprocess: bool = True, group=None):
+        """group: a torch.distributed process group - the images (2-D VAE) or per-view clips (temporal VAE) of one
+        sample are decoded 1/R per rank and all-gathered, so every rank returns the whole batch (the decode half of
+        the intra-sample sharding; the denoise half is CTSDDenoiser(frame_group=...))."""
         from .vae_cogvideox import AutoencoderKLCogVideoX
-        self.vae, self.batch, self.postprocess = vae, memory_efficient_batch, postprocess
+        self.vae, self.batch, self.postprocess, self.group = vae, memory_efficient_batch, postprocess, group
         self.is_temporal_vae = isinstance(vae, AutoencoderKLCogVideoX)
+
+    def _sharded(self, fn, x: torch.Tensor) -> torch.Tensor:
+        """fn over this rank's contiguous share of dim 0, all-gathered; shares are padded to equal size with item 0"""
+        if self.group is None:
+            return fn(x)
+        import torch.distributed as dist
+        R, r, n = dist.get_world_size(self.group), dist.get_rank(self.group), x.shape[0]
+        per = -(-n // R)
+        mine = x[r * per:(r + 1) * per]
+        if mine.shape[0] < per:
+            mine = torch.cat([mine, x[:1].expand(per - mine.shape[0], *x.shape[1:])])
+        y = fn(mine.contiguous()).contiguous()
+        parts = [torch.empty_like(y) for _ in range(R)]
+        dist.all_gather(parts, y, group=self.group)
+        return torch.cat(parts)[:n]
 
     def _split_call(self, x: torch.Tensor) -> torch.Tensor:
         """dwm.functional.memory_efficient_split_call, src/dwm/functional.py:184-193"""
@@ -74,12 +92,13 @@ class LatentDecoder:
             if diffusion_forcing:
                 if t != 1:
                     raise ValueError("diffusion forcing decodes one queue slot at a time")
-                img = self.vae.decode(torch.cat([clips, clips * 0], 2), return_dict=False)[0].chunk(2, dim=2)[0]
+                img = self._sharded(lambda c: self.vae.decode(torch.cat([c, c * 0], 2), return_dict=False)[0].chunk(2, dim=2)[0], clips)
             else:
-                img = self._split_call(clips)
+                img = self._sharded(self._split_call, clips)
             img = img.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5).flatten(0, 2)   # (b v) c t h w -> (b t v) c h w
         else:
-            img = self._split_call(x.flatten(0, 2)) if not diffusion_forcing else self.vae.decode(x.flatten(0, 2), return_dict=False)[0]
+            img = self._sharded(self._split_call if not diffusion_forcing else (lambda c: self.vae.decode(c, return_dict=False)[0]),
+                                x.flatten(0, 2))
         return (img.float() / 2 + 0.5).clamp(0, 1) if self.postprocess else img
 
 

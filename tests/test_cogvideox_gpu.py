@@ -213,3 +213,63 @@ def test_latent_decoder_layouts(dev):
     e1 = rel_err(got1, want1)
     _log("latent_decoder_tvae", rel_clip=e, rel_df_frame=e1)
     assert got1.shape == (B * 4 * V, 3, 32, 48) and e1 < TOL_MODEL
+
+
+def _sharded_decode_worker(rank, world, port, kind, cfg, sd, lat, path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opendwm_amd import _lib
+    from opendwm_amd.drivers import LatentDecoder
+    _lib.load()
+    dev = torch.device("cuda:0")
+    vae = _decode_model(kind, cfg, sd, dev)
+    dec = LatentDecoder(vae, group=dist.group.WORLD)
+    out = [dec(lat.to(dev)), dec(lat[:, 1:2].to(dev), diffusion_forcing=True)]
+    torch.save([o.cpu() for o in out], f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _decode_model(kind, cfg, sd, dev):
+    if kind == "temporal":
+        return _model(cfg, sd, dev)
+    from opendwm_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(**cfg)
+    vae.load_state_dict(sd)
+    return vae.to(dev).to(bf16).eval()
+
+
+@pytest.mark.parametrize("kind", ["temporal", "2d"])
+def test_latent_decoder_sharded_over_two_ranks(dev, kind):
+    """LatentDecoder(group=...): the decode half of the intra-sample sharding - 3 per-view clips (temporal VAE; uneven
+    2 + 1 shares, the short one padded) or 9 images (2-D VAE; 5 + 4) decoded on two ranks (gloo, both on the one GPU)
+    and all-gathered: every rank returns the whole batch, equal to the single-process decode (5e-3: other GEMM grids)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from opendwm_amd.drivers import LatentDecoder
+    if kind == "temporal":
+        cfg = small_cfg()
+        sd = _bf_sd(CV.make_state_dict(cfg, 1))
+    else:
+        from oracle import ctsd_oracle as O
+        cfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
+        sd = _bf_sd(O.make_vae_state_dict(cfg, 0))
+    B, T, V = 1, 3, 3
+    lat = torch.randn(B, T, V, 16, 8, 8, generator=torch.Generator().manual_seed(8)).to(bf16).float()
+    dec = LatentDecoder(_decode_model(kind, cfg, sd, dev))
+    single = [dec(lat.to(dev)).cpu(), dec(lat[:, 1:2].to(dev), diffusion_forcing=True).cpu()]
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() + 41) % 2000
+    path = os.path.join(tempfile.mkdtemp(), "sharded_decode")
+    procs = [ctx.Process(target=_sharded_decode_worker, args=(r, 2, port, kind, cfg, sd, lat, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    a, b = torch.load(path + ".0"), torch.load(path + ".1")
+    errs = [rel_err(x, s) for x, s in zip(a, single)]
+    _log("latent_decoder_sharded", kind=kind, rel_full=errs[0], rel_df_frame=errs[1])
+    assert all(x.shape == s.shape for x, s in zip(a, single)) and all(torch.equal(x, y) for x, y in zip(a, b))
+    assert max(errs) < 5e-3
