@@ -6,7 +6,11 @@ touches, wired together the way src/dwm/pipelines/ctsd.py wires them -
       model forward at the CFG batch + guidance + scheduler ctsd.py:1496-1575  (opendwm_amd.pipeline.CTSDDenoiser, HIP graph)
     VAE.decode(latents / scaling + shift), postprocess     ctsd.py:1606-1647  (opendwm_amd.drivers.LatentDecoder)
 
-usage: python scripts/e2e_demo.py [--temporal-vae] [--frames 7] [--out /tmp/frames.pt]"""
+usage: python scripts/e2e_demo.py [--temporal-vae] [--frames 7] [--window 3] [--out /tmp/frames.pt]
+       python -m torch.distributed.run --nproc-per-node R --master-addr 127.0.0.1 scripts/e2e_demo.py --window 4
+           -> ONE sample over R ranks: frame-sharded denoise windows (all-to-all around the temporal blocks) and a VAE
+              decode split over the ranks; RCCL when every rank has its own GPU, gloo when the ranks share one
+              (the window length and the token-row count must be multiples of R)"""
 import argparse
 import json
 import os
@@ -34,9 +38,18 @@ def main():
     ap.add_argument("--temporal-vae", action="store_true")
     ap.add_argument("--frames", type=int, default=7)
     ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--window", type=int, default=3, help="latent frames per window")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    dev = torch.device("cuda:0")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    group = None
+    own_gpu = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if own_gpu else 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl" if own_gpu else "gloo", **({"device_id": dev} if own_gpu else {}))
+        group = dist.group.WORLD
     cfg = small_config()
     model = DiTCrossviewTemporalConditionModel(**cfg)
     model.load_state_dict(O.make_state_dict(cfg, 0))
@@ -51,7 +64,7 @@ def main():
         vae.load_state_dict(O.make_vae_state_dict(vcfg, 0))
     vae = vae.to(dev).to(bf16).eval()
 
-    B, T, V, H, W = 1, 3, 3, 8, 16                         # latent window [B, T, V, 16, H, W]; pixels 8x
+    B, T, V, H, W = 1, a.window, 3, 8, 16                         # latent window [B, T, V, 16, H, W]; pixels 8x
     # (the drivers slice per-frame conditions by latent frame; with the temporal VAE one window = 3 latent frames
     #  = 9 pixel frames is generated - the reference maps pixel-frame clips to latent windows in its dataset glue)
     total = T if a.temporal_vae else a.frames
@@ -68,22 +81,28 @@ def main():
     else:
         lat = (vae.encode(ref_px.flatten(0, 2).to(dev)).latent_dist.mode() - sh) * sf
         image_latents = lat.unflatten(0, (B, 1, V))
-    den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=a.steps).enable_graph()
+    den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=a.steps, frame_group=group)
+    if group is None:
+        den.enable_graph()
     drv = AutoregressiveDriver(den, dict(inference_steps=a.steps, sequence_length_per_iteration=T, reference_frame_count=1,
                                          autoregression_data_exception_for_take_sequence=["disable_crossview", "disable_temporal",
                                                                                           "crossview_attention_mask"]),
-                               decode=LatentDecoder(vae), generator=gen)
+                               decode=LatentDecoder(vae, group=group), generator=gen)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = drv.run((B, T, V, 16, H, W), cond, total, dev, image_latents=image_latents)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     img = out["images"]
-    print(json.dumps({"frames_x_views": int(img.shape[0]), "image_shape": list(img.shape[1:]), "seconds": round(dt, 3),
-                      "min": float(img.min()), "max": float(img.max()), "finite": bool(torch.isfinite(img).all()),
-                      "windows": len(drv.plan(T, total, True)), "vae": type(vae).__name__}))
-    if a.out:
+    if rank == 0:
+        print(json.dumps({"ranks": world, "checksum": float(img.double().sum()), "frames_x_views": int(img.shape[0]), "image_shape": list(img.shape[1:]), "seconds": round(dt, 3),
+                          "min": float(img.min()), "max": float(img.max()), "finite": bool(torch.isfinite(img).all()),
+                          "windows": len(drv.plan(T, total, True)), "vae": type(vae).__name__}))
+    if a.out and rank == 0:
         torch.save(img.cpu(), a.out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
