@@ -93,7 +93,7 @@ def make_conditions(dev, seed, w=WORKLOAD, n_time_ids=None, layout=False):
     return cond
 
 
-def _make_conditions(dev, seed, w, n_time_ids):
+def _make_conditions(dev, seed, w, n_time_ids, text_dim=4096, pooled_dim=2048):
     g = torch.Generator(device="cuda").manual_seed(1000 + seed)
     B2, T, V = 2 * w["B"], w["T"], w["V"]
     ring = torch.zeros(V, V, dtype=torch.bool)
@@ -101,8 +101,8 @@ def _make_conditions(dev, seed, w, n_time_ids):
         for d in (-1, 0, 1):
             ring[i, (i + d) % V] = True
     return dict(
-        encoder_hidden_states=(torch.randn(B2, T, V, w["text_len"], 4096, device=dev, generator=g) * 0.1).to(torch.bfloat16),
-        pooled_projections=(torch.randn(B2, T, V, 2048, device=dev, generator=g) * 0.1).to(torch.bfloat16),
+        encoder_hidden_states=(torch.randn(B2, T, V, w["text_len"], text_dim, device=dev, generator=g) * 0.1).to(torch.bfloat16),
+        pooled_projections=(torch.randn(B2, T, V, pooled_dim, device=dev, generator=g) * 0.1).to(torch.bfloat16),
         disable_crossview=torch.zeros(B2, dtype=torch.bool, device=dev),
         disable_temporal=torch.zeros(B2, dtype=torch.bool, device=dev),
         crossview_attention_mask=ring[None].repeat(B2, 1, 1).to(dev),

@@ -21,14 +21,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import cogvideox_vae_oracle as CV   # synthetic weights only (state-dict generators); no oracle compute here
-from oracle import ctsd_oracle as O
+import bench                                     # synthetic weights / conditions (seeded, generated on the device)
 from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
 from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder
 from opendwm_amd.pipeline import CTSDDenoiser
 from opendwm_amd.vae import AutoencoderKL
 from opendwm_amd.vae_cogvideox import AutoencoderKLCogVideoX
-from tests.common import small_config
 
 bf16 = torch.bfloat16
 
@@ -50,26 +48,24 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl" if own_gpu else "gloo", **({"device_id": dev} if own_gpu else {}))
         group = dist.group.WORLD
-    cfg = small_config()
-    model = DiTCrossviewTemporalConditionModel(**cfg)
-    model.load_state_dict(O.make_state_dict(cfg, 0))
-    model = model.to(dev).to(bf16).eval()
+    # the full module graph of the SD 3.5 CTSD model (dual blocks, cross-view + temporal VT blocks, implicit camera
+    # embedding) at 2 heads x 64
+    cfg = dict(bench.MODEL_KWARGS, num_layers=4, dual_attention_layers=[0, 1], num_attention_heads=2, caption_projection_dim=128,
+               joint_attention_dim=128, pooled_projection_dim=64, pos_embed_max_size=32, sample_size=32,
+               crossview_block_layers=[1], temporal_block_layers=[2, 3])
+    model = bench.build_model(cfg, dev, seed=0)
     if a.temporal_vae:
-        vcfg = CV.make_cogvideox_config(block_out_channels=(64, 64, 128, 128), layers_per_block=1, norm_num_groups=8)
-        vae = AutoencoderKLCogVideoX(**{k: vcfg[k] for k in ("block_out_channels", "layers_per_block", "norm_num_groups", "latent_channels")})
-        vae.load_state_dict(CV.make_state_dict(vcfg, 0))
+        vae = AutoencoderKLCogVideoX(block_out_channels=(64, 64, 128, 128), layers_per_block=1, norm_num_groups=8, latent_channels=16)
     else:
-        vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
-        vae = AutoencoderKL(**vcfg)
-        vae.load_state_dict(O.make_vae_state_dict(vcfg, 0))
+        vae = AutoencoderKL(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
     vae = vae.to(dev).to(bf16).eval()
+    bench.synth_init_(vae, 1)
 
     B, T, V, H, W = 1, a.window, 3, 8, 16                         # latent window [B, T, V, 16, H, W]; pixels 8x
     # (the drivers slice per-frame conditions by latent frame; with the temporal VAE one window = 3 latent frames
     #  = 9 pixel frames is generated - the reference maps pixel-frame clips to latent windows in its dataset glue)
     total = T if a.temporal_vae else a.frames
-    inp = O.make_inputs(cfg, 2 * B, total, V, H, W, seed=0, text_len=10)
-    cond = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items() if k not in ("sample", "timestep")}
+    cond = bench._make_conditions(dev, 0, dict(B=B, T=total, V=V, text_len=10), 11, text_dim=128, pooled_dim=64)
     gen = torch.Generator().manual_seed(0)
     # reference frame -> latents
     ref_px = torch.rand(B, 1, V, 3, 8 * H, 8 * W, generator=gen) * 2 - 1

@@ -179,6 +179,25 @@ def test_full_width_decoder_block_vs_oracle(dev):
     assert out.shape == (1, 3, 9, 16, 32) and e < TOL_MODEL
 
 
+def test_full_width_clip_vs_oracle_on_device(dev):
+    """THUDM/CogVideoX-2b widths end to end - decode AND encode of one view x 5 latent frames x 8x14 latents (17 frames of
+    64x112 px) - against the fp32 oracle evaluated on the device (on the host it takes minutes)."""
+    cfg = CV.make_cogvideox_config()
+    sd = _bf_sd(CV.make_state_dict(cfg, 0))
+    m = _model(cfg, sd, dev)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    z = torch.randn(1, 16, 5, 8, 14, generator=torch.Generator().manual_seed(0)).to(bf16).float().to(dev)
+    ref = CV.decode(sdd, cfg, z)
+    out = m.decode(z, return_dict=False)[0]
+    e_dec = rel_err(out, ref)
+    x = ref.clamp(-1, 1).to(bf16).float()
+    mref = CV.encode_moments(sdd, cfg, x)
+    mout = m.encode(x).latent_dist.parameters
+    e_enc = rel_err(mout, mref)
+    _log("cogvideox_full_width_clip", frames=ref.shape[2], rel_decode=e_dec, rel_encode=e_enc)
+    assert out.shape == (1, 3, 17, 64, 112) and e_dec < TOL_MODEL and e_enc < TOL_MODEL
+
+
 def test_rejects_cpu_and_bad_rank(dev):
     cfg = small_cfg()
     m = _model(cfg, _bf_sd(CV.make_state_dict(cfg, 0)), dev)

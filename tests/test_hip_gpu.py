@@ -567,6 +567,23 @@ def test_vae_decode_vs_oracle(dev):
     assert out.shape == (3, 3, 64, 64) and e < TOL_MODEL
 
 
+def test_vae_full_width_decode_vs_oracle_on_device(dev):
+    """the SD 3.5 VAE decoder at its real widths (128 / 256 / 512 / 512, 32 groups) on two 32x56 latents (256x448 px: the
+    images of BASELINE config 3), against the fp32 oracle evaluated on the device"""
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32, latent_channels=16)
+    sd = _bf16_round_sd(O.make_vae_state_dict(vcfg, 0))
+    vae = AutoencoderKL(**vcfg)
+    vae.load_state_dict(sd)
+    vae = vae.to(dev).to(bf16).eval()
+    z = torch.randn(2, 16, 32, 56, generator=torch.Generator().manual_seed(0)).to(bf16).float().to(dev)
+    ref = O.vae_decode({k: v.to(dev) for k, v in sd.items()}, vcfg, z)
+    out = vae.decode(z, return_dict=False)[0]
+    e = rel_err(out, ref)
+    _log("vae_decode_full_width", rel=e, shape=list(out.shape))
+    assert out.shape == (2, 3, 256, 448) and e < TOL_MODEL
+
+
 def test_vae_encode_vs_oracle(dev):
     from opendwm_amd.vae import AutoencoderKL
     vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16)
