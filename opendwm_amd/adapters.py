@@ -7,7 +7,6 @@ block2.*, zero_convs.{i}.*, zero_gates.  All features are produced token-major
 convolutions run as implicit GEMMs of dwm_gemm_bf16 over a zero-padded token grid."""
 from __future__ import annotations
 
-import math
 from typing import List, Optional
 
 import torch

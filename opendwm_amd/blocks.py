@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .ops import (ACT_GELU_TANH, ACT_NONE, ACT_SILU, EPI_GEGLU, EPI_PLAIN, EPI_RESID, EPI_RMSHEAD)
+from .ops import ACT_GELU_TANH, ACT_SILU, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD
 
 bf16 = torch.bfloat16
 

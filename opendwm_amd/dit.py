@@ -16,7 +16,6 @@ forward raises.
 """
 from __future__ import annotations
 
-import math
 import types
 from typing import Optional
 

@@ -4,7 +4,7 @@ function raises if its tensors are not bf16 CUDA(HIP) tensors — there is no fa
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import torch

@@ -17,7 +17,7 @@ Activations stay token-major `[(b t v)(h w), C]` bf16 for the whole network:
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 from torch import nn
@@ -25,7 +25,7 @@ from torch import nn
 from . import ops
 from . import train_ops as T
 from .blocks import AlphaBlender, Attention, FeedForward, TimestepEmbedding, VTSelfAttentionBlock, _bf, geglu_pack, STORE
-from .ops import ACT_SILU, EPI_GEGLU, EPI_RESID, PaddedGrid, TimeGrid
+from .ops import EPI_GEGLU, EPI_RESID, PaddedGrid, TimeGrid
 
 bf16 = torch.bfloat16
 

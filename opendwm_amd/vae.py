@@ -11,7 +11,7 @@ upsample and the mid-block softmax are HIP kernels (csrc/vae.hip)."""
 from __future__ import annotations
 
 import types
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 from torch import nn

@@ -22,7 +22,7 @@ HIP model (opendwm_amd/unet.py) and the reference class.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F

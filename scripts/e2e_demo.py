@@ -22,7 +22,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench                                     # synthetic weights / conditions (seeded, generated on the device)
-from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
 from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder
 from opendwm_amd.pipeline import CTSDDenoiser
 from opendwm_amd.vae import AutoencoderKL

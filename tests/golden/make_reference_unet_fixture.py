@@ -13,7 +13,6 @@ usage: python tests/golden/make_reference_unet_fixture.py  ->  tests/golden/refe
 """
 import os
 import sys
-import types
 
 import torch
 import torch.nn.functional as F
