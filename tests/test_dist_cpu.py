@@ -4,6 +4,7 @@ independent replica (the oracle stands in for the device kernels here)."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -123,20 +124,21 @@ def _frame_shard_worker(rank, world, port, q):
     D.shutdown()
 
 
-def test_frame_shard_exchange_and_temporal_block_gloo():
-    """frames of one sample on two ranks.  The all-to-all re-shard (my frames, all token rows) <->
+@pytest.mark.parametrize("world", [2, 4])
+def test_frame_shard_exchange_and_temporal_block_gloo(world):
+    """frames of one sample on two / four ranks.  The all-to-all re-shard (my frames, all token rows) <->
     (all frames, my token rows) is exact, and a temporal block + mixer run on the re-sharded rows reproduces the
     unsharded block (fp32 oracle compute; 1e-5 abs: only the summation order inside torch kernels may differ)."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_frame_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_frame_shard_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r in (0, 1):
+    for r in range(world):
         assert res[r]["rows_ok"] and res[r]["round_trip"] and res[r]["gather"] and res[r]["full_rejected"], res[r]
         assert res[r]["rowwise"] < 1e-5 and res[r]["pointwise"] < 1e-5, res[r]
