@@ -4,7 +4,8 @@
 `dwm.pipelines.ctsd` is imported behind import-only stubs of its third-party dependencies (diffusers, transformers,
 torchvision, ...; see make_reference_fixtures.py) and the REAL methods are called on a hand-built instance:
 
-  * CrossviewTemporalSD.inference_pipeline                      ctsd.py:1439-1654  (full sequence, reference frames, diffusion forcing)
+  * CrossviewTemporalSD.inference_pipeline                      ctsd.py:1439-1654  (full sequence, reference frames, diffusion forcing;
+                                                                its decode tail :1604-1647 also with non-trivial stand-in VAEs, 2-D and temporal)
   * CrossviewTemporalSD.autoregressive_inference_pipeline       ctsd.py:1656-1833
   * StreamingCrossviewTemporalSD.reset_streaming / inference_pipeline / send_frame_condition / receive_frame /
     fifo_inference_pipeline                                     ctsd.py:2009-2275
@@ -69,6 +70,28 @@ class FakeVae:
 
     def decode(self, x, return_dict=False):
         return (x,)
+
+
+class FakeImageVae:
+    """2-D stand-in with scaling / shift factors and a decode that is not the identity (per-channel affine + 2x nearest)"""
+    dtype = torch.float32
+    config = types.SimpleNamespace(scaling_factor=0.7, shift_factor=0.1)
+
+    def decode(self, x, return_dict=False):
+        w = torch.linspace(0.5, 1.5, x.shape[1]).view(1, -1, 1, 1)
+        return ((x * w).repeat_interleave(2, -1).repeat_interleave(2, -2),)
+
+
+class FakeClipVae:
+    """temporal stand-in: [N, C, t, h, w] -> [N, C, 2 t, h, w]; every output frame carries its own offset, so a wrong
+    "(b v) c t h w" <-> "(b t v) c h w" rearrange or a wrong half of the [frame, zeros] decode changes the result"""
+    dtype = torch.float32
+    config = types.SimpleNamespace(scaling_factor=0.7, shift_factor=None)
+
+    def decode(self, x, return_dict=False):
+        y = x.repeat_interleave(2, 2) * 1.25
+        ramp = torch.arange(y.shape[2], dtype=y.dtype).view(1, 1, -1, 1, 1) * 0.01
+        return (y + ramp,)
 
 
 def make_scheduler(Sched, steps):
@@ -141,6 +164,25 @@ def main():
         single[name] = dict(kwargs={k: v for k, v in kw.items()}, batch=batch, latents=r["latents"], images=r["images"], seed=11,
                             shape=shape, steps=steps)
     out["inference_pipeline"] = single
+
+    # ---- the decode tail of inference_pipeline (ctsd.py:1604-1647) with non-trivial stand-in VAEs: 2-D and temporal
+    # ("(b v) c t h w" clips, the [frame, zeros] decode of the diffusion-forcing mode), memory_efficient_batch on / off
+    tail = {}
+    for name, vae, temporal, df, meb, kw in (
+            ("image_full", FakeImageVae(), False, False, -1, {}),
+            ("image_split2", FakeImageVae(), False, False, 2, dict(image_latents=img, reference_frame_count=1)),
+            ("image_df", FakeImageVae(), False, True, -1, dict(image_latents=img, start_timestep=6, stop_timestep=8, take_time=1)),
+            ("clip_full", FakeClipVae(), True, False, -1, {}),
+            ("clip_split1", FakeClipVae(), True, False, 1, dict(image_latents=img, reference_frame_count=2)),
+            ("clip_df", FakeClipVae(), True, True, -1, dict(image_latents=img, start_timestep=6, stop_timestep=8, take_time=2))):
+        p = make_pipeline(C, Sched, C.CrossviewTemporalSD, steps, df, {"_seed": 13}, None)
+        p.vae, p.is_temporal_vae = vae, temporal
+        p.common_config = dict(p.common_config, memory_efficient_batch=meb)
+        batch = batch_of(B, T, V, 6)
+        r = C.CrossviewTemporalSD.inference_pipeline(p, shape, batch, "pt", **kw)
+        tail[name] = dict(temporal=temporal, df=df, memory_efficient_batch=meb, take_time=kw.get("take_time", 0),
+                          latents=r["latents"], images=r["images"])
+    out["decode_tail"] = tail
 
     # ---- autoregressive_inference_pipeline over the REAL inference_pipeline
     ar = {}

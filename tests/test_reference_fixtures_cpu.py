@@ -165,6 +165,23 @@ def test_oracle_denoise_loop_equals_reference_inference_pipeline(dfx, fake_model
     assert torch.equal(d["images"], want_img)
 
 
+@pytest.mark.parametrize("name", ["image_full", "image_split2", "image_df", "clip_full", "clip_split1", "clip_df"])
+def test_latent_decoder_equals_reference_decode_tail(dfx, name):
+    """drivers.LatentDecoder against the decode tail of the REAL inference_pipeline (ctsd.py:1604-1647) run with
+    stand-in VAEs whose output depends on channel and frame position: scaling / shift factors, the `(b t v)` image batch
+    or `(b v) c t h w` clips, memory_efficient_split_call chunks, the diffusion-forcing decode of the frame `take_time`
+    (for the temporal VAE as [frame, zeros], first half kept), reference frames spliced in before decoding."""
+    from opendwm_amd.drivers import LatentDecoder
+    from tests.golden.make_reference_driver_fixtures import FakeClipVae, FakeImageVae
+    d = dfx["decode_tail"][name]
+    dec = LatentDecoder.__new__(LatentDecoder)
+    dec.vae = FakeClipVae() if d["temporal"] else FakeImageVae()
+    dec.batch, dec.postprocess, dec.group, dec.is_temporal_vae = d["memory_efficient_batch"], False, None, d["temporal"]
+    lat = d["latents"]
+    got = dec(lat[:, d["take_time"]:d["take_time"] + 1], diffusion_forcing=True) if d["df"] else dec(lat)
+    assert got.shape == d["images"].shape and torch.equal(got, d["images"])
+
+
 class _LoopDenoiser:
     def __init__(self, steps, g):
         self.steps, self.g, self.calls = steps, g, []
