@@ -102,6 +102,34 @@ class LatentDecoder:
         return (img.float() / 2 + 0.5).clamp(0, 1) if self.postprocess else img
 
 
+class LatentEncoder:
+    """images [B, t, V, 3, H, W], already in the VAE's input range (VaeImageProcessor.preprocess: 2 x - 1) -> latents
+    [B, t', V, C, h, w] = `(vae.encode(x).latent_dist.sample() - shift_factor) * scaling_factor` through
+    memory_efficient_split_call chunks: the encode of the training step (ctsd.py:1196-1225, `.sample()`) and of the
+    reference frames of the autoregressive pipeline (:1677-1703, `.mode()`).  2-D VAE: "(b t v) c h w" images; temporal
+    VAE: "(b v) c t h w" clips."""
+
+    def __init__(self, vae, memory_efficient_batch: int = -1, is_temporal_vae: Optional[bool] = None):
+        if is_temporal_vae is None:
+            from .vae_cogvideox import AutoencoderKLCogVideoX
+            is_temporal_vae = isinstance(vae, AutoencoderKLCogVideoX)
+        self.vae, self.batch, self.is_temporal_vae = vae, memory_efficient_batch, is_temporal_vae
+
+    def __call__(self, images: torch.Tensor, sample: bool = True) -> torch.Tensor:
+        B, t, V = images.shape[:3]
+        cfgv = self.vae.config
+        shift = cfgv.shift_factor if cfgv.shift_factor is not None else 0
+        x = images.permute(0, 2, 3, 1, 4, 5).flatten(0, 1) if self.is_temporal_vae else images.flatten(0, 2)
+
+        def enc(c):
+            dist = self.vae.encode(c).latent_dist
+            return ((dist.sample() if sample else dist.mode()) - shift) * cfgv.scaling_factor
+        lat = enc(x) if self.batch == -1 else torch.cat([enc(c) for c in x.split(self.batch)])
+        if self.is_temporal_vae:
+            return lat.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5)          # (b v) c t h w -> b t v c h w
+        return lat.unflatten(0, (B, t, V))
+
+
 @dataclass
 class Window:
     """One call of the per-window denoise loop."""

@@ -1,7 +1,7 @@
 """End-to-end generation on synthetic weights (reduced-width models, seconds on one MI355X): the pieces a CTSD user
 touches, wired together the way src/dwm/pipelines/ctsd.py wires them -
 
-    VAE.encode(reference frames).latent_dist.mode()        ctsd.py:1677-1703
+    VAE.encode(reference frames).latent_dist.mode()        ctsd.py:1677-1703  (opendwm_amd.drivers.LatentEncoder)
     autoregressive windows over the denoise loop           ctsd.py:1656-1833  (opendwm_amd.drivers.AutoregressiveDriver)
       model forward at the CFG batch + guidance + scheduler ctsd.py:1496-1575  (opendwm_amd.pipeline.CTSDDenoiser, HIP graph)
     VAE.decode(latents / scaling + shift), postprocess     ctsd.py:1606-1647  (opendwm_amd.drivers.LatentDecoder)
@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench                                     # synthetic weights / conditions (seeded, generated on the device)
-from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder
+from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder, LatentEncoder
 from opendwm_amd.pipeline import CTSDDenoiser
 from opendwm_amd.vae import AutoencoderKL
 from opendwm_amd.vae_cogvideox import AutoencoderKLCogVideoX
@@ -68,14 +68,7 @@ def main():
     gen = torch.Generator().manual_seed(0)
     # reference frame -> latents
     ref_px = torch.rand(B, 1, V, 3, 8 * H, 8 * W, generator=gen) * 2 - 1
-    sf, sh = vae.config.scaling_factor, vae.config.shift_factor or 0
-    if a.temporal_vae:
-        x = ref_px.permute(0, 2, 3, 1, 4, 5).flatten(0, 1).to(dev)                       # (b v) c t h w
-        lat = (vae.encode(x).latent_dist.mode() - sh) * sf
-        image_latents = lat.unflatten(0, (B, V)).permute(0, 3, 1, 2, 4, 5).contiguous()     # b t v c h w
-    else:
-        lat = (vae.encode(ref_px.flatten(0, 2).to(dev)).latent_dist.mode() - sh) * sf
-        image_latents = lat.unflatten(0, (B, 1, V))
+    image_latents = LatentEncoder(vae)(ref_px.to(dev), sample=False).contiguous()          # b t v c h w
     den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=a.steps, frame_group=group)
     if group is None:
         den.enable_graph()

@@ -94,6 +94,19 @@ class FakeClipVae:
         return (y + ramp,)
 
 
+class FakeRefVae(FakeVae):
+    """identity decode (like FakeVae) + an encoder for the reference frames: [N, 3, 6, 8] -> [N, 2, 3, 4]"""
+    config = types.SimpleNamespace(scaling_factor=0.7, shift_factor=0.1)
+
+    def encode(self, x):
+        p = torch.nn.functional.avg_pool2d(x, 2)
+        y = p[:, :2] + 0.3 * p[:, 2:3]
+        return types.SimpleNamespace(latent_dist=types.SimpleNamespace(mode=lambda: y, sample=lambda: y + 0.01))
+
+    def decode(self, x, return_dict=False):
+        return (x,)
+
+
 def make_scheduler(Sched, steps):
     """the reference scheduler class with the diffusers half (sigma table, Euler step) filled in by hand"""
     from oracle import ctsd_oracle as O
@@ -187,26 +200,41 @@ def main():
     # ---- autoregressive_inference_pipeline over the REAL inference_pipeline
     ar = {}
     for name, df, cfg, total, steps in (
+            # reference frames GIVEN (generate_frames_for_reference = False): encoded with vae.encode(...).latent_dist.mode()
+            ("full_ref1_given", False, dict(sequence_length_per_iteration=4, reference_frame_count=1, generate_frames_for_reference=False), 10, 3),
+            ("full_ref2_given_split", False, dict(sequence_length_per_iteration=4, reference_frame_count=2, generate_frames_for_reference=False,
+                                                  _meb=3), 8, 3),
             ("full_ref1", False, dict(sequence_length_per_iteration=4, reference_frame_count=1), 10, 3),
             ("full_ref2", False, dict(sequence_length_per_iteration=4, reference_frame_count=2), 12, 3),
             ("df_clear0", True, dict(sequence_length_per_iteration=4, reference_frame_count=3, clear_reference_frame_count=0), 7, 8),
             ("df_clear1", True, dict(sequence_length_per_iteration=4, reference_frame_count=3, clear_reference_frame_count=1), 9, 6)):
         cfg = dict(cfg, autoregression_data_exception_for_take_sequence=["scale"], _seed=7)
         p = make_pipeline(C, Sched, C.CrossviewTemporalSD, steps, df, cfg, None)
+        given = not cfg.get("generate_frames_for_reference", True)
+        if given:
+            p.vae = FakeRefVae()
+            p.image_processor = types.SimpleNamespace(postprocess=lambda x, output_type=None: x, preprocess=lambda x: x * 2 - 1)
+            p.common_config = dict(p.common_config, memory_efficient_batch=cfg.get("_meb", -1))
         calls = []
+        first_ref = []
         real = C.CrossviewTemporalSD.inference_pipeline
 
         def spy(latent_shape, batch, output_type, image_latents=None, reference_frame_count=0, start_timestep=0,
                 stop_timestep=None, take_time=0, _p=p, _calls=calls):
             _calls.append((start_timestep, stop_timestep, take_time, reference_frame_count))
+            if not first_ref:
+                first_ref.append(None if image_latents is None else image_latents.clone())
             return real(_p, latent_shape, batch, output_type, image_latents, reference_frame_count, start_timestep, stop_timestep, take_time)
         p.inference_pipeline = spy
         p.get_latent_sequence_length = lambda n, _p=p: C.CrossviewTemporalSD.get_latent_sequence_length(_p, n)
         batch = batch_of(B, total, V, 1)
+        if given:
+            batch["vae_images"] = torch.rand(B, total, V, 3, 6, 8, generator=torch.Generator().manual_seed(17))
         shape = (B, 4, V, 2, 3, 4)
         r = C.CrossviewTemporalSD.autoregressive_inference_pipeline(p, shape, batch, "pt")
         ar[name] = dict(config={k: v for k, v in cfg.items() if not k.startswith("_")}, df=df, total=total, steps=steps, batch=batch,
-                        shape=shape, images=r["images"], calls=calls, seed=7)
+                        shape=shape, images=r["images"], calls=calls, seed=7, memory_efficient_batch=cfg.get("_meb", -1),
+                        reference_latents=first_ref[0])
     out["autoregressive"] = ar
 
     # ---- streaming FIFO (every method real; only the fakes listed in the header)

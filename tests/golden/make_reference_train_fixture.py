@@ -51,15 +51,26 @@ def main():
         def encode(self, x):
             return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: torch.nn.functional.avg_pool2d(x, 8)))
 
+    class FakeClipVae:
+        """temporal stand-in: "(b v) c t h w" clips -> [N, 3, t, h/8, w/8] with a per-frame offset (frame order matters)"""
+        config = types.SimpleNamespace(shift_factor=None, scaling_factor=0.8)
+
+        def encode(self, x):
+            y = torch.nn.functional.avg_pool3d(x, (1, 8, 8)) + torch.arange(x.shape[2], dtype=x.dtype).view(1, 1, -1, 1, 1) * 0.05
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: y))
+
     out = {}
-    for name, tcfg in (("plain", {}), ("loss_coef", {"loss_coef_dict": {"sd": 0.5}, "max_norm_for_grad_clip": 0.01})):
+    for name, tcfg in (("plain", {}), ("loss_coef", {"loss_coef_dict": {"sd": 0.5}, "max_norm_for_grad_clip": 0.01}),
+                       ("temporal_vae", {"_temporal": True, "_meb": 1})):
         p = object.__new__(C.CrossviewTemporalSD)
         p.model = FakeSD3()
         p.model_wrapper = p.model
-        p.vae = FakeVae()
-        p.is_temporal_vae = False
+        temporal = tcfg.pop("_temporal", False)
+        meb = tcfg.pop("_meb", -1)
+        p.vae = FakeClipVae() if temporal else FakeVae()
+        p.is_temporal_vae = temporal
         p.image_processor = types.SimpleNamespace(preprocess=lambda x: x * 2 - 1)
-        p.common_config, p.training_config, p.inference_config = {}, dict(tcfg), {}
+        p.common_config, p.training_config, p.inference_config = {"memory_efficient_batch": meb}, dict(tcfg), {}
         p.device, p.model_dtype = torch.device("cpu"), torch.float32
         p.generator = torch.Generator().manual_seed(5)
         sig = O.flow_match_train_sigmas()
@@ -76,7 +87,7 @@ def main():
         torch.manual_seed(1234)                     # sd3_compute_density_for_timestep_sampling draws from the global generator
         C.CrossviewTemporalSD.train_step(p, batch, 0)
         x_t, ts = p.model.seen[0]
-        out[name] = dict(batch=batch, training_config=dict(tcfg), generator_seed=5, global_seed=1234, noisy_latents=x_t, timesteps=ts,
+        out[name] = dict(batch=batch, training_config=dict(tcfg), temporal_vae=temporal, memory_efficient_batch=meb, generator_seed=5, global_seed=1234, noisy_latents=x_t, timesteps=ts,
                          loss=torch.tensor(p.loss_report_list[0]["loss"]), w_before=torch.tensor(0.3), w_after=p.model.w.detach().clone(), lr=0.1)
         print(name, "loss", p.loss_report_list[0]["loss"], "w", float(p.model.w), "timesteps", ts[:, 0, 0].tolist())
     torch.save(out, os.path.join(HERE, "reference_train_step.pt"))

@@ -191,25 +191,56 @@ class _LoopDenoiser:
         return O.denoise(None, None, latents, conditions, self.steps, self.g, stop=stop, start=start, **kw)
 
 
-@pytest.mark.parametrize("name", ["full_ref1", "full_ref2", "df_clear0", "df_clear1"])
+class _RefVae:
+    """FakeRefVae of make_reference_driver_fixtures.py: reference-frame encoder [N, 3, 6, 8] -> [N, 2, 3, 4], identity decode"""
+
+    def __init__(self):
+        import types
+        self.config = types.SimpleNamespace(scaling_factor=0.7, shift_factor=0.1)
+        self.dtype = torch.float32
+
+    def encode(self, x):
+        import types
+        p = torch.nn.functional.avg_pool2d(x, 2)
+        y = p[:, :2] + 0.3 * p[:, 2:3]
+        return types.SimpleNamespace(latent_dist=types.SimpleNamespace(mode=lambda: y, sample=lambda: y + 0.01))
+
+    def decode(self, x, return_dict=False):
+        return (x,)
+
+
+@pytest.mark.parametrize("name", ["full_ref1_given", "full_ref2_given_split", "full_ref1", "full_ref2", "df_clear0", "df_clear1"])
 def test_autoregressive_drivers_equal_reference(dfx, fake_model, name):
+    """`*_given`: generate_frames_for_reference = False - the reference frames are ENCODED (ctsd.py:1677-1703,
+    `.latent_dist.mode()`, shift / scaling, split-call) and carried into the first window: drivers.LatentEncoder must
+    produce the very latents the reference hands to its first inference_pipeline call, and drivers.LatentDecoder the
+    emitted images (decode of latents / scaling + shift)."""
     from oracle import drivers_oracle as DO
-    from opendwm_amd.drivers import AutoregressiveDriver
+    from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder, LatentEncoder
     d = dfx["autoregressive"][name]
     cfg = dict(d["config"], inference_steps=d["steps"])
-    cond = _cond(d["batch"])
+    cond = {k: v for k, v in d["batch"].items() if k not in ("pts", "vae_images")}
     G = dfx["guidance"]
+    il, post, decode = None, (lambda x: x), None
+    if d["reference_latents"] is not None:
+        vae = _RefVae()
+        ref = cfg.get("reference_frame_count", 1)
+        il = LatentEncoder(vae, d["memory_efficient_batch"], is_temporal_vae=False)(d["batch"]["vae_images"][:, :ref] * 2 - 1, sample=False)
+        assert torch.equal(il, d["reference_latents"])
+        post = lambda x: x / 0.7 + 0.1
+        decode = LatentDecoder.__new__(LatentDecoder)
+        decode.vae, decode.batch, decode.postprocess, decode.group, decode.is_temporal_vae = vae, d["memory_efficient_batch"], False, None, False
 
-    def window(latent_shape, c, il, ref, start, stop, take_time, noise):
+    def window(latent_shape, c, il_, ref, start, stop, take_time, noise):
         lat0 = noise if noise is not None else torch.zeros(tuple(latent_shape))
-        lat = O.denoise(None, None, lat0, c, d["steps"], G, stop=stop, start=start, image_latents=il, reference_frame_count=ref,
+        lat = O.denoise(None, None, lat0, c, d["steps"], G, stop=stop, start=start, image_latents=il_, reference_frame_count=ref,
                         diffusion_forcing=d["df"], take_time=take_time, clear_reference_frame_count=cfg.get("clear_reference_frame_count", 0))
-        return {"latents": lat, "images": lat[:, take_time].flatten(0, 1) if d["df"] else lat.flatten(0, 2)}
-    want = DO.autoregressive(window, d["shape"], cond, d["total"], cfg, d["df"], torch.Generator().manual_seed(d["seed"]))
-    assert torch.allclose(want["images"], d["images"], atol=1e-6)
+        return {"latents": lat, "images": post(lat[:, take_time].flatten(0, 1) if d["df"] else lat.flatten(0, 2))}
+    want = DO.autoregressive(window, d["shape"], cond, d["total"], cfg, d["df"], torch.Generator().manual_seed(d["seed"]), image_latents=il)
+    assert want["images"].shape == d["images"].shape and torch.allclose(want["images"], d["images"], atol=1e-6)
     den = _LoopDenoiser(d["steps"], G)
-    got = AutoregressiveDriver(den, cfg, diffusion_forcing=d["df"], generator=torch.Generator().manual_seed(d["seed"])).run(
-        d["shape"], cond, d["total"], "cpu")
+    got = AutoregressiveDriver(den, cfg, diffusion_forcing=d["df"], decode=decode, generator=torch.Generator().manual_seed(d["seed"])).run(
+        d["shape"], cond, d["total"], "cpu", image_latents=il)
     assert torch.allclose(got["images"], d["images"], atol=1e-6)
     ref_calls = [(s, st, tt) for s, st, tt, _ in d["calls"]]
     if d["df"]:
@@ -283,13 +314,35 @@ def test_oracle_unet_composition_equals_reference_forward(name):
 
 # ------------------------------------------------------------------------------------------------------------------
 # training step: fixture from the REAL CrossviewTemporalSD.train_step (tests/golden/make_reference_train_fixture.py)
-@pytest.mark.parametrize("name", ["plain", "loss_coef"])
+class _EncVae:
+    """the stand-in VAEs of make_reference_train_fixture.py (2-D: average pooling, shift 0.1, scale 1.5; temporal:
+    "(b v) c t h w" clips with a per-frame offset, no shift, scale 0.8)"""
+
+    def __init__(self, temporal):
+        import types
+        self.temporal = temporal
+        self.config = types.SimpleNamespace(shift_factor=None if temporal else 0.1, scaling_factor=0.8 if temporal else 1.5)
+
+    def encode(self, x):
+        import types
+        if self.temporal:
+            y = torch.nn.functional.avg_pool3d(x, (1, 8, 8)) + torch.arange(x.shape[2], dtype=x.dtype).view(1, 1, -1, 1, 1) * 0.05
+        else:
+            y = torch.nn.functional.avg_pool2d(x, 8)
+        return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: y, mode=lambda: y))
+
+
+@pytest.mark.parametrize("name", ["plain", "loss_coef", "temporal_vae"])
 def test_training_pair_and_loss_equal_reference_train_step(name, monkeypatch):
+    """the product's encode call site (drivers.LatentEncoder: image batch / "(b v) c t h w" clips, split-call chunks,
+    shift / scaling), flow-matching pair and the oracle's loss / gradient against the REAL train_step"""
+    from opendwm_amd.drivers import LatentEncoder
     from opendwm_amd.pipeline import CTSDTrainer, flow_match_train_sigmas, sample_timestep_indices
     d = torch.load(os.path.join(GOLDEN, "reference_train_step.pt"))[name]
     img = d["batch"]["vae_images"]
     B, T, V = img.shape[:3]
-    lat = ((torch.nn.functional.avg_pool2d(img.flatten(0, 2) * 2 - 1, 8) - 0.1) * 1.5).unflatten(0, (B, T, V))
+    lat = LatentEncoder(_EncVae(d["temporal_vae"]), d["memory_efficient_batch"], is_temporal_vae=d["temporal_vae"])(img * 2 - 1, sample=True)
+    assert lat.shape[:3] == (B, T, V)
     noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(d["generator_seed"]))
     torch.manual_seed(d["global_seed"])
     idx = sample_timestep_indices((B,))                                # global generator, like the reference's torch.normal
