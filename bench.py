@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0          # HBM3E (same guide; 6.29 TB/s measured copy)
 
 # model kwargs of examples/ctsd_35_6views_video_generation.json:45-107 (reference repo)
 MODEL_KWARGS = dict(
@@ -116,6 +117,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []           # (kind, flops, start_event, end_event)
+        self.small_bytes = 0.0      # algorithmic bytes of the short-sequence (packed kernel) attention launches
         self.shapes = []            # per GEMM record: (M, N, K, epilogue, implicit conv)
         self.enabled = False
 
@@ -148,7 +150,11 @@ class KernelTimer:
             attn0(q, k, v, out, rowmap, heads, **kw)
             e.record(st)
             L = rowmap.L0 + (kw["q1"].shape[0] // rowmap.n_problems if kw.get("q1") is not None else 0)
-            timer.records.append(("attn", 4.0 * rowmap.n_problems * heads * L * L * 64, s, e))
+            fl = 4.0 * rowmap.n_problems * heads * L * L * 64
+            small = L <= 32 and kw.get("q1") is None and kw.get("group_mask") is None and kw.get("dense_mask") is None
+            timer.records.append(("attn_small" if small else "attn", fl, s, e))
+            if small:           # attn_small_kernel is HBM-bound: q, k, v read + o written once
+                timer.small_bytes += 4.0 * rowmap.n_problems * L * heads * 64 * 2
 
         ops.gemm, ops.attention = gemm, attention
         import opendwm_amd.blocks as blocks
@@ -176,7 +182,7 @@ class KernelTimer:
 
     def summary(self):
         out = {}
-        for kind in ("gemm", "attn"):
+        for kind in ("gemm", "attn", "attn_small"):
             rs = [(f, s.elapsed_time(e)) for k, f, s, e in self.records if k == kind]
             if rs:
                 fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
@@ -520,7 +526,7 @@ def main():
             for row in timer.shape_table():
                 print(json.dumps(row), file=sys.stderr)
         step_ms = 1e3 * dt / args.steps
-        gm, at = ks.get("gemm", {}), ks.get("attn", {})
+        gm, at, asm = ks.get("gemm", {}), ks.get("attn", {}), ks.get("attn_small", {})
         line = {
             "metric": "denoise-steps/sec (6-view x16f 448x256), SD-3.5 CTSD",
             "value": n_samples * args.steps / dt, "unit": "denoise-steps/s", "n_gpus": world,
@@ -545,11 +551,19 @@ def main():
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
-            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel + attn_small_kernel (all attention launches)", "achieved": at.get("tflops"),
-                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel (joint, dual, cross-view, row-wise temporal)",
+                                   "achieved": at.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
-                                   "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms},
+                                   "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms,
+                                   "all_attention_launches_tflops": ((at.get("flops") or 0.0) + (asm.get("flops") or 0.0)) /
+                                   max((at.get("ms") or 0.0) + (asm.get("ms") or 0.0), 1e-9) / 1e9},
+            "roofline_attention_pointwise": None if not asm else {
+                "bound": "hbm", "kernel": "attn_small_kernel (point-wise temporal attention, L = frames)",
+                "achieved": timer.small_bytes / (asm["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": timer.small_bytes / (asm["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                "algorithmic_bytes_per_launch": timer.small_bytes / asm["launches"], "launches": asm["launches"],
+                "avg_launch_us": asm["avg_us"], "share_of_step_time": (asm["ms"] / args.steps) / step_ms},
             "whole_step_mfma_frac": step_flop / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
         }
         if other is not None:
