@@ -379,3 +379,45 @@ def test_oracle_layout_branch_equals_reference_forward():
     inp = small_inputs(cfg, 0)
     inp["condition_image_tensor"] = torch.rand(2, 3, 3, 6, 64, 96, generator=torch.Generator().manual_seed(5))
     assert torch.allclose(O.dit_forward(sd, cfg, **inp), fxf["output"], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# condition builder: fixtures from the REAL CrossviewTemporalSD.get_conditions (tests/golden/make_reference_condition_fixtures.py)
+CONDITION_CASES = ["layout_cfg", "layout_nocfg", "text_only_first_frame_images", "masks", "action_mask_off", "streaming_first",
+                   "streaming_next", "explicit_view", "explicit_view_no_ego", "temporal_vae_5_to_2", "temporal_vae_4_to_2"]
+
+
+@pytest.mark.parametrize("name", CONDITION_CASES)
+def test_build_conditions_equals_reference_get_conditions(name):
+    """opendwm_amd.conditions.build_conditions against get_conditions itself (ctsd.py:159-453, text branch excluded): layout
+    images with the unconditional colour and the CFG doubling, fps / camera / action ids (13 added time ids of the layout
+    checkpoints, 11 of the text-only ones; -1000 action ids for the unconditional half, for masked or motionless samples),
+    streaming mode with the previous ego pose, explicit-view camera matrices, flags, masks, temporal-VAE frame striding.
+    The index lists are the ones of the reference's example JSONs."""
+    from opendwm_amd.conditions import build_conditions
+    d = torch.load(os.path.join(GOLDEN, "reference_conditions.pt"))[name]
+    batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d["batch"].items()}
+    got = build_conditions(d["common_config"], d["latent_shape"], batch, torch.device("cpu"), torch.float32, **d["kwargs"])
+    want = d["result"]
+    assert set(got) == set(want)
+    for k, w in want.items():
+        g = got[k]
+        if w is None:
+            assert g is None, k
+            continue
+        assert g is not None and g.shape == w.shape and g.dtype == w.dtype, (k, None if g is None else (g.shape, g.dtype), w.shape, w.dtype)
+        assert torch.equal(g, w) if not w.is_floating_point() else torch.allclose(g, w, rtol=1e-6, atol=1e-6), k
+    for k, v in d["batch"].items():                      # the caller's batch is left untouched
+        assert not torch.is_tensor(v) or torch.equal(batch[k], v), k
+
+
+def test_build_conditions_passes_text_embeddings_through():
+    from opendwm_amd.conditions import build_conditions
+    d = torch.load(os.path.join(GOLDEN, "reference_conditions.pt"))["temporal_vae_5_to_2"]
+    B2, T = 4, 5
+    ehs, pooled = torch.randn(B2, T, 6, 3, 8), torch.randn(B2, T, 6, 4)
+    got = build_conditions(d["common_config"], d["latent_shape"], d["batch"], "cpu", torch.bfloat16, encoder_hidden_states=ehs,
+                           pooled_projections=pooled, **d["kwargs"])
+    # strided like every other per-frame condition (frames 0 and 1 of 5 for 2 latent frames), cast to the model dtype
+    assert got["encoder_hidden_states"].shape == (B2, 2, 6, 3, 8) and got["encoder_hidden_states"].dtype == torch.bfloat16
+    assert torch.equal(got["pooled_projections"], torch.cat([pooled[:, :1], pooled[:, 1::4]], 1).to(torch.bfloat16))
