@@ -257,6 +257,56 @@ def sample_timestep_indices(shape, generator: Optional[torch.Generator] = None, 
     return (u * num_train_timesteps).long().clamp_(max=num_train_timesteps - 1)
 
 
+def make_input_for_prediction(noisy_input: torch.Tensor, latents: torch.Tensor, timesteps: torch.Tensor, training_config: dict,
+                              common_config: dict, generator: Optional[torch.Generator] = None, reference_latent_count=None):
+    """CrossviewTemporalSD.try_make_input_for_prediction (ctsd.py:619-741): the training task mixer.  Host random draws in the
+    reference's order (CPU generator), tensors stay on the latents' device.
+
+    frame_prediction_style None: nothing changes.  "diffusion_forcing": per-sample image task (temporal blocks disabled, with
+    probability image_generation_ratio), otherwise the reference-frame scale / offset augmentation of the noisy input.
+    "ctsd": generation vs prediction tasks - for prediction the first `reference_latent_count` frames (an int, or a
+    {count: probability} dict) are shown clean (timestep 0), all of them or a random subset.
+    Returns (model input, timesteps, extra conditions or None, reference_frame_indicator [B, T, V])."""
+    import itertools
+    dev = latents.device
+    B, T, V = noisy_input.shape[:3]
+    rf_scale, rf_offset = 1, 0
+    if "reference_frame_scale_std" in training_config:
+        rf_scale = (torch.randn(latents.shape[:2], generator=generator) * training_config["reference_frame_scale_std"] + 1) \
+            .view(B, T, 1, 1, 1, 1).to(dev)
+    if "reference_frame_offset_std" in training_config:
+        rf_offset = (torch.randn(latents.shape[:2], generator=generator) * training_config["reference_frame_offset_std"]) \
+            .view(B, T, 1, 1, 1, 1).to(dev)
+    style = common_config.get("frame_prediction_style", None)
+    indicator = torch.zeros(B, T, V, dtype=torch.bool, device=dev)
+    if style is None:
+        return noisy_input, timesteps, None, indicator
+    if style == "diffusion_forcing":
+        disable_temporal = torch.rand((B, 1, 1), generator=generator) < training_config.get("image_generation_ratio", 0.0)
+        made = torch.where(disable_temporal.view(B, 1, 1, 1, 1, 1).to(dev), noisy_input, noisy_input * rf_scale + rf_offset)
+        return made, timesteps, {"disable_temporal": disable_temporal.to(dev)}, indicator
+    if style != "ctsd":
+        raise ValueError("Unknown frame prediction type")
+    generation = torch.rand((B, 1, 1), generator=generator) < training_config.get("generation_task_ratio", 0.0)
+    disable_temporal = torch.logical_and(
+        torch.rand((B, 1, 1), generator=generator) < training_config.get("image_generation_ratio", 0.0), generation)
+    all_visible = torch.rand((B, 1, 1), generator=generator) < training_config.get("all_reference_visible_ratio", 0.0)
+    partial = torch.rand((B, T, V), generator=generator) < training_config.get("reference_visible_rate", 1.0)
+    if isinstance(reference_latent_count, int):
+        count = reference_latent_count * torch.ones((B, 1, 1), dtype=torch.int32)
+    elif isinstance(reference_latent_count, dict):
+        counts = torch.tensor([int(i) for i in reference_latent_count.keys()], dtype=torch.int32)
+        cum = torch.tensor(list(itertools.accumulate(reference_latent_count.values())))
+        count = counts[torch.searchsorted(cum, torch.rand((B, 1, 1), generator=generator))]
+    else:
+        raise NotImplementedError("Un implemented dynamic reference frame count")
+    in_count = torch.arange(T, dtype=torch.int32).view(1, T, 1).repeat(B, 1, V) < count
+    indicator = torch.logical_and(torch.logical_and(torch.logical_not(generation), torch.logical_or(all_visible, partial)), in_count)
+    made = torch.where(indicator.view(B, T, V, 1, 1, 1).to(dev), latents * rf_scale + rf_offset, noisy_input)
+    made_timesteps = torch.where(indicator.to(timesteps.device), torch.zeros_like(timesteps), timesteps)
+    return made, made_timesteps, {"disable_temporal": disable_temporal.to(dev)}, indicator
+
+
 class CTSDTrainer:
     """The SD 3 branch of CrossviewTemporalSD.train_step (ctsd.py:1195-1437) on latents that are already
     VAE-encoded and conditions that are already embedded:
@@ -274,7 +324,11 @@ class CTSDTrainer:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  shift: float = 3.0, num_train_timesteps: int = 1000, loss_coef: float = 1.0,
                  max_grad_norm: Optional[float] = None, weighting_scheme: str = "logit_normal", ddp: bool = False,
-                 ddp_kwargs: Optional[dict] = None):
+                 ddp_kwargs: Optional[dict] = None, common_config: Optional[dict] = None, training_config: Optional[dict] = None,
+                 reference_latent_count=0):
+        """common_config["frame_prediction_style"] (None | "diffusion_forcing" | "ctsd") and training_config select the
+        training task mix of `make_input_for_prediction`; with "diffusion_forcing" every frame draws its own timestep
+        (ctsd.py:1232-1237)."""
         from . import train as _train
         self.model = model.train()
         self.wrapper = model
@@ -287,19 +341,36 @@ class CTSDTrainer:
         self.sigmas = flow_match_train_sigmas(num_train_timesteps, shift)
         self.num_train_timesteps, self.loss_coef = num_train_timesteps, loss_coef
         self.max_grad_norm, self.weighting_scheme = max_grad_norm, weighting_scheme
+        self.common_config, self.training_config = dict(common_config or {}), dict(training_config or {})
+        self.reference_latent_count = reference_latent_count
+
+    def draw_condition_masks(self, batch_size: int, generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        """the per-sample condition dropout masks of the training step in the reference's draw order (ctsd.py:1278-1301):
+        keyword arguments of conditions.build_conditions (text_condition_mask is a list, for the caller's text encoders)"""
+        tc, draw = self.training_config, lambda: torch.rand((batch_size,), generator=generator)
+        out = {"text_condition_mask": (draw() < tc.get("text_prompt_condition_ratio", 1.0)).tolist(),
+               "_3dbox_condition_mask": draw() < tc.get("3dbox_condition_ratio", 1.0),
+               "hdmap_condition_mask": draw() < tc.get("hdmap_condition_ratio", 1.0),
+               "action_condition_mask": draw() < tc.get("action_condition_ratio", 1.0)}
+        if self.common_config.get("explicit_view_modeling", False):
+            out["explicit_view_modeling_mask"] = draw() < tc.get("explicit_view_modeling_ratio", 1.0)
+        return out
 
     def make_training_pair(self, latents: torch.Tensor, generator: Optional[torch.Generator] = None,
                            timestep_indices: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
-        """returns (noisy_latents, timesteps [B,T,V], sigmas [B,1,1,1,1,1], noise); host RNG like the reference (CPU generator)"""
+        """returns (noisy_latents, timesteps [B,T,V], sigmas [B,1|T,1,1,1,1], noise); host RNG like the reference (CPU
+        generator).  One timestep per sample, or per (sample, frame) in the diffusion-forcing style (ctsd.py:1232-1272)."""
         B, T, V = latents.shape[:3]
         if noise is None:
             noise = torch.randn(latents.shape, generator=generator)
         if timestep_indices is None:
-            timestep_indices = sample_timestep_indices((B,), generator, self.weighting_scheme, self.num_train_timesteps)
+            per_frame = getattr(self, "common_config", {}).get("frame_prediction_style") == "diffusion_forcing"
+            timestep_indices = sample_timestep_indices((B, T) if per_frame else (B,), generator, self.weighting_scheme, self.num_train_timesteps)
         sig = self.sigmas[timestep_indices.cpu()]
-        timesteps = (sig * self.num_train_timesteps).view(B, 1, 1).expand(B, T, V).contiguous()
+        F = sig.shape[1] if sig.dim() == 2 else 1
+        timesteps = (sig * self.num_train_timesteps).view(B, F, 1).expand(B, T, V).contiguous()
         dev = latents.device
-        sig_b = sig.view(B, 1, 1, 1, 1, 1).to(dev)
+        sig_b = sig.view(B, F, 1, 1, 1, 1).to(dev)
         noise = noise.to(dev)
         noisy = sig_b * noise + (1.0 - sig_b) * latents.float()
         return noisy, timesteps.to(dev), sig_b, noise
@@ -307,11 +378,18 @@ class CTSDTrainer:
     def loss(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
              timestep_indices=None, noise=None) -> torch.Tensor:
         noisy, timesteps, sig, _ = self.make_training_pair(latents, generator, timestep_indices, noise)
+        noisy, timesteps, extra, reference = make_input_for_prediction(
+            noisy, latents.float(), timesteps, self.training_config, self.common_config, generator, self.reference_latent_count)
         cond = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
                 for k, v in conditions.items()}
+        if extra is not None:
+            cond.update(extra)
         pred = self.wrapper(noisy.to(bf16), timesteps, **cond)[0][0]
-        x0_hat = pred.float() * (-sig) + noisy
-        return torch.nn.functional.mse_loss(x0_hat, latents.float(), reduction="mean") * self.loss_coef
+        x0_hat, target = pred.float() * (-sig) + noisy, latents.float()
+        if self.training_config.get("disable_reference_frame_loss", False):          # ctsd.py:1363-1367
+            keep = ~reference.view(*x0_hat.shape[:3], 1, 1, 1).to(x0_hat.device)
+            x0_hat, target = x0_hat * keep, target * keep
+        return torch.nn.functional.mse_loss(x0_hat, target, reduction="mean") * self.loss_coef
 
     def train_step(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
                    timestep_indices=None, noise=None) -> torch.Tensor:

@@ -421,3 +421,56 @@ def test_build_conditions_passes_text_embeddings_through():
     # strided like every other per-frame condition (frames 0 and 1 of 5 for 2 latent frames), cast to the model dtype
     assert got["encoder_hidden_states"].shape == (B2, 2, 6, 3, 8) and got["encoder_hidden_states"].dtype == torch.bfloat16
     assert torch.equal(got["pooled_projections"], torch.cat([pooled[:, :1], pooled[:, 1::4]], 1).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training task mixer: the REAL try_make_input_for_prediction (ctsd.py:619-741) and train_step in its diffusion-forcing /
+# "ctsd" styles (tests/golden/make_reference_train_fixture.py)
+@pytest.mark.parametrize("name", ["none_with_augment_draws", "diffusion_forcing", "ctsd_int", "ctsd_dict"])
+def test_task_mixer_equals_reference(name):
+    from opendwm_amd.pipeline import make_input_for_prediction
+    d = torch.load(os.path.join(GOLDEN, "reference_train_step.pt"))["task_mixer"][name]
+    made, ts, extra, ind = make_input_for_prediction(d["noisy"].clone(), d["latents"].clone(), d["timesteps"].clone(), d["training_config"],
+                                                     d["common_config"], torch.Generator().manual_seed(d["seed"]), d["reference_latent_count"])
+    assert torch.equal(made, d["made_noisy"]) and torch.equal(ts, d["made_timesteps"]) and torch.equal(ind, d["indicator"])
+    if d["additional"] is None:
+        assert extra is None
+    else:
+        assert set(extra) == set(d["additional"]) and all(torch.equal(extra[k], v) for k, v in d["additional"].items())
+
+
+@pytest.mark.parametrize("name", ["df_style", "ctsd_style"])
+def test_trainer_task_styles_equal_reference_train_step(name):
+    """CTSDTrainer's pieces in the reference's draw order - noise, timestep indices (per frame in the diffusion-forcing style),
+    condition dropout masks, task mixer - give the very tensors the REAL train_step hands to its model (input, timesteps,
+    disable_temporal); loss (with the reference-frame loss mask) and the SGD update follow in closed form for the stand-in model."""
+    from opendwm_amd.drivers import LatentEncoder
+    from opendwm_amd.pipeline import CTSDTrainer, flow_match_train_sigmas, make_input_for_prediction, sample_timestep_indices
+    d = torch.load(os.path.join(GOLDEN, "reference_train_step.pt"))[name]
+    img = d["batch"]["vae_images"]
+    B, T, V = img.shape[:3]
+    lat = LatentEncoder(_EncVae(False), -1, is_temporal_vae=False)(img * 2 - 1, sample=True)
+    tr = CTSDTrainer.__new__(CTSDTrainer)
+    tr.sigmas, tr.num_train_timesteps, tr.weighting_scheme = flow_match_train_sigmas(), 1000, "logit_normal"
+    tr.common_config, tr.training_config = d["common_config"], d["training_config"]
+    gen = torch.Generator().manual_seed(d["generator_seed"])
+    noise = torch.randn(lat.shape, generator=gen)
+    torch.manual_seed(d["global_seed"])
+    per_frame = d["common_config"].get("frame_prediction_style") == "diffusion_forcing"
+    idx = sample_timestep_indices((B, T) if per_frame else (B,))
+    noisy, ts, sig, _ = tr.make_training_pair(lat, timestep_indices=idx, noise=noise)
+    tr.draw_condition_masks(B, gen)                                        # consumed in the reference's order
+    rlc = d["training_config"].get("reference_frame_count", 0)
+    made, mts, extra, ind = make_input_for_prediction(noisy, lat, ts, d["training_config"], d["common_config"], gen, rlc)
+    assert torch.allclose(made, d["noisy_latents"], atol=1e-6) and torch.allclose(mts, d["timesteps"], atol=1e-4)
+    assert torch.equal(extra["disable_temporal"], d["seen_kwargs"]["disable_temporal"])
+    w = torch.tensor(0.3, requires_grad=True)
+    pred = w * (made + 1e-3 * mts[..., None, None, None] + 0.05 * d["batch"]["c"][..., None, None, None])
+    x0, target = pred * (-sig) + made, lat
+    if d["training_config"].get("disable_reference_frame_loss", False):
+        keep = ~ind.view(B, T, V, 1, 1, 1)
+        x0, target = x0 * keep, target * keep
+    loss = torch.nn.functional.mse_loss(x0, target)
+    assert abs(loss.item() - d["loss"].item()) < 1e-6
+    loss.backward()
+    assert abs((0.3 - d["lr"] * w.grad).item() - d["w_after"].item()) < 1e-6

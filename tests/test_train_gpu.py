@@ -416,6 +416,47 @@ def test_train_step_loss_and_descent(dev):
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("style", ["diffusion_forcing", "ctsd"])
+def test_trainer_task_styles_vs_oracle(dev, style):
+    """CTSDTrainer.loss in the two non-trivial training styles (ctsd.py:619-741, 1232-1237, 1363-1367): per-frame timesteps
+    and the image-task / reference-augmentation mix of the diffusion-forcing checkpoints, or clean reference frames at
+    timestep 0 excluded from the loss.  Reference value: the same host draws (make_training_pair / make_input_for_prediction
+    are pinned against the executed reference code in tests/test_reference_fixtures_cpu.py) through the fp32 oracle forward."""
+    from oracle import ctsd_oracle as O
+    from opendwm_amd.pipeline import CTSDTrainer, make_input_for_prediction
+    from tests.common import small_config, small_inputs, to_dev
+    cfg = small_config()
+    sd = {k: v.to(bf16).float() for k, v in O.make_state_dict(cfg, 0).items()}
+    inp = small_inputs(cfg, 0)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v) for k, v in inp.items()}
+    lat = inp.pop("sample")
+    inp.pop("timestep")
+    inp.pop("disable_temporal", None)                      # set by the task mixer
+    B, T, V = lat.shape[:3]
+    common = {"frame_prediction_style": style}
+    tcfg = {"diffusion_forcing": {"image_generation_ratio": 0.5, "reference_frame_scale_std": 0.05, "reference_frame_offset_std": 0.05},
+            "ctsd": {"all_reference_visible_ratio": 0.5, "reference_visible_rate": 0.7, "disable_reference_frame_loss": True}}[style]
+    rlc = 0 if style == "diffusion_forcing" else 2
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(5))
+    idx = torch.tensor([[250, 800, 40], [600, 10, 990]]) if style == "diffusion_forcing" else torch.tensor([250, 800])
+    m = _train_model(cfg, sd, dev)
+    tr = CTSDTrainer(m, lr=2e-4, weight_decay=0.0, common_config=common, training_config=tcfg, reference_latent_count=rlc)
+    # reference: the same pieces on the host, fp32 oracle forward
+    noisy, ts, sig, _ = tr.make_training_pair(lat, timestep_indices=idx, noise=noise)
+    made, mts, extra, ind = make_input_for_prediction(noisy, lat, ts, tcfg, common, torch.Generator().manual_seed(9), rlc)
+    pred = O.dit_forward(sd, cfg, made.to(bf16).float(), mts, **dict(inp, **extra))
+    x0, target = pred * (-sig) + made, lat
+    if tcfg.get("disable_reference_frame_loss"):
+        keep = ~ind.view(B, T, V, 1, 1, 1)
+        x0, target = x0 * keep, target * keep
+    ref = torch.nn.functional.mse_loss(x0, target).item()
+    ours = tr.loss(lat.to(dev), to_dev(inp, dev), generator=torch.Generator().manual_seed(9), timestep_indices=idx, noise=noise)
+    _log("train_task_style", style=style, ours=ours.item(), oracle=ref, reference_frames=int(ind.sum()))
+    assert abs(ours.item() - ref) / ref < 2e-2
+    ours.backward()                                        # the gradient path through the task-mixed input works
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+
+
 def _ddp_worker(rank, world, port, cfg, sd, inp, wgt, path):
     import torch.distributed as dist
     from opendwm_amd import train
