@@ -3,6 +3,8 @@
 package (the boundary takes embedded text).  Pure host-side tensor logic on whatever device the batch
 lives on; the classifier-free-guidance doubling puts the unconditional half first, as the reference does.
 
+    flatten_clip_text        ctsd.py:39-82     nested per-sample / per-frame / per-view prompts -> flat list (+ "" for CFG)
+    assemble_sd3_text        ctsd.py:219-253   the two CLIP embeddings padded to the T5 width and stacked with T5
     camera_transform_ids     ctsd.py:85-95     intrinsics / image size and extrinsic entries picked by index lists
     action_ids               ctsd.py:97-156    speed [km/h] and steering from consecutive ego poses (-1000 = unconditioned)
     build_conditions         ctsd.py:255-453   layout images (3-D boxes + HD map, unconditional colour), added_time_ids,
@@ -15,6 +17,59 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import torch
+
+
+def flatten_clip_text(clip_text, text_condition_mask=None, do_classifier_free_guidance: bool = False):
+    """(flat prompt list, parsed shape) of a nested prompt structure - a string per sample, or lists per sample / frame /
+    view (ctsd.py:39-82).  Under CFG the unconditional prompts ("" for every leaf) come first, the level-0 count doubles;
+    prompts whose `text_condition_mask` entry (bool, or nested list of bools) is false are replaced by ""."""
+    flat, shape = [], []
+
+    def walk(node, level, mask, cfg):
+        count = 0
+        if isinstance(node, list) and len(shape) <= level:
+            shape.append(0)
+        if cfg:
+            if isinstance(node, str):
+                flat.append("")
+                count += 1
+            else:
+                for child in node:
+                    walk(child, level + 1, mask, cfg)
+                    count += 1
+        if level == 0 or not cfg:
+            if isinstance(node, str):
+                flat.append(node if mask is None or (isinstance(mask, bool) and mask) else "")
+                count += 1
+            else:
+                for i, child in enumerate(node):
+                    walk(child, level + 1, None if mask is None else (mask[i] if isinstance(mask, list) else mask), False)
+                    count += 1
+        if isinstance(node, list):
+            shape[level] = count
+
+    walk(clip_text, 0, text_condition_mask, do_classifier_free_guidance)
+    return flat, shape
+
+
+def assemble_sd3_text(clip_embeddings, clip_pooled, t5_embeddings: torch.Tensor, parsed_shape, sequence_length: int,
+                      view_count: int, dtype):
+    """SD 3 text conditioning from the encoder outputs for the FLAT prompt list (ctsd.py:219-253): the two CLIP hidden
+    states concatenated on the feature axis and zero-padded to the T5 width, stacked with the T5 states on the token
+    axis; pooled CLIP vectors concatenated.  One prompt per sample is repeated over frames and views, otherwise the
+    flat axis is unflattened to the parsed (sample, frame, view) shape.
+    -> encoder_hidden_states [B', T, V, L, D], pooled_projections [B', T, V, P]"""
+    clip = torch.cat(list(clip_embeddings), dim=-1)
+    pooled = torch.cat(list(clip_pooled), dim=-1)
+    clip = torch.nn.functional.pad(clip, (0, t5_embeddings.shape[-1] - clip.shape[-1]))
+    text = torch.cat([clip, t5_embeddings], dim=-2)
+    if len(parsed_shape) == 1:
+        text = text[:, None, None].repeat(1, sequence_length, view_count, 1, 1).to(dtype=dtype)
+        pooled = pooled[:, None, None].repeat(1, sequence_length, view_count, 1).to(dtype=dtype)
+    else:
+        text = text.unflatten(0, parsed_shape).to(dtype=dtype)
+        pooled = pooled.unflatten(0, parsed_shape).to(dtype=dtype)
+    return text, pooled
 
 
 def camera_transform_ids(batch: Dict, common_config: dict) -> torch.Tensor:

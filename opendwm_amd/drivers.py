@@ -264,6 +264,8 @@ class StreamingDriver:
         self.condition_count = 0
         self.latents = None
         self.frames: List[torch.Tensor] = []
+        self.text_prompt_counter = 0
+        self.prev_ego_transforms = None          # the last frame's ego pose: the action ids are pose differences
 
     def _randn(self, shape):
         return (torch.randn(tuple(shape), generator=self.generator) * self.init_noise_sigma).to(self.device)
@@ -306,6 +308,33 @@ class StreamingDriver:
             B = self.latent_shape[0]
             self.latents = torch.cat([self.latents[:, 1:], self._randn((B, 1) + self.latent_shape[2:])], 1)
             self.latents = self._window(steps - self.spi, steps)
+
+    def send_frame(self, frame_batch: Optional[Dict], common_config: dict, embed_text: Optional[Callable] = None,
+                   dtype=torch.bfloat16):
+        """One frame of a dataset batch in (None = flush), the ingestion half of send_frame_condition (ctsd.py:2134-2160):
+        model kwargs through conditions.build_conditions in streaming mode (action ids against the previous frame's ego
+        pose), CFG iff the inference config has a guidance_scale; the prompts are embedded only every
+        `text_prompt_interval`-th frame - `embed_text(flat_prompts, parsed_shape, view_count) -> (encoder_hidden_states
+        [B', 1, V, L, D], pooled_projections [B', 1, V, P])`, e.g. the callers' encoders + conditions.assemble_sd3_text -
+        and the newest queued embeddings are reused in between."""
+        if frame_batch is None:
+            return self.send_frame_condition(None)
+        from .conditions import build_conditions, flatten_clip_text
+        cfg = "guidance_scale" in self.cfg
+        ehs = pooled = None
+        if self.text_prompt_counter == 0 and embed_text is not None:
+            flat, shape = flatten_clip_text(frame_batch["clip_text"], do_classifier_free_guidance=cfg)
+            ehs, pooled = embed_text(flat, shape, self.latent_shape[2])
+        cond = build_conditions(common_config, (self.latent_shape[0], 1) + tuple(self.latent_shape[2:]), frame_batch, self.device, dtype,
+                                encoder_hidden_states=ehs, pooled_projections=pooled, streaming_mode=True,
+                                prev_ego_transforms=self.prev_ego_transforms, do_classifier_free_guidance=cfg)
+        if "ego_transforms" in frame_batch:
+            self.prev_ego_transforms = frame_batch["ego_transforms"]
+        if self.text_prompt_counter > 0:
+            cond["encoder_hidden_states"] = self.conditions["encoder_hidden_states"][:, -1:]
+            cond["pooled_projections"] = self.conditions["pooled_projections"][:, -1:]
+        self.text_prompt_counter = (self.text_prompt_counter + 1) % self.cfg.get("text_prompt_interval", 1)
+        self.send_frame_condition(cond)
 
     def receive_frame(self):
         return self.frames.pop(0) if self.frames else None

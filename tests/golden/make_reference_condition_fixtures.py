@@ -48,6 +48,74 @@ def make_batch(g, B, T, V, sensors=6, images=True):
     return batch
 
 
+def text_embedding(prompt, L, D, seed):
+    """deterministic stand-in for a text encoder: depends on the prompt string only"""
+    h = sum((i + 1) * ord(ch) for i, ch in enumerate(prompt)) % 100003
+    return torch.randn(L, D, generator=torch.Generator().manual_seed(seed * 100003 + h)) * 0.5
+
+
+def stream_model(x, ts, encoder_hidden_states=None, pooled_projections=None, added_time_ids=None, condition_image_tensor=None, **kw):
+    """cheap denoiser that sees every streamed condition: text (tokens and pooled), action ids, layout images"""
+    act = added_time_ids[..., -2:].clamp(-5, 5).mean(-1)
+    c = encoder_hidden_states.float().mean((-1, -2)) + 0.5 * pooled_projections.float().mean(-1) + 0.02 * act \
+        + 0.3 * condition_image_tensor.float().mean((-1, -2, -3))
+    return 0.1 * x + 1e-4 * ts[..., None, None, None] + 0.05 * c[..., None, None, None]
+
+
+def streaming_ingest(C, layout_cfg):
+    """the REAL StreamingCrossviewTemporalSD.fifo_inference_pipeline / send_frame_condition / get_conditions (text branch
+    included: flatten_clip_text, the clip / t5 assembly :205-253) with stand-in text encoders and denoiser; prompts change
+    from frame to frame and are re-embedded every 3rd frame only (text_prompt_interval)"""
+    import diffusers
+    from dwm.schedulers.temporal_independent import FlowMatchEulerDiscreteScheduler as Sched
+    from tests.golden.make_reference_driver_fixtures import FakeVae, make_scheduler
+    diffusers.schedulers.scheduling_flow_match_euler_discrete.FlowMatchEulerDiscreteSchedulerOutput = \
+        lambda prev_sample: __import__("types").SimpleNamespace(prev_sample=prev_sample)
+
+    class Model(diffusers.SD3Transformer2DModel):
+        depth_net = None
+
+        def forward(self, x, ts, **kw):
+            return [stream_model(x.float(), ts.float(), **kw)], None, None
+
+    C.CrossviewTemporalSD.sd3_encode_prompt_with_clip = staticmethod(
+        lambda enc, tok, cc, prompt, device, num_images_per_prompt=1:
+        (torch.stack([text_embedding(p, 3, enc.dim, enc.seed) for p in prompt]),
+         torch.stack([text_embedding(p, 1, enc.dim, enc.seed + 7)[0] for p in prompt])))
+    C.CrossviewTemporalSD.sd3_encode_prompt_with_t5 = staticmethod(
+        lambda enc, tok, cc, max_sequence_length=77, prompt=None, num_images_per_prompt=1, device=None, joint_attention_dim=4096:
+        torch.stack([text_embedding(p, 4, 12, 3) for p in prompt]))
+    import types
+    steps, T, B, V, total = 8, 4, 1, 6, 7
+    p = object.__new__(C.StreamingCrossviewTemporalSD)
+    p.model = Model()
+    p.model_wrapper, p.model_dtype = p.model, torch.float32
+    p.common_config = dict(layout_cfg, frame_prediction_style="diffusion_forcing")
+    p.inference_config = dict(inference_steps=steps, guidance_scale=3.0, sequence_length_per_iteration=T, text_prompt_interval=3,
+                              autoregression_data_exception_for_take_sequence=["crossview_mask", "fps"],
+                              autoregression_condition_exception_for_take_sequence=[
+                                  "disable_crossview", "disable_temporal", "crossview_attention_mask", "camera_intrinsics_norm", "camera2referego"])
+    p.device, p.generator = torch.device("cpu"), torch.Generator().manual_seed(3)
+    p.vae, p.is_temporal_vae = FakeVae(), False
+    p.image_processor = types.SimpleNamespace(postprocess=lambda x, output_type=None: x)
+    p.test_scheduler = make_scheduler(Sched, steps)
+    p.text_encoders = [types.SimpleNamespace(dim=4, seed=1, device="cpu"), types.SimpleNamespace(dim=5, seed=2, device="cpu"), types.SimpleNamespace(device="cpu")]
+    p.tokenizers = [None, None, None]
+    p.text_encoder = p.tokenizer = None
+    import contextlib
+    p.get_autocast_context = lambda: contextlib.nullcontext()
+    g = torch.Generator().manual_seed(41)
+    batch = make_batch(g, B, total, V)
+    batch["clip_text"] = [[[f"frame {t} view {v}" for v in range(V)] for t in range(total)] for _ in range(B)]
+    shape = (B, T, V, 2, 3, 4)
+    inp = clone(batch)
+    inp["clip_text"] = batch["clip_text"]
+    r = C.StreamingCrossviewTemporalSD.fifo_inference_pipeline(p, shape, batch, "pt")
+    print("streaming_ingest", list(r["images"].shape), "queued conditions", {k: (None if v is None else list(v.shape)) for k, v in p.conditions.items()})
+    return dict(common_config=p.common_config, inference_config=p.inference_config, batch=inp, shape=shape, total=total, seed=3, steps=steps,
+                images=r["images"], final_latents=p.latents, final_conditions=p.conditions)
+
+
 def clone(x):
     return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in x.items()}
 
@@ -100,6 +168,29 @@ def main():
     run("temporal_vae_5_to_2", layout_cfg, make_batch(g, B, 5, V), (B, 2, V, 16, 4, 4), do_classifier_free_guidance=True,
         latents_shape=(B, 2, V, 16, 4, 4))
     run("temporal_vae_4_to_2", text_cfg, make_batch(g, B, 4, V), (B, 2, V, 16, 4, 4), latents_shape=(B, 2, V, 16, 4, 4))
+    cases["streaming_ingest"] = streaming_ingest(C, layout_cfg)           # (installs the stand-in text encoders used below)
+    # ---- the text branch alone: flatten_clip_text (:39-82) and the assembly inside get_conditions (:205-253)
+    flat_cases = {}
+    for name, text, mask, cfg_ in (("per_sample", ["a car", "a bus"], None, False), ("per_sample_cfg", ["a car", "a bus"], None, True),
+                                   ("per_sample_masked", ["a car", "a bus"], [True, False], True),
+                                   ("nested", [[["a", "b"], ["c", "d"], ["e", "f"]]], None, True),
+                                   ("nested_masked", [[["a", "b"], ["c", "d"]], [["g", "h"], ["i", "j"]]], [[[True, False], [True, True]], False], False)):
+        flat, shape_ = [], []
+        C.CrossviewTemporalSD.flatten_clip_text(text, flat, shape_, text_condition_mask=mask, do_classifier_free_guidance=cfg_)
+        flat_cases[name] = dict(text=text, mask=mask, cfg=cfg_, flat=flat, shape=shape_)
+    cases["flatten_clip_text"] = flat_cases
+    import diffusers
+    import types
+    encs = [types.SimpleNamespace(dim=4, seed=1, device="cpu"), types.SimpleNamespace(dim=5, seed=2, device="cpu"), types.SimpleNamespace(device="cpu")]
+    tb = make_batch(g, B, T, V)
+    text_results = {}
+    for name, text, mask in (("shared_prompt", ["a car", "a bus"], [True, False]),
+                             ("per_view_prompts", [[[f"s{b} t{t} v{v}" for v in range(V)] for t in range(T)] for b in range(B)], None)):
+        tb["clip_text"] = text
+        r = C.CrossviewTemporalSD.get_conditions(type("M", (diffusers.SD3Transformer2DModel,), {})(), encs, [None] * 3, text_cfg, shape, clone(tb),
+                                                 torch.device("cpu"), torch.float32, text_condition_mask=mask, do_classifier_free_guidance=True)
+        text_results[name] = dict(text=text, mask=mask, encoder_hidden_states=r["encoder_hidden_states"], pooled_projections=r["pooled_projections"])
+    cases["text_branch"] = text_results
     torch.save(cases, os.path.join(HERE, "reference_conditions.pt"))
     print("wrote reference_conditions.pt", len(cases), "cases")
 

@@ -474,3 +474,65 @@ def test_trainer_task_styles_equal_reference_train_step(name):
     assert abs(loss.item() - d["loss"].item()) < 1e-6
     loss.backward()
     assert abs((0.3 - d["lr"] * w.grad).item() - d["w_after"].item()) < 1e-6
+
+
+def test_streaming_frame_ingestion_equals_reference(monkeypatch):
+    """StreamingDriver.send_frame - dataset frames in, generated frames out - against the REAL fifo_inference_pipeline /
+    send_frame_condition / get_conditions (text branch included) with stand-in text encoders and denoiser: prompts flattened
+    with the CFG "" half first, the two CLIP embeddings padded and stacked with T5 (conditions.assemble_sd3_text), text
+    re-embedded every 3rd frame only and the newest queued embedding reused in between, action ids against the previous
+    frame's ego pose, layout images with the unconditional colour, every condition queued / slid / replaced as configured."""
+    from opendwm_amd.conditions import assemble_sd3_text
+    from opendwm_amd.drivers import StreamingDriver, take_sequence_clip
+    from tests.golden.make_reference_condition_fixtures import stream_model, text_embedding
+    d = torch.load(os.path.join(GOLDEN, "reference_conditions.pt"))["streaming_ingest"]
+    monkeypatch.setattr(O, "dit_forward", lambda sd, cfg, sample, timestep, **kw: stream_model(sample.float(), timestep.float(), **kw))
+    embedded = []
+
+    def embed_text(flat, shape, view_count):
+        embedded.append(list(flat))
+        clip = [torch.stack([text_embedding(p, 3, dim, seed) for p in flat]) for dim, seed in ((4, 1), (5, 2))]
+        pooled = [torch.stack([text_embedding(p, 1, dim, seed + 7)[0] for p in flat]) for dim, seed in ((4, 1), (5, 2))]
+        t5 = torch.stack([text_embedding(p, 4, 12, 3) for p in flat])
+        return assemble_sd3_text(clip, pooled, t5, shape, 1, view_count, torch.float32)
+
+    icfg = d["inference_config"]
+    den = _LoopDenoiser(d["steps"], icfg["guidance_scale"])
+    drv = StreamingDriver(den, icfg, generator=torch.Generator().manual_seed(d["seed"]))
+    drv.reset_streaming(d["shape"], "cpu")
+    exc, out = icfg["autoregression_data_exception_for_take_sequence"], []
+    for i in range(d["total"]):
+        frame = {k: (v if k in exc else take_sequence_clip(v, i, i + 1)) for k, v in d["batch"].items()}
+        drv.send_frame(frame, d["common_config"], embed_text, dtype=torch.float32)
+        f = drv.receive_frame()
+        if f is not None:
+            out.append(f)
+    drv.send_frame(None, d["common_config"])
+    while (f := drv.receive_frame()) is not None:
+        out.append(f)
+    got = torch.cat(out)
+    assert got.shape == d["images"].shape and torch.allclose(got, d["images"], atol=1e-6)
+    assert torch.allclose(drv.latents, d["final_latents"], atol=1e-6)
+    assert len(embedded) == 3 and embedded[0][:6] == [""] * 6 and embedded[1][6] == "frame 3 view 0"     # frames 0, 3, 6
+    for k, w in d["final_conditions"].items():
+        g = drv.conditions[k]
+        assert (g is None and w is None) or (g.shape == w.shape and torch.allclose(g.float(), w.float(), atol=1e-6)), k
+
+
+def test_text_flattening_and_assembly_equal_reference():
+    """conditions.flatten_clip_text / assemble_sd3_text against flatten_clip_text (ctsd.py:39-82) and the text branch of
+    get_conditions (:205-253) run with stand-in encoders: shared prompts repeated over frames and views, per-view prompts
+    unflattened, masked prompts blanked, CFG halves in the reference's order."""
+    from opendwm_amd.conditions import assemble_sd3_text, flatten_clip_text
+    from tests.golden.make_reference_condition_fixtures import text_embedding
+    fx = torch.load(os.path.join(GOLDEN, "reference_conditions.pt"))
+    for name, d in fx["flatten_clip_text"].items():
+        flat, shape = flatten_clip_text(d["text"], d["mask"], d["cfg"])
+        assert flat == d["flat"] and shape == d["shape"], name
+    for name, d in fx["text_branch"].items():
+        flat, shape = flatten_clip_text(d["text"], d["mask"], True)
+        clip = [torch.stack([text_embedding(p, 3, dim, seed) for p in flat]) for dim, seed in ((4, 1), (5, 2))]
+        pooled = [torch.stack([text_embedding(p, 1, dim, seed + 7)[0] for p in flat]) for dim, seed in ((4, 1), (5, 2))]
+        t5 = torch.stack([text_embedding(p, 4, 12, 3) for p in flat])
+        ehs, pp = assemble_sd3_text(clip, pooled, t5, shape, 3, 6, torch.float32)
+        assert torch.equal(ehs, d["encoder_hidden_states"]) and torch.equal(pp, d["pooled_projections"]), name
