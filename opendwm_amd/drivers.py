@@ -214,7 +214,12 @@ class AutoregressiveDriver:
         images = []
         carried = image_latents
         for w in self.plan(T, total_frame_count, image_latents is not None):
-            cond = {k: (v if k in exc else take_sequence_clip(v, *w.clip)) for k, v in conditions.items()}
+            # `conditions`: the embedded model kwargs of the whole sequence (sliced per window), or a callable
+            # (first frame, last frame + 1) -> model kwargs of that window.  The reference builds the conditions from each
+            # window's clip of the batch (ctsd.py:1478-1488), so anything derived from neighbouring frames - the action ids
+            # are pose differences - restarts at the window's first frame; `conditions_from_batch` reproduces that.
+            cond = conditions(*w.clip) if callable(conditions) else \
+                {k: (v if k in exc else take_sequence_clip(v, *w.clip)) for k, v in conditions.items()}
             if self.df:
                 noise = self._randn(latent_shape, device) if (w.draws_noise or carried is None) else carried
                 lat = self.denoiser.run(noise, cond, stop=w.stop, start=w.start, image_latents=carried,
@@ -237,6 +242,28 @@ class AutoregressiveDriver:
                                                self.cfg.get("vae_stride", 1))
                     carried = lat[:, -n:]
         return {"images": torch.cat(images), "latents": carried}
+
+
+def conditions_from_batch(batch: Dict, common_config: dict, inference_config: dict, latent_shape, device, dtype,
+                          embed_text: Optional[Callable] = None) -> Callable:
+    """-> callable(first frame, last frame + 1) for AutoregressiveDriver.run: the model kwargs of one window built from that
+    window's clip of a dataset batch, as inference_pipeline does (ctsd.py:1478-1488 with the clip of :1735-1745):
+    take_sequence_clip over the batch (minus `autoregression_data_exception_for_take_sequence`), prompts flattened and
+    embedded (`embed_text(flat_prompts, parsed_shape, frames, view_count) -> (encoder_hidden_states, pooled_projections)`),
+    conditions.build_conditions with CFG iff the inference config has a guidance_scale."""
+    from .conditions import build_conditions, flatten_clip_text
+    exc = inference_config.get("autoregression_data_exception_for_take_sequence", [])
+    cfg = "guidance_scale" in inference_config
+
+    def window_conditions(start: int, stop: int) -> Dict:
+        clip = {k: (v if k in exc else take_sequence_clip(v, start, stop)) for k, v in batch.items()}
+        ehs = pooled = None
+        if embed_text is not None:
+            flat, shape = flatten_clip_text(clip["clip_text"], do_classifier_free_guidance=cfg)
+            ehs, pooled = embed_text(flat, shape, clip["pts"].shape[1], latent_shape[2])
+        return build_conditions(common_config, latent_shape, clip, device, dtype, encoder_hidden_states=ehs,
+                                pooled_projections=pooled, do_classifier_free_guidance=cfg, latents_shape=tuple(latent_shape))
+    return window_conditions
 
 
 class StreamingDriver:

@@ -116,6 +116,51 @@ def streaming_ingest(C, layout_cfg):
                 images=r["images"], final_latents=p.latents, final_conditions=p.conditions)
 
 
+def autoregressive_batch(C, layout_cfg):
+    """the REAL autoregressive_inference_pipeline over the REAL inference_pipeline and get_conditions (stand-in text encoders
+    and denoiser as in streaming_ingest): the conditions of every window come from that window's clip of the batch"""
+    import contextlib
+    import types
+    import diffusers
+    from dwm.schedulers.temporal_independent import FlowMatchEulerDiscreteScheduler as Sched
+    from tests.golden.make_reference_driver_fixtures import FakeVae, make_scheduler
+
+    class Model(diffusers.SD3Transformer2DModel):
+        depth_net = None
+
+        def forward(self, x, ts, **kw):
+            return [stream_model(x.float(), ts.float(), **kw)], None, None
+
+    steps, T, B, V, total = 3, 4, 1, 6, 10
+    p = object.__new__(C.CrossviewTemporalSD)
+    p.model = Model()
+    p.model_wrapper, p.model_dtype = p.model, torch.float32
+    p.common_config = dict(layout_cfg)
+    p.inference_config = dict(inference_steps=steps, guidance_scale=3.0, sequence_length_per_iteration=T, reference_frame_count=1,
+                              autoregression_data_exception_for_take_sequence=["crossview_mask", "fps"])
+    p.device, p.generator = torch.device("cpu"), torch.Generator().manual_seed(5)
+    p.vae, p.is_temporal_vae = FakeVae(), False
+    p.image_processor = types.SimpleNamespace(postprocess=lambda x, output_type=None: x)
+    p.test_scheduler = make_scheduler(Sched, steps)
+    p.text_encoders = [types.SimpleNamespace(dim=4, seed=1, device="cpu"), types.SimpleNamespace(dim=5, seed=2, device="cpu"), types.SimpleNamespace(device="cpu")]
+    p.tokenizers = [None, None, None]
+    p.text_encoder = p.tokenizer = None
+    p.get_autocast_context = lambda: contextlib.nullcontext()
+    real = C.CrossviewTemporalSD.inference_pipeline
+    p.inference_pipeline = lambda *a, _p=p, **kw: real(_p, *a, **kw)
+    p.get_latent_sequence_length = lambda n, _p=p: C.CrossviewTemporalSD.get_latent_sequence_length(_p, n)
+    g = torch.Generator().manual_seed(43)
+    batch = make_batch(g, B, total, V)
+    batch["clip_text"] = [[[f"frame {t} view {v}" for v in range(V)] for t in range(total)] for _ in range(B)]
+    shape = (B, T, V, 2, 3, 4)
+    inp = clone(batch)
+    inp["clip_text"] = batch["clip_text"]
+    r = C.CrossviewTemporalSD.autoregressive_inference_pipeline(p, shape, batch, "pt")
+    print("autoregressive_batch", list(r["images"].shape))
+    return dict(common_config=p.common_config, inference_config=p.inference_config, batch=inp, shape=shape, total=total, seed=5, steps=steps,
+                images=r["images"])
+
+
 def clone(x):
     return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in x.items()}
 
@@ -169,6 +214,7 @@ def main():
         latents_shape=(B, 2, V, 16, 4, 4))
     run("temporal_vae_4_to_2", text_cfg, make_batch(g, B, 4, V), (B, 2, V, 16, 4, 4), latents_shape=(B, 2, V, 16, 4, 4))
     cases["streaming_ingest"] = streaming_ingest(C, layout_cfg)           # (installs the stand-in text encoders used below)
+    cases["autoregressive_batch"] = autoregressive_batch(C, layout_cfg)
     # ---- the text branch alone: flatten_clip_text (:39-82) and the assembly inside get_conditions (:205-253)
     flat_cases = {}
     for name, text, mask, cfg_ in (("per_sample", ["a car", "a bus"], None, False), ("per_sample_cfg", ["a car", "a bus"], None, True),

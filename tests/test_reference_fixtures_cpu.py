@@ -536,3 +536,25 @@ def test_text_flattening_and_assembly_equal_reference():
         t5 = torch.stack([text_embedding(p, 4, 12, 3) for p in flat])
         ehs, pp = assemble_sd3_text(clip, pooled, t5, shape, 3, 6, torch.float32)
         assert torch.equal(ehs, d["encoder_hidden_states"]) and torch.equal(pp, d["pooled_projections"]), name
+
+
+def test_autoregressive_windows_from_a_batch_equal_reference(monkeypatch):
+    """AutoregressiveDriver over drivers.conditions_from_batch (the conditions of every window built from that window's clip
+    of the dataset batch: prompts, layout images, camera / action ids that restart at the window's first frame) against the
+    REAL autoregressive_inference_pipeline over the REAL inference_pipeline and get_conditions with stand-in encoders."""
+    from opendwm_amd.conditions import assemble_sd3_text
+    from opendwm_amd.drivers import AutoregressiveDriver, conditions_from_batch
+    from tests.golden.make_reference_condition_fixtures import stream_model, text_embedding
+    d = torch.load(os.path.join(GOLDEN, "reference_conditions.pt"))["autoregressive_batch"]
+    monkeypatch.setattr(O, "dit_forward", lambda sd, cfg, sample, timestep, **kw: stream_model(sample.float(), timestep.float(), **kw))
+
+    def embed_text(flat, shape, frames, view_count):
+        clip = [torch.stack([text_embedding(p, 3, dim, seed) for p in flat]) for dim, seed in ((4, 1), (5, 2))]
+        pooled = [torch.stack([text_embedding(p, 1, dim, seed + 7)[0] for p in flat]) for dim, seed in ((4, 1), (5, 2))]
+        return assemble_sd3_text(clip, pooled, torch.stack([text_embedding(p, 4, 12, 3) for p in flat]), shape, frames, view_count, torch.float32)
+
+    icfg = d["inference_config"]
+    cond = conditions_from_batch(d["batch"], d["common_config"], icfg, d["shape"], "cpu", torch.float32, embed_text)
+    den = _LoopDenoiser(d["steps"], icfg["guidance_scale"])
+    got = AutoregressiveDriver(den, icfg, generator=torch.Generator().manual_seed(d["seed"])).run(d["shape"], cond, d["total"], "cpu")
+    assert got["images"].shape == d["images"].shape and torch.allclose(got["images"], d["images"], atol=1e-6)
