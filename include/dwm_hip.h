@@ -148,7 +148,10 @@ typedef struct dwm_attn_args {
     int64_t pdiv[3], pmod[3], pstride[3];
     int64_t ldiv[2], lstride[3];
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
-    int32_t variant;                           /* 0 = auto; tuning knob, see attention.hip    */
+    int32_t variant;                           /* 0 = auto.  Tuning / test knob (attention.hip): bits 0-3 queries per wave
+                                                * (1: 32, 2: 64), bit 4 skip the output stores (benchmarks), bit 5 keep the
+                                                * tiled kernel for L <= 32 (default there: the packed short-sequence kernel),
+                                                * bits 8-11 heads per workgroup / per wave */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */
