@@ -75,6 +75,7 @@ def main():
     from dwm.models.crossview_temporal import AlphaBlender
     from dwm.models.crossview_temporal_dit import DiTCrossviewTemporalConditionModel as RefDiT
 
+    torch.manual_seed(0)                 # torch.nn.Linear below draws from the global generator
     g = torch.Generator().manual_seed(0)
     B, T, V, h, w, C = 2, 3, 3, 2, 3, 128
     hidden = torch.randn(B * T * V, h * w, C, generator=g)
