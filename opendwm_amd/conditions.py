@@ -5,6 +5,7 @@ lives on; the classifier-free-guidance doubling puts the unconditional half firs
 
     flatten_clip_text        ctsd.py:39-82     nested per-sample / per-frame / per-view prompts -> flat list (+ "" for CFG)
     assemble_sd3_text        ctsd.py:219-253   the two CLIP embeddings padded to the T5 width and stacked with T5
+    assemble_clip_text       ctsd.py:186-203   SD 2.1: one CLIP embedding per prompt, repeated or unflattened
     camera_transform_ids     ctsd.py:85-95     intrinsics / image size and extrinsic entries picked by index lists
     action_ids               ctsd.py:97-156    speed [km/h] and steering from consecutive ego poses (-1000 = unconditioned)
     build_conditions         ctsd.py:255-453   layout images (3-D boxes + HD map, unconditional colour), added_time_ids,
@@ -70,6 +71,15 @@ def assemble_sd3_text(clip_embeddings, clip_pooled, t5_embeddings: torch.Tensor,
         text = text.unflatten(0, parsed_shape).to(dtype=dtype)
         pooled = pooled.unflatten(0, parsed_shape).to(dtype=dtype)
     return text, pooled
+
+
+def assemble_clip_text(text_embeddings: torch.Tensor, parsed_shape, sequence_length: int, view_count: int) -> torch.Tensor:
+    """SD 2.1 text conditioning (ctsd.py:186-203): the CLIP hidden states of the FLAT prompt list [N, 77, D], one prompt per
+    sample repeated over frames and views, otherwise unflattened to the parsed (sample, frame, view) shape
+    -> encoder_hidden_states [B', T, V, 77, D]"""
+    if len(parsed_shape) == 1:
+        return text_embeddings[:, None, None].repeat(1, sequence_length, view_count, 1, 1)
+    return text_embeddings.unflatten(0, parsed_shape)
 
 
 def camera_transform_ids(batch: Dict, common_config: dict) -> torch.Tensor:

@@ -237,6 +237,22 @@ def main():
                                                  torch.device("cpu"), torch.float32, text_condition_mask=mask, do_classifier_free_guidance=True)
         text_results[name] = dict(text=text, mask=mask, encoder_hidden_states=r["encoder_hidden_states"], pooled_projections=r["pooled_projections"])
     cases["text_branch"] = text_results
+    # SD 2.1 (UNet) text branch (:186-203): one CLIP encoder, no pooled projections
+    class Ids(list):
+        def to(self, device):
+            return self
+    tok = lambda prompts, **kw: types.SimpleNamespace(input_ids=Ids(prompts))
+    tok.model_max_length = 77
+    enc = lambda prompts: (torch.stack([text_embedding(p, 5, 8, 11) for p in prompts]),)
+    unet_results = {}
+    for name, text in (("shared_prompt", ["a car", "a bus"]),
+                       ("per_view_prompts", [[[f"s{b} t{t} v{v}" for v in range(V)] for t in range(T)] for b in range(B)])):
+        tb["clip_text"] = text
+        r = C.CrossviewTemporalSD.get_conditions(type("U", (diffusers.UNetSpatioTemporalConditionModel,), {})(), enc, tok, text_cfg, shape,
+                                                 clone(tb), torch.device("cpu"), torch.float32, do_classifier_free_guidance=True)
+        assert "pooled_projections" not in r
+        unet_results[name] = dict(text=text, encoder_hidden_states=r["encoder_hidden_states"])
+    cases["text_branch_sd21"] = unet_results
     torch.save(cases, os.path.join(HERE, "reference_conditions.pt"))
     print("wrote reference_conditions.pt", len(cases), "cases")
 

@@ -536,6 +536,11 @@ def test_text_flattening_and_assembly_equal_reference():
         t5 = torch.stack([text_embedding(p, 4, 12, 3) for p in flat])
         ehs, pp = assemble_sd3_text(clip, pooled, t5, shape, 3, 6, torch.float32)
         assert torch.equal(ehs, d["encoder_hidden_states"]) and torch.equal(pp, d["pooled_projections"]), name
+    from opendwm_amd.conditions import assemble_clip_text
+    for name, d in fx["text_branch_sd21"].items():                      # SD 2.1 UNet: one CLIP encoder (:186-203)
+        flat, shape = flatten_clip_text(d["text"], None, True)
+        ehs = assemble_clip_text(torch.stack([text_embedding(p, 5, 8, 11) for p in flat]), shape, 3, 6)
+        assert torch.equal(ehs, d["encoder_hidden_states"]), name
 
 
 def test_autoregressive_windows_from_a_batch_equal_reference(monkeypatch):
