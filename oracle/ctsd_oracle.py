@@ -14,7 +14,11 @@ methods, the inference / autoregressive / streaming control flow and
 tests/golden/make_reference_fixtures.py, make_reference_driver_fixtures.py) -
 ``alpha_blender``, ``crossview_block_and_mix``, ``temporal_block_and_mix`` and
 ``denoise`` below are checked against those vectors
-(tests/test_reference_fixtures_cpu.py).  This file is
+(tests/test_reference_fixtures_cpu.py); so are ``dit_forward`` - against the real
+``DiTCrossviewTemporalConditionModel.forward`` / ``VTSelfAttentionBlock.forward`` /
+``ImageAdapter.forward`` composed over this file's leaf functions
+(make_reference_forward_fixture.py) - and ``train_loss`` - against the real
+``train_step`` (make_reference_train_fixture.py).  This file is
 a plain-PyTorch fp32 *restatement* of
 
 * the reference-owned arithmetic
