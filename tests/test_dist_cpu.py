@@ -142,3 +142,76 @@ def test_frame_shard_exchange_and_temporal_block_gloo(world):
     for r in range(world):
         assert res[r]["rows_ok"] and res[r]["round_trip"] and res[r]["gather"] and res[r]["full_rejected"], res[r]
         assert res[r]["rowwise"] < 1e-5 and res[r]["pointwise"] < 1e-5, res[r]
+
+
+# ---------------------------------------------------------------- CTSDDenoiser host logic, one process and frame-sharded,
+# against the REAL inference_pipeline (tests/golden/reference_drivers.pt).  The two HIP ops the loop calls are replaced by
+# torch stand-ins HERE (test-only: the product has no such fallback), the model by the fixtures' cheap per-frame denoiser.
+def _install_fake_ops(P):
+    import types
+    bf16 = torch.bfloat16
+
+    def cfg_euler_step(pred, latents, guidance, dsigma, model_in=None, group_elems=0):
+        u, c = pred.float().chunk(2)
+        d = dsigma.reshape(*dsigma.shape, *([1] * (latents.dim() - dsigma.dim()))) if torch.is_tensor(dsigma) else dsigma
+        latents += d * (u + guidance * (c - u))
+        if model_in is not None:
+            B = latents.shape[0]
+            model_in[:B].copy_(latents)
+            model_in[B:].copy_(latents)
+    P.ops = types.SimpleNamespace(cast_bf16=lambda t: t.to(bf16), cfg_euler_step=cfg_euler_step)
+
+
+class _FrameModel(torch.nn.Module):
+    """fake_pred of make_reference_driver_fixtures.py: per-frame, so it needs no exchange between frame shards"""
+    frame_shard = None
+
+    def forward(self, x, ts, c=None, scale=None, **kw):
+        return [((0.1 * x.float() + 1e-4 * ts.float()[..., None, None, None] + 0.01 * c.float()[..., None, None, None]) * scale)
+                .to(torch.bfloat16)], None, None
+
+
+def _denoiser_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    group = None
+    if world > 1:
+        D.init("gloo")
+        import torch.distributed as dist
+        group = dist.group.WORLD
+    import opendwm_amd.pipeline as P
+    _install_fake_ops(P)
+    fx = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_drivers.pt"))
+    res = {}
+    for mode, d in fx["inference_pipeline"].items():
+        kw = dict(d["kwargs"])
+        start, stop, take = kw.pop("start_timestep", 0), kw.pop("stop_timestep", None), kw.pop("take_time", 0)
+        df = mode.startswith("diffusion_forcing")
+        noise = torch.randn(tuple(d["shape"]), generator=torch.Generator().manual_seed(d["seed"]))
+        den = P.CTSDDenoiser(_FrameModel(), guidance_scale=fx["guidance"], inference_steps=d["steps"], frame_group=group)
+        cond = {k: v for k, v in d["batch"].items() if k != "pts"}
+        out = den.run(noise, cond, stop=stop, start=start, diffusion_forcing=df, take_time=take, **kw)
+        res[mode] = float(((out - d["latents"]).norm() / d["latents"].norm()))
+    q.put((rank, res))
+    if world > 1:
+        D.shutdown()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_ctsd_denoiser_host_logic_vs_reference_pipeline(world):
+    """pipeline.CTSDDenoiser - step inputs per frame, reference-frame injection, diffusion-forcing windows, CFG + Euler call
+    order, and with two ranks the frame-shard slicing / gather - against the latents of the REAL inference_pipeline in its
+    four modes.  bf16 model input and prediction (as on the device): 1e-2 relative."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_denoiser_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert set(res[r]) == {"full", "reference_frames", "diffusion_forcing", "diffusion_forcing_warmup"}
+        assert all(e < 1e-2 for e in res[r].values()), res[r]
