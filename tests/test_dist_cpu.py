@@ -171,7 +171,7 @@ class _FrameModel(torch.nn.Module):
                 .to(torch.bfloat16)], None, None
 
 
-def _denoiser_worker(rank, world, port, q):
+def _denoiser_worker(rank, world, port, q, split="frames"):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     group = None
@@ -188,7 +188,8 @@ def _denoiser_worker(rank, world, port, q):
         start, stop, take = kw.pop("start_timestep", 0), kw.pop("stop_timestep", None), kw.pop("take_time", 0)
         df = mode.startswith("diffusion_forcing")
         noise = torch.randn(tuple(d["shape"]), generator=torch.Generator().manual_seed(d["seed"]))
-        den = P.CTSDDenoiser(_FrameModel(), guidance_scale=fx["guidance"], inference_steps=d["steps"], frame_group=group)
+        den = P.CTSDDenoiser(_FrameModel(), guidance_scale=fx["guidance"], inference_steps=d["steps"],
+                             **({"frame_group": group} if split == "frames" else {"cfg_group": group}))
         cond = {k: v for k, v in d["batch"].items() if k != "pts"}
         out = den.run(noise, cond, stop=stop, start=start, diffusion_forcing=df, take_time=take, **kw)
         res[mode] = float(((out - d["latents"]).norm() / d["latents"].norm()))
@@ -197,15 +198,16 @@ def _denoiser_worker(rank, world, port, q):
         D.shutdown()
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_ctsd_denoiser_host_logic_vs_reference_pipeline(world):
+@pytest.mark.parametrize("world,split", [(1, "frames"), (2, "frames"), (2, "cfg")])
+def test_ctsd_denoiser_host_logic_vs_reference_pipeline(world, split):
     """pipeline.CTSDDenoiser - step inputs per frame, reference-frame injection, diffusion-forcing windows, CFG + Euler call
-    order, and with two ranks the frame-shard slicing / gather - against the latents of the REAL inference_pipeline in its
+    order, and with two ranks the frame-shard slicing / gather or the CFG split (halves of the guidance batch on the two ranks, one
+    all-gather of the prediction per step) - against the latents of the REAL inference_pipeline in its
     four modes.  bf16 model input and prediction (as on the device): 1e-2 relative."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_denoiser_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_denoiser_worker, args=(r, world, port, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
