@@ -356,6 +356,17 @@ class CTSDTrainer:
             out["explicit_view_modeling_mask"] = draw() < tc.get("explicit_view_modeling_ratio", 1.0)
         return out
 
+    def draw_training_inputs(self, latents_shape, generator: Optional[torch.Generator] = None):
+        """(noise, timestep_indices, condition masks) of one training step, drawn in the reference's order (ctsd.py:1229-1301:
+        noise from the pipeline generator, timestep density from the global generator, then the dropout masks); pass the
+        first two to loss() / train_step() - whose task mixer continues on the same generator - and the masks to
+        conditions.build_conditions."""
+        B, T = latents_shape[:2]
+        noise = torch.randn(tuple(latents_shape), generator=generator)
+        per_frame = self.common_config.get("frame_prediction_style") == "diffusion_forcing"
+        idx = sample_timestep_indices((B, T) if per_frame else (B,), None, self.weighting_scheme, self.num_train_timesteps)
+        return noise, idx, self.draw_condition_masks(B, generator)
+
     def make_training_pair(self, latents: torch.Tensor, generator: Optional[torch.Generator] = None,
                            timestep_indices: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
         """returns (noisy_latents, timesteps [B,T,V], sigmas [B,1|T,1,1,1,1], noise); host RNG like the reference (CPU

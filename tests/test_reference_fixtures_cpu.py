@@ -563,3 +563,29 @@ def test_autoregressive_windows_from_a_batch_equal_reference(monkeypatch):
     den = _LoopDenoiser(d["steps"], icfg["guidance_scale"])
     got = AutoregressiveDriver(den, icfg, generator=torch.Generator().manual_seed(d["seed"])).run(d["shape"], cond, d["total"], "cpu")
     assert got["images"].shape == d["images"].shape and torch.allclose(got["images"], d["images"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["plain", "loss_coef", "temporal_vae", "df_style", "ctsd_style"])
+def test_trainer_loss_end_to_end_equals_reference_train_step(name):
+    """CTSDTrainer.draw_training_inputs + CTSDTrainer.loss as a whole (the stand-in model of the fixture as `wrapper`, on the
+    CPU): same random streams as the REAL train_step, same loss - to the bf16 rounding of the model input (1e-2 relative)."""
+    from opendwm_amd.drivers import LatentEncoder
+    from opendwm_amd.pipeline import CTSDTrainer, flow_match_train_sigmas
+    d = torch.load(os.path.join(GOLDEN, "reference_train_step.pt"))[name]
+    img = d["batch"]["vae_images"]
+    lat = LatentEncoder(_EncVae(d["temporal_vae"]), d["memory_efficient_batch"], is_temporal_vae=d["temporal_vae"])(img * 2 - 1, sample=True)
+    w = torch.tensor(0.3)
+
+    def wrapper(x, ts, c=None, **kw):
+        return [w * (x.float() + 1e-3 * ts[..., None, None, None] + 0.05 * c[..., None, None, None])], None, None
+    tr = CTSDTrainer.__new__(CTSDTrainer)
+    tr.wrapper, tr.sigmas, tr.num_train_timesteps, tr.weighting_scheme = wrapper, flow_match_train_sigmas(), 1000, "logit_normal"
+    tr.common_config, tr.training_config = d.get("common_config", {}), d["training_config"]
+    tr.reference_latent_count = d["training_config"].get("reference_frame_count", 0)
+    tr.loss_coef = d["training_config"].get("loss_coef_dict", {}).get("sd", 1.0)
+    gen = torch.Generator().manual_seed(d["generator_seed"])
+    torch.manual_seed(d["global_seed"])
+    noise, idx, masks = tr.draw_training_inputs(lat.shape, gen)
+    assert set(masks) >= {"text_condition_mask", "_3dbox_condition_mask", "hdmap_condition_mask", "action_condition_mask"}
+    loss = tr.loss(lat, {"c": d["batch"]["c"]}, generator=gen, timestep_indices=idx, noise=noise)
+    assert abs(loss.item() - d["loss"].item()) / d["loss"].item() < 1e-2, (loss.item(), d["loss"].item())
