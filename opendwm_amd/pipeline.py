@@ -402,6 +402,29 @@ class CTSDTrainer:
             x0_hat, target = x0_hat * keep, target * keep
         return torch.nn.functional.mse_loss(x0_hat, target, reduction="mean") * self.loss_coef
 
+    # ---- checkpoint / resume in the reference's on-disk layout (ctsd.py:1134-1155 save_checkpoint, :988-992 and
+    # :1093-1096 resume; src/dwm/distributed.py): <output>/checkpoints/<step>.pth = the model's state dict (reference
+    # keys), <output>/optimizer/<step>.pth = the optimizer state in torch.optim.AdamW's format.  Rank 0 writes.
+    def save_checkpoint(self, output_path: str, steps: int) -> None:
+        import os
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return
+        os.makedirs(os.path.join(output_path, "checkpoints"), exist_ok=True)
+        os.makedirs(os.path.join(output_path, "optimizer"), exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                   os.path.join(output_path, "checkpoints", f"{steps}.pth"))
+        osd = self.optimizer.state_dict()
+        osd["state"] = {i: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in osd["state"].items()}
+        torch.save(osd, os.path.join(output_path, "optimizer", f"{steps}.pth"))
+
+    def load_checkpoint(self, output_path: str, resume_from: int) -> None:
+        import os
+        self.model.load_state_dict(torch.load(os.path.join(output_path, "checkpoints", f"{resume_from}.pth"),
+                                              map_location="cpu", weights_only=True))
+        self.optimizer.load_state_dict(torch.load(os.path.join(output_path, "optimizer", f"{resume_from}.pth"),
+                                                  map_location="cpu", weights_only=True))
+
     def train_step(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
                    timestep_indices=None, noise=None) -> torch.Tensor:
         loss = self.loss(latents, conditions, generator, timestep_indices, noise)

@@ -759,6 +759,37 @@ class AdamW:
         self.state = {}
         self.t = 0
 
+    # ---- torch.optim.AdamW's state-dict format: what the reference writes to <output>/optimizer/<step>.pth
+    # (src/dwm/distributed.py:7-40) and reads back on --resume-from (:43-70); parameters are numbered in order
+    def state_dict(self) -> dict:
+        state = {}
+        for i, p in enumerate(self.params):
+            st = self.state.get(id(p))
+            if st is not None:
+                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": st[0], "exp_avg_sq": st[1]}
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(self.params))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict):
+        groups = sd["param_groups"]
+        if sum(len(g["params"]) for g in groups) != len(self.params):
+            raise ValueError("optimizer state has a different number of parameters")
+        g0 = groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+        order = [i for g in groups for i in g["params"]]
+        self.state, self.t = {}, 0
+        for slot, p in zip(order, self.params):
+            st = sd["state"].get(slot)
+            if st is None:
+                continue
+            if st["exp_avg"].shape != p.shape:
+                raise ValueError(f"optimizer state {slot}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+            self.state[id(p)] = (st["exp_avg"].to(device=p.device, dtype=torch.float32).clone(),
+                                 st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone())
+            self.t = max(self.t, int(float(st["step"])))
+
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             if set_to_none:

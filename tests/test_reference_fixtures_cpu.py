@@ -589,3 +589,43 @@ def test_trainer_loss_end_to_end_equals_reference_train_step(name):
     assert set(masks) >= {"text_condition_mask", "_3dbox_condition_mask", "hdmap_condition_mask", "action_condition_mask"}
     loss = tr.loss(lat, {"c": d["batch"]["c"]}, generator=gen, timestep_indices=idx, noise=noise)
     assert abs(loss.item() - d["loss"].item()) / d["loss"].item() < 1e-2, (loss.item(), d["loss"].item())
+
+
+def test_checkpoint_layout_resumes_from_reference_files(tmp_path):
+    """CTSDTrainer.load_checkpoint / save_checkpoint against files written by the REAL save_checkpoint +
+    distributed_save_optimizer_state (tests/golden/make_reference_checkpoint_fixture.py): <output>/checkpoints/<step>.pth and
+    <output>/optimizer/<step>.pth in torch.optim.AdamW's format.  The loaded moments / step count / hyper-parameters
+    reproduce the reference's next AdamW step, and what we write back is a file torch.optim.AdamW resumes from."""
+    from opendwm_amd.pipeline import CTSDTrainer
+    from opendwm_amd.train import AdamW
+    from tests.golden.make_reference_checkpoint_fixture import tiny_model
+    root = os.path.join(GOLDEN, "reference_checkpoint")
+    exp = torch.load(os.path.join(root, "expected.pt"))
+    tr = CTSDTrainer.__new__(CTSDTrainer)
+    tr.model = tiny_model()
+    with torch.no_grad():
+        for q in tr.model.parameters():
+            q.zero_()                                           # everything must come from the files
+    tr.optimizer = AdamW(tr.model.parameters(), lr=123.0)
+    tr.load_checkpoint(root, 3)
+    opt = tr.optimizer
+    assert (opt.lr, opt.betas, opt.eps, opt.weight_decay, opt.t) == (1e-2, (0.9, 0.95), 1e-8, 0.05, 3)
+    # one AdamW step by the textbook formula from OUR loaded state == the reference's 4th step
+    t = opt.t + 1
+    for q, g, want in zip(tr.model.parameters(), exp["grads_step_4"], exp["params_after_step_4"]):
+        m, v = opt.state[id(q)]
+        m = opt.betas[0] * m + (1 - opt.betas[0]) * g
+        v = opt.betas[1] * v + (1 - opt.betas[1]) * g * g
+        upd = (m / (1 - opt.betas[0] ** t)) / ((v / (1 - opt.betas[1] ** t)).sqrt() + opt.eps)
+        got = q.detach() * (1 - opt.lr * opt.weight_decay) - opt.lr * upd
+        assert torch.allclose(got, want, atol=1e-6)
+    # write it back in the same layout: torch.optim.AdamW (= the reference's resume path) takes it and makes the same step
+    tr.save_checkpoint(str(tmp_path), 3)
+    ref_model = tiny_model()
+    ref_model.load_state_dict(torch.load(tmp_path / "checkpoints" / "3.pth", map_location="cpu", weights_only=True))
+    ref_opt = torch.optim.AdamW(ref_model.parameters())
+    ref_opt.load_state_dict(torch.load(tmp_path / "optimizer" / "3.pth", map_location="cpu", weights_only=True))
+    for q, g in zip(ref_model.parameters(), exp["grads_step_4"]):
+        q.grad = g.clone()
+    ref_opt.step()
+    assert all(torch.allclose(q, w, atol=1e-6) for q, w in zip(ref_model.parameters(), exp["params_after_step_4"]))
