@@ -251,6 +251,13 @@ def main():
         st[name] = dict(config={k: v for k, v in cfg.items() if not k.startswith("_")}, total=total, steps=steps, batch=batch, shape=shape,
                         images=r["images"], final_latents=p.latents, seed=3)
     out["streaming"] = st
+    # ---- get_latent_sequence_length (ctsd.py:1113-1118) for 2-D and temporal VAEs (vae_pre / vae_stride)
+    table = []
+    for n, pre, stride in ((0, 0, 1), (3, 0, 1), (4, 0, 2), (0, 1, 4), (1, 1, 4), (5, 1, 4), (9, 1, 4), (17, 1, 4), (33, 1, 8)):
+        q = object.__new__(C.CrossviewTemporalSD)
+        q.inference_config = {"vae_pre": pre, "vae_stride": stride} if (pre, stride) != (0, 1) else {}
+        table.append((n, pre, stride, C.CrossviewTemporalSD.get_latent_sequence_length(q, n)))
+    out["latent_sequence_length"] = table
     torch.save(out, os.path.join(HERE, "reference_drivers.pt"))
     print("wrote reference_drivers.pt", {k: list(v["images"].shape) for k, v in ar.items()}, {k: list(v["images"].shape) for k, v in st.items()},
           {k: list(v["latents"].shape) for k, v in single.items()})

@@ -629,3 +629,12 @@ def test_checkpoint_layout_resumes_from_reference_files(tmp_path):
         q.grad = g.clone()
     ref_opt.step()
     assert all(torch.allclose(q, w, atol=1e-6) for q, w in zip(ref_model.parameters(), exp["params_after_step_4"]))
+
+
+def test_latent_sequence_length_equals_reference(dfx):
+    from opendwm_amd.drivers import latent_sequence_length
+    assert len(dfx["latent_sequence_length"]) == 9
+    for n, pre, stride, want in dfx["latent_sequence_length"]:
+        assert latent_sequence_length(n, pre, stride) == want, (n, pre, stride)
+    with pytest.raises(ValueError):
+        latent_sequence_length(6, 1, 4)                       # the reference asserts here
