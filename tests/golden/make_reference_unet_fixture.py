@@ -138,7 +138,12 @@ def main():
     import dwm.models.crossview_temporal_unet as RU
     out = {}
     with torch.no_grad():
-        for name, over in (("rowwise", {}), ("pointwise", dict(enable_rowwise_crossview=False, enable_rowwise_temporal=False))):
+        acfg = dict(in_channels=3, channels=[128, 128, 256, 512, 512], is_downblocks=[False, True, True, True, False], num_res_blocks=2,
+                    downscale_factor=8, use_zero_convs=True)
+        for name, over in (("rowwise", {}), ("pointwise", dict(enable_rowwise_crossview=False, enable_rowwise_temporal=False)),
+                           # layout branch: the REAL ImageAdapter.forward (adapters.py:40-60) feeding the residual insertion of the
+                           # REAL UNet forward (crossview_temporal_unet.py:719-729, 753-754)
+                           ("layout", dict(condition_image_adapter_config=acfg))):
             cfg = dict(unet_small_config(), **over)
             sd = U.make_unet_state_dict(cfg, 0)
             inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
@@ -147,6 +152,11 @@ def main():
             if name == "pointwise":
                 inp["crossview_attention_mask"] = None
             m = build(R, RU, cfg, sd)
+            if name == "layout":
+                from dwm.models.adapters import ImageAdapter as RefAdapter
+                from tests.golden.make_reference_forward_fixture import build_adapter
+                m.condition_image_adapter = build_adapter(RefAdapter, cfg, sd)
+                inp["condition_image_tensor"] = torch.rand(2, 2, 3, 3, 64, 128, generator=torch.Generator().manual_seed(5))
             res = RU.UNetCrossviewTemporalConditionModel.forward(m, **inp)
             ref = res[0][0] if isinstance(res[0], tuple) else res[0]
             mine = U.unet_forward(sd, cfg, **inp)

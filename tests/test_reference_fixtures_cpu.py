@@ -294,7 +294,7 @@ def test_reference_keeps_the_view_axis_for_5d_inputs():
     assert fxf["five_dim"]["output"].dim() == 6 and fxf["five_dim"]["output"].shape[2] == 1
 
 
-@pytest.mark.parametrize("name", ["rowwise", "pointwise"])
+@pytest.mark.parametrize("name", ["rowwise", "pointwise", "layout"])
 def test_oracle_unet_composition_equals_reference_forward(name):
     """tests/golden/reference_unet_forward.pt: the REAL UNetCrossviewTemporalConditionModel.forward with the real down / mid /
     up block, ResBlock, TransformerModel and TemporalBasicTransformerBlock classes over oracle leaf modules
@@ -308,6 +308,8 @@ def test_oracle_unet_composition_equals_reference_forward(name):
     inp["disable_crossview"], inp["disable_temporal"] = fxu["flags"]
     if name == "pointwise":
         inp["crossview_attention_mask"] = None
+    if name == "layout":              # the REAL ImageAdapter.forward feeding the REAL forward's residual insertion (:719-729, :753-754)
+        inp["condition_image_tensor"] = torch.rand(2, 2, 3, 3, 64, 128, generator=torch.Generator().manual_seed(5))
     out = U.unet_forward(sd, cfg, **inp)
     assert torch.allclose(out, fxu["output"], atol=5e-5)
 
