@@ -1,6 +1,6 @@
 """denoise-steps/sec of the CTSD SD-3.5 MMDiT hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps 5 --warmup 2          (N > 1: re-launches itself, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -395,6 +395,48 @@ def main_train(args):
     D.shutdown()
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): re-execute this command line
+    under torch.distributed.run with one rank per GPU (one process per GPU as src/dwm/train.py:60-67 of the reference
+    is launched); rank 0 of that job prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main_debug_cpu(args):
+    """--debug-cpu-launch: the launch / timing path of this file on CPU (gloo) with a stand-in step - rank environment,
+    process-group init, barrier-bracketed timing, MAX over ranks, one JSON line from rank 0.  No kernel runs: the line is
+    NOT a measurement and says so."""
+    from opendwm_amd import dist as D
+    rank, local_rank, world = D.env_ranks()
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    D.init("gloo")
+    x = torch.randn(64, 64)
+
+    def step(i):
+        (x @ x).sum().item()
+        if rank == world - 1:
+            time.sleep(0.02)             # the slowest rank defines the reported time
+
+    dt = D.timed_steps(step, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps({"metric": "DEBUG launch-path check (no kernels) - INVALID as a bench line", "value": world * args.steps / dt,
+                          "unit": "stand-in steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "debug-cpu-launch"}}))
+    D.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,7 +474,13 @@ def main():
                          "(examples/ctsd_21_6views_video_generation.json: DPM-Solver++ 50 steps, guidance 3)")
     ap.add_argument("--freeze-base", action="store_true",
                     help="with --train: freezing_pattern ^(transformer_blocks|time_text_embed)$ of the reference's warm-up configs")
+    ap.add_argument("--debug-cpu-launch", action="store_true",
+                    help="debug: exercise the launch / timing path on CPU over gloo with a stand-in step (INVALID as a bench line)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.debug_cpu_launch:
+        return main_debug_cpu(args)
     if args.train:
         return main_train(args)
     if args.unet:

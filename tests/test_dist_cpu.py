@@ -217,3 +217,29 @@ def test_ctsd_denoiser_host_logic_vs_reference_pipeline(world, split):
     for r in range(world):
         assert set(res[r]) == {"full", "reference_frames", "diffusion_forcing", "diffusion_forcing_warmup"}
         assert all(e < 1e-2 for e in res[r].values()), res[r]
+
+
+# ---------------------------------------------------------------- bench.py started the way the driver starts it
+def test_bench_self_launches_ranks_when_started_plainly():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment must start its own ranks (torch.distributed.run,
+    127.0.0.1 rendezvous) and print ONE JSON line from rank 0; --debug-cpu-launch swaps RCCL + kernels for gloo + a stand-in
+    step so this runs without a GPU.  The torchrun-launched form must keep working too."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--debug-cpu-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["ms_per_step"] >= 20.0                       # the slow rank's sleep: MAX over ranks
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]   # whole-job aggregate
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "0", "--debug-cpu-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
