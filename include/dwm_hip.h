@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 11
+#define DWM_ABI_VERSION 12
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -347,6 +347,10 @@ int dwm_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols
  * (bias gradients, AdaLN shift / scale / gate gradients per image, mixer alpha gradient). */
 int dwm_segsum(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int64_t ncols,
                int64_t rows_per_group, float* out, int64_t ld_out, void* stream);
+/* out[g, n] += sum of a[r, n] * (b[r, n] - b2[r, n]), the difference taken in fp32 before the product: the AlphaBlender
+ * gradient d(alpha) = <dy, x_spatial - x_temporal> (crossview_temporal.py:68-72) in one pass over the three tensors. */
+int dwm_segsum_diff(const void* a, int64_t lda, const void* b, int64_t ldb, const void* b2, int64_t ldb2, int64_t rows,
+                    int64_t ncols, int64_t rows_per_group, float* out, int64_t ld_out, void* stream);
 
 /* y = act(x) / dx = dy * act'(x); act = DWM_ACT_GELU_TANH | DWM_ACT_SILU; n % 8 == 0 */
 int dwm_act_fwd(const void* x, void* y, int64_t n, int32_t act, void* stream);

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -130,6 +130,7 @@ SIGNATURES = {
     # training
     "dwm_transpose_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
     "dwm_segsum": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dwm_segsum_diff": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dwm_act_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "dwm_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "dwm_geglu_fwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),

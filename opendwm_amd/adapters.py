@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .blocks import _bf
+from .blocks import STORE, _bf
 from .ops import ACT_RELU, EPI_RESID, PaddedGrid
 
 bf16 = torch.bfloat16
@@ -27,14 +27,13 @@ class AdapterResnetBlock(nn.Module):
         self.block1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
         self.act = nn.ReLU()
         self.block2 = nn.Conv2d(channels, channels, kernel_size=1)
-        self._pk = None
 
     def packed(self):
-        if self._pk is None:
-            w = _bf(self.block1.weight)                    # [N, C, 3, 3] -> tap-major [N, 9*C]
-            self._pk = {"w3": w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(),
-                        "w1": _bf(self.block2.weight).reshape(self.block2.weight.shape[0], -1).contiguous()}
-        return self._pk
+        """tap-major 3x3 weight [N, 9*C] and the 1x1 weight [N, C]; rebuilt after every optimizer step / state-dict load
+        (STORE.derived keys on the optimizer step and the parameter version, as every other packed weight does)"""
+        w3, w1 = self.block1.weight, self.block2.weight
+        return {"w3": STORE.derived(w3, "c3tap", lambda: _bf(w3).permute(0, 2, 3, 1).reshape(w3.shape[0], -1).contiguous()),
+                "w1": STORE.derived(w1, "c1", lambda: _bf(w1).reshape(w1.shape[0], -1).contiguous())}
 
     def run(self, x_pad: torch.Tensor, grid: PaddedGrid) -> torch.Tensor:
         """x_pad: padded token grid [grid.rows, C] (zero border), updated in place."""

@@ -63,6 +63,7 @@ transpose8_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int64_t rows, in
 constexpr int SEG_RB = 128;
 __global__ void __launch_bounds__(256)
 segsum_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb,
+              const bf16_t* __restrict__ b2, int64_t ldb2,
               int64_t rows, int64_t ncols, int64_t rpg, int chunks_per_group, float* __restrict__ out, int64_t ld_out) {
     __shared__ float red[8][256];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -77,7 +78,13 @@ segsum_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restric
         for (int64_t r = rbeg + ry; r < rend; r += 8) {
             float va[8], vb[8];
             unpack8(*(const uint4*)(a + r * lda + c), va);
-            if (b) {
+            if (b2) {           // a * (b - b2): the difference is taken in fp32 before the product (AlphaBlender d(alpha))
+                float vc[8];
+                unpack8(*(const uint4*)(b + r * ldb + c), vb);
+                unpack8(*(const uint4*)(b2 + r * ldb2 + c), vc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += va[j] * (vb[j] - vc[j]);
+            } else if (b) {
                 unpack8(*(const uint4*)(b + r * ldb + c), vb);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += va[j] * vb[j];
@@ -489,7 +496,21 @@ extern "C" int dwm_segsum(const void* a, int64_t lda, const void* b, int64_t ldb
     if (groups * cpg >= 65536 * 16) return DWM_EUNSUPPORTED;
     const dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)(groups * cpg));
     hipLaunchKernelGGL(segsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
-                       rows, ncols, rows_per_group, cpg, out, ld_out);
+                       (const bf16_t*)nullptr, (int64_t)0, rows, ncols, rows_per_group, cpg, out, ld_out);
+    DWM_RET();
+}
+
+extern "C" int dwm_segsum_diff(const void* a, int64_t lda, const void* b, int64_t ldb, const void* b2, int64_t ldb2, int64_t rows,
+                               int64_t ncols, int64_t rows_per_group, float* out, int64_t ld_out, void* stream) {
+    if (!a || !b || !b2 || !out || rows <= 0 || ncols <= 0 || ncols % 8 != 0 || rows_per_group <= 0) return DWM_EINVAL;
+    if (lda % 8 != 0 || ldb % 8 != 0 || ldb2 % 8 != 0 || !dwm_aligned16(a) || !dwm_aligned16(b) || !dwm_aligned16(b2)) return DWM_EALIGN;
+    const int64_t groups = (rows + rows_per_group - 1) / rows_per_group;
+    const int64_t rpg = rows_per_group < rows ? rows_per_group : rows;
+    const int cpg = (int)((rpg + SEG_RB - 1) / SEG_RB);
+    if (groups * cpg >= 65536 * 16) return DWM_EUNSUPPORTED;
+    const dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)(groups * cpg));
+    hipLaunchKernelGGL(segsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                       (const bf16_t*)b2, ldb2, rows, ncols, rows_per_group, cpg, out, ld_out);
     DWM_RET();
 }
 

@@ -341,9 +341,12 @@ class DiTCrossviewTemporalConditionModel(_Base):
         # images, which do not change across denoise steps: cached on the tensor's identity.
         condition_residuals = None
         if self.condition_image_adapter is not None and condition_image_tensor is not None:
-            key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape))
+            # the key holds the optimizer step (residuals of old adapter weights must not survive a training step) and
+            # the cache keeps the tensor alive (a freed tensor's address can be handed to the next same-shape batch)
+            from .blocks import STORE
+            key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape), STORE.step)
             if self._adapter_cache[0] != key:
-                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor))
+                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor), condition_image_tensor)
             condition_residuals = list(self._adapter_cache[1])
             for f in condition_residuals:
                 if f.shape != h.shape:

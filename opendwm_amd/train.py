@@ -327,7 +327,9 @@ def vt_block_backward(blk: VTSelfAttentionBlock, h: torch.Tensor, emb: torch.Ten
 
     # ---------------- mixer: blended = alpha * h + (1 - alpha) * out
     one_minus = (1.0 - alpha).contiguous()
-    dalpha = (T.segsum(dy, h, rows_per_group=rows_per_alpha).sum(-1) - T.segsum(dy, out, rows_per_group=rows_per_alpha).sum(-1))
+    # d(alpha) = <dy, h - out>: one pass, fp32 difference before the product, fp32 column sums, summed in fp64 - the value
+    # is a heavily cancelling sum (sum|terms| / |sum| = 200-3000 on the test configurations), so no partial sum is rounded
+    dalpha = T.segsum_diff(dy, h, out, rows_per_group=rows_per_alpha).double().sum(-1).float()
     dout = T.rowcombine(dy, coef_a=one_minus, rows_per_coef_a=rows_per_alpha)
     del out
 
@@ -750,69 +752,58 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
 
 
 # ------------------------------------------------------------------------------------------ optimizer
-class AdamW:
-    """torch.optim.AdamW semantics on the HIP kernel; also refreshes the bf16 shadows of blocks.STORE."""
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics with the update done by the HIP kernel (`dwm_adamw`), which also refreshes the bf16
+    compute shadows of blocks.STORE.
+
+    It IS a torch.optim.Optimizer: parameter groups, the (sparse) per-parameter state with its own step count, and the
+    state-dict format are torch's bookkeeping, so `optimizer/<step>.pth` files interchange with the reference's
+    torch.optim.AdamW (src/dwm/distributed.py:7-70) - including the warm-up configs whose `freezing_pattern` leaves frozen
+    parameters in the list (ctsd.py:1014-1022, 1089-1092: the optimizer is built from ALL `model_wrapper.parameters()`) -
+    and torch LR schedulers attach to it (ctsd.py:1098-1100, 1434-1435)."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.state = {}
-        self.t = 0
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
 
-    # ---- torch.optim.AdamW's state-dict format: what the reference writes to <output>/optimizer/<step>.pth
-    # (src/dwm/distributed.py:7-40) and reads back on --resume-from (:43-70); parameters are numbered in order
-    def state_dict(self) -> dict:
-        state = {}
-        for i, p in enumerate(self.params):
-            st = self.state.get(id(p))
-            if st is not None:
-                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": st[0], "exp_avg_sq": st[1]}
-        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
-                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
-                     params=list(range(len(self.params))))
-        return {"state": state, "param_groups": [group]}
+    # group-0 hyper-parameters (the trainer has one group) and the step count, for callers and tests
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: tuple(self.param_groups[0]["betas"]))
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
 
-    def load_state_dict(self, sd: dict):
-        groups = sd["param_groups"]
-        if sum(len(g["params"]) for g in groups) != len(self.params):
-            raise ValueError("optimizer state has a different number of parameters")
-        g0 = groups[0]
-        self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
-        order = [i for g in groups for i in g["params"]]
-        self.state, self.t = {}, 0
-        for slot, p in zip(order, self.params):
-            st = sd["state"].get(slot)
-            if st is None:
-                continue
-            if st["exp_avg"].shape != p.shape:
-                raise ValueError(f"optimizer state {slot}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
-            self.state[id(p)] = (st["exp_avg"].to(device=p.device, dtype=torch.float32).clone(),
-                                 st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone())
-            self.t = max(self.t, int(float(st["step"])))
-
-    def zero_grad(self, set_to_none: bool = True):
-        for p in self.params:
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
+    @property
+    def t(self) -> int:
+        """largest per-parameter step count"""
+        return max((int(float(st["step"])) for st in self.state.values() if "step" in st), default=0)
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0):
-        self.t += 1
-        for p in self.params:
-            if p.grad is None:
-                continue
-            if p.dtype != torch.float32:
-                raise RuntimeError("AdamW: fp32 master parameters expected")
-            st = self.state.get(id(p))
-            if st is None:
-                st = (torch.zeros_like(p), torch.zeros_like(p))
-                self.state[id(p)] = st
-            g = p.grad if p.grad.dtype == torch.float32 else p.grad.float()
-            shadow = STORE.bf(p) if (p.is_cuda and p.numel() % 4 == 0 and p.is_contiguous()) else None
-            if shadow is None:
-                STORE._shadow.pop(id(p), None)      # re-cast on next use
-            T.adamw_(p.data, g.contiguous(), st[0], st[1], shadow, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                     eps=self.eps, weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale)
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):
+                raise NotImplementedError("AdamW: amsgrad / maximize")
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:              # frozen, or unused in this step: no state, no step (as torch)
+                    continue
+                if p.dtype != torch.float32:
+                    raise RuntimeError("AdamW: fp32 master parameters expected")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.dtype == torch.float32 else p.grad.float()
+                shadow = STORE.bf(p) if (p.is_cuda and p.numel() % 4 == 0 and p.is_contiguous()) else None
+                if shadow is None:
+                    STORE._shadow.pop(id(p), None)      # re-cast on next use
+                T.adamw_(p.data, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], shadow, lr=float(group["lr"]), beta1=b1, beta2=b2,
+                         eps=group["eps"], weight_decay=group["weight_decay"], step=int(st["step"].item()), grad_scale=grad_scale)
         STORE.bump(keep_shadows=True)
+        return loss

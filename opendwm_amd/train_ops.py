@@ -48,6 +48,20 @@ def segsum(a: torch.Tensor, b: Optional[torch.Tensor] = None, rows_per_group: Op
     return out
 
 
+def segsum_diff(a: torch.Tensor, b: torch.Tensor, b2: torch.Tensor, rows_per_group: Optional[int] = None) -> torch.Tensor:
+    """fp32 [groups, ncols]: per-group column sums of a * (b - b2), the difference taken in fp32 before the product."""
+    for t, n in ((a, "a"), (b, "b"), (b2, "b2")):
+        _rows2d(t, n)
+    if b.shape != a.shape or b2.shape != a.shape:
+        raise RuntimeError("segsum_diff: shape mismatch")
+    rows, ncols = a.shape
+    rpg = rows if rows_per_group is None else rows_per_group
+    out = torch.zeros(((rows + rpg - 1) // rpg, ncols), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().dwm_segsum_diff(_p(a), a.stride(0), _p(b), b.stride(0), _p(b2), b2.stride(0), rows, ncols, rpg,
+                                           _p(out), out.stride(0), _stream()), "dwm_segsum_diff")
+    return out
+
+
 def act_fwd(x: torch.Tensor, act: int) -> torch.Tensor:
     y = torch.empty_like(x)
     _lib.check(_lib.load().dwm_act_fwd(_p(x), _p(y), x.numel(), act, _stream()), "dwm_act_fwd")

@@ -29,17 +29,33 @@ def batch(i):
     return torch.randn(5, 4, generator=g), torch.randn(5, 4, generator=g)
 
 
+FREEZING_PATTERN = "^0$"        # the first Linear of tiny_model(): a training_config["freezing_pattern"]
+
+
 def main():
     sys.meta_path.insert(0, _Finder())
     sys.path.insert(0, "/root/reference/src")
     import dwm.pipelines.ctsd as C
-    out = os.path.join(HERE, "reference_checkpoint")
+    make(C, "reference_checkpoint", None)
+    # the warm-up configs freeze modules (ctsd.py:1014-1022) BEFORE the optimizer is built from all parameters (:1089-1092):
+    # the saved state is sparse over the full parameter list
+    make(C, "reference_checkpoint_frozen", FREEZING_PATTERN)
+
+
+def make(C, name, freezing_pattern):
+    import re
+    out = os.path.join(HERE, name)
     shutil.rmtree(out, ignore_errors=True)
     p = object.__new__(C.CrossviewTemporalSD)
     p.model = tiny_model()
     p.model_wrapper = p.model
     p.should_save = True
-    p.optimizer = torch.optim.AdamW(p.model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    if freezing_pattern is not None:          # the loop of ctsd.py:1014-1022
+        pattern = re.compile(freezing_pattern)
+        for mname, module in p.model.named_modules():
+            if pattern.match(mname) is not None:
+                module.requires_grad_(False)
+    p.optimizer = torch.optim.AdamW(p.model_wrapper.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
     for i in range(3):
         x, y = batch(i)
         torch.nn.functional.mse_loss(p.model(x), y).backward()
@@ -48,7 +64,7 @@ def main():
     C.CrossviewTemporalSD.save_checkpoint(p, out, 3)
     x, y = batch(3)                                   # one more step: what a resumed run must reproduce
     torch.nn.functional.mse_loss(p.model(x), y).backward()
-    grads = [q.grad.clone() for q in p.model.parameters()]
+    grads = [None if q.grad is None else q.grad.clone() for q in p.model.parameters()]
     p.optimizer.step()
     torch.save({"params_after_step_4": [q.detach().clone() for q in p.model.parameters()], "grads_step_4": grads},
                os.path.join(out, "expected.pt"))

@@ -243,3 +243,110 @@ def test_bench_self_launches_ranks_when_started_plainly():
                         "--warmup", "0", "--debug-cpu-launch"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+
+
+# ---------------------------------------------------------------- train step: accumulation + no_sync + bf16 buckets + LR schedule
+def _adamw_cpu(p, g, m, v, p_bf16, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """what dwm_adamw computes (torch.optim.AdamW's update), for the CPU ranks of the test below"""
+    g = g * grad_scale
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    p.mul_(1 - lr * weight_decay)
+    p.addcdiv_(m / (1 - beta1 ** step), (v / (1 - beta2 ** step)).sqrt() + eps, value=-lr)
+
+
+class _StandInDenoiser(torch.nn.Module):
+    """forward signature / 3-tuple return of the model; `frozen` never trains (freezing_pattern)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.frozen = torch.nn.Linear(4, 4)
+        self.mix = torch.nn.Linear(4, 4)
+        self.scale = torch.nn.Parameter(torch.tensor([0.5, -0.25, 0.1, 0.3]))
+
+    def forward(self, x, timestep, c=None, **kw):
+        h = self.mix(self.frozen(x.float().movedim(3, -1))).movedim(-1, 3)
+        return [h * self.scale.view(1, 1, 1, 4, 1, 1) + 1e-3 * timestep[..., None, None, None]], None, None
+
+
+def _trainer_worker(rank, world, port, comm, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    D.init("gloo")
+    import copy
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from opendwm_amd import train_ops
+    from opendwm_amd.pipeline import CTSDTrainer
+    train_ops.adamw_ = _adamw_cpu                      # the HIP kernel needs a GPU; the host logic around it is what runs here
+    calls = []
+    hook0 = default_hooks.bf16_compress_hook
+
+    def counting_hook(state, bucket):
+        calls.append(bucket.buffer().numel())
+        return hook0(state, bucket)
+    default_hooks.bf16_compress_hook = counting_hook
+    tc = {"gradient_accumulation_steps": 2, "max_norm_for_grad_clip": 0.5, "freezing_pattern": "^frozen$"}
+    mk_sched = lambda opt: torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1 + s))
+    model = _StandInDenoiser()
+    ref_model = copy.deepcopy(model)
+    tr = CTSDTrainer(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01, ddp=True, training_config=tc, lr_scheduler=mk_sched,
+                     ddp_comm_dtype=comm)
+    assert tr.frozen_modules == ["frozen"] and len(tr.optimizer.param_groups[0]["params"]) == 5    # frozen ones stay listed
+
+    def data(r, step):
+        g = torch.Generator().manual_seed(1000 * r + step)
+        return torch.randn(1, 2, 2, 4, 4, 6, generator=g), torch.Generator().manual_seed(77 + 1000 * r + step)
+
+    for step in range(4):
+        lat, gen = data(rank, step)
+        tr.train_step(lat, {}, generator=gen)
+    # expectation, computed locally from BOTH ranks' data: mean over ranks of the gradient summed over the two micro-steps,
+    # clipped, torch.optim.AdamW, the LR schedule advanced once per call (ctsd.py:1401-1435)
+    rt = CTSDTrainer(ref_model, training_config={"freezing_pattern": "^frozen$"})
+    ropt = torch.optim.AdamW(ref_model.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
+    rsched = mk_sched(ropt)
+    for ostep in range(2):
+        acc = None
+        for r in range(world):
+            for micro in range(2):
+                lat, gen = data(r, 2 * ostep + micro)
+                ref_model.zero_grad()
+                rt.loss(lat, {}, generator=gen).backward()
+                gs = [None if p.grad is None else p.grad.clone() for p in ref_model.parameters()]
+                acc = gs if acc is None else [a if g is None else a + g for a, g in zip(acc, gs)]
+        for p, a in zip(ref_model.parameters(), acc):
+            p.grad = None if a is None else a / world
+        torch.nn.utils.clip_grad_norm_(ref_model.parameters(), 0.5)
+        rsched.step()                                  # the micro-step call
+        ropt.step()
+        ropt.zero_grad()
+        rsched.step()
+    err = max((p - r_).abs().max().item() for p, r_ in zip(model.parameters(), ref_model.parameters()))
+    osd = tr.optimizer.state_dict()
+    q.put((rank, err, len(calls), tr.optimizer.lr, ropt.param_groups[0]["lr"], sorted(osd["state"]), tr.optimizer.t,
+           [p.detach().flatten().tolist() for p in model.parameters()]))
+    D.shutdown()
+
+
+@pytest.mark.parametrize("comm", [torch.bfloat16, None])
+def test_trainer_accumulation_no_sync_bf16_buckets_lr_schedule_two_ranks(comm):
+    """CTSDTrainer over DDP on two gloo ranks with a stand-in model: gradient_accumulation_steps = 2 (one bucket all-reduce per
+    OPTIMIZER step - the micro-step runs under no_sync), bf16 buckets (bf16_compress_hook) or fp32, gradient clipping, a
+    frozen module that stays in the optimizer's parameter list, and an LR scheduler stepped every call."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, comm, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, ncalls, lr, ref_lr, state_keys, t, params in res:
+        assert err < (2e-4 if comm is not None else 1e-6), err       # bf16 buckets round the gradient to 8 bits
+        assert ncalls == (2 if comm is not None else 0)               # one bucket, two optimizer steps: NOT four
+        assert abs(lr - ref_lr) < 1e-12 and abs(lr - 1e-2 / 5) < 1e-12   # scheduler stepped on all four calls
+        assert state_keys == [0, 3, 4] and t == 2                    # frozen parameters 1, 2 (own parameters come first): listed, no state
+    assert res[0][-1] == res[1][-1]                  # replicas stay identical

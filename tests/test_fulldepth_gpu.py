@@ -1,0 +1,192 @@
+"""Parity at the sizes BASELINE.json quotes, against the fp32 oracle evaluated ON THE DEVICE (plain PyTorch fp32 of
+oracle/ctsd_oracle.py; the CPU needs ~15 minutes for one such forward, the GPU seconds):
+
+  * configs[2] at FULL depth and size - 24 layers, d = 1536, latents [2,16,6,16,32,56] (CFG batch), 154 text tokens - for
+    BOTH models of that config: text only (row-wise temporal attention) and text+layout (ImageAdapter + point-wise temporal
+    attention), i.e. exactly the two forwards `bench.py` times;
+  * 40 FlowMatch-Euler steps with classifier-free guidance (the whole loop of ctsd.py:1496-1575) at full width on a reduced
+    geometry, bf16 HIP against the fp32 oracle loop: the error after the LAST step is what north_star bounds;
+  * configs[1]: the SD 2.1 UNet at full width on 6 views x 6 frames x 32x56 latents;
+  * configs[3]: one training forward + backward at full width (3-layer slice, one sample) - parameter gradients against fp32
+    autograd through the oracle.
+Tolerance: 2e-2 relative (Frobenius) for bf16 storage with fp32 accumulation, BASELINE.json north_star."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ctsd_oracle as O          # noqa: E402  (checker only)
+from tests.common import rel_err, to_dev     # noqa: E402
+
+pytestmark = pytest.mark.gpu
+bf16 = torch.bfloat16
+TOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need a HIP device (torch.cuda.is_available() is False)")
+    from opendwm_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _log(name, **kw):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/gpu_parity.log", "a") as f:
+        f.write(name + " " + " ".join(f"{k}={v}" for k, v in kw.items()) + "\n")
+
+
+def _oracle_on_device(fn):
+    """the oracle's loops build their timestep tensors on the host: move them next to the sample"""
+    def wrapped(sd, cfg, sample, timestep, **kw):
+        return fn(sd, cfg, sample, timestep.to(sample.device), **kw)
+    return wrapped
+
+
+@pytest.mark.parametrize("layout", [False, True], ids=["text_only_rowwise", "text_layout_pointwise"])
+def test_full_depth_full_size_forward_vs_oracle_on_device(dev, layout):
+    """the model `bench.py` times (same constructor kwargs, same seeded weights, same synthetic conditions), one CFG forward"""
+    import bench
+    kwargs = bench.variant_kwargs(layout)
+    model = bench.build_model(kwargs, dev, seed=0)
+    cond = bench.make_conditions(dev, seed=0, layout=layout)
+    w = bench.WORKLOAD
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2 * w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g).to(bf16)
+    ts = torch.full((2 * w["B"], w["T"], w["V"]), 500.0, device=dev)
+    with torch.no_grad():
+        out = model(x, ts, **cond)[0][0].float()
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    del model
+    torch.cuda.empty_cache()
+    cfg = O.make_config(**kwargs)
+    with torch.no_grad():
+        ref = O.dit_forward(sd, cfg, x.float(), ts, **{k: (v.float() if v.is_floating_point() else v) for k, v in cond.items()})
+    e = rel_err(out, ref)
+    _log("full_depth_forward", variant="text+layout" if layout else "text_only", layers=kwargs["num_layers"],
+         latents=list(x.shape), rel=e, finite=bool(torch.isfinite(out).all()))
+    del sd, ref
+    torch.cuda.empty_cache()
+    assert e < TOL, e
+
+
+@pytest.mark.parametrize("layout", [False, True], ids=["text_only_rowwise", "text_layout_pointwise"])
+def test_forty_step_denoise_vs_oracle_loop_on_device(dev, layout):
+    """all 40 guided FlowMatch-Euler steps (examples/ctsd_35_6views_video_generation.json:34-35: 40 steps, guidance 4) at
+    full width - 8 layers (dual joint blocks, cross-view after 1 and 5, temporal after 2, 3, 6, 7), 6 views x 4 frames x 32x56
+    latents: CTSDDenoiser (bf16 model input, fp32 latents, fused CFG + Euler kernel) against O.denoise in fp32"""
+    import bench
+    from opendwm_amd.pipeline import CTSDDenoiser
+    kwargs = bench.variant_kwargs(layout)
+    n = 8
+    kwargs.update(num_layers=n, dual_attention_layers=list(range(n)), crossview_block_layers=[1, 5], temporal_block_layers=[2, 3, 6, 7])
+    model = bench.build_model(kwargs, dev, seed=0)
+    wl = dict(bench.WORKLOAD, T=4)
+    cond = bench.make_conditions(dev, seed=3, w=wl, layout=layout)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lat = torch.randn(1, wl["T"], wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=g)
+    den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=40)
+    with torch.no_grad():
+        out = den.run(lat, cond).clone()
+        one = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=40).run(lat, cond, stop=1).clone()
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    del model, den
+    torch.cuda.empty_cache()
+    cfg = O.make_config(**kwargs)
+    fwd0 = O.dit_forward
+    O.dit_forward = _oracle_on_device(fwd0)
+    try:
+        condf = {k: (v.float() if v.is_floating_point() else v) for k, v in cond.items()}
+        with torch.no_grad():
+            ref1 = O.denoise(sd, cfg, lat, condf, steps=40, guidance_scale=4.0, stop=1)
+            ref = O.denoise(sd, cfg, lat, condf, steps=40, guidance_scale=4.0)
+    finally:
+        O.dit_forward = fwd0
+    e1, e40 = rel_err(one, ref1), rel_err(out, ref)
+    # the displacement is what the model contributes: error relative to |x_40 - x_0| as well
+    move = ((out.double() - ref.double()).norm() / (ref.double() - lat.double()).norm()).item()
+    _log("denoise_40_steps", variant="text+layout" if layout else "text_only", layers=n, latents=list(lat.shape), rel_step1=e1,
+         rel_step40=e40, rel_to_displacement=move, finite=bool(torch.isfinite(out).all()))
+    assert e40 < TOL and e1 < TOL, (e1, e40)
+
+
+def test_unet_full_width_config1_six_frames_vs_oracle_on_device(dev):
+    """BASELINE.json configs[1] as `bench.py --unet` runs it: SD 2.1 cross-view temporal UNet at full width (1.92 B
+    parameters), 6 views x 6 frames x 32x56 latents, CFG batch 2, 77 text tokens, ring cross-view mask"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = U.make_unet_config()
+    sd = {k: v.to(bf16) for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 6, 6, 32, 56, text_len=77)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    m = m.to(dev).to(bf16).eval()
+    di = to_dev(inp, dev)
+    with torch.no_grad():
+        out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0].float()
+    del m
+    torch.cuda.empty_cache()
+    sd_dev = {k: v.to(dev).float() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = U.unet_forward(sd_dev, cfg, **to_dev(inp, dev))
+    e = rel_err(out, ref)
+    _log("unet_full_width_config1", latents=list(out.shape), rel=e, finite=bool(torch.isfinite(out).all()))
+    assert out.shape == (2, 6, 6, 4, 32, 56) and e < TOL
+
+
+def test_full_width_train_gradients_vs_oracle_autograd_on_device(dev):
+    """BASELINE.json configs[3] geometry at full width on a 3-layer slice (dual joint blocks 0-2, cross-view block after 1,
+    temporal block after 2), one sample of 6 views x 4 frames x 32x56 latents: d<prediction, w>/d(parameter) of the HIP
+    training path (checkpointed block Functions, hand-written backward kernels, fp32 master weights) against fp32 autograd
+    through the oracle on the device"""
+    from opendwm_amd import train
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    cfg = O.make_config(num_layers=3, dual_attention_layers=[0, 1, 2], crossview_block_layers=[1], temporal_block_layers=[2],
+                        pos_embed_max_size=64)
+    gen = torch.Generator().manual_seed(0)
+    sd = {n: O.synth_param(n, s, cfg, gen).to(bf16).float() for n, s in O.param_shapes(cfg).items()}
+    inp = O.make_inputs(cfg, 1, 4, 6, 32, 56, seed=0)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v) for k, v in inp.items()}
+    di = to_dev(inp, dev)
+    wgt = torch.randn(inp["sample"].shape, generator=torch.Generator().manual_seed(11)).to(dev)
+
+    m = DiTCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    kw = dict(di)
+    out = train.forward_train(m, kw.pop("sample"), kw.pop("timestep"), kw.pop("encoder_hidden_states"), kw.pop("pooled_projections"),
+                              crossview_attention_mask=kw.get("crossview_attention_mask"), added_time_ids=kw.get("added_time_ids"))
+    (out.float() * wgt).sum().backward()
+    ours = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    out = out.detach().float()
+    del m
+    torch.cuda.empty_cache()
+
+    sdo = {k: (v.to(dev).clone().requires_grad_(True) if v.is_floating_point() else v.to(dev)) for k, v in sd.items()}
+    ref = O.dit_forward(sdo, cfg, **di)
+    (ref * wgt).sum().backward()
+    e_fwd = rel_err(out, ref.detach())
+    errs, num, den, missing = {}, 0.0, 0.0, []
+    for name, v in sdo.items():
+        if not (torch.is_tensor(v) and v.requires_grad) or v.grad is None:
+            continue
+        if name not in ours:
+            missing.append(name)
+            continue
+        a, b = ours[name], v.grad.double().cpu()
+        errs[name] = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        num += float((a - b).pow(2).sum())
+        den += float(b.pow(2).sum())
+    glob = (num / den) ** 0.5
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    mix = {n: v for n, v in errs.items() if n.endswith("mix_factor")}
+    _log("full_width_train_gradients", fwd=e_fwd, global_rel=glob, n_params=len(errs), worst=worst, mixers=mix, missing=missing)
+    assert not missing, missing
+    assert e_fwd < TOL and glob < 3e-2, (e_fwd, glob, worst)

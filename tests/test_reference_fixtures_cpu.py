@@ -593,18 +593,25 @@ def test_trainer_loss_end_to_end_equals_reference_train_step(name):
     assert abs(loss.item() - d["loss"].item()) / d["loss"].item() < 1e-2, (loss.item(), d["loss"].item())
 
 
-def test_checkpoint_layout_resumes_from_reference_files(tmp_path):
+@pytest.mark.parametrize("case", ["reference_checkpoint", "reference_checkpoint_frozen"])
+def test_checkpoint_layout_resumes_from_reference_files(tmp_path, case):
     """CTSDTrainer.load_checkpoint / save_checkpoint against files written by the REAL save_checkpoint +
     distributed_save_optimizer_state (tests/golden/make_reference_checkpoint_fixture.py): <output>/checkpoints/<step>.pth and
     <output>/optimizer/<step>.pth in torch.optim.AdamW's format.  The loaded moments / step count / hyper-parameters
-    reproduce the reference's next AdamW step, and what we write back is a file torch.optim.AdamW resumes from."""
-    from opendwm_amd.pipeline import CTSDTrainer
+    reproduce the reference's next AdamW step, and what we write back is a file torch.optim.AdamW resumes from.
+    "_frozen": a training_config["freezing_pattern"] froze the first layer before the optimizer was built from ALL
+    parameters (ctsd.py:1014-1022, 1089-1092) - the state is sparse over the full parameter list."""
+    from opendwm_amd.pipeline import CTSDTrainer, freeze_modules
     from opendwm_amd.train import AdamW
-    from tests.golden.make_reference_checkpoint_fixture import tiny_model
-    root = os.path.join(GOLDEN, "reference_checkpoint")
+    from tests.golden.make_reference_checkpoint_fixture import FREEZING_PATTERN, tiny_model
+    root = os.path.join(GOLDEN, case)
     exp = torch.load(os.path.join(root, "expected.pt"))
+    frozen = case.endswith("frozen")
     tr = CTSDTrainer.__new__(CTSDTrainer)
     tr.model = tiny_model()
+    if frozen:
+        assert freeze_modules(tr.model, FREEZING_PATTERN) == ["0"]
+        assert [q.requires_grad for q in tr.model.parameters()] == [False, False, True, True]
     with torch.no_grad():
         for q in tr.model.parameters():
             q.zero_()                                           # everything must come from the files
@@ -612,31 +619,48 @@ def test_checkpoint_layout_resumes_from_reference_files(tmp_path):
     tr.load_checkpoint(root, 3)
     opt = tr.optimizer
     assert (opt.lr, opt.betas, opt.eps, opt.weight_decay, opt.t) == (1e-2, (0.9, 0.95), 1e-8, 0.05, 3)
+    assert len(opt.state) == (2 if frozen else 4)
     # one AdamW step by the textbook formula from OUR loaded state == the reference's 4th step
-    t = opt.t + 1
     for q, g, want in zip(tr.model.parameters(), exp["grads_step_4"], exp["params_after_step_4"]):
-        m, v = opt.state[id(q)]
-        m = opt.betas[0] * m + (1 - opt.betas[0]) * g
-        v = opt.betas[1] * v + (1 - opt.betas[1]) * g * g
+        if g is None:
+            assert q not in opt.state and torch.equal(q.detach(), want)     # frozen: untouched, no state
+            continue
+        st = opt.state[q]
+        t = int(st["step"]) + 1
+        m = opt.betas[0] * st["exp_avg"] + (1 - opt.betas[0]) * g
+        v = opt.betas[1] * st["exp_avg_sq"] + (1 - opt.betas[1]) * g * g
         upd = (m / (1 - opt.betas[0] ** t)) / ((v / (1 - opt.betas[1] ** t)).sqrt() + opt.eps)
         got = q.detach() * (1 - opt.lr * opt.weight_decay) - opt.lr * upd
         assert torch.allclose(got, want, atol=1e-6)
     # write it back in the same layout: torch.optim.AdamW (= the reference's resume path) takes it and makes the same step
     tr.save_checkpoint(str(tmp_path), 3)
     ref_model = tiny_model()
+    if frozen:
+        freeze_modules(ref_model, FREEZING_PATTERN)
     ref_model.load_state_dict(torch.load(tmp_path / "checkpoints" / "3.pth", map_location="cpu", weights_only=True))
     ref_opt = torch.optim.AdamW(ref_model.parameters())
-    ref_opt.load_state_dict(torch.load(tmp_path / "optimizer" / "3.pth", map_location="cpu", weights_only=True))
+    ours, theirs = torch.load(tmp_path / "optimizer" / "3.pth", map_location="cpu", weights_only=True), \
+        torch.load(os.path.join(root, "optimizer", "3.pth"), map_location="cpu", weights_only=True)
+    assert sorted(ours["state"]) == sorted(theirs["state"]) and ours["param_groups"][0]["params"] == theirs["param_groups"][0]["params"]
+    ref_opt.load_state_dict(ours)
     for q, g in zip(ref_model.parameters(), exp["grads_step_4"]):
-        q.grad = g.clone()
+        q.grad = None if g is None else g.clone()
     ref_opt.step()
     assert all(torch.allclose(q, w, atol=1e-6) for q, w in zip(ref_model.parameters(), exp["params_after_step_4"]))
 
 
-def test_latent_sequence_length_equals_reference(dfx):
-    from opendwm_amd.drivers import latent_sequence_length
-    assert len(dfx["latent_sequence_length"]) == 9
-    for n, pre, stride, want in dfx["latent_sequence_length"]:
-        assert latent_sequence_length(n, pre, stride) == want, (n, pre, stride)
-    with pytest.raises(ValueError):
-        latent_sequence_length(6, 1, 4)                       # the reference asserts here
+def test_adamw_is_a_torch_optimizer_with_per_parameter_steps_and_lr_schedulers():
+    """host-side contract of train.AdamW (no kernel call: step() needs the GPU): torch LR schedulers attach
+    (ctsd.py:1098-1100), a parameter without gradient keeps no state, the state dict is torch's"""
+    from opendwm_amd.train import AdamW
+    a, b = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))
+    opt = AdamW([a, b], lr=1.0)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 0.5 ** s)
+    sched.step()
+    assert opt.lr == 0.5 and opt.param_groups[0]["initial_lr"] == 1.0
+    assert opt.state_dict()["state"] == {} and opt.t == 0
+    opt.zero_grad()
+    assert a.grad is None
+
+

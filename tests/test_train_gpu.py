@@ -301,11 +301,30 @@ def _train_model(cfg, sd, dev):
     return m.to(dev).train()          # fp32 master parameters; bf16 shadows are made on first use
 
 
-def _oracle_grads(sd, cfg, inp, wgt, dev):
+def _oracle_grads(sd, cfg, inp, wgt, dev, mixer_cond=None):
+    """fp32 autograd through the oracle.  `mixer_cond` (a dict) receives, per AlphaBlender, the conditioning of its
+    d(alpha) = sum dy * (x_spatial - x_temporal): sum |terms| / |sum terms| over the samples whose flag is off."""
     from oracle import ctsd_oracle as O
     sdo = {k: (v.to(dev).clone().requires_grad_(True) if v.is_floating_point() else v.to(dev)) for k, v in sd.items()}
-    ref = O.dit_forward(sdo, cfg, **inp)
-    (ref * wgt).sum().backward()
+    blend0, recs = O.alpha_blender, []
+
+    def blender(sd_, p, a, b, image_only):
+        out = blend0(sd_, p, a, b, image_only)
+        rec = dict(p=p, d=(a - b).detach(), on=(~image_only).detach())
+        out.register_hook(lambda gr, rec=rec: rec.__setitem__("dy", gr.detach()))
+        recs.append(rec)
+        return out
+    O.alpha_blender = blender
+    try:
+        ref = O.dit_forward(sdo, cfg, **inp)
+        (ref * wgt).sum().backward()
+    finally:
+        O.alpha_blender = blend0
+    if mixer_cond is not None:
+        for rec in recs:
+            t = (rec["dy"] * rec["d"]).double()
+            t = t * rec["on"].view(-1, *([1] * (t.dim() - 1))).to(t.dtype)
+            mixer_cond[rec["p"] + ".mix_factor"] = (t.abs().sum() / t.sum().abs().clamp_min(1e-300)).item()
     return ref.detach(), {k: v.grad for k, v in sdo.items() if torch.is_tensor(v) and v.requires_grad}
 
 
@@ -323,7 +342,8 @@ def test_model_gradients_vs_oracle(dev, tt):
     di = to_dev(inp, dev)
     g = torch.Generator(device="cpu").manual_seed(11)
     wgt = torch.randn(inp["sample"].shape, generator=g).to(dev)
-    ref, gref = _oracle_grads(sd, cfg, di, wgt, dev)
+    cond = {}
+    ref, gref = _oracle_grads(sd, cfg, di, wgt, dev, mixer_cond=cond)
 
     m = _train_model(cfg, sd, dev)
     kw = dict(di)
@@ -344,12 +364,17 @@ def test_model_gradients_vs_oracle(dev, tt):
         den += float(b.pow(2).sum())
     glob = (num / den) ** 0.5
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    _log("model_gradients", temporal=tt, fwd=e_fwd, global_rel=glob, worst=worst, n_params=len(errs), missing=missing)
+    mixers = {n: dict(rel=errs[n], cond=cond[n]) for n in cond}
+    _log("model_gradients", temporal=tt, fwd=e_fwd, global_rel=glob, worst=worst, n_params=len(errs), missing=missing, mixers=mixers)
     assert not missing, missing
     assert e_fwd < 2e-2 and glob < 3e-2, (glob, worst)
-    # scalar mixer parameters: d(alpha) = <dy, h - block(h)> is a difference of two large bf16-rounded sums
-    sizes = {n: p.numel() for n, p in m.named_parameters()}
-    assert all(v < (0.15 if sizes[n] > 1 else 0.5) for n, v in errs.items()), worst
+    assert all(v < 0.15 for n, v in errs.items() if n not in cond), worst
+    # scalar mixer parameters: d(alpha) = <dy, h - block(h)> is ONE heavily cancelling sum over every activation of the block
+    # (fp32 difference and accumulation in dwm_segsum_diff).  Held to 5e-2 where the sum is reasonably conditioned
+    # (sum|terms| / |sum| <= 400); beyond that the bf16 rounding of dy alone - everything else exact - moves the value by
+    # ~1.3e-5 x the conditioning (scripts/alpha_grad_conditioning.py: 3.9e-2 at 2900), so the bound scales with it
+    for n, v in mixers.items():
+        assert v["rel"] < max(5e-2, 1.25e-4 * v["cond"]), (n, v)
 
 
 def test_adamw_step_updates_shadows(dev):
@@ -558,3 +583,52 @@ def test_model_gradients_with_layout_adapter_vs_oracle(dev):
     # adapter gradients, 15 % on any single tensor
     assert e_fwd < 2e-2 and glob < 4e-2, (glob, worst)
     assert all(v < 0.15 for v in ad.values()), worst
+
+
+def test_adapter_weights_are_repacked_after_optimizer_step(dev):
+    """two optimizer steps with the layout ImageAdapter: the packed 3x3 / 1x1 weights of its resnets must follow the
+    masters (they were cached once and kept the step-0 values).  After the steps the training-mode forward, the eval
+    forward AND the layout residual cache must all see the updated adapter: the forward equals the oracle evaluated
+    with the model's CURRENT parameters, and differs from the oracle with the initial ones."""
+    from oracle import ctsd_oracle as O
+    from opendwm_amd.pipeline import CTSDTrainer
+    from tests.common import small_config, small_inputs, to_dev
+    acfg = dict(in_channels=6, channels=[128, 128, 128], is_downblocks=[True, False, False], num_res_blocks=2,
+                downscale_factor=8, use_zero_convs=True)
+    cfg = small_config(condition_image_adapter_config=acfg)
+    sd0 = {k: v.to(bf16).float() for k, v in O.make_state_dict(cfg, 0).items()}
+    inp = small_inputs(cfg, 0)
+    inp["condition_image_tensor"] = torch.rand(2, 3, 3, 6, 64, 96, generator=torch.Generator().manual_seed(5))
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v) for k, v in inp.items()}
+    lat = inp.pop("sample")
+    ts = inp.pop("timestep")
+    m = _train_model(cfg, sd0, dev)
+    # only the adapter resnets train, with a large step: a stale packed copy cannot hide behind other parameters
+    m.requires_grad_(False)
+    for blk in m.condition_image_adapter.body:
+        blk.resnets.requires_grad_(True)
+    tr = CTSDTrainer(m, lr=3e-2, weight_decay=0.0)
+    di = to_dev(inp, dev)
+    m.eval()
+    with torch.no_grad():
+        before = m(lat.to(dev).to(bf16), ts.to(dev), **di)[0][0].float()     # fills the residual cache with step-0 weights
+    m.train()
+    idx, noise = torch.tensor([250, 800]), torch.randn(lat.shape, generator=torch.Generator().manual_seed(5))
+    for _ in range(2):
+        tr.train_step(lat.to(dev), di, timestep_indices=idx, noise=noise)
+    sd_now = {k: v.detach().float().cpu().to(bf16).float() for k, v in m.state_dict().items()}
+    moved = max((sd_now[k] - sd0[k]).abs().max().item() for k in sd0 if ".resnets." in k)
+    assert moved > 1e-2, moved
+    xin = lat.to(bf16).float()
+    ref_now = O.dit_forward(sd_now, cfg, xin, ts, **inp)
+    ref_old = O.dit_forward(sd0, cfg, xin, ts, **inp)
+    m.eval()
+    with torch.no_grad():
+        after = m(lat.to(dev).to(bf16), ts.to(dev), **di)[0][0].float()      # same condition tensor object: cache key must miss
+    m.train()
+    after_train = m(lat.to(dev).to(bf16), ts.to(dev), **di)[0][0].detach().float()
+    e_now, e_old, e_train = rel_err(after, ref_now), rel_err(after, ref_old), rel_err(after_train, ref_now)
+    _log("adapter_two_step", rel_vs_current_weights=e_now, rel_vs_initial_weights=e_old, train_mode=e_train,
+         weights_moved=moved, changed=rel_err(after, before))
+    assert e_now < 2e-2 and e_train < 2e-2, (e_now, e_train)
+    assert e_old > 3 * e_now, (e_old, e_now)
