@@ -320,6 +320,24 @@ int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, const dwm_ro
 /* y[r, :L] = softmax(scale * x[r, :L]) (fp32 math, bf16 storage; single-head mid-block attention). */
 int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream);
 
+/* out = coef[g][0] * x + coef[g][1] * y, fp32, one coefficient pair per group of `group_elems` consecutive elements
+ * (g = element / group_elems); `out` (fp32) and / or `out_bf16` receive the result.  DDPMScheduler.add_noise / get_velocity
+ * with one timestep per (sample, frame, view) (src/dwm/schedulers/temporal_independent.py:8-45). */
+int dwm_frame_affine(const float* x, const float* y, const float* coef, float* out, void* out_bf16, int64_t n,
+                     int64_t group_elems, void* stream);
+
+/* Classifier-free guidance + the tensor-timestep DDIM update (src/dwm/schedulers/temporal_independent.py:67-170) in one pass.
+ * pred: model output, bf16 (pred_is_f32 = 0) or fp32, [2n] = (unconditional ; conditional) when cfg != 0, else [n];
+ * latents fp32 [n] updated in place; coef fp32 [n / group_elems, 6] =
+ *   { sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev), sqrt(1 - a_prev - std^2), std, 0 } per (sample, frame, view) timestep;
+ * prediction_type 0 epsilon | 1 sample | 2 v_prediction; clip_range > 0 clamps the predicted x0 (config.clip_sample);
+ * use_clipped_model_output re-derives epsilon from the clipped x0; noise (fp32 [n], may be NULL) is the eta > 0 variance
+ * noise; x0_out (may be NULL) receives pred_original_sample; model_in (may be NULL) the bf16 next model input (CFG-doubled
+ * when cfg != 0). */
+int dwm_cfg_ddim_step(const void* pred, int32_t pred_is_f32, int32_t cfg, float* latents, void* model_in, float* x0_out,
+                      const float* noise, const float* coef, int64_t n, int64_t group_elems, float guidance,
+                      int32_t prediction_type, float clip_range, int32_t use_clipped_model_output, void* stream);
+
 /* classifier-free guidance + one step of a linear multistep scheduler on fp32 latents (SD 2.1 configs:
  * diffusers DPMSolverMultistepScheduler, dpmsolver++ / midpoint, called at ctsd.py:1548-1575):
  *   out = u + g (c - u);  x0 = kx * x + ko * out  (epsilon: kx = 1/alpha_t, ko = -sigma_t/alpha_t; v: kx = alpha_t, ko = -sigma_t)

@@ -117,6 +117,82 @@ cfg_multistep_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat, f
     }
 }
 
+// per-frame affine combination of two fp32 tensors (coefficients per group of `group_elems` consecutive elements):
+//   out = c[g][0] * x + c[g][1] * y      - DDPMScheduler.add_noise / get_velocity with a timestep per (sample, frame, view)
+//   (src/dwm/schedulers/temporal_independent.py:8-45)
+__global__ void __launch_bounds__(256)
+frame_affine_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ coef,
+                    float* __restrict__ out, bf16_t* __restrict__ out_bf16, int64_t n, int64_t group_elems) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int64_t g = i / group_elems;
+    const float c0 = coef[2 * g], c1 = coef[2 * g + 1];
+    const float4 a = *(const float4*)(x + i), b = *(const float4*)(y + i);
+    const float o[4] = {c0 * a.x + c1 * b.x, c0 * a.y + c1 * b.y, c0 * a.z + c1 * b.z, c0 * a.w + c1 * b.w};
+    if (out) *(float4*)(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (out_bf16) *(uint2*)(out_bf16 + i) = pack4(o);
+}
+
+// classifier-free guidance + the tensor-timestep DDIM update (src/dwm/schedulers/temporal_independent.py:67-170), one
+// coefficient row per group of `group_elems` elements (= per (sample, frame, view) timestep):
+//   coef[g] = { sqrt(a_t), sqrt(1 - a_t), sqrt(a_prev), sqrt(1 - a_prev - std^2), std, 0 }
+//   m = u + g (c - u) | u;   (x0, eps) from (sample, m) by prediction type;   x0 clipped;   eps re-derived if asked;
+//   prev = sqrt(a_prev) x0 + dir eps + std noise
+template <typename PT>
+__global__ void __launch_bounds__(256)
+cfg_ddim_kernel(const PT* __restrict__ pred, int64_t cond_offset, float* __restrict__ lat, bf16_t* __restrict__ model_in,
+                float* __restrict__ x0_out, const float* __restrict__ noise, const float* __restrict__ coef, int64_t n,
+                int64_t group_elems, float guidance, int ptype, float clip, int use_clipped) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* cg = coef + 6 * (i / group_elems);
+    const float sa = cg[0], sb = cg[1], sap = cg[2], dir = cg[3], sd = cg[4];
+    float m[4];
+    if constexpr (sizeof(PT) == 2) {
+        unpack4(*(const uint2*)(pred + i), m);
+        if (cond_offset) {
+            float c[4];
+            unpack4(*(const uint2*)(pred + cond_offset + i), c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] += guidance * (c[j] - m[j]);
+        }
+    } else {
+        const float4 u = *(const float4*)(pred + i);
+        m[0] = u.x; m[1] = u.y; m[2] = u.z; m[3] = u.w;
+        if (cond_offset) {
+            const float4 c = *(const float4*)(pred + cond_offset + i);
+            m[0] += guidance * (c.x - m[0]); m[1] += guidance * (c.y - m[1]);
+            m[2] += guidance * (c.z - m[2]); m[3] += guidance * (c.w - m[3]);
+        }
+    }
+    const float4 l = *(const float4*)(lat + i);
+    const float s[4] = {l.x, l.y, l.z, l.w};
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (noise) {
+        const float4 q = *(const float4*)(noise + i);
+        nz[0] = q.x; nz[1] = q.y; nz[2] = q.z; nz[3] = q.w;
+    }
+    float o[4], z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0, eps;
+        if (ptype == 0) { x0 = (s[j] - sb * m[j]) / sa; eps = m[j]; }                       // epsilon
+        else if (ptype == 1) { x0 = m[j]; eps = (s[j] - sa * x0) / sb; }                    // sample
+        else { x0 = sa * s[j] - sb * m[j]; eps = sa * m[j] + sb * s[j]; }                   // v_prediction
+        if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+        if (use_clipped) eps = (s[j] - sa * x0) / sb;
+        z[j] = x0;
+        o[j] = sap * x0 + dir * eps + sd * nz[j];
+    }
+    *(float4*)(lat + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (x0_out) *(float4*)(x0_out + i) = make_float4(z[0], z[1], z[2], z[3]);
+    if (model_in) {
+        const uint2 b = pack4(o);
+        *(uint2*)(model_in + i) = b;
+        if (cond_offset) *(uint2*)(model_in + n + i) = b;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -264,6 +340,38 @@ extern "C" int dwm_cfg_multistep(const void* pred, float* latents, float* x0_pre
         return DWM_EALIGN;
     hipLaunchKernelGGL(cfg_multistep_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred,
                        latents, x0_prev, (bf16_t*)model_in, n, guidance, kx, ko, A, B, C);
+    return finish();
+}
+
+extern "C" int dwm_frame_affine(const float* x, const float* y, const float* coef, float* out, void* out_bf16, int64_t n,
+                                int64_t group_elems, void* stream) {
+    if (x == nullptr || y == nullptr || coef == nullptr || (out == nullptr && out_bf16 == nullptr) || n <= 0 || group_elems <= 0) return DWM_EINVAL;
+    if (n % 4 != 0 || group_elems % 4 != 0 || n % group_elems != 0 || !dwm_aligned16(x) || !dwm_aligned16(y) || (out && !dwm_aligned16(out)) ||
+        (out_bf16 && (((uintptr_t)out_bf16) & 7u)))
+        return DWM_EALIGN;
+    hipLaunchKernelGGL(frame_affine_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, coef, out,
+                       (bf16_t*)out_bf16, n, group_elems);
+    return finish();
+}
+
+extern "C" int dwm_cfg_ddim_step(const void* pred, int32_t pred_is_f32, int32_t cfg, float* latents, void* model_in, float* x0_out,
+                                 const float* noise, const float* coef, int64_t n, int64_t group_elems, float guidance,
+                                 int32_t prediction_type, float clip_range, int32_t use_clipped_model_output, void* stream) {
+    if (pred == nullptr || latents == nullptr || coef == nullptr || n <= 0 || group_elems <= 0) return DWM_EINVAL;
+    if (prediction_type < 0 || prediction_type > 2) return DWM_EINVAL;
+    if (n % 4 != 0 || group_elems % 4 != 0 || n % group_elems != 0 || !dwm_aligned16(latents) || (x0_out && !dwm_aligned16(x0_out)) ||
+        (noise && !dwm_aligned16(noise)) || (model_in && (((uintptr_t)model_in) & 7u)) ||
+        (((uintptr_t)pred) & (pred_is_f32 ? 15u : 7u)))
+        return DWM_EALIGN;
+    const int64_t off = cfg ? n : 0;
+    if (pred_is_f32)
+        hipLaunchKernelGGL(cfg_ddim_kernel<float>, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)pred, off,
+                           latents, (bf16_t*)model_in, x0_out, noise, coef, n, group_elems, guidance, prediction_type, clip_range,
+                           use_clipped_model_output);
+    else
+        hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, off,
+                           latents, (bf16_t*)model_in, x0_out, noise, coef, n, group_elems, guidance, prediction_type, clip_range,
+                           use_clipped_model_output);
     return finish();
 }
 

@@ -577,6 +577,45 @@ def cfg_multistep(pred: torch.Tensor, latents: torch.Tensor, x0_prev: torch.Tens
                "dwm_cfg_multistep")
 
 
+def frame_affine(x: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, group_elems: int, out: Optional[torch.Tensor] = None,
+                 out_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = coef[g, 0] * x + coef[g, 1] * y (fp32), g = element // group_elems; see dwm_frame_affine."""
+    n = x.numel()
+    for t in (x, y):
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda or t.numel() != n:
+            raise RuntimeError("frame_affine: x / y must be contiguous fp32 device tensors of one size")
+    if coef.dtype != torch.float32 or not coef.is_contiguous() or not coef.is_cuda or coef.numel() * group_elems != 2 * n:
+        raise RuntimeError("frame_affine: coef must be a contiguous fp32 device tensor [n / group_elems, 2]")
+    if out is None and out_bf16 is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().dwm_frame_affine(x.data_ptr(), y.data_ptr(), coef.data_ptr(), _p(out), _p(out_bf16), n, group_elems,
+                                            _stream()), "dwm_frame_affine")
+    return out if out is not None else out_bf16
+
+
+def cfg_ddim_step(pred: torch.Tensor, latents: torch.Tensor, coef: torch.Tensor, group_elems: int, prediction_type: int,
+                  guidance: Optional[float] = None, clip_range: float = 0.0, use_clipped_model_output: bool = False,
+                  noise: Optional[torch.Tensor] = None, x0_out: Optional[torch.Tensor] = None,
+                  model_in: Optional[torch.Tensor] = None) -> None:
+    """[CFG combine +] tensor-timestep DDIM update of `latents` (fp32, in place); see dwm_cfg_ddim_step.
+    guidance None: pred holds n elements; otherwise pred = [uncond; cond] with 2n."""
+    n = latents.numel()
+    cfg = guidance is not None
+    if pred.dtype not in (bf16, torch.float32) or pred.numel() != (2 * n if cfg else n) or not pred.is_contiguous() or not pred.is_cuda:
+        raise RuntimeError("cfg_ddim_step: pred must be a contiguous bf16 / fp32 device tensor with n (2n with guidance) elements")
+    for t in (latents, noise, x0_out):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or not t.is_cuda):
+            raise RuntimeError("cfg_ddim_step: latents / noise / x0_out must be contiguous fp32 device tensors of one size")
+    if coef.dtype != torch.float32 or not coef.is_contiguous() or not coef.is_cuda or coef.numel() * group_elems != 6 * n:
+        raise RuntimeError("cfg_ddim_step: coef must be a contiguous fp32 device tensor [n / group_elems, 6]")
+    if model_in is not None and (model_in.dtype != bf16 or model_in.numel() != (2 * n if cfg else n) or not model_in.is_contiguous()):
+        raise RuntimeError("cfg_ddim_step: model_in must be contiguous bf16")
+    _lib.check(_lib.load().dwm_cfg_ddim_step(pred.data_ptr(), int(pred.dtype == torch.float32), int(cfg), latents.data_ptr(), _p(model_in),
+                                             _p(x0_out), _p(noise), coef.data_ptr(), n, group_elems, float(guidance or 0.0),
+                                             int(prediction_type), float(clip_range), int(bool(use_clipped_model_output)), _stream()),
+               "dwm_cfg_ddim_step")
+
+
 def unshuffle_tokens(x: torch.Tensor, r: int, ldo: Optional[int] = None) -> torch.Tensor:
     """PixelUnshuffle(r): [I, C, H, W] (fp32 / bf16) -> token-major bf16 [I*(H/r)*(W/r), ldo]."""
     if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, bf16):

@@ -523,10 +523,19 @@ class UNetDenoiser:
     CFG batch + guidance combine + DPM-Solver++(2M) update in one kernel.  latents fp32 [B,T,V,4,H,W]; conditions =
     CFG-doubled model kwargs (unconditional half first)."""
 
-    def __init__(self, model, guidance_scale: float = 3.0, inference_steps: int = 50, prediction_type: str = "v_prediction"):
+    def __init__(self, model, guidance_scale: float = 3.0, inference_steps: int = 50, prediction_type: str = "v_prediction",
+                 scheduler=None):
+        """scheduler None: DPM-Solver++(2M) (the example JSONs); a schedulers.DDIMScheduler: the reference's default test
+        scheduler of the UNet (ctsd.py:969-974, `inference_config` without "scheduler"), its tensor-timestep step
+        (temporal_independent.py:67-170) fused with the guidance combine."""
         self.model, self.guidance_scale, self.inference_steps = model, guidance_scale, inference_steps
         self.prediction_type = prediction_type
-        self.timesteps, self.sigmas = dpm_solver_tables(inference_steps)
+        self.scheduler = scheduler
+        if scheduler is not None:
+            scheduler.set_timesteps(inference_steps)
+            self.timesteps, self.sigmas = scheduler.timesteps.cpu(), None
+        else:
+            self.timesteps, self.sigmas = dpm_solver_tables(inference_steps)
 
     def prepare(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor]):
         dev = latents.device
@@ -547,6 +556,14 @@ class UNetDenoiser:
         ts = self._ts[i].expand(2 * B, T, V)
         out = self.model(self.model_in, ts, **self.conditions)
         pred = out["noise_pred"] if isinstance(out, dict) else out[0][0]
+        if self.scheduler is not None:
+            from .schedulers import PREDICTION_TYPES
+            sc = self.scheduler
+            coef = sc.coefficients(self.timesteps[i].to(self.latents.device).expand(B, T, V))
+            ops.cfg_ddim_step(pred, self.latents, coef.view(-1, 6), self.latents[0, 0, 0].numel(), PREDICTION_TYPES[sc.config.prediction_type],
+                              guidance=self.guidance_scale, clip_range=sc.config.clip_sample_range if sc.config.clip_sample else 0.0,
+                              model_in=self.model_in)
+            return
         kx, ko, A, Bc, Cc = dpm_solver_coefficients(self.sigmas, i, self.prediction_type)
         ops.cfg_multistep(pred, self.latents, self.x0_prev, self.guidance_scale, kx, ko, A, Bc, Cc, model_in=self.model_in)
 

@@ -968,3 +968,49 @@ def test_vae_sd21_quant_convs(dev):
     e2 = rel_err(vae.decode(z.to(dev))[0], O.vae_decode(sd, vcfg, z))
     _log("vae_sd21", encode=e1, decode=e2)
     assert dist.parameters.shape == (2, 8, 8, 8) and e1 < TOL_MODEL and e2 < TOL_MODEL
+
+
+# ---------------------------------------------------------------- tensor-timestep schedulers (temporal_independent.py)
+def test_schedulers_vs_reference_fixture(dev):
+    """opendwm_amd.schedulers (HIP kernels dwm_frame_affine / dwm_cfg_ddim_step) against the vectors of the EXECUTED
+    reference DDPMScheduler.add_noise / get_velocity and DDIMScheduler.step (tests/golden/reference_schedulers.pt), all
+    prediction types, eta > 0, clipping, per-sample / per-frame / per-view timesteps; then the fused CFG form against the
+    same step applied to the guided prediction."""
+    from opendwm_amd.schedulers import DDIMScheduler, DDPMScheduler
+    fx = torch.load(os.path.join(GOLDEN, "reference_schedulers.pt"))
+    d = fx["ddpm"]
+    sch = DDPMScheduler()
+    worst = 0.0
+    for name, c in d["cases"].items():
+        noisy = sch.add_noise(d["x0"].to(dev), d["noise"].to(dev), c["timesteps"].to(dev))
+        vel = sch.get_velocity(d["x0"].to(dev), d["noise"].to(dev), c["timesteps"])
+        worst = max(worst, (noisy.cpu() - c["noisy"]).abs().max().item(), (vel.cpu() - c["velocity"]).abs().max().item())
+    assert worst < 2e-6, worst
+    dd = fx["ddim"]
+    errs = {}
+    for name, c in dd["cases"].items():
+        kw = c["kw"]
+        s = DDIMScheduler(prediction_type=kw["prediction_type"], clip_sample=kw.get("clip_sample", False),
+                          clip_sample_range=kw.get("clip_sample_range", 1.0), set_alpha_to_one=kw.get("set_alpha_to_one", False))
+        s.set_timesteps(c["num_inference_steps"])
+        sample = dd["sample"].to(dev)
+        keep = sample.clone()
+        prev, x0 = s.step(dd["model_output"].to(dev), c["timesteps"].to(dev), sample, eta=kw.get("eta", 0.0),
+                          use_clipped_model_output=kw.get("use_clipped", False),
+                          variance_noise=dd["variance_noise"].to(dev) if kw.get("eta", 0.0) > 0 else None, return_dict=False)
+        assert torch.equal(sample, keep)                                   # the caller's sample is not modified
+        errs[name] = max((prev.cpu() - c["prev_sample"]).abs().max().item(), (x0.cpu() - c["pred_original_sample"]).abs().max().item())
+    _log("schedulers_vs_reference", ddpm_max_abs=worst, ddim_max_abs=errs)
+    assert all(v < 3e-5 for v in errs.values()), errs
+    # fused classifier-free guidance (ctsd.py:1548-1552) + step + next bf16 model input
+    c = dd["cases"]["v_eta0"]
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    u, cnd = dd["model_output"].to(dev).to(bf16), dd["variance_noise"].to(dev).to(bf16)
+    guided = u.float() + 3.0 * (cnd.float() - u.float())
+    want, _ = s.step(guided, c["timesteps"].to(dev), dd["sample"].to(dev), return_dict=False)
+    model_in = torch.empty(2, *dd["sample"].shape, dtype=bf16, device=dev)
+    got, _ = s.step(torch.stack([u, cnd]).contiguous(), c["timesteps"].to(dev), dd["sample"].to(dev), return_dict=False, guidance_scale=3.0,
+                    model_in=model_in)
+    assert (got - want).abs().max().item() < 1e-5
+    assert torch.equal(model_in[0], got.to(bf16)) and torch.equal(model_in[1], got.to(bf16))

@@ -664,3 +664,52 @@ def test_adamw_is_a_torch_optimizer_with_per_parameter_steps_and_lr_schedulers()
     assert a.grad is None
 
 
+
+
+# ---------------------------------------------------------------- tensor-timestep schedulers (temporal_independent.py)
+def test_scheduler_oracle_and_coefficient_tables_equal_reference():
+    """oracle/scheduler_oracle.py and the host half of opendwm_amd.schedulers (coefficient rows handed to the HIP kernels)
+    against the REAL DDPMScheduler.add_noise / get_velocity and DDIMScheduler.step / _get_variance
+    (tests/golden/make_reference_scheduler_fixture.py)."""
+    from oracle import scheduler_oracle as SO
+    from opendwm_amd.schedulers import DDIMScheduler, DDPMScheduler
+    fx = torch.load(os.path.join(GOLDEN, "reference_schedulers.pt"))
+    acp = fx["alphas_cumprod"]
+    assert torch.equal(DDPMScheduler().alphas_cumprod, acp)                 # the restated scaled_linear table
+    d = fx["ddpm"]
+    for name, c in d["cases"].items():
+        assert torch.allclose(SO.add_noise(acp, d["x0"], d["noise"], c["timesteps"]), c["noisy"], atol=1e-6), name
+        assert torch.allclose(SO.get_velocity(acp, d["x0"], d["noise"], c["timesteps"]), c["velocity"], atol=1e-6), name
+    dd = fx["ddim"]
+    for name, c in dd["cases"].items():
+        kw = c["kw"]
+        prev, x0 = SO.ddim_step(acp, c["final_alpha_cumprod"], 1000, c["num_inference_steps"], kw["prediction_type"], dd["model_output"],
+                                c["timesteps"], dd["sample"], eta=kw.get("eta", 0.0), use_clipped_model_output=kw.get("use_clipped", False),
+                                variance_noise=dd["variance_noise"], clip_sample=kw.get("clip_sample", False),
+                                clip_sample_range=kw.get("clip_sample_range", 1.0))
+        assert torch.allclose(prev, c["prev_sample"], atol=2e-5) and torch.allclose(x0, c["pred_original_sample"], atol=2e-5), name
+        # the product's coefficient rows: the kernel formula evaluated in torch must give the reference's step
+        sch = DDIMScheduler(prediction_type=kw["prediction_type"], clip_sample=kw.get("clip_sample", False),
+                            clip_sample_range=kw.get("clip_sample_range", 1.0), set_alpha_to_one=kw.get("set_alpha_to_one", False))
+        sch.set_timesteps(c["num_inference_steps"])
+        assert torch.allclose(sch._get_variance(c["timesteps"], c["timesteps"] - 20), c["variance"], atol=1e-7), name
+        co = sch.coefficients(c["timesteps"], kw.get("eta", 0.0)).view(*c["timesteps"].shape, 1, 1, 1, 6)
+        sa, sb, sap, dr, sd = (co[..., i] for i in range(5))
+        s, m = dd["sample"], dd["model_output"]
+        if kw["prediction_type"] == "epsilon":
+            x0k, eps = (s - sb * m) / sa, m
+        elif kw["prediction_type"] == "sample":
+            x0k, eps = m, (s - sa * m) / sb
+        else:
+            x0k, eps = sa * s - sb * m, sa * m + sb * s
+        if kw.get("clip_sample"):
+            x0k = x0k.clamp(-kw["clip_sample_range"], kw["clip_sample_range"])
+        if kw.get("use_clipped"):
+            eps = (s - sa * x0k) / sb
+        got = sap * x0k + dr * eps + sd * dd["variance_noise"]
+        assert torch.allclose(got, c["prev_sample"], atol=2e-5), name
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    assert sch.timesteps[0].item() == 981 and sch.timesteps[-1].item() == 1 and len(sch.timesteps) == 50      # leading + offset 1
+    with pytest.raises(ValueError):
+        DDIMScheduler().coefficients(torch.tensor([1]))                     # set_timesteps not called: the reference raises too

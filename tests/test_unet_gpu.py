@@ -179,6 +179,41 @@ def test_unet_denoise_loop_vs_oracle(dev):
     assert e < 3e-2
 
 
+def test_unet_ddim_denoise_loop_vs_oracle(dev):
+    """the reference's DEFAULT test scheduler of the UNet (ctsd.py:969-974: DDIMScheduler when inference_config names none):
+    UNetDenoiser(scheduler=DDIMScheduler()) - CFG + tensor-timestep DDIM step in one kernel - against the oracle UNet driven
+    by oracle/scheduler_oracle.ddim_step (pinned by the executed reference step)"""
+    from oracle import scheduler_oracle as SO
+    from oracle import unet_oracle as U
+    from opendwm_amd.pipeline import UNetDenoiser
+    from opendwm_amd.schedulers import DDIMScheduler
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = _small_unet_cfg()
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 16, 24, text_len=10)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    lat = inp.pop("sample")[:1]
+    inp.pop("timesteps")
+    steps = 4
+    sch = DDIMScheduler()
+    sch.set_timesteps(steps)
+    x = lat.float().clone()
+    B, T, V = x.shape[:3]
+    for i in range(steps):
+        t = sch.timesteps[i]
+        out = U.unet_forward(sd, cfg, torch.cat([x, x]), t.float().expand(2 * B, T, V), **inp)
+        u, c = out.chunk(2)
+        x, _ = SO.ddim_step(sch.alphas_cumprod, sch.final_alpha_cumprod, 1000, steps, "v_prediction", u + 3.0 * (c - u),
+                            t.expand(B, T, V), x)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).to(bf16).eval()
+    got = UNetDenoiser(m, 3.0, steps, scheduler=DDIMScheduler()).run(lat.to(dev), to_dev(inp, dev))
+    e = rel_err(got, x)
+    _log("unet_ddim_denoise_loop", steps=steps, rel=e)
+    assert e < 3e-2
+
+
 def test_unet_matches_golden_fixture(dev):
     """the committed oracle fixture (tests/golden/unet_small.pt) through the HIP path"""
     from oracle import unet_oracle as U
