@@ -320,6 +320,12 @@ int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, const dwm_ro
 /* y[r, :L] = softmax(scale * x[r, :L]) (fp32 math, bf16 storage; single-head mid-block attention). */
 int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream);
 
+/* Explicit perspective modelling (RayEncoder / get_rays, src/dwm/models/crossview_temporal_dit.py:11-102): the 72 inputs of
+ * RayEncoder.proj for every latent token of I images of h x w tokens.  cam fp32 [I, 21] = { inverse of the token-resolution
+ * intrinsics (9, row-major), camera->reference-ego rotation (9), camera origin (3) };
+ * out bf16 [I*h*w, ldo >= 72]: [ sin(o_d 2^k pi), d-major, k < 8 | cos | sin(ray_d 2^k pi), k < 4 | cos ], rest zero. */
+int dwm_ray_features(const float* cam, int64_t I, int32_t h, int32_t w, void* out, int64_t ldo, void* stream);
+
 /* out = coef[g][0] * x + coef[g][1] * y, fp32, one coefficient pair per group of `group_elems` consecutive elements
  * (g = element / group_elems); `out` (fp32) and / or `out_bf16` receive the result.  DDPMScheduler.add_noise / get_velocity
  * with one timestep per (sample, frame, view) (src/dwm/schedulers/temporal_independent.py:8-45). */

@@ -95,6 +95,43 @@ class PatchEmbed(nn.Module):
         return ops.gemm(cols, wp, _bf(self.proj.bias), epilogue=EPI_RESID, res=self.cropped(h, w), res_mod=h * w)
 
 
+class RayEncoder(nn.Module):
+    """Explicit perspective modelling (crossview_temporal_dit.py:39-64): positional encodings of the camera origin (8 octaves)
+    and of the per-token view ray (4 octaves) -> Linear(72, D, bias=False).  State-dict key: `proj.weight`."""
+
+    def __init__(self, pos_octaves=8, pos_start_octave=0, ray_octaves=4, ray_start_octave=0, cond_proj_dim=72, in_channels=1536):
+        super().__init__()
+        if (pos_octaves, pos_start_octave, ray_octaves, ray_start_octave, cond_proj_dim) != (8, 0, 4, 0, 72):
+            raise NotImplementedError("RayEncoder: the reference's fixed octave layout (8 + 4 octaves from 0, 72 inputs)")
+        self.proj = nn.Linear(cond_proj_dim, in_channels, bias=False)
+
+    def packed(self) -> torch.Tensor:
+        """proj.weight with K zero-padded 72 -> 128 (GEMM K granularity)"""
+        from .blocks import STORE
+        w = self.proj.weight
+
+        def make():
+            wp = torch.zeros((w.shape[0], 128), dtype=bf16, device=w.device)
+            wp[:, :w.shape[1]] = _bf(w)
+            return wp
+        return STORE.derived(w, "k128", make)
+
+    @staticmethod
+    def camera_rows(camera_intrinsics_norm: torch.Tensor, camera2referego: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        """[I, 21] fp32 rows of dwm_ray_features: inverse token-resolution intrinsics (:441-449, get_rays :66-102),
+        camera -> reference-ego rotation, camera origin.  3x3 matrices per image: host-sized arithmetic."""
+        K = camera_intrinsics_norm.flatten(0, -3).to(torch.float32).clone()
+        K[:, 0, 0] *= width
+        K[:, 1, 1] *= height
+        K[:, 0, 2] *= width
+        K[:, 1, 2] *= height
+        M = camera2referego.flatten(0, -3).to(torch.float32)
+        return torch.cat([torch.inverse(K).reshape(-1, 9), M[:, :3, :3].reshape(-1, 9), M[:, :3, 3]], 1).contiguous()
+
+    def features(self, camera_intrinsics_norm, camera2referego, height: int, width: int) -> torch.Tensor:
+        return ops.ray_features(self.camera_rows(camera_intrinsics_norm, camera2referego, height, width), height, width, 128)
+
+
 class DiTCrossviewTemporalConditionModel(_Base):
     def __init__(
         self,
@@ -134,8 +171,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
             raise NotImplementedError("mask_module (MaskGWM) is training-only and out of scope (SURVEY.md §2)")
         if mixer_type != "AlphaBlender":
             raise NotImplementedError("only mixer_type='AlphaBlender' (every shipped config) is supported")
-        if perspective_modeling_type not in ("", "implicit"):
-            raise NotImplementedError("perspective_modeling_type='explicit' (UniMLVG RayEncoder) is not built yet")
+        if perspective_modeling_type not in ("", "implicit", "explicit"):
+            raise NotImplementedError(f"perspective_modeling_type={perspective_modeling_type!r}")
         if attention_head_dim != 64:
             raise NotImplementedError("the attention kernel is built for head_dim 64 (SD 3 / 3.5)")
 
@@ -178,6 +215,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
         self.perspective_modeling_type = perspective_modeling_type
         if perspective_modeling_type == "implicit":
             self.view_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, inner_dim)
+        elif perspective_modeling_type == "explicit":
+            self.rayencoder = RayEncoder(cond_proj_dim=72, in_channels=inner_dim)                  # :156-159
 
         self.enable_crossview = enable_crossview
         self.crossview_attention_type = crossview_attention_type
@@ -328,9 +367,19 @@ class DiTCrossviewTemporalConditionModel(_Base):
         silu_temb = ops.silu(temb)
 
         view_cam_emb = None
+        ray_feat = None
         if self.perspective_modeling_type == "implicit":
             ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256).view(I, -1)
             view_cam_emb = self.view_embedding.run(ve)                                 # [I, D]
+        elif self.perspective_modeling_type == "explicit":
+            # per-TOKEN embedding raymap[I*N, D] (:440-458).  Kept as its 72 (padded 128) input features: every VT block
+            # builds `index embedding + raymap` in ONE small GEMM (K = 128) whose residual is the per-image index
+            # embedding, instead of holding a 264 MB raymap and adding it in a separate pass
+            if camera_intrinsics_norm is None or camera2referego is None:
+                raise RuntimeError("perspective_modeling_type='explicit' needs camera_intrinsics_norm and camera2referego")
+            if fs is not None:
+                raise NotImplementedError("explicit perspective modelling with frame sharding")
+            ray_feat = self.rayencoder.features(camera_intrinsics_norm, camera2referego, height, width)
 
         if self.enable_crossview and disable_crossview is None:
             disable_crossview = torch.zeros(B, dtype=torch.bool, device=sample.device)
@@ -366,13 +415,17 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 if use_cam and fs is not None and cam_all is None:
                     cam_all = fs.gather_frames(view_cam_emb.view(B, T, V, D), 1).view(-1, D)
                 seq_emb = self.time_pos_embeds[k].run(seq, res=(view_cam_emb if fs is None else cam_all) if use_cam else None)
+                rpe = N
+                if ray_feat is not None and self.enable_crossview and not self.disable_view_emb_on_temporal_module:
+                    seq_emb = ops.gemm(ray_feat, self.rayencoder.packed(), None, epilogue=ops.EPI_RESID, res=seq_emb, res_mod=-N)
+                    rpe = 1
                 tt = self.temporal_attention_type
                 mk = ops.rowmap_temporal_full if tt == "full" else \
                     ops.rowmap_temporal_rowwise if tt == "rowwise" else ops.rowmap_temporal_pointwise
                 alpha = self.time_mixers[k].get_alpha(disable_temporal, B)
                 if fs is None:
                     self.temporal_transformer_blocks[k].run(
-                        h, mk(B, T, V, height, width), emb=seq_emb, rows_per_emb=N,
+                        h, mk(B, T, V, height, width), emb=seq_emb, rows_per_emb=rpe,
                         blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
                 else:
                     # frames of this sample live on other ranks: all frames of MY token rows, block + mixer, and back
@@ -388,6 +441,10 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 idx = torch.arange(V, device=h.device).view(1, 1, V).expand(B, T, V)
                 ve = ops.timestep_sinusoid(idx, D)
                 view_emb = self.view_pos_embeds[k].run(ve, res=view_cam_emb)
+                rpe = N
+                if ray_feat is not None:
+                    view_emb = ops.gemm(ray_feat, self.rayencoder.packed(), None, epilogue=ops.EPI_RESID, res=view_emb, res_mod=-N)
+                    rpe = 1
                 ct = self.crossview_attention_type
                 gmask = dmask = None
                 if ct == "rowwise":
@@ -400,7 +457,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
                     raise NotImplementedError(f"Not support {ct}")
                 alpha = self.view_mixers[k].get_alpha(disable_crossview, B)
                 self.crossview_transformer_blocks[k].run(
-                    h, rm, emb=view_emb, rows_per_emb=N, group_mask=gmask, dense_mask=dmask,
+                    h, rm, emb=view_emb, rows_per_emb=rpe, group_mask=gmask, dense_mask=dmask,
                     blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
 
         # norm_out (AdaLayerNormContinuous: scale first) + proj_out + unpatchify

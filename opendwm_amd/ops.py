@@ -577,6 +577,15 @@ def cfg_multistep(pred: torch.Tensor, latents: torch.Tensor, x0_prev: torch.Tens
                "dwm_cfg_multistep")
 
 
+def ray_features(cam: torch.Tensor, h: int, w: int, ldo: int = 128) -> torch.Tensor:
+    """cam fp32 [I, 21] (see dwm_ray_features) -> bf16 [I*h*w, ldo]: RayEncoder's 72 positional-encoding inputs per token."""
+    if cam.dtype != torch.float32 or cam.dim() != 2 or cam.shape[1] != 21 or not cam.is_contiguous() or not cam.is_cuda:
+        raise RuntimeError("ray_features: cam must be a contiguous fp32 device tensor [I, 21]")
+    out = torch.empty((cam.shape[0] * h * w, ldo), dtype=bf16, device=cam.device)
+    _lib.check(_lib.load().dwm_ray_features(cam.data_ptr(), cam.shape[0], h, w, out.data_ptr(), ldo, _stream()), "dwm_ray_features")
+    return out
+
+
 def frame_affine(x: torch.Tensor, y: torch.Tensor, coef: torch.Tensor, group_elems: int, out: Optional[torch.Tensor] = None,
                  out_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = coef[g, 0] * x + coef[g, 1] * y (fp32), g = element // group_elems; see dwm_frame_affine."""

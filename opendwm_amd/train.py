@@ -696,6 +696,9 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
     st = SiluFn.apply(temb)
 
     view_cam_emb = None
+    if model.perspective_modeling_type == "explicit":
+        raise NotImplementedError("training with perspective_modeling_type='explicit' (RayEncoder weight gradient) is not built; "
+                                  "the inference forward is (DiTCrossviewTemporalConditionModel.eval())")
     if model.perspective_modeling_type == "implicit":
         ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256).view(I, -1)
         view_cam_emb = mlp_train(model.view_embedding, ve)

@@ -388,6 +388,51 @@ def image_adapter(sd: SD, cfg: dict, x: Tensor, prefix: str = "condition_image_a
 # the model forward
 # --------------------------------------------------------------------------
 
+def positional_encoding(coords: Tensor, num_octaves: int, start_octave: int = 0) -> Tensor:
+    """``PositionalEncoding.forward`` (crossview_temporal_dit.py:11-36): coords [B, P, dim] ->
+    [B, P, 2 * dim * num_octaves] = cat(sin, cos) of coords * 2^k * pi, laid out dim-major."""
+    Bn, P, dim = coords.shape
+    mult = 2.0 ** torch.arange(start_octave, start_octave + num_octaves).float().to(coords) * math.pi
+    sc = coords.unsqueeze(-1) * mult.view(1, 1, 1, -1)
+    return torch.cat((torch.sin(sc).reshape(Bn, P, dim * num_octaves), torch.cos(sc).reshape(Bn, P, dim * num_octaves)), -1)
+
+
+def ray_encoder(sd: SD, pos: Tensor, rays: Tensor, prefix: str = "rayencoder") -> Tensor:
+    """``RayEncoder.forward`` (crossview_temporal_dit.py:39-64; pos 8 octaves, rays 4 octaves, proj 72 -> D, no bias):
+    pos [I, 3], rays [I, h, w, 3] -> [I, h, w, D]."""
+    I, hh, ww, _ = rays.shape
+    pe = positional_encoding(pos.unsqueeze(1), 8).view(I, 1, 1, -1).repeat(1, hh, ww, 1)
+    re = positional_encoding(rays.flatten(1, 2), 4).view(I, hh, ww, -1)
+    return F.linear(torch.cat((pe, re), -1), sd[prefix + ".proj.weight"])
+
+
+def get_rays(camera_intrinsics: Tensor, camera_transforms: Tensor, target_size) -> tuple:
+    """``get_rays`` (crossview_temporal_dit.py:66-102): intrinsics [I,3,3], cam2world [I,4,4] ->
+    (rays_o [I,3], unit rays_d [I,H,W,3]) through the pixel centres of an H x W grid."""
+    dtype = camera_transforms.dtype
+    ct, ci = camera_transforms.float(), camera_intrinsics.float()
+    Hh, Ww = (target_size, target_size) if isinstance(target_size, int) else target_size
+    dev = ct.device
+    xs = torch.arange(Ww, device=dev).float().repeat(Hh) + 0.5          # x fastest (the transposed meshgrid of :84-88)
+    ys = torch.arange(Hh, device=dev).float().repeat_interleave(Ww) + 0.5
+    pts = torch.stack([xs, ys, torch.ones_like(xs)])                    # [3, H*W]
+    d = ct[:, :3, :3] @ (torch.inverse(ci) @ pts.unsqueeze(0))
+    d = d / torch.norm(d, dim=1, keepdim=True)
+    return ct[:, :3, 3].to(dtype), d.transpose(1, 2).reshape(-1, Hh, Ww, 3).to(dtype)
+
+
+def explicit_view_embedding(sd: SD, camera_intrinsics_norm: Tensor, camera2referego: Tensor, height: int, width: int) -> Tensor:
+    """the 'explicit' branch of the forward (crossview_temporal_dit.py:440-458): normalised intrinsics scaled to the token
+    grid, rays in the reference ego frame, RayEncoder -> per-token embedding [I, h*w, D]."""
+    K = camera_intrinsics_norm.clone()
+    K[..., 0, 0] = K[..., 0, 0] * width
+    K[..., 1, 1] = K[..., 1, 1] * height
+    K[..., 0, 2] = K[..., 0, 2] * width
+    K[..., 1, 2] = K[..., 1, 2] * height
+    ro, rd = get_rays(K.flatten(0, 2), camera2referego.flatten(0, 2), (height, width))
+    return ray_encoder(sd, ro, rd).flatten(1, 2)
+
+
 def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
                 encoder_hidden_states: Tensor, pooled_projections: Tensor,
                 disable_crossview: Optional[Tensor] = None,
@@ -395,7 +440,9 @@ def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
                 crossview_attention_mask: Optional[Tensor] = None,
                 added_time_ids: Optional[Tensor] = None,
                 condition_image_tensor: Optional[Tensor] = None,
-                trace: Optional[dict] = None) -> Tensor:
+                trace: Optional[dict] = None,
+                camera_intrinsics_norm: Optional[Tensor] = None,
+                camera2referego: Optional[Tensor] = None) -> Tensor:
     """``DiTCrossviewTemporalConditionModel.forward`` (crossview_temporal_dit.py:372-630)
     for 6-D inputs, implicit / no perspective modelling, no image adapter and no
     mask module (the configuration of examples/ctsd_35_6views_video_generation.json).
@@ -419,6 +466,8 @@ def dit_forward(sd: SD, cfg: dict, sample: Tensor, timestep: Tensor,
     if cfg.get("perspective_modeling_type", "") == "implicit":
         ve = timesteps_sinusoid(added_time_ids.flatten(), 256).to(h.dtype)
         view_cam_emb = timestep_embedding_mlp(sd, "view_embedding", ve.view(B * T * V, -1)).unsqueeze(1)
+    elif cfg.get("perspective_modeling_type", "") == "explicit":                 # :440-458, per-token embedding [I, N, D]
+        view_cam_emb = explicit_view_embedding(sd, camera_intrinsics_norm, camera2referego, height, width).to(h.dtype)
 
     condition_residuals = None
     if cfg.get("condition_image_adapter_config") is not None and condition_image_tensor is not None:
@@ -785,6 +834,8 @@ def param_shapes(cfg: dict) -> Dict[str, tuple]:
     if cfg.get("perspective_modeling_type", "") == "implicit":
         lin("view_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], D)
         lin("view_embedding.linear_2", D, D)
+    elif cfg.get("perspective_modeling_type", "") == "explicit":
+        S["rayencoder.proj.weight"] = (D, 72)                      # RayEncoder(cond_proj_dim=72), crossview_temporal_dit.py:156-159
 
     ac = cfg.get("condition_image_adapter_config")
     if ac is not None:
@@ -896,6 +947,36 @@ def make_inputs(cfg: dict, B: int, T: int, V: int, H: int, W: int, seed: int = 0
         crossview_attention_mask=ring_crossview_mask(B, V),
         added_time_ids=torch.rand(B, T, V, n_time_ids, generator=g) * 2 - 1,
     )
+
+
+def make_camera_inputs(B: int, T: int, V: int, seed: int = 0) -> dict:
+    """synthetic `camera_intrinsics_norm` [B,T,V,3,3] (pinhole intrinsics divided by the image size, as get_conditions
+    builds them) and `camera2referego` [B,T,V,4,4] (a ring of cameras yawed 360/V degrees apart with a small pitch, 1-2 m
+    off the ego origin, the ego advancing a little per frame) for the explicit perspective modelling"""
+    g = torch.Generator().manual_seed(seed + 4242)
+    K = torch.zeros(B, T, V, 3, 3)
+    K[..., 0, 0] = 0.75 + 0.1 * torch.rand(B, T, V, generator=g)
+    K[..., 1, 1] = 1.30 + 0.1 * torch.rand(B, T, V, generator=g)
+    K[..., 0, 2] = 0.5 + 0.02 * torch.randn(B, T, V, generator=g)
+    K[..., 1, 2] = 0.5 + 0.02 * torch.randn(B, T, V, generator=g)
+    K[..., 2, 2] = 1.0
+    M = torch.zeros(B, T, V, 4, 4)
+    for v in range(V):
+        yaw = torch.full((B, T), 2 * math.pi * v / max(V, 1)) + 0.05 * torch.randn(B, T, generator=g)
+        pitch = 0.03 * torch.randn(B, T, generator=g)
+        cy, sy, cp, sp = torch.cos(yaw), torch.sin(yaw), torch.cos(pitch), torch.sin(pitch)
+        Rz = torch.stack([torch.stack([cy, -sy, torch.zeros_like(cy)], -1), torch.stack([sy, cy, torch.zeros_like(cy)], -1),
+                          torch.stack([torch.zeros_like(cy), torch.zeros_like(cy), torch.ones_like(cy)], -1)], -2)
+        Ry = torch.stack([torch.stack([cp, torch.zeros_like(cp), sp], -1), torch.stack([torch.zeros_like(cp), torch.ones_like(cp), torch.zeros_like(cp)], -1),
+                          torch.stack([-sp, torch.zeros_like(cp), cp], -1)], -2)
+        # camera axes (x right, y down, z forward) into the ego frame (x forward, y left, z up)
+        C2E = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+        M[:, :, v, :3, :3] = Rz @ Ry @ C2E
+        M[:, :, v, 0, 3] = 1.5 * torch.cos(yaw) + 0.4 * torch.arange(T).float().view(1, T)
+        M[:, :, v, 1, 3] = 0.8 * torch.sin(yaw)
+        M[:, :, v, 2, 3] = 1.5 + 0.05 * torch.randn(B, T, generator=g)
+    M[..., 3, 3] = 1.0
+    return dict(camera_intrinsics_norm=K, camera2referego=M)
 
 
 def flops_per_forward(cfg: dict, B: int, T: int, V: int, H: int, W: int, text_len: int = 154) -> dict:

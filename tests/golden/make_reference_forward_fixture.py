@@ -147,6 +147,29 @@ def main():
         res, _, _ = RefDiT.forward(m, **five)
         print("5-D vs oracle on the V = 1 6-D input:", float((res[0] - O.dit_forward(sd, cfg, **inp)).abs().max()), list(res[0].shape))
         out["five_dim"] = dict(output=res[0].clone())
+        # explicit perspective modelling (:440-458): the REAL get_rays and RayEncoder.forward (pure torch) inside the REAL forward
+        from dwm.models.crossview_temporal_dit import RayEncoder as RefRayEncoder, get_rays as ref_get_rays
+        cfg = small_config(perspective_modeling_type="explicit")
+        sd = O.make_state_dict(cfg, 0)
+        inp = small_inputs(cfg, 0)
+        inp.pop("added_time_ids")
+        cams = O.make_camera_inputs(2, 3, 3, seed=0)
+        inp.update(cams)
+        m = build(RefDiT, VTSelfAttentionBlock, AlphaBlender, cfg, sd)
+        D = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+        m.rayencoder = RefRayEncoder(cond_proj_dim=72, in_channels=D)
+        m.rayencoder.proj.weight.data.copy_(sd["rayencoder.proj.weight"])
+        res, _, _ = RefDiT.forward(m, **inp)
+        print("explicit: reference forward vs oracle forward: max abs diff", float((res[0] - O.dit_forward(sd, cfg, **inp)).abs().max()))
+        hh, ww = inp["sample"].shape[-2] // 2, inp["sample"].shape[-1] // 2
+        K = cams["camera_intrinsics_norm"].clone()
+        K[..., 0, 0] *= ww
+        K[..., 1, 1] *= hh
+        K[..., 0, 2] *= ww
+        K[..., 1, 2] *= hh
+        ro, rd = ref_get_rays(K.flatten(0, 2), cams["camera2referego"].flatten(0, 2), (hh, ww))
+        out["explicit"] = dict(output=res[0].clone(), rays_o=ro.clone(), rays_d=rd.clone(),
+                               raymap=m.rayencoder(ro, rd).clone(), **cams)
     torch.save(out, os.path.join(HERE, "reference_forward.pt"))
     print("wrote reference_forward.pt", {k: list(v["output"].shape) for k, v in out.items()})
 

@@ -1014,3 +1014,36 @@ def test_schedulers_vs_reference_fixture(dev):
                     model_in=model_in)
     assert (got - want).abs().max().item() < 1e-5
     assert torch.equal(model_in[0], got.to(bf16)) and torch.equal(model_in[1], got.to(bf16))
+
+
+# ---------------------------------------------------------------- explicit perspective modelling (RayEncoder / get_rays)
+def test_explicit_perspective_forward_vs_oracle_and_reference_fixture(dev):
+    """perspective_modeling_type="explicit" (examples/ctsd_unimlvg_6views_video_generation.json, configs/ctsd/unimlvg/*;
+    crossview_temporal_dit.py:11-102, 156-159, 440-458): the ray-feature kernel against the oracle's positional encodings of
+    the executed reference rays, and the whole forward against the oracle (bf16-rounded weights) and against the vector of
+    the executed reference forward (fp32 weights)."""
+    fx = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))["explicit"]
+    cfg = small_config(perspective_modeling_type="explicit")
+    sd32 = O.make_state_dict(cfg, 0)
+    sd = _bf16_round_sd(sd32)
+    m = _hip_model(cfg, sd, dev)
+    inp = small_inputs(cfg, 0)
+    inp.pop("added_time_ids")
+    cams = {k: fx[k] for k in ("camera_intrinsics_norm", "camera2referego")}
+    hh, ww = inp["sample"].shape[-2] // 2, inp["sample"].shape[-1] // 2
+    feat = m.rayencoder.features(cams["camera_intrinsics_norm"].to(dev), cams["camera2referego"].to(dev), hh, ww)
+    I = fx["rays_o"].shape[0]
+    want = torch.cat([O.positional_encoding(fx["rays_o"].unsqueeze(1), 8).view(I, 1, 1, -1).repeat(1, hh, ww, 1),
+                      O.positional_encoding(fx["rays_d"].flatten(1, 2), 4).view(I, hh, ww, -1)], -1).view(I * hh * ww, 72)
+    e_feat = (feat[:, :72].float().cpu() - want).abs().max().item()
+    assert feat.shape == (I * hh * ww, 128) and torch.count_nonzero(feat[:, 72:]) == 0
+    ref = O.dit_forward(sd, cfg, **inp, **cams)
+    di = to_dev({**inp, **cams}, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e, efx = rel_err(out[0], ref), rel_err(out[0], fx["output"])
+    _log("explicit_perspective", feature_max_abs=e_feat, rel_vs_oracle=e, rel_vs_reference_forward=efx)
+    assert e_feat < 5e-3           # bf16 features of sin / cos in [-1, 1]: 2^-9 rounding + fp32 argument reduction at 128 pi |o|
+    assert e < TOL_MODEL and efx < TOL_MODEL
+    with pytest.raises(RuntimeError):
+        di = to_dev(inp, dev)
+        m(di.pop("sample"), di.pop("timestep"), **di)                     # camera matrices are required in this mode

@@ -287,6 +287,42 @@ def test_oracle_forward_composition_equals_reference_forward(tt):
     assert torch.allclose(out, fxf[tt]["output"], atol=1e-6)
 
 
+def test_oracle_explicit_perspective_equals_reference():
+    """explicit perspective modelling (crossview_temporal_dit.py:11-102, 440-458): oracle.get_rays / ray_encoder and the whole
+    oracle forward against the REAL get_rays, RayEncoder.forward and model forward (pure-torch reference code, executed)"""
+    from tests.common import small_config, small_inputs
+    fx = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))["explicit"]
+    cfg = small_config(perspective_modeling_type="explicit")
+    sd = O.make_state_dict(cfg, 0)
+    assert "rayencoder.proj.weight" in sd and "view_embedding.linear_1.weight" not in sd
+    inp = small_inputs(cfg, 0)
+    inp.pop("added_time_ids")
+    cams = O.make_camera_inputs(2, 3, 3, seed=0)
+    assert torch.equal(cams["camera2referego"], fx["camera2referego"])
+    hh, ww = inp["sample"].shape[-2] // 2, inp["sample"].shape[-1] // 2
+    K = cams["camera_intrinsics_norm"].clone()
+    K[..., 0, 0] *= ww
+    K[..., 1, 1] *= hh
+    K[..., 0, 2] *= ww
+    K[..., 1, 2] *= hh
+    ro, rd = O.get_rays(K.flatten(0, 2), cams["camera2referego"].flatten(0, 2), (hh, ww))
+    assert torch.allclose(ro, fx["rays_o"], atol=1e-6) and torch.allclose(rd, fx["rays_d"], atol=1e-6)
+    assert torch.allclose(O.ray_encoder(sd, ro, rd), fx["raymap"], atol=1e-5)
+    out = O.dit_forward(sd, cfg, **inp, **cams)
+    assert (out - fx["output"]).abs().max().item() < 1e-5
+    # the product's host half: the 21 camera scalars per image handed to dwm_ray_features reproduce the rays
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel, RayEncoder
+    rows = RayEncoder.camera_rows(cams["camera_intrinsics_norm"], cams["camera2referego"], hh, ww)
+    I = rows.shape[0]
+    ys, xs = torch.meshgrid(torch.arange(hh).float() + 0.5, torch.arange(ww).float() + 0.5, indexing="ij")
+    pts = torch.stack([xs, ys, torch.ones_like(xs)], -1).view(1, hh * ww, 3, 1)
+    d = (rows[:, 9:18].view(I, 1, 3, 3) @ (rows[:, :9].view(I, 1, 3, 3) @ pts)).squeeze(-1)
+    d = d / d.norm(dim=-1, keepdim=True)
+    assert torch.allclose(d.view(I, hh, ww, 3), fx["rays_d"], atol=1e-5) and torch.allclose(rows[:, 18:], fx["rays_o"], atol=1e-6)
+    m = DiTCrossviewTemporalConditionModel(**cfg)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+
+
 def test_reference_keeps_the_view_axis_for_5d_inputs():
     """`result = [output]` is built before the squeeze (crossview_temporal_dit.py:620-630): 5-D inputs come back 6-D in the
     tuple form; the product mirrors that (opendwm_amd/dit.py) - checked on the GPU in test_hip_gpu.py"""
