@@ -118,6 +118,7 @@ class KernelTimer:
     def __init__(self):
         self.records = []           # (kind, flops, start_event, end_event)
         self.small_bytes = 0.0      # algorithmic bytes of the short-sequence (packed kernel) attention launches
+        self.group_bytes = 0.0      # the same for the group-masked (cross-view) launches
         self.shapes = []            # per GEMM record: (M, N, K, epilogue, implicit conv)
         self.enabled = False
 
@@ -152,9 +153,14 @@ class KernelTimer:
             L = rowmap.L0 + (kw["q1"].shape[0] // rowmap.n_problems if kw.get("q1") is not None else 0)
             fl = 4.0 * rowmap.n_problems * heads * L * L * 64
             small = L <= 32 and kw.get("q1") is None and kw.get("group_mask") is None and kw.get("dense_mask") is None
-            timer.records.append(("attn_small" if small else "attn", fl, s, e))
+            # attn_group_kernel: group-masked problems of G whole groups of 8..32 tokens (row-wise cross-view attention)
+            grouped = (kw.get("group_mask") is not None and kw.get("q1") is None and kw.get("lse") is None and
+                       8 <= rowmap.group_size <= 32 and kw["group_mask"].shape[-1] * rowmap.group_size == L)
+            timer.records.append(("attn_small" if small else "attn_group" if grouped else "attn", fl, s, e))
             if small:           # attn_small_kernel is HBM-bound: q, k, v read + o written once
                 timer.small_bytes += 4.0 * rowmap.n_problems * L * heads * 64 * 2
+            if grouped:
+                timer.group_bytes += 4.0 * rowmap.n_problems * L * heads * 64 * 2
 
         ops.gemm, ops.attention = gemm, attention
         import opendwm_amd.blocks as blocks
@@ -182,7 +188,7 @@ class KernelTimer:
 
     def summary(self):
         out = {}
-        for kind in ("gemm", "attn", "attn_small"):
+        for kind in ("gemm", "attn", "attn_small", "attn_group"):
             rs = [(f, s.elapsed_time(e)) for k, f, s, e in self.records if k == kind]
             if rs:
                 fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
@@ -574,7 +580,7 @@ def main():
             for row in timer.shape_table():
                 print(json.dumps(row), file=sys.stderr)
         step_ms = 1e3 * dt / args.steps
-        gm, at, asm = ks.get("gemm", {}), ks.get("attn", {}), ks.get("attn_small", {})
+        gm, at, asm, agr = ks.get("gemm", {}), ks.get("attn", {}), ks.get("attn_small", {}), ks.get("attn_group", {})
         line = {
             "metric": "denoise-steps/sec (6-view x16f 448x256), SD-3.5 CTSD",
             "value": n_samples * args.steps / dt, "unit": "denoise-steps/s", "n_gpus": world,
@@ -599,13 +605,20 @@ def main():
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
-            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel (joint, dual, cross-view, row-wise temporal)",
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel (joint L=602, dual L=448, row-wise temporal L=448)",
                                    "achieved": at.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
                                    "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms,
-                                   "all_attention_launches_tflops": ((at.get("flops") or 0.0) + (asm.get("flops") or 0.0)) /
-                                   max((at.get("ms") or 0.0) + (asm.get("ms") or 0.0), 1e-9) / 1e9},
+                                   "all_attention_launches_tflops": ((at.get("flops") or 0.0) + (asm.get("flops") or 0.0) + (agr.get("flops") or 0.0)) /
+                                   max((at.get("ms") or 0.0) + (asm.get("ms") or 0.0) + (agr.get("ms") or 0.0), 1e-9) / 1e9},
+            "roofline_attention_crossview": None if not agr else {
+                "bound": "hbm", "kernel": "attn_group_kernel (row-wise cross-view attention, ring view mask: one wave per query view, "
+                                          "allowed key views only)",
+                "achieved": timer.group_bytes / (agr["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": timer.group_bytes / (agr["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                "algorithmic_bytes_per_launch": timer.group_bytes / agr["launches"], "launches": agr["launches"],
+                "avg_launch_us": agr["avg_us"], "nominal_tflops": agr["tflops"], "share_of_step_time": (agr["ms"] / args.steps) / step_ms},
             "roofline_attention_pointwise": None if not asm else {
                 "bound": "hbm", "kernel": "attn_small_kernel (point-wise temporal attention, L = frames)",
                 "achieved": timer.small_bytes / (asm["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",

@@ -523,6 +523,162 @@ attn_small_kernel(const AttnParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Group-masked attention over short groups: the row-wise cross-view attention (crossview_temporal_dit.py:300-327; every
+// problem = one latent row of one frame, L = views x row width, the [B, V, V] view mask expanded to tokens).  When a
+// problem is exactly G groups of <= 32 tokens (L = G * group_size), the mask is block structured at the granularity of one
+// MFMA tile: a wave owns the queries of ONE group (query-per-lane, as above) and visits only the key groups its mask row
+// allows - the ring mask of the 6-camera rigs allows 3 of 6, so half of the tiled kernel's score work is never issued and
+// no per-score mask arithmetic remains.  Structure of attn_small_kernel: no LDS ring, no barrier; Q and K fragments are
+// the lanes' own rows straight from global memory (a K / V row is read by the waves of the <= G query groups that see it:
+// L2 / L1 hits), V passes through 4 KiB of wave-private LDS for the transposing read, online softmax across the visited
+// groups, output rows returned through the same 4 KiB as whole 128-byte rows.  HBM-bound: q, k, v read + o written once
+// (1.06 GB at BASELINE config 3).
+__global__ void __launch_bounds__(256, 3)
+attn_group_kernel(const AttnParams P) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 4096];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    char* const sc = smem + wave * 4096;
+
+    // block -> (4 consecutive (problem, query group) units, head group); head group fastest
+    const uint32_t quad = fdiv(blockIdx.x, P.fd_heads);
+    const int hgrp = (int)(blockIdx.x - quad * P.fd_heads.d);
+    const uint32_t unit = quad * 4 + (uint32_t)wave;
+    const int G = P.mask_G, gs = P.group_size;
+    if (unit >= (uint32_t)P.n_problems * (uint32_t)G) return;     // wave-uniform; no block-level barrier below
+    const int prob = (int)fdiv(unit, P.fd_G);
+    const int gq = (int)(unit - (uint32_t)prob * (uint32_t)G);
+    const int hpb = P.hpb;
+    const int64_t hoff = (int64_t)hgrp * hpb * 64;
+    const int64_t base = seg0_base(P.rm, prob);
+
+    const bool qvalid = l31 < gs;
+    const int lclamp = qvalid ? l31 : gs - 1;
+    const int64_t qrow = seg0_row(P.rm, base, gq * gs + lclamp);
+    const bf16_t* const qp = P.q0 + qrow * P.ld0 + hoff + half * 8;
+    const int64_t orow = (int64_t)(P.o0 + qrow * P.ldo0 + hoff);
+
+    // the key groups this wave's queries may attend to (one mask row per (sample, query group): wave-uniform)
+    uint32_t bits = 0;
+    {
+        const uint8_t* mrow = P.mask + ((int64_t)fdiv((uint32_t)prob, P.fd_ppm) * G + gq) * G;
+        for (int g = 0; g < G; ++g) bits |= (mrow[g] ? 1u : 0u) << g;
+        bits = __builtin_amdgcn_readfirstlane(bits);
+    }
+    // keys this lane's 16 score registers stand for inside a group: (r & 3) + 8 (r >> 2) + 4 half; valid = key < gs
+    uint32_t kmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) + 4 * half < gs) kmask |= 1u << r;
+    // tr-read geometry of the V^T fragments (see attn_fwd_kernel)
+    const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+    int vra[2], vrb[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+        const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+        vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+    }
+    const int vswz = ((l31 >> 1) & 1) << 2;
+    char* const myrow = sc + l31 * 128;
+
+    for (int hh = 0; hh < hpb; ++hh) {
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(*(const bf16x8*)(qp + hh * 64 + ks * 16), P.scale_log2);
+        f32x16 ot[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;          // l_run: this lane's keys only; the partner's half is added at the end
+
+        for (uint32_t rem = bits; rem != 0; rem &= rem - 1) {
+            const int g = __builtin_ctz(rem);
+            const int64_t krow = seg0_row(P.rm, base, g * gs + lclamp);      // rows past the group's end: clamped, masked below
+            const bf16_t* const kp = P.k0 + krow * P.ld0 + hoff + hh * 64 + half * 8;
+            const bf16_t* const vp = P.v0 + krow * P.ld0 + hoff + hh * 64 + half * 8;
+            bf16x8 kf[4];
+            uint4 vv[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[ks] = *(const bf16x8*)(kp + ks * 16);
+                vv[ks] = *(const uint4*)(vp + ks * 16);
+            }
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) *(uint4*)(myrow + (((2 * ks + half) ^ vswz) << 4)) = vv[ks];
+
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!((kmask >> r) & 1u)) st[r] = -INFINITY;
+                mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // a group holds >= 1 valid key: finite
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 for the first group (m_run = -inf)
+            m_run = m_new;
+            float pv[16], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+                sum += pv[r];
+            }
+            l_run = l_run * alpha + sum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 pk = pack8(pv + 8 * s);
+                pf[s] = *reinterpret_cast<const bf16x8*>(&pk);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sc + vra[dt] + s * (16 * 128)));
+                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sc + vrb[dt] + s * (16 * 128)));
+                    const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], ot[dt], 0, 0, 0);
+                }
+        }
+        // normalise; transpose the 32 x 64 output tile through the wave's LDS (same-wave LDS ops complete in order)
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(l_tot);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ot[dt][rg * 4 + j] * inv;
+                *(uint2*)(myrow + (((dt * 4 + rg) ^ (l31 & 7)) << 4) + half * 8) = pack4(v);
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (lane >> 3), c = lane & 7;
+            const uint4 val = *(const uint4*)(sc + r * 128 + ((c ^ (r & 7)) << 4));
+            const int64_t rp = __shfl(orow, r, 64);
+            if (r < gs && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+        }
+    }
+}
+
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
 __global__ void __launch_bounds__(64)
@@ -593,6 +749,22 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         if (sl == 8) hipLaunchKernelGGL((attn_small_kernel<8>), dim3((unsigned)nblk), dim3(256), 0, s, P);
         else if (sl == 16) hipLaunchKernelGGL((attn_small_kernel<16>), dim3((unsigned)nblk), dim3(256), 0, s, P);
         else hipLaunchKernelGGL((attn_small_kernel<32>), dim3((unsigned)nblk), dim3(256), 0, s, P);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? DWM_OK : (int)e;
+    }
+    // group-masked problems made of G whole groups of <= 32 tokens (row-wise cross-view attention): one wave per query group,
+    // only the key groups its mask row allows; variant bit 5 keeps the tiled kernel (A/B measurements, tests)
+    if (P.mask_mode == 1 && P.L1 == 0 && P.lse == nullptr && P.group_size >= 8 && P.group_size <= 32 && (int64_t)P.mask_G * P.group_size == L &&
+        !((a->variant >> 5) & 1)) {
+        int hs = (a->variant >> 8) & 15;
+        if (hs == 0) { for (hs = 8; P.heads % hs != 0; --hs) {} }
+        if (P.heads % hs != 0) return DWM_EINVAL;
+        P.hpb = hs;
+        P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
+        const int64_t units = (int64_t)P.n_problems * P.mask_G;
+        const int64_t nblk = ((units + 3) / 4) * (P.heads / hs);
+        if (nblk >= (1ll << 31) || units >= (1ll << 31)) return DWM_EUNSUPPORTED;
+        hipLaunchKernelGGL(attn_group_kernel, dim3((unsigned)nblk), dim3(256), 0, s, P);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }

@@ -71,6 +71,28 @@ def bench_pointwise():
         print(json.dumps({"kernel": "attn-pointwise", "case": name, "ms": round(ms, 4), "GBps": round(gb / ms * 1e3, 1)}), flush=True)
 
 
+def bench_crossview():
+    """row-wise cross-view attention with the ring view mask (6 x 28 tokens per problem): group kernel (hs = heads per wave) vs
+    the tiled kernel (variant bit 5); GB/s of algorithmic q / k / v / o bytes"""
+    H, D = 24, 1536
+    B, T, V, h, w = 2, 16, 6, 16, 28
+    R = B * T * V * h * w
+    qkv = rnd(R, 3 * D)
+    out = torch.empty(R, D, device=dev, dtype=bf16)
+    rm = ops.rowmap_crossview_rowwise(B, T, V, h, w)
+    ring = torch.zeros(V, V, dtype=torch.bool)
+    for i in range(V):
+        for d in (-1, 0, 1):
+            ring[i, (i + d) % V] = True
+    mask = ring[None].repeat(B, 1, 1).to(dev)
+    gb = 4 * R * D * 2 / 1e9
+    timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, group_mask=mask), iters=300)
+    for name, var in (("group hs=8", 0), ("group hs=4", 4 << 8), ("group hs=12", 12 << 8), ("group hs=2", 2 << 8), ("group hs=24", 0),
+                      ("group hs=8 nostore", 16), ("tiled", 32), ("group hs=8", 0)):
+        ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, group_mask=mask, variant=var))
+        print(json.dumps({"kernel": "attn-crossview", "case": name, "ms": round(ms, 4), "GBps": round(gb / ms * 1e3, 1)}), flush=True)
+
+
 def bench_transpose():
     from opendwm_amd import train_ops as T
     for rows, cols in ((86016, 1536), (86016, 6144), (29568, 1536)):
@@ -125,12 +147,14 @@ def bench_ln():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["attn", "gemm", "ln"]
+    what = sys.argv[1:] or ["cv", "attn", "gemm", "ln"]
     print(torch.cuda.get_device_name(0))
     if "tr" in what:
         bench_transpose()
     if "pw" in what:
         bench_pointwise()
+    if "cv" in what:
+        bench_crossview()
     if "attn" in what:
         bench_attn([1])
     if "gemm" in what:
