@@ -437,6 +437,29 @@ int dwm_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_
 int dwm_cast_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols,
                          int32_t accumulate, void* stream);
 
+/* ------------------------------------------------------------------------
+ * fp32 accuracy path (BASELINE.json north_star: outputs "within 1e-3 rel fp32" of the reference's fp32 CPU path; the
+ * reference runs the same graph in whatever dtype the caller / autocast selects, src/dwm/pipelines/ctsd.py:1189-1193).
+ * Same argument structs and semantics as the bf16 entry points above with EVERY tensor pointer fp32 (masks stay bytes,
+ * alpha stays fp32).  Not a throughput path: exact-fp32 MFMA for the attention contractions, libm-accurate
+ * transcendental functions, and for the GEMM three bf16 MFMA products of a two-plane split of both operands.
+ * ---------------------------------------------------------------------- */
+/* C fp32 = epilogue(A fp32 [M, K] x W^T).  W: the PRE-SPLIT bf16 weight [N, 3K] = [ hi | lo | hi ] with hi = bf16(w),
+ * lo = bf16(w - hi) (opendwm_amd.ops.split_weight); bias / gate / res / blend / rms_w fp32.  workspace (16-byte aligned):
+ * at least 4*M*K + 4*M*N bytes (+ 256).  No implicit convolution (ntaps / a_map / c_map) in this mode. */
+int dwm_gemm_f32(const dwm_gemm_args* args, void* stream);
+int dwm_layernorm_f32(const dwm_layernorm_args* args, void* stream);
+/* strides in fp32 elements; head_dim 64; every mask / row-map / segment mode of dwm_attention_fwd; optional lse */
+int dwm_attention_f32(const dwm_attn_args* args, void* stream);
+int dwm_silu_f32(const float* x, float* y, int64_t n, void* stream);
+int dwm_timestep_sinusoid_f32(const float* t, int64_t n, int32_t C, float* out, void* stream);
+int dwm_patchify_f32(const float* x, int64_t I, int32_t C, int32_t H, int32_t W, int32_t p, float* out, int64_t ldo, void* stream);
+int dwm_unpatchify_f32(const float* x, int64_t ldx, int64_t I, int32_t C, int32_t h, int32_t w, int32_t p, float* out, void* stream);
+/* latents += dsigma * (u + g (c - u)) with pred = [uncond; cond] fp32; dsigma_group (or NULL): one step per group of
+ * group_elems elements (diffusion forcing); model_in (or NULL): fp32 [2n], the next CFG-doubled model input */
+int dwm_cfg_euler_step_f32(const float* pred, float* latents, float* model_in, int64_t n, float guidance, float dsigma,
+                           const float* dsigma_group, int64_t group_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

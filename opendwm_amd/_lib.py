@@ -114,6 +114,14 @@ SIGNATURES = {
     "dwm_cfg_euler_step": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
     "dwm_cfg_euler_step_grouped": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _i64, _vp]),
     "dwm_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_gemm_f32": (_i32, [C.POINTER(GemmArgs), _vp]),
+    "dwm_layernorm_f32": (_i32, [C.POINTER(LayerNormArgs), _vp]),
+    "dwm_attention_f32": (_i32, [C.POINTER(AttnArgs), _vp]),
+    "dwm_silu_f32": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_timestep_sinusoid_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dwm_patchify_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "dwm_unpatchify_f32": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dwm_cfg_euler_step_f32": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
     "dwm_ray_features": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "dwm_frame_affine": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "dwm_cfg_ddim_step": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _f32, _i32, _vp]),

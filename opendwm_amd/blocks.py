@@ -32,8 +32,39 @@ class ParamStore:
         self.step = 0
         self._shadow = {}       # id(param) -> (key, bf16 tensor)
         self._derived = {}      # (id(param), tag) -> (step, tensor)
+        self.precision = bf16   # compute dtype of the forward in flight: bf16, or torch.float32 (the accuracy path)
+
+    def set_precision(self, dtype: torch.dtype) -> None:
+        """bf16 (default) or fp32 compute copies; packed / derived tensors are per precision, so a switch rebuilds them"""
+        if dtype not in (bf16, torch.float32):
+            raise ValueError("compute dtype must be torch.bfloat16 or torch.float32")
+        self.precision = dtype
+
+    def cached(self, owner, make):
+        """packed tensors of a module (`make()` -> dict), one entry per compute precision, rebuilt after an optimizer step /
+        state-dict load (`bump`) or when `owner._pk` was reset to None"""
+        slot = getattr(owner, "_pk", None)
+        if not isinstance(slot, dict) or "_by_precision" not in slot:
+            slot = {"_by_precision": {}}
+            owner._pk = slot
+        hit = slot["_by_precision"].get(self.precision)
+        if hit is None or hit[0] != self.step:
+            hit = (self.step, make())
+            slot["_by_precision"][self.precision] = hit
+        return hit[1]
 
     def bf(self, t: torch.Tensor) -> torch.Tensor:
+        """the compute copy of a parameter: bf16, or fp32 while the fp32 accuracy path runs"""
+        if self.precision == torch.float32:
+            d = t.detach()
+            if d.dtype == torch.float32:
+                return d if d.is_contiguous() else d.contiguous()
+            key = (t.data_ptr(), t._version, tuple(t.shape), "f32")
+            hit = self._shadow.get(id(t))
+            if hit is None or hit[0] != key:
+                hit = (key, d.float().contiguous())
+                self._shadow[id(t)] = hit
+            return hit[1]
         if t.dtype == bf16:
             d = t.detach()
             return d if d.is_contiguous() else d.contiguous()
@@ -51,7 +82,7 @@ class ParamStore:
 
     def derived(self, t: torch.Tensor, tag: str, make):
         """cache of a tensor derived from parameter(s) (transpose, fused qkv, ...) valid for one optimizer step"""
-        k = (id(t), tag)
+        k = (id(t), tag, self.precision)
         hit = self._derived.get(k)
         if hit is None or hit[0] != (self.step, t.data_ptr(), t._version):
             hit = ((self.step, t.data_ptr(), t._version), make())
@@ -61,6 +92,7 @@ class ParamStore:
     def bump(self, keep_shadows: bool = False) -> None:
         self.step += 1
         self._derived.clear()
+        ops.clear_split_weights()           # operand planes of the fp32 path: keyed on tensors that are rebuilt now
         if not keep_shadows:
             self._shadow.clear()
 
@@ -137,7 +169,7 @@ class CombinedTimestepTextProjEmbeddings(nn.Module):
         self.text_embedder = TimestepEmbedding(pooled_projection_dim, embedding_dim)   # PixArtAlphaTextProjection: same keys
 
     def run(self, timestep: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
-        t_emb = self.timestep_embedder.run(ops.timestep_sinusoid(timestep, 256))
+        t_emb = self.timestep_embedder.run(ops.timestep_sinusoid(timestep, 256, dtype=STORE.precision))
         return self.text_embedder.run(pooled, res=t_emb)
 
 
@@ -181,8 +213,7 @@ class Attention(nn.Module):
         self._pk_step = -1
 
     def packed(self) -> dict:
-        if self._pk is None or self._pk_step != STORE.step:
-            self._pk_step = STORE.step
+        def make():
             def fuse(q, k, v):
                 w = torch.cat([_bf(q.weight), _bf(k.weight), _bf(v.weight)], 0).contiguous()
                 b = None if q.bias is None else torch.cat([_bf(q.bias), _bf(k.bias), _bf(v.bias)]).contiguous()
@@ -197,8 +228,8 @@ class Attention(nn.Module):
                 if self.has_qk_norm:
                     pk["rms_add"] = torch.cat([_bf(self.norm_added_q.weight).repeat(self.heads),
                                                _bf(self.norm_added_k.weight).repeat(self.heads)]).contiguous()
-            self._pk = pk
-        return self._pk
+            return pk
+        return STORE.cached(self, make)
 
     def project_qkv(self, x: torch.Tensor, added: bool = False) -> torch.Tensor:
         """x [rows, dim] -> fused [rows, 3*inner] with q,k RMS-normalised per head."""
@@ -333,14 +364,13 @@ class VTSelfAttentionBlock(nn.Module):
         self._pk_step = -1
 
     def packed(self) -> dict:
-        if self._pk is None or self._pk_step != STORE.step:
-            self._pk_step = STORE.step
+        def make():
             pk = {}
             for name, ff in (("ff_in", self.ff_in), ("ff", self.ff)):
                 pk[name + "_w"] = geglu_pack(_bf(ff.net[0].proj.weight))
                 pk[name + "_b"] = geglu_pack(_bf(ff.net[0].proj.bias))
-            self._pk = pk
-        return self._pk
+            return pk
+        return STORE.cached(self, make)
 
     def run(self, h: torch.Tensor, rowmap: ops.RowMap, *, emb: Optional[torch.Tensor] = None,
             rows_per_emb: int = 1, group_mask: Optional[torch.Tensor] = None,

@@ -498,7 +498,201 @@ splitk_finish_kernel(const dwm_gemm_args p, const ConvParams cp) {
     *(uint4*)((bf16_t*)p.C + mr * p.ldc + n) = pack8(v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 accuracy path (BASELINE north_star: "within 1e-3 rel fp32"): C = epi(A W^T) for fp32 A / W on the SAME bf16 MFMA main
+// loop.  Each fp32 operand is split into two bf16 planes x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits)
+// and the three leading products hi*hi + hi*lo + lo*hi are ONE GEMM over K' = 3K that accumulates in the fp32 MFMA
+// accumulators: the A side walks the planes [A_hi ; A_lo] as three "taps" (row shifts 0, 0, M - the implicit-GEMM tap
+// mechanism), the W side is the pre-split [W_hi | W_lo | W_hi] (N x 3K, packed once per weight).  The dropped lo*lo term and
+// the plane rounding are ~2^-16 relative per product.  The main loop leaves raw fp32 sums in the workspace (the split-K form);
+// f32_finish_kernel applies bias / activation / GEGLU / q-k RMSNorm / gate, residual, blend in fp32 with libm-accurate
+// functions and writes fp32.  Three times the MFMA work plus two extra passes over the output: an accuracy mode, not the
+// throughput path.
+__global__ void __launch_bounds__(256)
+split_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int64_t K, bf16_t* __restrict__ planes) {
+    const int64_t k8 = K >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * k8) return;
+    const int64_t m = i / k8, k = (i - m * k8) << 3;
+    const float4 a = *(const float4*)(x + m * ldx + k), b = *(const float4*)(x + m * ldx + k + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float hi[8], lo[8];
+    const uint4 ph = pack8(v);
+    unpack8(ph, hi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lo[j] = v[j] - hi[j];
+    *(uint4*)(planes + m * K + k) = ph;
+    *(uint4*)(planes + (M + m) * K + k) = pack8(lo);
+}
+
+DWM_DEVINL float act_f32(float x, int act) {
+    if (act == DWM_ACT_GELU_TANH) return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    if (act == DWM_ACT_SILU) return x / (1.f + expf(-x));
+    if (act == DWM_ACT_RELU) return fmaxf(x, 0.f);
+    return x;
+}
+
+// one thread per 8 OUTPUT columns; slices of a split-K run are summed in a fixed order
+template <int EPI>
+__global__ void __launch_bounds__(256)
+f32_finish_kernel(const dwm_gemm_args p, const ConvParams cp) {
+    constexpr bool kGeglu = EPI == DWM_EPI_GEGLU;
+    const int64_t Nout = kGeglu ? (p.N >> 1) : p.N;
+    const int64_t n8 = Nout >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < p.M * n8;
+    const int64_t m = live ? i / n8 : 0, n = live ? (i - m * n8) << 3 : 0;
+    // accumulator columns of this thread: GEGLU groups of 64 = [32 value | 32 gate]
+    const int64_t nv = kGeglu ? ((n >> 5) << 6) + (n & 31) : n;
+    auto load8 = [&](int64_t col, float* v) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        const float* w = cp.ws + m * p.N + col;
+        for (int s = 0; s < cp.ksplit; ++s) {
+            const float4 a = *(const float4*)(w + s * cp.ws_slice), b = *(const float4*)(w + s * cp.ws_slice + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        if (p.bias) {
+            const float* bp = (const float*)p.bias + col;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bp[j];
+        }
+    };
+    float v[8];
+    load8(nv, v);
+    if constexpr (kGeglu) {
+        float g[8];
+        load8(nv + 32, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= 0.5f * g[j] * (1.f + erff(g[j] * 0.7071067811865476f));      // exact-erf GELU
+    } else if constexpr (EPI == DWM_EPI_RMSHEAD) {
+        // per-head (64 columns = 8 neighbouring threads) RMSNorm of the q / k columns; N % 64 == 0 keeps a head inside a wave
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        if (n < p.rms_ncols) {
+            const float rinv = 1.f / sqrtf(ss * (1.f / 64.f) + p.rms_eps);
+            const float* rw = (const float*)p.rms_w + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * rinv * rw[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_f32(v[j], p.act);
+    }
+    if (!live) return;
+    const int64_t mr = map_row(cp.c, m);
+    if constexpr (EPI == DWM_EPI_RESID) {
+        if (p.gate) {
+            const float* t = (const float*)p.gate + (int64_t)fdiv((uint32_t)m, cp.fd_rpg) * p.ld_gate + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= t[j];
+        }
+        if (p.res) {
+            const int64_t rr = p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m, cp.fd_rmod) : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m, cp.fd_rmod) : mr;
+            const float* t = (const float*)p.res + rr * p.ld_res + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += t[j];
+        }
+        if (p.blend) {
+            const float* t = (const float*)p.blend + mr * p.ld_blend + n;
+            const float al = p.alpha[fdiv((uint32_t)m, cp.fd_rpa)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = al * t[j] + (1.f - al) * v[j];
+        }
+    }
+    float* o = (float*)p.C + mr * p.ldc + n;
+    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 }  // namespace
+
+extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
+    if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr || a->workspace == nullptr) return DWM_EINVAL;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 30) || a->N >= (1ll << 31)) return DWM_EINVAL;
+    if (a->K % BK != 0 || a->N % 8 != 0) return DWM_EUNSUPPORTED;
+    if (a->ntaps > 0 || a->a_map.rw > 0 || a->c_map.rw > 0) return DWM_EUNSUPPORTED;         // no implicit convolution in this mode
+    if (a->lda % 4 != 0 || a->ldc % 4 != 0 || !dwm_aligned16(a->A) || !dwm_aligned16(a->W) || !dwm_aligned16(a->C) ||
+        !dwm_aligned16(a->workspace)) return DWM_EALIGN;
+    const int64_t nout = a->epilogue == DWM_EPI_GEGLU ? a->N / 2 : a->N;
+    if (a->ldc < nout || a->lda < a->K) return DWM_EINVAL;
+    switch (a->epilogue) {
+        case DWM_EPI_PLAIN: break;
+        case DWM_EPI_GEGLU: if (a->N % 64 != 0) return DWM_EUNSUPPORTED; break;
+        case DWM_EPI_RESID:
+            if (a->gate && (a->rows_per_gate <= 0 || a->ld_gate % 4 != 0 || !dwm_aligned16(a->gate))) return DWM_EINVAL;
+            if (a->res && (a->ld_res % 4 != 0 || !dwm_aligned16(a->res))) return DWM_EALIGN;
+            if (a->blend && (a->alpha == nullptr || a->rows_per_alpha <= 0 || a->ld_blend % 4 != 0 || !dwm_aligned16(a->blend))) return DWM_EINVAL;
+            if (a->gate && a->blend) return DWM_EUNSUPPORTED;
+            break;
+        case DWM_EPI_RMSHEAD: if (a->rms_w == nullptr || a->rms_ncols % 64 != 0 || a->N % 64 != 0) return DWM_EINVAL; break;
+        default: return DWM_EINVAL;
+    }
+    if (a->rows_per_gate > (1ll << 30) || a->res_mod > (1ll << 30) || a->res_mod < -(1ll << 30) || a->rows_per_alpha > (1ll << 30)) return DWM_EINVAL;
+    // workspace: [A_hi ; A_lo] bf16 planes, then the fp32 partial sums
+    const int64_t plane_bytes = ((2 * a->M * a->K * 2 + 255) / 256) * 256;
+    const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
+    const int64_t tiles = (int64_t)ntm * ntn, nk = 3 * a->K / BK, slice_bytes = a->M * a->N * 4;
+    int ksplit = 1;
+    if (tiles <= 128 && nk >= 16) {
+        ksplit = (int)(256 / tiles);
+        if (ksplit > nk / 8) ksplit = (int)(nk / 8);
+        if (ksplit > 32) ksplit = 32;
+        if (ksplit < 1) ksplit = 1;
+    }
+    while (ksplit > 1 && plane_bytes + ksplit * slice_bytes > a->workspace_bytes) --ksplit;
+    if (plane_bytes + slice_bytes > a->workspace_bytes) return DWM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* planes = (bf16_t*)a->workspace;
+    {
+        const int64_t nthr = a->M * (a->K >> 3);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)a->A, a->lda, a->M,
+                           a->K, planes);
+    }
+    dwm_gemm_args g = *a;
+    g.A = planes; g.lda = a->K; g.K = 3 * a->K;
+    ConvParams cp;
+    cp.a.enabled = cp.c.enabled = 0;
+    cp.a.xstep = cp.c.xstep = 1;
+    cp.a.rw = cp.a.rh = cp.c.rw = cp.c.rh = make_fastdiv(1);
+    cp.a.rpitch = cp.a.ipitch = cp.a.origin = cp.c.rpitch = cp.c.ipitch = cp.c.origin = 0;
+    cp.steps_per_tap = (int)(a->K / BK);
+    cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
+    cp.fd_rpg = make_fastdiv((uint32_t)(a->rows_per_gate > 0 ? a->rows_per_gate : 1));
+    cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : a->res_mod < 0 ? -a->res_mod : 1));
+    cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
+    for (int t = 0; t < 27; ++t) cp.tap_shift[t] = 0;
+    cp.tap_shift[2] = a->M;                           // taps: A_hi (x W_hi), A_hi (x W_lo), A_lo (x W_hi)
+    cp.ksplit = ksplit;
+    cp.ws = (float*)((char*)a->workspace + plane_bytes);
+    cp.ws_slice = a->M * a->N;
+    hipError_t e;
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+    }
+    g.reserved = 0;
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI_SPLITK>, dim3((unsigned)(ntm * ntn * ksplit)), dim3(512), LDS_BYTES, s, g, cp, ntm, ntn);
+    const int64_t nthr = a->M * (nout >> 3);
+    const dim3 fg((unsigned)((nthr + 255) / 256));
+    switch (a->epilogue) {
+        case DWM_EPI_PLAIN: hipLaunchKernelGGL(f32_finish_kernel<DWM_EPI_PLAIN>, fg, dim3(256), 0, s, *a, cp); break;
+        case DWM_EPI_GEGLU: hipLaunchKernelGGL(f32_finish_kernel<DWM_EPI_GEGLU>, fg, dim3(256), 0, s, *a, cp); break;
+        case DWM_EPI_RESID: hipLaunchKernelGGL(f32_finish_kernel<DWM_EPI_RESID>, fg, dim3(256), 0, s, *a, cp); break;
+        default: hipLaunchKernelGGL(f32_finish_kernel<DWM_EPI_RMSHEAD>, fg, dim3(256), 0, s, *a, cp); break;
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}
 
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return DWM_EINVAL;

@@ -64,26 +64,30 @@ class PatchEmbed(nn.Module):
         self._wcache = {}
 
     def cropped(self, h: int, w: int) -> torch.Tensor:
-        key = (h, w, self.pos_embed.device, self.pos_embed.data_ptr())
+        from .blocks import STORE
+        cd = STORE.precision
+        key = (h, w, self.pos_embed.device, self.pos_embed.data_ptr(), cd)
         if key not in self._cache:
             m = self.pos_embed_max_size
             if h > m or w > m:
                 raise ValueError(f"Height/width ({h},{w}) exceed pos_embed_max_size {m}")
             top, left = (m - h) // 2, (m - w) // 2
             t = self.pos_embed.reshape(1, m, m, -1)[:, top:top + h, left:left + w, :]
-            self._cache = {key: t.reshape(h * w, -1).to(bf16).contiguous()}
+            self._cache = {kk: v for kk, v in self._cache.items() if kk[:4] == key[:4]}          # the other precision of this crop stays
+            self._cache[key] = t.reshape(h * w, -1).to(cd).contiguous()
         return self._cache[key]
 
     def packed_weight(self):
         from .blocks import STORE
-        key = (self.proj.weight.data_ptr(), self.proj.weight._version, STORE.step)
+        key = (self.proj.weight.data_ptr(), self.proj.weight._version, STORE.step, STORE.precision)
         if key not in self._wcache:
             w = self.proj.weight.detach().reshape(self.proj.weight.shape[0], -1)
             k = w.shape[1]
             kp = (k + 63) // 64 * 64
-            wp = torch.zeros((w.shape[0], kp), dtype=bf16, device=w.device)
+            wp = torch.zeros((w.shape[0], kp), dtype=STORE.precision, device=w.device)
             wp[:, :k] = w
-            self._wcache = {key: wp}
+            self._wcache = {kk: v for kk, v in self._wcache.items() if kk[:3] == key[:3]}      # drop stale steps, keep the other precision
+            self._wcache[key] = wp
         return self._wcache[key]
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
@@ -91,7 +95,7 @@ class PatchEmbed(nn.Module):
         p = self.patch_size
         h, w = x.shape[-2] // p, x.shape[-1] // p
         wp = self.packed_weight()
-        cols = ops.patchify(x, p, wp.shape[1])
+        cols = ops.patchify(x, p, wp.shape[1], dtype=wp.dtype)
         return ops.gemm(cols, wp, _bf(self.proj.bias), epilogue=EPI_RESID, res=self.cropped(h, w), res_mod=h * w)
 
 
@@ -212,6 +216,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
             self.condition_image_adapter = None
         self._adapter_cache = (None, None)
         self.frame_shard = None             # set by CTSDDenoiser(frame_group=...): opendwm_amd.sharding.FrameShard
+        self.compute_dtype = bf16           # torch.float32 selects the fp32 accuracy path of the inference forward
         self.perspective_modeling_type = perspective_modeling_type
         if perspective_modeling_type == "implicit":
             self.view_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, inner_dim)
@@ -304,7 +309,11 @@ class DiTCrossviewTemporalConditionModel(_Base):
             if kw.get("return_dict"):                       # crossview_temporal_dit.py:620-630: only the dict form is squeezed
                 return {"noise_pred": out.squeeze(2) if squeeze else out}
             return [out], None, None
-        return self._forward_infer(sample, timestep, *args, **kwargs)
+        from .blocks import STORE
+        try:
+            return self._forward_infer(sample, timestep, *args, **kwargs)
+        finally:
+            STORE.set_precision(bf16)       # the fp32 accuracy path is scoped to this forward (compute_dtype = torch.float32)
 
     @torch.no_grad()
     def _forward_infer(
@@ -352,11 +361,26 @@ class DiTCrossviewTemporalConditionModel(_Base):
         if fs is not None and self.enable_temporal:
             fs.check(height, self.temporal_attention_type)
 
+        # compute dtype: bf16 (storage bf16, fp32 accumulation / statistics), or - `model.compute_dtype = torch.float32` -
+        # the fp32 accuracy path (north_star's 1e-3 tolerance; the reference runs this graph in fp32 when no autocast /
+        # fp16 cast is configured, ctsd.py:1189-1193)
+        from .blocks import STORE
+        cd = self.compute_dtype
+        STORE.set_precision(cd)           # reset to bf16 by `forward` on the way out
+        if cd == torch.float32 and (fs is not None or (self.condition_image_adapter is not None and condition_image_tensor is not None)
+                                    or self.perspective_modeling_type == "explicit"):
+            raise NotImplementedError("the fp32 accuracy path covers the text-conditioned model (no ImageAdapter, no explicit "
+                                      "perspective modelling, no frame sharding)")
+
         def as_bf16(t):
+            if cd == torch.float32:
+                return t if t.dtype == torch.float32 else t.float()
             return t if t.dtype == bf16 else (ops.cast_bf16(t.contiguous()) if t.dtype == torch.float32 else t.to(bf16))
 
         x = sample.flatten(0, 2).contiguous()
-        if x.dtype not in (torch.float32, bf16):
+        if cd == torch.float32:
+            x = x.float()
+        elif x.dtype not in (torch.float32, bf16):
             x = x.to(bf16)
         h = self.pos_embed.run(x)                                                      # [I*N, D]
         ehs = as_bf16(encoder_hidden_states.flatten(0, 2))
@@ -369,7 +393,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
         view_cam_emb = None
         ray_feat = None
         if self.perspective_modeling_type == "implicit":
-            ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256).view(I, -1)
+            ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256, dtype=cd).view(I, -1)
             view_cam_emb = self.view_embedding.run(ve)                                 # [I, D]
         elif self.perspective_modeling_type == "explicit":
             # per-TOKEN embedding raymap[I*N, D] (:440-458).  Kept as its 72 (padded 128) input features: every VT block
@@ -409,7 +433,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
             if self.enable_temporal and i in self.temporal_block_layers:
                 k = self.temporal_block_layers.index(i)
                 idx = torch.arange(Tg, device=h.device).view(1, Tg, 1).expand(B, Tg, V)
-                seq = ops.timestep_sinusoid(idx, D)
+                seq = ops.timestep_sinusoid(idx, D, dtype=cd)
                 use_cam = self.enable_crossview and not self.disable_view_emb_on_temporal_module \
                     and view_cam_emb is not None
                 if use_cam and fs is not None and cam_all is None:
@@ -439,7 +463,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
             if self.enable_crossview and i in self.crossview_block_layers:
                 k = self.crossview_block_layers.index(i)
                 idx = torch.arange(V, device=h.device).view(1, 1, V).expand(B, T, V)
-                ve = ops.timestep_sinusoid(idx, D)
+                ve = ops.timestep_sinusoid(idx, D, dtype=cd)
                 view_emb = self.view_pos_embeds[k].run(ve, res=view_cam_emb)
                 rpe = N
                 if ray_feat is not None:

@@ -169,6 +169,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids.
     split_k: 0 = the kernel's rule (small tile grid + long K -> K ranges, fp32 partials, ordered reduction),
     1 = never, n > 1 = exactly n ranges."""
+    if a.dtype == torch.float32:            # the fp32 accuracy path (dwm_gemm_f32)
+        if a_grid is not None or c_grid is not None or conv3x3 or conv_taps is not None or stride2:
+            raise NotImplementedError("gemm: implicit convolutions are not part of the fp32 path")
+        return _gemm_f32(a, w, bias, out=out, epilogue=epilogue, act=act, gate=gate, rows_per_gate=rows_per_gate, res=res,
+                         res_mod=res_mod, blend=blend, alpha=alpha, rows_per_alpha=rows_per_alpha, rms_w=rms_w,
+                         rms_ncols=rms_ncols, rms_eps=rms_eps, rows=rows)
     _chk2d(a, "a")
     _chk2d(w, "w")
     if not w.is_contiguous():
@@ -237,6 +243,83 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
     return out
+
+
+_SPLIT_WEIGHTS: dict = {}
+
+
+def split_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [N, K] -> the pre-split bf16 operand [N, 3K] = [hi | lo | hi] of dwm_gemm_f32 (hi = bf16(w), lo = bf16(w - hi)).
+    Cached on the tensor's storage / version (weights and packed weights are long-lived); `clear_split_weights()` drops it."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _SPLIT_WEIGHTS.get(key)
+    if hit is None:
+        hi = w.to(bf16)
+        lo = (w - hi.float()).to(bf16)
+        hit = (torch.cat([hi, lo, hi], 1).contiguous(), w)          # keeps `w` alive: its address is the key
+        _SPLIT_WEIGHTS[key] = hit
+    return hit[0]
+
+
+def clear_split_weights() -> None:
+    _SPLIT_WEIGHTS.clear()
+
+
+def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_mod, blend, alpha, rows_per_alpha, rms_w, rms_ncols,
+              rms_eps, rows):
+    f32 = torch.float32
+    _chk2d(a, "a", f32)
+    _chk2d(w, "w", f32)
+    if not w.is_contiguous():
+        raise RuntimeError("w must be contiguous [N, K]")
+    N, K = w.shape
+    M = a.shape[0] if rows is None else rows
+    if a.shape[1] != K:
+        raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
+    nout = N // 2 if epilogue == EPI_GEGLU else N
+    if out is None:
+        out = torch.empty((M, nout), dtype=f32, device=a.device)
+    _chk2d(out, "out", f32)
+    if out.shape != (M, nout):
+        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(M, nout)}")
+    _chkvec(bias, "bias", f32)
+    ws = split_weight(w)
+    g = _lib.GemmArgs()
+    g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), ws.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)
+    g.M, g.N, g.K, g.epilogue, g.act = M, N, K, epilogue, act
+    if gate is not None:
+        _chk2d(gate, "gate", f32)
+        g.gate, g.ld_gate, g.rows_per_gate = gate.data_ptr(), gate.stride(0), rows_per_gate
+    if res is not None:
+        _chk2d(res, "res", f32)
+        g.res, g.ld_res, g.res_mod = res.data_ptr(), res.stride(0), res_mod
+    if blend is not None:
+        _chk2d(blend, "blend", f32)
+        _chkvec(alpha, "alpha", f32)
+        g.blend, g.ld_blend, g.alpha, g.rows_per_alpha = blend.data_ptr(), blend.stride(0), alpha.data_ptr(), rows_per_alpha
+    if rms_w is not None:
+        _chkvec(rms_w, "rms_w", f32)
+        g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
+    need = 4 * M * K + 256 + 4 * M * N
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles <= 128:
+        need += 4 * M * N * min(32, 256 // tiles)          # room for the kernel's own split-K rule
+    wsb = _f32_workspace(a.device, need)
+    g.workspace, g.workspace_bytes = wsb.data_ptr(), wsb.numel() * 4
+    _lib.check(_lib.load().dwm_gemm_f32(C.byref(g), _stream()), "dwm_gemm_f32")
+    return out
+
+
+_F32_WORKSPACES: dict = {}
+
+
+def _f32_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """scratch of dwm_gemm_f32 (operand planes + fp32 partial sums), one per (device, stream), grown on demand"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _F32_WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _F32_WORKSPACES[key] = torch.empty((nbytes + (64 << 20)) // 4, dtype=torch.float32, device=device)
+    return ws
 
 
 _WORKSPACES: dict = {}
@@ -333,8 +416,9 @@ def rowmap_temporal_pointwise(B: int, T: int, V: int, h: int, w: int) -> RowMap:
 
 def _attn_args(a, q, k, v, out, rowmap, heads, q1, k1, v1, out1, scale, group_mask, dense_mask):
     """fill a dwm_attn_args; returns the uint8 mask tensor that must outlive the launch (or None)"""
+    dt = q.dtype if q.dtype == torch.float32 else bf16             # fp32: the accuracy path (dwm_attention_f32)
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
-        _chk2d(t, name)
+        _chk2d(t, name, dt)
     if not (q.stride(0) == k.stride(0) == v.stride(0)):
         raise RuntimeError("q, k, v must share a row stride")
     a.q0, a.k0, a.v0, a.ld0 = q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0)
@@ -342,7 +426,7 @@ def _attn_args(a, q, k, v, out, rowmap, heads, q1, k1, v1, out1, scale, group_ma
     a.L0, a.L1, a.n_problems = rowmap.L0, 0, rowmap.n_problems
     if q1 is not None:
         for name, t in (("q1", q1), ("k1", k1), ("v1", v1), ("out1", out1)):
-            _chk2d(t, name)
+            _chk2d(t, name, dt)
         if q1.shape[0] % rowmap.n_problems != 0:
             raise RuntimeError("segment 1 rows must be n_problems * L1")
         a.q1, a.k1, a.v1, a.ld1 = q1.data_ptr(), k1.data_ptr(), v1.data_ptr(), q1.stride(0)
@@ -388,7 +472,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != a.n_problems * heads * (a.L0 + a.L1):
             raise RuntimeError("lse: fp32 contiguous [n_problems, heads, L0+L1] expected")
         a.lse = lse.data_ptr()
-    _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
+    if q.dtype == torch.float32:
+        _lib.check(_lib.load().dwm_attention_f32(C.byref(a), _stream()), "dwm_attention_f32")
+    else:
+        _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
     if keep is not None:
         keep.record_stream(torch.cuda.current_stream())
 
@@ -460,36 +547,40 @@ def layernorm(x: torch.Tensor, *, eps: float, out: Optional[torch.Tensor] = None
               xsum: Optional[torch.Tensor] = None):
     """See dwm_layernorm.  scale/shift (and scale2/shift2) are 2-D views sharing one row
     stride (column slices of the AdaLN modulation matrix)."""
-    _chk2d(x, "x")
+    dt = x.dtype if x.dtype == torch.float32 else bf16             # fp32: the accuracy path (dwm_layernorm_f32)
+    _chk2d(x, "x", dt)
     rows, D = x.shape
     if out is None:
-        out = torch.empty((rows, D), dtype=bf16, device=x.device)
-    _chk2d(out, "out")
+        out = torch.empty((rows, D), dtype=dt, device=x.device)
+    _chk2d(out, "out", dt)
     a = _lib.LayerNormArgs()
     a.x, a.ldx, a.y, a.ldy = x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0)
     a.rows, a.D, a.eps = rows, D, eps
-    _chkvec(weight, "weight")
-    _chkvec(bias, "bias")
+    _chkvec(weight, "weight", dt)
+    _chkvec(bias, "bias", dt)
     a.weight, a.bias = _p(weight), _p(bias)
     if scale is not None:
-        _chk2d(scale, "scale")
-        _chk2d(shift, "shift")
+        _chk2d(scale, "scale", dt)
+        _chk2d(shift, "shift", dt)
         if scale.stride(0) != shift.stride(0):
             raise RuntimeError("scale/shift must share a row stride")
         a.scale, a.shift, a.ld_mod, a.rows_per_mod = scale.data_ptr(), shift.data_ptr(), scale.stride(0), rows_per_mod
     if out2 is not None:
-        _chk2d(out2, "out2")
-        _chk2d(scale2, "scale2")
-        _chk2d(shift2, "shift2")
+        _chk2d(out2, "out2", dt)
+        _chk2d(scale2, "scale2", dt)
+        _chk2d(shift2, "shift2", dt)
         if scale2.stride(0) != a.ld_mod or shift2.stride(0) != a.ld_mod:
             raise RuntimeError("scale2/shift2 must share the row stride of scale/shift")
         a.y2, a.ldy2, a.scale2, a.shift2 = out2.data_ptr(), out2.stride(0), scale2.data_ptr(), shift2.data_ptr()
     if addvec is not None:
-        _chk2d(addvec, "addvec")
+        _chk2d(addvec, "addvec", dt)
         a.addvec, a.ld_add, a.rows_per_add = addvec.data_ptr(), addvec.stride(0), rows_per_add
         if xsum is not None:
-            _chk2d(xsum, "xsum")
+            _chk2d(xsum, "xsum", dt)
             a.xsum, a.ldxsum = xsum.data_ptr(), xsum.stride(0)
+    if dt == torch.float32:
+        _lib.check(_lib.load().dwm_layernorm_f32(C.byref(a), _stream()), "dwm_layernorm_f32")
+        return out
     _lib.check(_lib.load().dwm_layernorm(C.byref(a), _stream()), "dwm_layernorm")
     return out
 
@@ -505,30 +596,46 @@ def rmsnorm_heads_(x: torch.Tensor, w_expanded: torch.Tensor, eps: float) -> tor
 
 # -------------------------------------------------------------------------- elementwise
 def silu(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == torch.float32:
+        _chkvec(x, "x", torch.float32)
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().dwm_silu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "dwm_silu_f32")
+        return y
     _chkvec(x, "x")
     y = torch.empty_like(x)
     _lib.check(_lib.load().dwm_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "dwm_silu")
     return y
 
 
-def timestep_sinusoid(t: torch.Tensor, channels: int) -> torch.Tensor:
-    """diffusers Timesteps(channels, flip_sin_to_cos=True, downscale_freq_shift=0) -> bf16 [n, channels]."""
+def timestep_sinusoid(t: torch.Tensor, channels: int, dtype: torch.dtype = bf16) -> torch.Tensor:
+    """diffusers Timesteps(channels, flip_sin_to_cos=True, downscale_freq_shift=0) -> [n, channels] bf16 (or fp32: the accuracy path)."""
     t = t.reshape(-1).to(torch.float32).contiguous()
     if not t.is_cuda:
         raise RuntimeError("timestep_sinusoid: expected a device tensor")
+    if dtype == torch.float32:
+        out = torch.empty((t.numel(), channels), dtype=torch.float32, device=t.device)
+        _lib.check(_lib.load().dwm_timestep_sinusoid_f32(t.data_ptr(), t.numel(), channels, out.data_ptr(), _stream()),
+                   "dwm_timestep_sinusoid_f32")
+        return out
     out = torch.empty((t.numel(), channels), dtype=bf16, device=t.device)
     _lib.check(_lib.load().dwm_timestep_sinusoid(t.data_ptr(), t.numel(), channels, out.data_ptr(), _stream()),
                "dwm_timestep_sinusoid")
     return out
 
 
-def patchify(x: torch.Tensor, p: int, ldo: Optional[int] = None) -> torch.Tensor:
-    """[I, C, H, W] (fp32 / bf16) -> bf16 [I*(H/p)*(W/p), ldo] im2col rows (zero padded to ldo)."""
+def patchify(x: torch.Tensor, p: int, ldo: Optional[int] = None, dtype: torch.dtype = bf16) -> torch.Tensor:
+    """[I, C, H, W] (fp32 / bf16) -> [I*(H/p)*(W/p), ldo] im2col rows (zero padded to ldo), bf16 (or fp32: the accuracy path)."""
     if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, bf16):
         raise RuntimeError("patchify: expected a contiguous fp32/bf16 [I,C,H,W] device tensor")
     I, Cc, H, W = x.shape
     cols = Cc * p * p
     ldo = ldo or (cols + 63) // 64 * 64
+    if dtype == torch.float32:
+        if x.dtype != torch.float32:
+            raise RuntimeError("patchify: the fp32 path takes fp32 images")
+        out = torch.empty((I * (H // p) * (W // p), ldo), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().dwm_patchify_f32(x.data_ptr(), I, Cc, H, W, p, out.data_ptr(), ldo, _stream()), "dwm_patchify_f32")
+        return out
     out = torch.empty((I * (H // p) * (W // p), ldo), dtype=bf16, device=x.device)
     _lib.check(_lib.load().dwm_patchify(x.data_ptr(), int(x.dtype == torch.float32), I, Cc, H, W, p,
                                         out.data_ptr(), ldo, _stream()), "dwm_patchify")
@@ -536,6 +643,12 @@ def patchify(x: torch.Tensor, p: int, ldo: Optional[int] = None) -> torch.Tensor
 
 
 def unpatchify(x: torch.Tensor, I: int, Cc: int, h: int, w: int, p: int) -> torch.Tensor:
+    if x.dtype == torch.float32:
+        _chk2d(x, "x", torch.float32)
+        out = torch.empty((I, Cc, h * p, w * p), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().dwm_unpatchify_f32(x.data_ptr(), x.stride(0), I, Cc, h, w, p, out.data_ptr(), _stream()),
+                   "dwm_unpatchify_f32")
+        return out
     _chk2d(x, "x")
     out = torch.empty((I, Cc, h * p, w * p), dtype=bf16, device=x.device)
     _lib.check(_lib.load().dwm_unpatchify(x.data_ptr(), x.stride(0), I, Cc, h, w, p, out.data_ptr(), _stream()),
@@ -545,8 +658,21 @@ def unpatchify(x: torch.Tensor, I: int, Cc: int, h: int, w: int, p: int) -> torc
 
 def cfg_euler_step(pred: torch.Tensor, latents: torch.Tensor, guidance: float, dsigma,
                    model_in: Optional[torch.Tensor] = None, group_elems: int = 0) -> None:
-    """latents(fp32, in place) += dsigma * (u + g (c - u)) with pred = [uncond; cond] bf16."""
+    """latents(fp32, in place) += dsigma * (u + g (c - u)) with pred = [uncond; cond] bf16 (fp32 pred + fp32 model_in: the
+    accuracy path)."""
     n = latents.numel()
+    if pred.dtype == torch.float32:
+        if pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda or latents.dtype != torch.float32 or not latents.is_contiguous():
+            raise RuntimeError("cfg_euler_step: fp32 pred must be contiguous with 2x the (fp32, contiguous) latent elements")
+        if model_in is not None and (model_in.dtype != torch.float32 or model_in.numel() != 2 * n or not model_in.is_contiguous()):
+            raise RuntimeError("cfg_euler_step: model_in of the fp32 path must be contiguous fp32 [2, n]")
+        grp = dsigma if torch.is_tensor(dsigma) else None
+        if grp is not None and (grp.dtype != torch.float32 or not grp.is_cuda or not grp.is_contiguous() or grp.numel() * group_elems != n):
+            raise RuntimeError("cfg_euler_step: dsigma must be a contiguous fp32 device tensor with n / group_elems entries")
+        _lib.check(_lib.load().dwm_cfg_euler_step_f32(pred.data_ptr(), latents.data_ptr(), _p(model_in), n, float(guidance),
+                                                      0.0 if grp is not None else float(dsigma), _p(grp), group_elems, _stream()),
+                   "dwm_cfg_euler_step_f32")
+        return
     if pred.dtype != bf16 or pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda:
         raise RuntimeError("cfg_euler_step: pred must be contiguous bf16 with 2x the latent elements")
     if latents.dtype != torch.float32 or not latents.is_contiguous() or not latents.is_cuda:

@@ -115,15 +115,18 @@ class CTSDDenoiser:
                               else v) for k, v in conditions.items()}
         self.latents = latents.to(torch.float32).contiguous().clone()
         self.image_latents = None if image_latents is None else image_latents.to(torch.float32).to(dev)
-        self.model_in = torch.empty((2 * B, *latents.shape[1:]), dtype=bf16, device=dev)
+        # model input / conditions / prediction in the model's compute dtype: bf16, or fp32 for the accuracy path
+        # (`model.compute_dtype = torch.float32`)
+        self.cd = cd = getattr(self.model, "compute_dtype", bf16)
+        self.model_in = torch.empty((2 * B, *latents.shape[1:]), dtype=cd, device=dev)
         self._refresh_model_in()
-        self.conditions = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
+        self.conditions = {k: (v.to(cd) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
                            for k, v in conditions.items()}
         if self.cfg_group is not None:                                 # this rank's half of every CFG-doubled condition
             r = self.cfg_rank
             self.conditions = {k: (v[r * B:(r + 1) * B].contiguous() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == 2 * B else v)
                                for k, v in self.conditions.items()}
-            self._pred_full = torch.empty((2 * B, *latents.shape[1:]), dtype=bf16, device=dev)
+            self._pred_full = torch.empty((2 * B, *latents.shape[1:]), dtype=cd, device=dev)
         self._ts_dev = self.schedule.timesteps.to(dev)
         self._sig_dev = self.schedule.sigmas.to(dev)
         return self
@@ -133,7 +136,7 @@ class CTSDDenoiser:
 
     def _refresh_model_in(self):
         B = self.latents.shape[0]
-        lat16 = ops.cast_bf16(self.latents)
+        lat16 = self.latents if self.cd == torch.float32 else ops.cast_bf16(self.latents)
         self.model_in[:B].copy_(lat16)
         self.model_in[B:].copy_(lat16)
         self._inject_reference()
@@ -141,7 +144,7 @@ class CTSDDenoiser:
     def _inject_reference(self):
         if self.ref > 0:                                              # clean reference frames, every step
             B = self.latents.shape[0]
-            r16 = self.image_latents[:, :self.ref].to(bf16)
+            r16 = self.image_latents[:, :self.ref].to(self.cd)
             self.model_in[:B, :self.ref].copy_(r16)
             self.model_in[B:, :self.ref].copy_(r16)
 

@@ -675,6 +675,7 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
                   disable_temporal=None, crossview_attention_mask=None, added_time_ids=None, condition_image_tensor=None):
     """Autograd-enabled forward of DiTCrossviewTemporalConditionModel (text-conditioned configuration;
     crossview_temporal_dit.py:372-630).  Returns the prediction [B, T, V, C, H, W] (bf16) with a grad_fn."""
+    STORE.set_precision(bf16)               # training runs in bf16 compute over fp32 masters
     B, Tn, V, _, H, W = sample.shape
     p = model._cfg.patch_size
     height, width = H // p, W // p

@@ -472,6 +472,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
                 condition_image_tensor=None, disable_crossview=None, disable_temporal=None, crossview_attention_mask=None,
                 camera_intrinsics=None, camera_transforms=None, added_time_ids=None, camera_intrinsics_norm=None,
                 camera2referego=None, return_dict=False):
+        STORE.set_precision(bf16)            # the UNet runs in bf16 only (the fp32 accuracy path covers the MMDiT forward)
         if not sample.is_cuda:
             raise RuntimeError("opendwm_amd runs on an MI355X (HIP) device only; got a CPU tensor")
         if isinstance(encoder_hidden_states, dict):

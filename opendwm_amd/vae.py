@@ -250,6 +250,8 @@ class AutoencoderKL(nn.Module):
     def encode(self, x: torch.Tensor, return_dict: bool = True, chunk: int = 8):
         """x [I, 3, H, W] in [-1, 1] -> object with .latent_dist (sample() / mode()), as ctsd.py uses it
         (ctsd.py:1213-1218 `.latent_dist.sample()`, :1689-1694 `.mode()`)."""
+        from .blocks import STORE
+        STORE.set_precision(torch.bfloat16)
         if not x.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
         moments = torch.cat([self._encode_chunk(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)], 0)
@@ -301,6 +303,8 @@ class AutoencoderKL(nn.Module):
     def decode(self, z: torch.Tensor, return_dict: bool = False, chunk: int = 8):
         """z [I, latent_channels, h, w] -> images [I, 3, 8h, 8w] (bf16).  Returns a 1-tuple like
         diffusers' decode(..., return_dict=False)."""
+        from .blocks import STORE
+        STORE.set_precision(torch.bfloat16)
         if not z.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
         outs = [self._decode_chunk(z[i:i + chunk]) for i in range(0, z.shape[0], chunk)]

@@ -318,6 +318,8 @@ class AutoencoderKLCogVideoX(nn.Module):
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         """x [B, 3, T, H, W] in [-1, 1] -> object with .latent_dist over the moments [B, 2*latent, T', H/8, W/8]
         (ctsd.py:1206-1218: `.latent_dist.sample()`; :1689-1694 `.mode()`)."""
+        from .blocks import STORE
+        STORE.set_precision(torch.bfloat16)
         if not x.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
         if x.dim() != 5:
@@ -357,6 +359,8 @@ class AutoencoderKLCogVideoX(nn.Module):
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
         """z [B, latent, T', h, w] -> frames [B, 3, T, 8h, 8w] (bf16); 1-tuple like diffusers' decode(return_dict=False)"""
+        from .blocks import STORE
+        STORE.set_precision(torch.bfloat16)
         if not z.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
         if z.dim() != 5:

@@ -1,0 +1,254 @@
+"""The fp32 accuracy path (BASELINE.json north_star: "within 1e-3 rel fp32" of the reference's fp32 path): every kernel of
+the mode against plain fp32 / fp64 PyTorch of the same op, then the MMDiT forward and the guided denoise loop against the
+fp32 oracle - small configuration vs the CPU oracle, the 6-layer full-width stack of BASELINE config 3 vs the oracle on the
+device.  Tolerance of the mode: 1e-3 relative (Frobenius); the kernels are held to 1e-4."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ctsd_oracle as O          # noqa: E402  (checker only)
+from tests.common import rel_err, small_config, small_inputs, to_dev     # noqa: E402
+
+pytestmark = pytest.mark.gpu
+f32 = torch.float32
+TOL_F32 = 1e-3
+TOL_KERNEL_F32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need a HIP device (torch.cuda.is_available() is False)")
+    from opendwm_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _log(name, **kw):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/gpu_parity.log", "a") as f:
+        f.write(name + " " + " ".join(f"{k}={v}" for k, v in kw.items()) + "\n")
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (1000, 512, 256), (4096, 1536, 1536), (77, 64, 64)])
+def test_gemm_f32_epilogues(dev, M, N, K):
+    """dwm_gemm_f32 (two-plane bf16 split of both operands on the bf16 MFMA main loop, fp32 finish) vs fp64 matmul:
+    plain + bias + activations, GEGLU, gated residual, row-modulo / per-image residual, blend, per-head q/k RMSNorm"""
+    from opendwm_amd import ops
+    from opendwm_amd.blocks import geglu_pack
+    a, w, b = _rand((M, K), dev, 1), _rand((N, K), dev, 2, K ** -0.5), _rand((N,), dev, 3, 0.1)
+    ref = (a.double() @ w.double().t()) + b.double()
+    errs = {}
+    errs["plain"] = rel_err(ops.gemm(a, w, b), ref)
+    errs["nobias"] = rel_err(ops.gemm(a, w, None), a.double() @ w.double().t())
+    errs["gelu"] = rel_err(ops.gemm(a, w, b, act=ops.ACT_GELU_TANH), torch.nn.functional.gelu(ref, approximate="tanh"))
+    errs["silu"] = rel_err(ops.gemm(a, w, b, act=ops.ACT_SILU), torch.nn.functional.silu(ref))
+    if N % 64 == 0:
+        h, g = ref.chunk(2, -1)
+        errs["geglu"] = rel_err(ops.gemm(a, geglu_pack(w), geglu_pack(b), epilogue=ops.EPI_GEGLU), h * torch.nn.functional.gelu(g))
+        nq = N // 64 // 2 * 64 if N >= 128 else 64
+        rw = 1 + _rand((nq,), dev, 9, 0.1)
+        x = ref.clone()
+        xh = x[:, :nq].view(M, -1, 64)
+        x[:, :nq] = (xh * torch.rsqrt(xh.pow(2).mean(-1, keepdim=True) + 1e-6)).view(M, nq) * rw.double()
+        errs["rmshead"] = rel_err(ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rw, rms_ncols=nq, rms_eps=1e-6), x)
+    rpg = 100
+    gate, res = _rand(((M + rpg - 1) // rpg, N), dev, 4), _rand((M, N), dev, 5)
+    rows = torch.arange(M, device=dev)
+    errs["gate_res"] = rel_err(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=rpg, res=res),
+                               ref * gate.double()[rows // rpg] + res.double())
+    tab = _rand((37, N), dev, 6)
+    errs["res_mod"] = rel_err(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=tab, res_mod=37), ref + tab.double()[rows % 37])
+    per = _rand(((M + 49) // 50, N), dev, 7)
+    errs["res_per_image"] = rel_err(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=per, res_mod=-50), ref + per.double()[rows // 50])
+    blend, alpha = _rand((M, N), dev, 8), torch.tensor([0.3, 1.0, 0.88], device=dev)
+    rpa = (M + 2) // 3
+    al = alpha.double()[rows // rpa][:, None]
+    errs["blend"] = rel_err(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=res, blend=blend, alpha=alpha, rows_per_alpha=rpa),
+                            al * blend.double() + (1 - al) * (ref + res.double()))
+    inplace = res.clone()
+    ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=inplace, out=inplace)
+    errs["inplace"] = rel_err(inplace, ref + res.double())
+    _log("gemm_f32", M=M, N=N, K=K, **{k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < TOL_KERNEL_F32 for v in errs.values()), errs
+
+
+def test_layernorm_f32(dev):
+    from opendwm_amd import ops
+    rows, D, rpm = 600, 1536, 150
+    x, mod = _rand((rows, D), dev, 1), _rand((rows // rpm, 6 * D), dev, 2, 0.3)
+    w, b = 1 + _rand((D,), dev, 3, 0.1), _rand((D,), dev, 4, 0.1)
+    emb = _rand((rows // 50, D), dev, 5, 0.3)
+    xd = x.double()
+    n = torch.nn.functional.layer_norm(xd, (D,), eps=1e-6)
+    r = torch.arange(rows, device=dev)
+    sl = lambda i: mod[:, i * D:(i + 1) * D]
+    y2 = torch.empty_like(x)
+    y = ops.layernorm(x, eps=1e-6, scale=sl(1), shift=sl(0), rows_per_mod=rpm, scale2=sl(4), shift2=sl(3), out2=y2)
+    e1 = rel_err(y, n * (1 + sl(1).double()[r // rpm]) + sl(0).double()[r // rpm])
+    e2 = rel_err(y2, n * (1 + sl(4).double()[r // rpm]) + sl(3).double()[r // rpm])
+    xs = torch.empty_like(x)
+    ya = ops.layernorm(x, eps=1e-5, weight=w, bias=b, addvec=emb, rows_per_add=50, xsum=xs)
+    xe = xd + emb.double()[r // 50]
+    e3 = rel_err(ya, torch.nn.functional.layer_norm(xe, (D,), w.double(), b.double(), eps=1e-5))
+    e4 = rel_err(xs, xe)
+    _log("layernorm_f32", mod=e1, mod2=e2, affine_add=e3, xsum=e4)
+    assert max(e1, e2, e3, e4) < 1e-5
+
+
+def _attn_ref(q, k, v, rows, heads, mask=None, q1=None, k1=None, v1=None):
+    P, L0 = rows.shape
+    D = heads * 64
+
+    def gather(x, x1):
+        g = x[rows.reshape(-1)].view(P, L0, heads, 64)
+        if x1 is not None:
+            g = torch.cat([g, x1.view(P, -1, heads, 64)], 1)
+        return g.transpose(1, 2)
+    Q, K, V = gather(q.double(), None if q1 is None else q1.double()), gather(k.double(), None if k1 is None else k1.double()), \
+        gather(v.double(), None if v1 is None else v1.double())
+    o = O.sdpa(Q, K, V, None if mask is None else mask[:, None]).transpose(1, 2).reshape(P, -1, D)
+    o0 = torch.zeros_like(q, dtype=torch.float64)
+    o0[rows.reshape(-1)] = o[:, :L0].reshape(-1, D)
+    return o0, None if q1 is None else o[:, L0:].reshape(-1, D)
+
+
+def test_attention_f32_joint_rowmaps_and_masks(dev):
+    """dwm_attention_f32: two-segment (joint) problems, every row map of the VT blocks, group and dense masks, ragged tails"""
+    from opendwm_amd import ops
+    heads = 3
+    D = heads * 64
+    errs = {}
+    for I, N, Lc in ((3, 100, 10), (2, 448, 154), (4, 33, 0)):
+        qkv = _rand((I * N, 3 * D), dev, 1)
+        cqkv = _rand((I * Lc, 3 * D), dev, 2) if Lc else None
+        out = torch.zeros((I * N, D), dtype=f32, device=dev)
+        cout = torch.zeros((I * Lc, D), dtype=f32, device=dev) if Lc else None
+        rm = ops.rowmap_identity(I, N)
+        kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout) if Lc else {}
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, **kw)
+        r0, r1 = _attn_ref(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], rm.rows().to(dev), heads,
+                           **({k: v for k, v in kw.items() if k != "out1"}))
+        errs[f"joint_{N}_{Lc}"] = max(rel_err(out, r0), rel_err(cout, r1) if Lc else 0.0)
+    B, T, V, h, w = 2, 3, 3, 4, 6
+    R = B * T * V * h * w
+    qkv = _rand((R, 3 * D), dev, 3)
+    for name, mk in (("cv_rowwise", ops.rowmap_crossview_rowwise), ("cv_full", ops.rowmap_crossview_full),
+                     ("t_rowwise", ops.rowmap_temporal_rowwise), ("t_pointwise", ops.rowmap_temporal_pointwise),
+                     ("t_full", ops.rowmap_temporal_full)):
+        rm = mk(B, T, V, h, w)
+        out = torch.zeros((R, D), dtype=f32, device=dev)
+        gmask = ref_mask = None
+        if name == "cv_rowwise":
+            gmask = O.ring_crossview_mask(B, V).to(dev)
+            gmask[1, 0, 2] = False
+            p = torch.arange(rm.n_problems, device=dev)[:, None, None]
+            l = torch.arange(rm.L0, device=dev)
+            ref_mask = gmask[p // rm.p_per_mask, ((l // rm.group_size) % V)[None, :, None], ((l // rm.group_size) % V)[None, None, :]]
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, group_mask=gmask)
+        r0, _ = _attn_ref(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], rm.rows().to(dev), heads, mask=ref_mask)
+        errs[name] = rel_err(out, r0)
+        if ref_mask is not None:
+            out2 = torch.zeros_like(out)
+            ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out2, rm, heads, dense_mask=ref_mask)
+            errs[name + "_dense"] = rel_err(out2, r0)
+    _log("attention_f32", **{k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < 1e-5 for v in errs.values()), errs
+
+
+def test_elementwise_f32(dev):
+    from opendwm_amd import ops
+    x = _rand((4096,), dev, 1, 3.0)
+    assert rel_err(ops.silu(x), torch.nn.functional.silu(x.double())) < 1e-6
+    t = torch.tensor([0.0, 1.0, 37.5, 999.0], device=dev)
+    assert rel_err(ops.timestep_sinusoid(t, 256, dtype=f32), O.timesteps_sinusoid(t.cpu(), 256)) < 1e-4
+    img = _rand((3, 16, 8, 12), dev, 2)
+    cols = ops.patchify(img, 2, 64, dtype=f32)
+    want = torch.nn.functional.unfold(img.double(), 2, stride=2).transpose(1, 2).reshape(-1, 64)
+    assert torch.equal(cols.double(), want)
+    tok = _rand((3 * 4 * 6, 64), dev, 3)
+    back = ops.unpatchify(tok, 3, 16, 4, 6, 2)
+    ref = torch.einsum("nhwpqc->nchpwq", tok.view(3, 4, 6, 2, 2, 16)).reshape(3, 16, 8, 12)
+    assert torch.equal(back, ref)
+    pred, lat = _rand((2, 5000), dev, 4), _rand((5000,), dev, 5)
+    lat0, mi = lat.clone(), torch.empty(2, 5000, device=dev)
+    ops.cfg_euler_step(pred.reshape(-1), lat, 4.0, -0.03, model_in=mi.view(-1))
+    want = lat0.double() - 0.03 * (pred[0].double() + 4.0 * (pred[1].double() - pred[0].double()))
+    assert rel_err(lat, want) < 1e-6 and torch.equal(mi[0], lat) and torch.equal(mi[1], lat)
+
+
+def _fp32_model(cfg, sd, dev):
+    from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
+    m = DiTCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()                   # fp32 parameters
+    m.compute_dtype = f32
+    return m
+
+
+@pytest.mark.parametrize("tt", ["rowwise", "pointwise", "full"])
+def test_model_forward_fp32_vs_cpu_oracle(dev, tt):
+    """small full-graph configuration, fp32 weights and inputs untouched (no bf16 rounding anywhere): the HIP fp32 path
+    against the CPU oracle - north_star's fp32 tolerance, 1e-3; then the same model object in bf16 mode still gives the
+    bf16 result (the precision switch is scoped to a forward)"""
+    cfg = small_config(temporal_attention_type=tt)
+    sd = O.make_state_dict(cfg, 0)
+    inp = small_inputs(cfg, 0)
+    inp["disable_temporal"] = torch.tensor([False, True])
+    ref = O.dit_forward(sd, cfg, **inp)
+    m = _fp32_model(cfg, sd, dev)
+    di = to_dev(inp, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e = rel_err(out[0], ref)
+    assert out[0].dtype == f32
+    m.compute_dtype = torch.bfloat16
+    di = to_dev(inp, dev)
+    out16, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e16 = rel_err(out16[0], ref)
+    _log("model_forward_fp32", temporal=tt, rel_fp32=e, rel_bf16_same_model=e16)
+    assert e < TOL_F32, e
+    assert out16[0].dtype == torch.bfloat16 and 1e-4 < e16 < 2e-2
+
+
+def test_denoise_fp32_vs_cpu_oracle(dev):
+    """four guided FlowMatch-Euler steps in the fp32 mode (fp32 model input, fp32 prediction, fp32 CFG + Euler kernel)"""
+    from opendwm_amd.pipeline import CTSDDenoiser
+    cfg = small_config()
+    sd = O.make_state_dict(cfg, 0)
+    inp = small_inputs(cfg, 0)
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    lat = torch.randn(1, 3, 3, 16, 8, 12, generator=torch.Generator().manual_seed(7))
+    ref = O.denoise(sd, cfg, lat, cond, steps=4, guidance_scale=4.0)
+    m = _fp32_model(cfg, sd, dev)
+    out = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=4).run(lat.to(dev), to_dev(cond, dev))
+    e = rel_err(out, ref)
+    _log("denoise_fp32", steps=4, rel=e)
+    assert e < TOL_F32, e
+
+
+def test_full_width_stack_fp32_vs_oracle_on_device(dev):
+    """BASELINE config-3 token geometry (6 views x 16 frames x 32x56 latents, CFG batch 2, d = 1536, 24 heads, 154 text
+    tokens) with the first 6 layers of the schedule, fp32 mode against the fp32 oracle on the same device"""
+    cfg = O.make_config(num_layers=6, dual_attention_layers=[0, 1, 2, 3, 4, 5], crossview_block_layers=[1, 5],
+                        temporal_block_layers=[2, 3])
+    gen = torch.Generator().manual_seed(0)
+    sd = {n: O.synth_param(n, s, cfg, gen) for n, s in O.param_shapes(cfg).items()}
+    m = _fp32_model(cfg, sd, dev)
+    inp = O.make_inputs(cfg, 2, 16, 6, 32, 56, seed=0)
+    di = to_dev(inp, dev)
+    with torch.no_grad():
+        ref = O.dit_forward({k: v.to(dev) for k, v in sd.items()}, cfg, **di)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e = rel_err(out[0], ref)
+    _log("full_width_6layers_fp32", rel=e, finite=bool(torch.isfinite(out[0]).all()))
+    assert e < TOL_F32, e
