@@ -394,7 +394,11 @@ def main_train(args):
                        "layers": kwargs["num_layers"], "parameters": n_all, "trainable_parameters": n_train,
                        "frozen_base": bool(args.freeze_base), "forward_flop": fwd,
                        "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "finite": finite,
-                       "peak_memory_GiB": mem},
+                       "peak_memory_GiB": mem,
+                       # DDP: one bucketed all-reduce of the trainable gradients per step, bf16 on the wire (bf16_compress_hook,
+                       # 200 MB buckets), overlapped with the rest of the backward; a ring over N GPUs moves 2 (N-1)/N of it per GPU
+                       "ddp_allreduce_GB_per_step": (2.0 * n_train / 1e9) if world > 1 else 0.0, "ddp_bucket_dtype": "bf16",
+                       "ddp_bucket_cap_mb": 200},
             # forward + recompute + 2x backward GEMMs (input + weight gradients); frozen weights skip their wgrad
             "approx_mfma_frac": (4.0 * fwd) / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12) if not args.freeze_base else None,
         }))
