@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 12
+#define DWM_ABI_VERSION 13
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -432,6 +432,15 @@ int dwm_rmsnorm_heads_bwd(const void* y, int64_t ldy, const float* rinv, const v
 int dwm_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
               void* stream);
+
+/* Backward of dwm_groupnorm_silu / dwm_groupnorm_silu_mapped (the UNet's ResnetBlock2D / TemporalResnetBlock / TransformerModel
+ * norms in the SD 2.1 training branch, src/dwm/pipelines/ctsd.py:1240-1253): x = the forward input (compact rows, through
+ * img_map if given), dz = gradient of the forward OUTPUT read through dz_map (the padded grid the forward wrote, or NULL for
+ * compact rows), dx [rows, C] bf16 = gradient of x (accumulate != 0: added to what dx holds), dgamma / dbeta fp32 [C] +=.
+ * `stats`: caller scratch of 2 * dwm_groupnorm_stats_floats(I, P, G) floats (forward statistics are recomputed). */
+int dwm_groupnorm_bwd(const void* x, const void* dz, void* dx, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                      const void* gamma, const void* beta, int32_t silu, int32_t accumulate, float* stats,
+                      float* dgamma, float* dbeta, const dwm_rowmap2d* dz_map, const dwm_gn_imgmap* img_map, void* stream);
 
 /* y fp32 [rows, ldy] (+)= x bf16 [rows, ldx] */
 int dwm_cast_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols,

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -152,6 +152,8 @@ SIGNATURES = {
     "dwm_rmsnorm_heads_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dwm_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "dwm_cast_bf16_to_f32": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "dwm_groupnorm_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
+                                 C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
 }
 
 _ERR = {-1: "DWM_EINVAL (bad shape / null pointer)", -2: "DWM_EALIGN (alignment)",

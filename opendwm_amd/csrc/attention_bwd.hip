@@ -40,6 +40,7 @@ delta_kernel(const AttnParams P) {
     const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= (int64_t)P.n_problems * P.L) return;
     const int prob = (int)(idx / P.L), l = (int)(idx - (int64_t)prob * P.L);
+    if (l >= P.qend) return;                       // cross-attention: only the queries (segment 0) have outputs
     const int64_t row = token_row(P, seg0_base(P.rm, prob), prob, l);
     const bf16_t* o = P.o0 + (l < P.L0 ? row * P.ldo0 : P.oseg1_delta + row * P.ldo1);
     const bf16_t* d = P.do0 + (l < P.L0 ? row * P.ldo0 : P.doseg1_delta + row * P.ldo1);
@@ -130,10 +131,11 @@ attn_dq_kernel(const AttnParams P) {
     }
     __syncthreads();
 
+    // queries are tokens [0, qend), keys tokens [kbeg, L): (L, 0), or (L0, L0) for cross-attention
     const int lq = qb * 128 + wave * 32 + l31;
-    const bool qok = lq < L;
-    const int lqc = qok ? lq : L - 1;
-    const bool wave_active = qb * 128 + wave * 32 < L;
+    const bool qok = lq < P.qend;
+    const int lqc = qok ? lq : P.qend - 1;
+    const bool wave_active = qb * 128 + wave * 32 < P.qend;
     const int64_t qrow = rowidx[lqc];
     const bool qseg0 = lqc < L0;
     bf16x8 qf[4], dof[4];
@@ -157,14 +159,14 @@ attn_dq_kernel(const AttnParams P) {
     else if (MASK == 2) dense_row = P.mask + ((int64_t)prob * L + lqc) * L;
 
     const Geo geo = make_geo(lane);
-    const int nkt = (L + KT - 1) / KT;
+    const int nkt = (L - P.kbeg + KT - 1) / KT;
     const int srow0 = wave * 16 + (lane >> 3), srow1 = srow0 + 8;
     const int kc0 = ((lane & 7) ^ ((srow0 >> 1) & 7)) << 3, kc1 = ((lane & 7) ^ ((srow1 >> 1) & 7)) << 3;
     const int vc0 = ((lane & 7) ^ (((srow0 >> 1) & 1) << 2)) << 3, vc1 = ((lane & 7) ^ (((srow1 >> 1) & 1) << 2)) << 3;
     const int sdst = wave * 2048;
 #define DQ_DMA(kt_, stage_)                                                                  \
     do {                                                                                     \
-        const int kb_ = (kt_) * KT;                                                          \
+        const int kb_ = P.kbeg + (kt_) * KT;                                                 \
         const int ra_ = kb_ + srow0 < L ? kb_ + srow0 : L - 1;                               \
         const int rb_ = kb_ + srow1 < L ? kb_ + srow1 : L - 1;                               \
         const int64_t oa_ = (ra_ < L0 ? (int64_t)rowidx[ra_] * P.ld0 : P.seg1_delta + (int64_t)rowidx[ra_] * P.ld1) + hoff; \
@@ -192,7 +194,7 @@ attn_dq_kernel(const AttnParams P) {
                     st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(kimg, geo, j, ks, half), qf[ks], ks == 0 ? neglse : st[j], 0, 0, 0);
                     dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(vimg, geo, j, ks, half), dof[ks], ks == 0 ? negdel : dp[j], 0, 0, 0);
                 }
-            const int kbase = kt * KT;
+            const int kbase = P.kbeg + kt * KT;
             if (kbase + KT > L) {
                 asm volatile("");
 #pragma unroll
@@ -273,10 +275,11 @@ attn_dkv_kernel(const AttnParams P) {
     }
     __syncthreads();
 
-    const int lk = kb * 128 + wave * 32 + l31;
+    const int lk = P.kbeg + kb * 128 + wave * 32 + l31;
     const bool kok = lk < L;
     const int lkc = kok ? lk : L - 1;
-    const bool wave_active = kb * 128 + wave * 32 < L;
+    const bool wave_active = P.kbeg + kb * 128 + wave * 32 < L;
+    const int QE = P.qend;                       // queries are tokens [0, qend)
     const int64_t krow = rowidx[lkc];
     const bool kseg0 = lkc < L0;
     bf16x8 kf[4], vf[4];
@@ -295,7 +298,7 @@ attn_dkv_kernel(const AttnParams P) {
     if (MASK == 1) kbits = group_bits(P, prob, lkc, true);
 
     const Geo geo = make_geo(lane);
-    const int nqt = (L + KT - 1) / KT;
+    const int nqt = (QE + KT - 1) / KT;
     const int srow0 = wave * 16 + (lane >> 3), srow1 = srow0 + 8;
     const int kc0 = ((lane & 7) ^ ((srow0 >> 1) & 7)) << 3, kc1 = ((lane & 7) ^ ((srow1 >> 1) & 7)) << 3;
     const int vc0 = ((lane & 7) ^ (((srow0 >> 1) & 1) << 2)) << 3, vc1 = ((lane & 7) ^ (((srow1 >> 1) & 1) << 2)) << 3;
@@ -304,8 +307,8 @@ attn_dkv_kernel(const AttnParams P) {
 #define DKV_DMA(qt_, stage_)                                                                 \
     do {                                                                                     \
         const int qb_ = (qt_) * KT;                                                          \
-        const int ra_ = qb_ + srow0 < L ? qb_ + srow0 : L - 1;                               \
-        const int rb_ = qb_ + srow1 < L ? qb_ + srow1 : L - 1;                               \
+        const int ra_ = qb_ + srow0 < QE ? qb_ + srow0 : QE - 1;                             \
+        const int rb_ = qb_ + srow1 < QE ? qb_ + srow1 : QE - 1;                             \
         const int64_t ia_ = rowidx[ra_], ib_ = rowidx[rb_];                                  \
         const int64_t qa_ = (ra_ < L0 ? ia_ * P.ld0 : P.seg1_delta + ia_ * P.ld1) + hoff;   \
         const int64_t qb2_ = (rb_ < L0 ? ib_ * P.ld0 : P.seg1_delta + ib_ * P.ld1) + hoff;  \
@@ -317,7 +320,7 @@ attn_dkv_kernel(const AttnParams P) {
         glds16(P.do0 + da_ + kc0, l_ + 2 * IMG);    glds16(P.do0 + db_ + kc1, l_ + 2 * IMG + 1024); \
         glds16(P.do0 + da_ + vc0, l_ + 3 * IMG);    glds16(P.do0 + db_ + vc1, l_ + 3 * IMG + 1024); \
         if (wave < 2) {                                                                      \
-            const int qi_ = qb_ + lane < L ? qb_ + lane : L - 1;                             \
+            const int qi_ = qb_ + lane < QE ? qb_ + lane : QE - 1;                           \
             glds4((wave == 0 ? P.lse : P.delta) + stat0 + qi_, smem + (stage_) * DKV_STAGE + 4 * IMG + wave * 256); \
         }                                                                                    \
     } while (0)
@@ -352,13 +355,13 @@ attn_dkv_kernel(const AttnParams P) {
                 }
             }
             const int qbase = qt * KT;
-            if (qbase + KT > L) {
+            if (qbase + KT > QE) {
                 asm volatile("");
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (qbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[j][r] = -INFINITY;
+                        if (qbase + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= QE) st[j][r] = -INFINITY;
             }
             if (MASK == 1) {
 #pragma unroll
@@ -415,7 +418,11 @@ attn_dkv_kernel(const AttnParams P) {
 
 template <int MASK>
 int launch_bwd(const AttnParams& P, hipStream_t s) {
-    const int64_t nblk = (int64_t)P.n_problems * P.heads * P.nqb;
+    // dq: one workgroup per 128 queries of [0, qend); dk / dv: one per 128 keys of [kbeg, L)
+    AttnParams Pk = P;
+    Pk.nqb = (int)((P.L - P.kbeg + 127) / 128);
+    Pk.fd_nqb = make_fastdiv((uint32_t)Pk.nqb);
+    const int64_t nblk = (int64_t)P.n_problems * P.heads * P.nqb, nblk_k = (int64_t)P.n_problems * P.heads * Pk.nqb;
     const size_t tab = (size_t)((P.L + 3) & ~3) * sizeof(int32_t);
     const size_t lds_q = 2 * DQ_STAGE + tab, lds_kv = 2 * DKV_STAGE + tab;
     static bool attr_set = false;
@@ -427,7 +434,7 @@ int launch_bwd(const AttnParams& P, hipStream_t s) {
     if (lds_kv > 128 * 1024) return DWM_EUNSUPPORTED;
     hipLaunchKernelGGL(delta_kernel, dim3((unsigned)(((int64_t)P.n_problems * P.L + 3) / 4)), dim3(256), 0, s, P);
     hipLaunchKernelGGL((attn_dq_kernel<MASK>), dim3((unsigned)nblk), dim3(256), lds_q, s, P);
-    hipLaunchKernelGGL((attn_dkv_kernel<MASK>), dim3((unsigned)nblk), dim3(256), lds_kv, s, P);
+    hipLaunchKernelGGL((attn_dkv_kernel<MASK>), dim3((unsigned)nblk_k), dim3(256), lds_kv, s, Pk);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }
@@ -436,7 +443,6 @@ int launch_bwd(const AttnParams& P, hipStream_t s) {
 
 extern "C" int dwm_attention_bwd(const dwm_attn_bwd_args* b, void* stream) {
     if (b == nullptr) return DWM_EINVAL;
-    if (b->fwd.cross) return DWM_EUNSUPPORTED;       // cross-attention has no backward yet (the UNet path is inference only)
     AttnParams P;
     const int rc = fill_params(&b->fwd, P);
     if (rc != DWM_OK) return rc;
@@ -452,14 +458,15 @@ extern "C" int dwm_attention_bwd(const dwm_attn_bwd_args* b, void* stream) {
     P.doseg1_delta = 0;
     if (P.L1 > 0) {
         if (b->do1 == nullptr || b->dq1 == nullptr || b->dk1 == nullptr || b->dv1 == nullptr) return DWM_EINVAL;
-        if (P.ldo1 % 8 != 0 || b->ld_d1 % 8 != 0 || !dwm_aligned16(b->do1) || !dwm_aligned16(b->dq1) || !dwm_aligned16(P.o1)) return DWM_EALIGN;
+        if (b->fwd.cross && (P.mask_mode != 0)) return DWM_EUNSUPPORTED;
+        if ((!b->fwd.cross && P.ldo1 % 8 != 0) || b->ld_d1 % 8 != 0 || !dwm_aligned16(b->do1) || !dwm_aligned16(b->dq1) || !dwm_aligned16(P.o1)) return DWM_EALIGN;
         const int64_t dq = (const bf16_t*)b->dq1 - P.dq0, dk = (const bf16_t*)b->dk1 - P.dk0, dv = (const bf16_t*)b->dv1 - P.dv0;
         if (dq != dk || dk != dv) return DWM_EUNSUPPORTED;
         P.dseg1_delta = dq;
         P.doseg1_delta = P.do1 - P.do0;
     }
     P.delta = b->delta;
-    P.nqb = (int)((P.L + 127) / 128);
+    P.nqb = (int)((P.qend + 127) / 128);
     P.fd_nqb = make_fastdiv((uint32_t)P.nqb);
     if ((int64_t)P.n_problems * P.heads * P.nqb >= (1ll << 31)) return DWM_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;

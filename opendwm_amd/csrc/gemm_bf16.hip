@@ -47,7 +47,7 @@ struct ConvParams {
     int64_t ws_slice;
 };
 constexpr int EPI_SPLITK = 100;     // internal epilogue id: fp32 partials to the workspace
-constexpr int kSchedDefault = 0;    // main-loop schedule variant when dwm_gemm_args.reserved bits 9-10 are clear
+constexpr int kSchedDefault = 2;    // main-loop schedule variant when dwm_gemm_args.reserved bits 9-10 are clear
 DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     if (!rm.enabled) return m;
     const uint32_t q = fdiv((uint32_t)m, rm.rw), x = (uint32_t)m - q * rm.rw.d;

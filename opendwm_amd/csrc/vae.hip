@@ -257,6 +257,136 @@ softmax_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_
     }
 }
 
+// ---- GroupNorm (+ SiLU) backward, two passes over (x, dz) with the forward's statistics recomputed first:
+//   y = xh * gamma + beta, xh = (x - mean) * rstd;  z = silu(y);  dy = dz * silu'(y)
+//   dgamma_c += sum dy * xh,  dbeta_c += sum dy                                   (fp32 atomics, one per block and channel)
+//   S1_g = sum gamma dy,  S2_g = sum gamma dy xh  per (image, group)               (fixed-order reduction like the forward)
+//   dx = rstd * (gamma dy - (S1_g + xh S2_g) / n)
+// dz is read through the same padded-grid map the forward wrote z with (the gradient of a 3x3 convolution's input grid).
+DWM_DEVINL float silu_grad_f(float y, float dz) {
+    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+    return dz * sg * (1.f + y * (1.f - sg));
+}
+
+__global__ void __launch_bounds__(256)
+gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, int64_t P, int C, int G, int64_t ppb,
+                    const float* __restrict__ fstats, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, float eps,
+                    int silu, float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, PadMap pm, ImgMap im) {
+    extern __shared__ float red[];            // [pstep][C8][4] group partials, then [pstep][C][2] channel partials
+    const int i = blockIdx.y;
+    const int C8 = C >> 3, CG = C / G;
+    const int TW = C8 < 256 ? C8 : 256;
+    const int prow = threadIdx.x / TW, pstep = 256 / TW;
+    float* red2 = red + (size_t)pstep * C8 * 4;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = p0 + ppb < P ? p0 + ppb : P;
+    const float n = (float)P * (float)CG;
+    if (prow < pstep) {
+        for (int c8 = threadIdx.x % TW; c8 < C8; c8 += TW) {
+            const int g0 = (c8 * 8) / CG;
+            const int bnd = (g0 + 1) * CG - c8 * 8;
+            float mean[2], rstd[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int g = g0 + hf < G ? g0 + hf : G - 1;
+                mean[hf] = fstats[((int64_t)i * G + g) * 2] / n;
+                const float var = fmaxf(fstats[((int64_t)i * G + g) * 2 + 1] / n - mean[hf] * mean[hf], 0.f);
+                rstd[hf] = rsqrtf(var + eps);
+            }
+            float ga[8], be[8], dg[8], db[8];
+            unpack8(*(const uint4*)(gamma + c8 * 8), ga);
+            unpack8(*(const uint4*)(beta + c8 * 8), be);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dg[j] = db[j] = 0.f;
+            float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+            for (int64_t p = p0 + prow; p < p1; p += pstep) {
+                const int64_t r = img_row(im, i, p, P);
+                float v[8], d[8];
+                unpack8(*(const uint4*)(x + r * C + c8 * 8), v);
+                unpack8(*(const uint4*)(dz + pad_row(pm, r) * C + c8 * 8), d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int hf = j < bnd ? 0 : 1;
+                    const float xh = (v[j] - mean[hf]) * rstd[hf];
+                    const float dy = silu ? silu_grad_f(xh * ga[j] + be[j], d[j]) : d[j];
+                    dg[j] += dy * xh;
+                    db[j] += dy;
+                    const float gd = ga[j] * dy;
+                    if (hf == 0) { a0 += gd; b0 += gd * xh; } else { a1 += gd; b1 += gd * xh; }
+                }
+            }
+            float* r4 = red + ((size_t)prow * C8 + c8) * 4;
+            r4[0] = a0; r4[1] = b0; r4[2] = a1; r4[3] = b1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red2[((size_t)prow * C + c8 * 8 + j) * 2] = dg[j];
+                red2[((size_t)prow * C + c8 * 8 + j) * 2 + 1] = db[j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float a = 0.f, b = 0.f;
+        const int c_lo = (g * CG) >> 3, c_hi = ((g + 1) * CG - 1) >> 3;
+        for (int c8 = c_lo; c8 <= c_hi; ++c8) {
+            const int slot = ((c8 * 8) / CG == g) ? 0 : 2;
+            for (int pr = 0; pr < pstep; ++pr) {
+                const float* r4 = red + ((size_t)pr * C8 + c8) * 4 + slot;
+                a += r4[0]; b += r4[1];
+            }
+        }
+        float* o = part + (((int64_t)i * gridDim.x + blockIdx.x) * G + g) * 2;
+        o[0] = a; o[1] = b;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sg = 0.f, sb = 0.f;
+        for (int pr = 0; pr < pstep; ++pr) { sg += red2[((size_t)pr * C + c) * 2]; sb += red2[((size_t)pr * C + c) * 2 + 1]; }
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, bf16_t* __restrict__ dx, int64_t I, int64_t P, int C,
+                    int G, const float* __restrict__ fstats, const float* __restrict__ bstats, const bf16_t* __restrict__ gamma,
+                    const bf16_t* __restrict__ beta, float eps, int silu, int accumulate, PadMap pm, ImgMap im) {
+    const int C8 = C >> 3, CG = C / G;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= I * P * C8) return;
+    const int c8 = (int)(idx % C8);
+    const int64_t ip = idx / C8;
+    const int64_t i = ip / P, pp = ip - i * P;
+    const int64_t r = img_row(im, i, pp, P);
+    const float n = (float)P * (float)CG;
+    const int g0 = (c8 * 8) / CG;
+    const int bnd = (g0 + 1) * CG - c8 * 8;
+    float mean[2], rstd[2], s1[2], s2[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int g = g0 + hf < G ? g0 + hf : G - 1;
+        mean[hf] = fstats[(i * G + g) * 2] / n;
+        const float var = fmaxf(fstats[(i * G + g) * 2 + 1] / n - mean[hf] * mean[hf], 0.f);
+        rstd[hf] = rsqrtf(var + eps);
+        s1[hf] = bstats[(i * G + g) * 2] / n;
+        s2[hf] = bstats[(i * G + g) * 2 + 1] / n;
+    }
+    float v[8], d[8], ga[8], be[8], o[8];
+    unpack8(*(const uint4*)(x + r * C + c8 * 8), v);
+    unpack8(*(const uint4*)(dz + pad_row(pm, r) * C + c8 * 8), d);
+    unpack8(*(const uint4*)(gamma + c8 * 8), ga);
+    unpack8(*(const uint4*)(beta + c8 * 8), be);
+    if (accumulate) unpack8(*(const uint4*)(dx + r * C + c8 * 8), o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int hf = j < bnd ? 0 : 1;
+        const float xh = (v[j] - mean[hf]) * rstd[hf];
+        const float dy = silu ? silu_grad_f(xh * ga[j] + be[j], d[j]) : d[j];
+        const float g = rstd[hf] * (ga[j] * dy - (s1[hf] + xh * s2[hf]));
+        o[j] = accumulate ? o[j] + g : g;
+    }
+    *(uint4*)(dx + r * C + c8 * 8) = pack8(o);
+}
+
 inline int finish() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
@@ -331,6 +461,60 @@ static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t 
     }
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
                        (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im);
+    return finish();
+}
+
+extern "C" int dwm_groupnorm_bwd(const void* x, const void* dz, void* dx, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                                 const void* gamma, const void* beta, int32_t silu, int32_t accumulate, float* stats,
+                                 float* dgamma, float* dbeta, const dwm_rowmap2d* dz_map, const dwm_gn_imgmap* img_map, void* stream) {
+    if (x == nullptr || dz == nullptr || dx == nullptr || gamma == nullptr || beta == nullptr || stats == nullptr || dgamma == nullptr ||
+        dbeta == nullptr)
+        return DWM_EINVAL;
+    if (I <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G != 0) return DWM_EINVAL;
+    const int CG = C / G;
+    if (C % 8 != 0 || !(CG == 4 || CG >= 8) || I > 65535 || I * P >= (1ll << 31)) return DWM_EUNSUPPORTED;
+    if (!dwm_aligned16(x) || !dwm_aligned16(dz) || !dwm_aligned16(dx) || !dwm_aligned16(gamma) || !dwm_aligned16(beta)) return DWM_EALIGN;
+    ImgMap im;
+    im.enabled = img_map != nullptr && img_map->iv > 0;
+    if (im.enabled) {
+        if (img_map->pn <= 0 || img_map->iv >= (1ll << 30) || img_map->pn >= (1ll << 30)) return DWM_EINVAL;
+        im.iv = make_fastdiv((uint32_t)img_map->iv); im.pn = make_fastdiv((uint32_t)img_map->pn);
+        im.s_ihi = img_map->s_ihi; im.s_ilo = img_map->s_ilo; im.s_phi = img_map->s_phi;
+    } else {
+        im.iv = make_fastdiv(1); im.pn = make_fastdiv(1); im.s_ihi = im.s_ilo = im.s_phi = 0;
+    }
+    PadMap pm;
+    pm.enabled = dz_map != nullptr && dz_map->rw > 0;
+    if (pm.enabled) {
+        if (dz_map->rh <= 0 || (!im.enabled && dz_map->rw * dz_map->rh != P)) return DWM_EINVAL;
+        pm.rw = make_fastdiv((uint32_t)dz_map->rw); pm.rh = make_fastdiv((uint32_t)dz_map->rh);
+        pm.rpitch = dz_map->rpitch; pm.ipitch = dz_map->ipitch; pm.origin = dz_map->origin;
+    } else {
+        pm.rw = make_fastdiv(1); pm.rh = make_fastdiv(1); pm.rpitch = pm.ipitch = pm.origin = 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ppb = gn_pixels_per_block(I, P);
+    const int nchunks = (int)((P + ppb - 1) / ppb);
+    const int C8 = C / 8, TW = C8 < 256 ? C8 : 256, pstep = 256 / TW;
+    const size_t lds_f = sizeof(float) * 4 * (size_t)pstep * C8;
+    const size_t lds_b = lds_f + sizeof(float) * 2 * (size_t)pstep * C;
+    if (lds_b > 64 * 1024) return DWM_EUNSUPPORTED;
+    // scratch: [forward statistics | forward partials | backward statistics | backward partials]
+    const int64_t half = dwm_groupnorm_stats_floats(I, P, G);
+    float* fstats = stats;
+    float* fpart = stats + 2 * (int64_t)G * I;
+    float* bstats = stats + half;
+    float* bpart = bstats + 2 * (int64_t)G * I;
+    const dim3 grid((unsigned)nchunks, (unsigned)I);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds_f, s, (const bf16_t*)x, P, C, G, ppb, fpart, im);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)I), dim3(64), 0, s, (const float*)fpart, fstats, nchunks, 2 * G);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), lds_b, s, (const bf16_t*)x, (const bf16_t*)dz, P, C, G, ppb,
+                       (const float*)fstats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, bpart, dgamma, dbeta, pm, im);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)I), dim3(64), 0, s, (const float*)bpart, bstats, nchunks, 2 * G);
+    const int64_t total = I * P * (C / 8);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dz,
+                       (bf16_t*)dx, I, P, C, G, (const float*)fstats, (const float*)bstats, (const bf16_t*)gamma, (const bf16_t*)beta,
+                       eps, silu, accumulate, pm, im);
     return finish();
 }
 

@@ -507,16 +507,11 @@ def attention_bwd(q, k, v, out, dout, dq, dk, dv, rowmap: RowMap, heads: int, ls
         keep.record_stream(torch.cuda.current_stream())
 
 
-def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_problems: int, heads: int,
-                    scale: Optional[float] = None) -> None:
-    """Cross-attention (diffusers BasicTransformerBlock.attn2): q/out [n_problems*Lq, heads*64], k/v
-    [n_problems*Lk, heads*64] (column slices of one buffer sharing a row stride); every query attends to all Lk keys of
-    its problem.  Runs dwm_attention_fwd in `cross` mode: queries = segment 0, keys / values = segment 1."""
+def _cross_args(a, q, k, v, out, n_problems, heads, scale):
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
         _chk2d(t, name)
     if k.stride(0) != v.stride(0) or q.shape[0] % n_problems or k.shape[0] % n_problems:
         raise RuntimeError("cross_attention: k, v must share a row stride; rows must be n_problems * L")
-    a = _lib.AttnArgs()
     a.q0 = a.q1 = q.data_ptr()
     a.k0 = a.k1 = k.data_ptr()
     a.v0 = a.v1 = v.data_ptr()
@@ -533,7 +528,43 @@ def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
         a.lstride[i] = rm.lstride[i]
     a.ldiv[0], a.ldiv[1] = rm.ldiv
     a.cross = 1
+
+
+def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, n_problems: int, heads: int,
+                    scale: Optional[float] = None, lse: Optional[torch.Tensor] = None) -> None:
+    """Cross-attention (diffusers BasicTransformerBlock.attn2): q/out [n_problems*Lq, heads*64], k/v
+    [n_problems*Lk, heads*64] (column slices of one buffer sharing a row stride); every query attends to all Lk keys of
+    its problem.  Runs dwm_attention_fwd in `cross` mode: queries = segment 0, keys / values = segment 1.
+    lse (optional, fp32 [n_problems, heads, Lq + Lk], the query entries are written): for cross_attention_bwd."""
+    a = _lib.AttnArgs()
+    _cross_args(a, q, k, v, out, n_problems, heads, scale)
+    if lse is not None:
+        if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != n_problems * heads * (a.L0 + a.L1):
+            raise RuntimeError("lse: fp32 contiguous [n_problems, heads, Lq+Lk] expected")
+        a.lse = lse.data_ptr()
     _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
+
+
+def cross_attention_bwd(q, k, v, out, dout, dq, dk, dv, n_problems: int, heads: int, lse: torch.Tensor,
+                        scale: Optional[float] = None) -> None:
+    """Backward of `cross_attention`: dq like q (row stride of its own), dk / dv like k / v (sharing a row stride)."""
+    b = _lib.AttnBwdArgs()
+    _cross_args(b.fwd, q, k, v, out, n_problems, heads, scale)
+    b.fwd.lse = lse.data_ptr()
+    for name, t in (("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
+        _chk2d(t, name)
+    if dout.stride(0) != out.stride(0) or dk.stride(0) != dv.stride(0) or dq.shape != q.shape or dk.shape != k.shape:
+        raise RuntimeError("cross_attention_bwd: dout like out, dq like q, dk / dv like k / v (one row stride)")
+    # one gradient base per tensor for both segments (the kernels address segment 1 relative to segment 0, cf. the forward)
+    b.do0 = b.do1 = dout.data_ptr()
+    b.dq0 = b.dq1 = dq.data_ptr()
+    b.dk0 = b.dk1 = dk.data_ptr()
+    b.dv0 = b.dv1 = dv.data_ptr()
+    b.ld_d0, b.ld_d1 = dq.stride(0), dk.stride(0)
+    delta = torch.empty(lse.numel(), dtype=torch.float32, device=lse.device)
+    b.delta = delta.data_ptr()
+    _lib.check(_lib.load().dwm_attention_bwd(C.byref(b), _stream()), "dwm_attention_bwd")
+    delta.record_stream(torch.cuda.current_stream())
 
 
 # -------------------------------------------------------------------------------- norms
