@@ -384,7 +384,7 @@ attn_fwd_kernel(const AttnParams P) {
             if (fetch_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * QT) : "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(MODE & 4)) __syncthreads();          // MODE bit 2: ablation without the per-tile barrier (wrong results)
 
         // ---- end of a head: normalise and store its output, reset the running state, switch Q.
         // The 32 x 64 bf16 output tile of a wave is transposed through the 4 KiB of the just-retired stage that
@@ -837,14 +837,15 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
 #define DWM_ATTN(QT_, MODE_)                                              \
     do {                                                                  \
         if (P.mask_mode == 0) launch_attn<QT_, 0, MODE_>(P, s);           \
-        else if (P.mask_mode == 1) launch_attn<QT_, 1, (MODE_) & 1>(P, s);      \
-        else launch_attn<QT_, 2, (MODE_) & 1>(P, s);                            \
+        else if (P.mask_mode == 1) launch_attn<QT_, 1, (MODE_) & 5>(P, s);      \
+        else launch_attn<QT_, 2, (MODE_) & 5>(P, s);                            \
     } while (0)
     {
         // (the pipelined body exists for the unmasked kernel only: with the mask arithmetic it does not fit 168 registers)
         const bool noprio = (a->variant >> 6) & 1;
         const bool pipe = (((a->variant >> 7) & 1) != 0) != kPipeDefault;
         if (qt == 2) { if (noprio) DWM_ATTN(2, 1); else DWM_ATTN(2, 0); }
+        else if ((a->variant >> 12) & 1) DWM_ATTN(1, 4);            // ablation: no per-tile barrier (results are wrong)
         else if (pipe) { if (noprio) DWM_ATTN(1, 3); else DWM_ATTN(1, 2); }
         else { if (noprio) DWM_ATTN(1, 1); else DWM_ATTN(1, 0); }
     }

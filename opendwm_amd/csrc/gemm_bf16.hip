@@ -18,6 +18,7 @@
 // stages for the activation tile (requested two K steps ahead: it is the operand that streams from HBM
 // when K is long) and two for the weight tile (one step ahead, L2-resident); one barrier per K step with a
 // counted vmcnt that leaves the newest activation requests in flight.
+#include <stdlib.h>
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -711,6 +712,16 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     return e == hipSuccess ? DWM_OK : (int)e;
 }
 
+// default main-loop schedule; DWM_GEMM_SCHED=0..3 overrides it for A/B measurements of the whole step
+static int sched_default() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DWM_GEMM_SCHED");
+        v = (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : kSchedDefault;
+    }
+    return v;
+}
+
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 31) || a->N >= (1ll << 31)) return DWM_EINVAL;
@@ -816,7 +827,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     } while (0)
 #define DWM_LAUNCH(EPI)                                                                              \
     do {                                                                                             \
-        switch (((a->reserved >> 9) & 3) ^ kSchedDefault) {                                          \
+        switch (((a->reserved >> 9) & 3) ^ sched_default()) {                                        \
             case 0: DWM_LAUNCH_S(EPI, 0); break;                                                     \
             case 1: DWM_LAUNCH_S(EPI, 1); break;                                                     \
             case 2: DWM_LAUNCH_S(EPI, 2); break;                                                     \

@@ -154,6 +154,15 @@ class Grid3D:
                 for dt in range(3) for dy in range(3) for dx in range(3)]
 
 
+def _overlaps(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """do the byte ranges spanned by two 2-D row-strided tensors intersect?"""
+    def span(t):
+        lo = t.data_ptr()
+        return lo, lo + ((t.shape[0] - 1) * t.stride(0) + t.shape[1]) * t.element_size() if t.numel() else lo
+    (a0, a1), (b0, b1) = span(a), span(b)
+    return a0 < b1 and b0 < a1
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, epilogue: int = EPI_PLAIN, act: int = ACT_NONE,
          gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
@@ -198,6 +207,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     _chk2d(out, "out")
     if out.shape != (orow, nout):
         raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(orow, nout)}")
+    if _overlaps(a, out):
+        raise RuntimeError("gemm: `out` overlaps the A operand (a tile's output would overwrite rows other tiles still read)")
     _chkvec(bias, "bias")
     g = _lib.GemmArgs()
     g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)

@@ -207,3 +207,38 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True) -> T
     dw = ops.gemm(dyt, xt, None)           # [N, K]
     db = segsum(dy)[0] if want_bias else None
     return dw, db
+
+
+def groupnorm_bwd(x: torch.Tensor, dz: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                  eps: float, dgamma: torch.Tensor, dbeta: torch.Tensor, *, silu: bool = True, dx: Optional[torch.Tensor] = None,
+                  accumulate: bool = False, dz_grid=None, img_map: Optional[tuple] = None) -> torch.Tensor:
+    """Backward of ops.groupnorm_silu: x [I*P, C] = the forward input, dz = gradient of the forward output - compact
+    rows, or (dz_grid) the padded grid the forward wrote into; returns dx [I*P, C] bf16 (accumulate: added to the given dx);
+    dgamma / dbeta: fp32 [C] accumulators (see dwm_groupnorm_bwd)."""
+    _rows2d(x, "x")
+    _rows2d(dz, "dz")
+    Cc = x.shape[1]
+    rows = dz_grid.rows if dz_grid is not None else I * P
+    if not x.is_contiguous() or x.shape[0] != I * P or not dz.is_contiguous() or dz.shape != (rows, Cc):
+        raise RuntimeError("groupnorm_bwd: x must be contiguous [I*P, C], dz [rows, C] (rows of the padded grid if dz_grid)")
+    for name, t in (("dgamma", dgamma), ("dbeta", dbeta)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != Cc or not t.is_cuda:
+            raise RuntimeError(f"groupnorm_bwd: {name} must be a contiguous fp32 CUDA vector of C elements")
+    if dx is None:
+        if accumulate:
+            raise RuntimeError("groupnorm_bwd: accumulate needs dx")
+        dx = torch.empty_like(x)
+    _rows2d(dx, "dx")
+    if dx.shape != x.shape or not dx.is_contiguous():
+        raise RuntimeError("groupnorm_bwd: bad dx")
+    lib = _lib.load()
+    stats = torch.empty(2 * lib.dwm_groupnorm_stats_floats(I, P, groups), dtype=torch.float32, device=x.device)
+    m = _lib.RowMap2D()
+    if dz_grid is not None:
+        dz_grid.fill(m)
+    im = _lib.GnImgMap()
+    if img_map is not None:
+        im.iv, im.pn, im.s_ihi, im.s_ilo, im.s_phi = img_map
+    _lib.check(lib.dwm_groupnorm_bwd(_p(x), _p(dz), _p(dx), I, P, Cc, groups, eps, _p(gamma), _p(beta), int(silu), int(accumulate),
+                                     _p(stats), _p(dgamma), _p(dbeta), C.byref(m), C.byref(im), _stream()), "dwm_groupnorm_bwd")
+    return dx

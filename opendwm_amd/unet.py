@@ -324,7 +324,9 @@ class TransformerModel(nn.Module):
                     ops.rowmap_temporal_pointwise(B, Tn, V, g.h, g.w)
                 self.temporal_transformer_blocks[l].run(h, rm, emb=seq_emb, rows_per_emb=g.N,
                                                         blend_alpha=alpha_t, rows_per_alpha=Tn * V * g.N, blend_into=h)
-        return ops.gemm(h, _bf(self.proj_out.weight), _bf(self.proj_out.bias), epilogue=EPI_RESID, res=x, out=h)
+        # (the output must not alias the A operand `h`: column tiles of one row panel do not all run at the same time once the
+        # grid exceeds the chip - 6 views x 6 frames at 32x56 - and a finished tile would overwrite rows another still reads)
+        return ops.gemm(h, _bf(self.proj_out.weight), _bf(self.proj_out.bias), epilogue=EPI_RESID, res=x, out=hn)
 
 
 class _Sampler(nn.Module):

@@ -96,7 +96,7 @@ class _VaeAttention(nn.Module):
             # rows of softmax sum to 1, so P @ (V + 1 b^T) = P @ V + b^T: the v bias is the column bias here
             ops.gemm(s, vt, _bf(self.to_v.bias), out=o[sl])
         to = self.to_out[0]
-        return ops.gemm(o, _bf(to.weight), _bf(to.bias), epilogue=EPI_RESID, res=x, out=o)
+        return ops.gemm(o, _bf(to.weight), _bf(to.bias), epilogue=EPI_RESID, res=x, out=xn)      # (never into the A operand)
 
 
 class _MidBlock(nn.Module):
