@@ -32,22 +32,11 @@ using namespace dwm_attn;
 
 namespace {
 
-constexpr bool kPipeDefault = false;    // tile body of the 32-queries-per-wave kernel when variant bit 7 is clear
-
 // MASK: 0 none, 1 group mask, 2 dense byte mask.  NW = 4 waves (256 threads).
 // occupancy target: 3 workgroups (waves per SIMD) for 32 queries/wave, 2 for 64 queries/wave
-// MODE bit 0: no s_setprio brackets around the MFMA sections; bit 1: "pipelined" tile body (QT = 1): all eight K fragment
-// reads of a tile are issued before its first S MFMA and all sixteen transposing V reads BEFORE the softmax (their LDS
-// latency hides under the ~100 softmax VALU instructions instead of in front of the PV MFMAs), the lane^32 exchange of the
-// row maximum is a v_permlane32_swap (a ds_bpermute would queue behind the V reads: LDS returns in order), and the K/V
-// LDS-DMA is issued from inline asm - the compiler cannot tell a pending LDS-DMA from an LDS store and would otherwise put
-// "s_waitcnt vmcnt(0)" in front of the hoisted V reads, draining the two tiles that are meant to stay in flight.
-template <int QT, int MASK, int MODE>
+template <int QT, int MASK>
 __global__ void __launch_bounds__(256, QT == 1 ? 3 : 2)
 attn_fwd_kernel(const AttnParams P) {
-    constexpr bool PRIO = !(MODE & 1);
-    constexpr bool PIPE = (MODE & 2) != 0;
-    static_assert(!PIPE || (QT == 1 && MASK == 0), "the pipelined body: one query tile per wave, no mask");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 4;
     constexpr int QB = NW * QT * 32;          // queries per block
@@ -144,18 +133,10 @@ attn_fwd_kernel(const AttnParams P) {
         const int64_t oa_ = ((int64_t)rowtab[ra_] << 3) + (ra_ < L0 ? 0 : P.seg1_delta);    \
         const int64_t ob_ = ((int64_t)rowtab[rb_] << 3) + (rb_ < L0 ? 0 : P.seg1_delta);    \
         char* kl_ = smem + (stage_) * STAGE_BYTES + sdst;                                   \
-        if constexpr (PIPE) {                                                               \
-            const uint32_t la_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)kl_;   \
-            glds16_asm(kg0 + oa_ + (ho_), la_);                                             \
-            glds16_asm(kg1 + ob_ + (ho_), la_ + 1024);                                      \
-            glds16_asm(vg0 + oa_ + (ho_), la_ + K_TILE_BYTES);                              \
-            glds16_asm(vg1 + ob_ + (ho_), la_ + K_TILE_BYTES + 1024);                       \
-        } else {                                                                            \
-            glds16(kg0 + oa_ + (ho_), kl_);                                                 \
-            glds16(kg1 + ob_ + (ho_), kl_ + 1024);                                          \
-            glds16(vg0 + oa_ + (ho_), kl_ + K_TILE_BYTES);                                  \
-            glds16(vg1 + ob_ + (ho_), kl_ + K_TILE_BYTES + 1024);                           \
-        }                                                                                   \
+        glds16(kg0 + oa_ + (ho_), kl_);                                                     \
+        glds16(kg1 + ob_ + (ho_), kl_ + 1024);                                              \
+        glds16(vg0 + oa_ + (ho_), kl_ + K_TILE_BYTES);                                      \
+        glds16(vg1 + ob_ + (ho_), kl_ + K_TILE_BYTES + 1024);                               \
     } while (0)
 
     // Softmax bookkeeping in the exponent domain: Q is pre-multiplied by scale*log2(e) and the S MFMAs
@@ -216,23 +197,7 @@ attn_fwd_kernel(const AttnParams P) {
 
         // ---- S^T = K Q^T for two 32-key sub-tiles (K fragments shared by the QT query tiles)
         f32x16 st[QT][2];
-        if constexpr (PIPE) {
-            bf16x8 kfr[8];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    kfr[j * 4 + ks] = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    st[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[j * 4 + ks], qf[0][ks], ks == 0 ? negm[0] : st[0][j], 0, 0, 0);
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        } else {
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -242,8 +207,7 @@ attn_fwd_kernel(const AttnParams P) {
                 for (int t = 0; t < QT; ++t)
                     st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], ks == 0 ? negm[t] : st[t][j], 0, 0, 0);
             }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        }
+        __builtin_amdgcn_s_setprio(0);
         if (fetch_q) {
             // issued as inline asm: a compiler-visible load that is still pending on the loop's back edge makes the
             // compiler put "s_waitcnt vmcnt(0)" in front of the S MFMAs of EVERY tile - which also drains the K/V
@@ -255,23 +219,6 @@ attn_fwd_kernel(const AttnParams P) {
                 for (int ks = 0; ks < 4; ++ks)
                     asm volatile("global_load_dwordx4 %0, %1, off"
                                  : "=v"(qf[t][ks]) : "v"(qbase[t] + (hh + 1) * 64 + ks * 16 + half * 8) : "memory");
-        }
-
-        // pipelined body: the V^T fragments of this tile are requested now and arrive under the softmax
-        bf16x8 vfr[8];
-        if constexpr (PIPE) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s * (16 * 128)));
-                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s * (16 * 128)));
-                    vfr[s * 2 + dt] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- masks (raw-score domain), online softmax; P^T fragments stay in registers
@@ -312,7 +259,7 @@ attn_fwd_kernel(const AttnParams P) {
         bf16x8 pf[QT][4];                      // B-operand fragments, step s = 2*j + s2
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float mx = PIPE ? tile_max32_swap(st[t][0], st[t][1]) : tile_max32(st[t][0], st[t][1]);     // relative to the running max
+            const float mx = tile_max32(st[t][0], st[t][1]);     // relative to the running max
             // deferred rescale: keep the old running max while the new one exceeds it by < 2^6
             // (P <= 64, exact in the fp32 sums; bf16 P keeps its relative precision); the first
             // finite score of a row always sets it
@@ -350,17 +297,7 @@ attn_fwd_kernel(const AttnParams P) {
         }
 
         // ---- O^T += V^T P^T   (V fragments shared by the QT query tiles)
-        if constexpr (PIPE) {
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    ot[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s * 2 + dt], pf[0][s], ot[0][dt], 0, 0, 0);
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        } else {
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -374,8 +311,7 @@ attn_fwd_kernel(const AttnParams P) {
                 for (int t = 0; t < QT; ++t)
                     ot[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], ot[t][dt], 0, 0, 0);
             }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        }
+        __builtin_amdgcn_s_setprio(0);
         }
 
         // tile s+1 landed (tile s+2 may stay in flight), everyone is done with this tile's slot, which then
@@ -384,7 +320,7 @@ attn_fwd_kernel(const AttnParams P) {
             if (fetch_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * QT) : "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!(MODE & 4)) __syncthreads();          // MODE bit 2: ablation without the per-tile barrier (wrong results)
+        __syncthreads();
 
         // ---- end of a head: normalise and store its output, reset the running state, switch Q.
         // The 32 x 64 bf16 output tile of a wave is transposed through the 4 KiB of the just-retired stage that
@@ -757,16 +693,16 @@ tr_probe_kernel(const int* __restrict__ offs, short* __restrict__ out) {
     for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
 }
 
-template <int QT, int MASK, int MODE>
+template <int QT, int MASK>
 void launch_attn(const AttnParams& P, hipStream_t s) {
     const int64_t nblk = (int64_t)P.n_problems * (P.heads / P.hpb) * P.nqb;
     const size_t lds = NSTAGE * STAGE_BYTES + (size_t)((P.L + 3) & ~3) * sizeof(int32_t);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<QT, MASK, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<QT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<QT, MASK, MODE>), dim3((unsigned)nblk), dim3(256), lds, s, P);
+    hipLaunchKernelGGL((attn_fwd_kernel<QT, MASK>), dim3((unsigned)nblk), dim3(256), lds, s, P);
 }
 
 }  // namespace
@@ -832,23 +768,13 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }
-    // variant bit 6: without the s_setprio brackets around the MFMA sections; bit 7: the other tile body (pipelined <->
-    // plain) than the default for 32 queries per wave (A/B measurements, tests)
-#define DWM_ATTN(QT_, MODE_)                                              \
-    do {                                                                  \
-        if (P.mask_mode == 0) launch_attn<QT_, 0, MODE_>(P, s);           \
-        else if (P.mask_mode == 1) launch_attn<QT_, 1, (MODE_) & 5>(P, s);      \
-        else launch_attn<QT_, 2, (MODE_) & 5>(P, s);                            \
+#define DWM_ATTN(QT_)                                              \
+    do {                                                           \
+        if (P.mask_mode == 0) launch_attn<QT_, 0>(P, s);           \
+        else if (P.mask_mode == 1) launch_attn<QT_, 1>(P, s);      \
+        else launch_attn<QT_, 2>(P, s);                            \
     } while (0)
-    {
-        // (the pipelined body exists for the unmasked kernel only: with the mask arithmetic it does not fit 168 registers)
-        const bool noprio = (a->variant >> 6) & 1;
-        const bool pipe = (((a->variant >> 7) & 1) != 0) != kPipeDefault;
-        if (qt == 2) { if (noprio) DWM_ATTN(2, 1); else DWM_ATTN(2, 0); }
-        else if ((a->variant >> 12) & 1) DWM_ATTN(1, 4);            // ablation: no per-tile barrier (results are wrong)
-        else if (pipe) { if (noprio) DWM_ATTN(1, 3); else DWM_ATTN(1, 2); }
-        else { if (noprio) DWM_ATTN(1, 1); else DWM_ATTN(1, 0); }
-    }
+    if (qt == 1) DWM_ATTN(1); else DWM_ATTN(2);
 #undef DWM_ATTN
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;

@@ -83,28 +83,6 @@ DWM_DEVINL float tile_max32(const f32x16& s0, const f32x16& s1) {
     const float mx = max3f(max3f(mxa, mxb, mxc), mxd, -INFINITY);
     return max3f(mx, __shfl_xor(mx, 32, 64), -INFINITY);
 }
-// same, the lane ^ 32 exchange as a v_permlane32_swap (no LDS round trip: a ds_bpermute would return behind every LDS read
-// the wave has in flight)
-DWM_DEVINL float tile_max32_swap(const f32x16& s0, const f32x16& s1) {
-    float mxa = max3f(s0[0], s0[1], s0[2]), mxb = max3f(s0[3], s0[4], s0[5]);
-    float mxc = max3f(s1[0], s1[1], s1[2]), mxd = max3f(s1[3], s1[4], s1[5]);
-#pragma unroll
-    for (int r = 6; r < 14; r += 4) {
-        mxa = max3f(mxa, s0[r], s0[r + 1]);
-        mxb = max3f(mxb, s0[r + 2], s0[r + 3]);
-        mxc = max3f(mxc, s1[r], s1[r + 1]);
-        mxd = max3f(mxd, s1[r + 2], s1[r + 3]);
-    }
-    mxa = max3f(mxa, s0[14], s0[15]);
-    mxc = max3f(mxc, s1[14], s1[15]);
-    const float mx = max3f(max3f(mxa, mxb, mxc), mxd, -INFINITY);
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    return max3f(__uint_as_float(sw[0]), __uint_as_float(sw[1]), -INFINITY);
-}
-// LDS-DMA (16 B per lane) issued from inline asm: M0 = wave-uniform LDS byte address of the 1 KiB destination
-DWM_DEVINL void glds16_asm(const void* gsrc, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gsrc) : "memory");
-}
 // 8 bf16 * c -> 8 bf16 (folds softmax scale * log2(e) into the Q fragments)
 DWM_DEVINL bf16x8 scale_frag(const bf16x8& v, float c) {
     const uint4 u = *reinterpret_cast<const uint4*>(&v);

@@ -18,7 +18,6 @@
 // stages for the activation tile (requested two K steps ahead: it is the operand that streams from HBM
 // when K is long) and two for the weight tile (one step ahead, L2-resident); one barrier per K step with a
 // counted vmcnt that leaves the newest activation requests in flight.
-#include <stdlib.h>
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -48,7 +47,6 @@ struct ConvParams {
     int64_t ws_slice;
 };
 constexpr int EPI_SPLITK = 100;     // internal epilogue id: fp32 partials to the workspace
-constexpr int kSchedDefault = 2;    // main-loop schedule variant when dwm_gemm_args.reserved bits 9-10 are clear
 DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     if (!rm.enabled) return m;
     const uint32_t q = fdiv((uint32_t)m, rm.rw), x = (uint32_t)m - q * rm.rw.d;
@@ -56,10 +54,7 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + (int64_t)x * rm.xstep + rm.origin;
 }
 
-// SCHED (experiment knob, dwm_gemm_args.reserved bits 9-10): bit 0 = the six fragment reads of the next sub-step are issued
-// two per chunk in chunks 0-2 (five MFMAs instead of two between the last read and its use); bit 1 = static s_setprio 1 for
-// the second-dispatched half of the workgroup (waves 4-7 share their SIMDs with waves 0-3)
-template <int EPI, int SCHED = 0>
+template <int EPI>
 __global__ void __launch_bounds__(512, 2)
 gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
     constexpr int NWN = 4;                       // wave columns of the 2 x 4 wave grid
@@ -180,7 +175,6 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + W_BASE + w_row_off + nt * (32 * 128) + coff[0]);
     }
-    if constexpr (SCHED & 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     for (int kt = 0; kt < nk; ++kt) {
         const int sa1 = sa == A_STAGES - 1 ? 0 : sa + 1, sa2 = sa1 == A_STAGES - 1 ? 0 : sa1 + 1;
         const char* la = smem + sa * TILE_BYTES;
@@ -207,18 +201,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     const int idx = c * MPC + u, mt = idx / NTW, nt = idx % NTW;
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
                 }
-                if constexpr (SCHED & 1) {
-                    if (2 * c < NDS) {
-                        const char* fa = ks < 3 ? la : lan;
-                        const char* fb = ks < 3 ? lb : lbn;
-                        const int kn = ks < 3 ? ks + 1 : 0;
-#pragma unroll
-                        for (int rr = 2 * c; rr < 2 * c + 2 && rr < NDS; ++rr) {
-                            if (rr < 4) af[(ks + 1) & 1][rr] = *(const bf16x8*)(fa + a_row_off + rr * (32 * 128) + coff[kn]);
-                            else wf[(ks + 1) & 1][rr - 4] = *(const bf16x8*)(fb + w_row_off + (rr - 4) * (32 * 128) + coff[kn]);
-                        }
-                    }
-                } else if (c < NDS) {
+                if (c < NDS) {
                     const char* fa = ks < 3 ? la : lan;
                     const char* fb = ks < 3 ? lb : lbn;
                     const int kn = ks < 3 ? ks + 1 : 0;
@@ -233,7 +216,6 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         sa = sa1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant last DMA must not land in the epilogue scratch
-    if constexpr (SCHED & 2) __builtin_amdgcn_s_setprio(0);
 
     // ------------------------------------------------------------------ epilogue
     // Stage A (MFMA layout, lane = one row x 4-column groups): bias, activation, GEGLU product,
@@ -712,16 +694,6 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     return e == hipSuccess ? DWM_OK : (int)e;
 }
 
-// default main-loop schedule; DWM_GEMM_SCHED=0..3 overrides it for A/B measurements of the whole step
-static int sched_default() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("DWM_GEMM_SCHED");
-        v = (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : kSchedDefault;
-    }
-    return v;
-}
-
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 31) || a->N >= (1ll << 31)) return DWM_EINVAL;
@@ -814,25 +786,16 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         return e == hipSuccess ? DWM_OK : (int)e;
     }
     const dim3 grid((unsigned)(ntm * ntn)), block(512);
-#define DWM_LAUNCH_S(EPI, SCHED)                                                                     \
+#define DWM_LAUNCH(EPI)                                                                              \
     do {                                                                                             \
         static bool attr_set = false;                                                                \
         if (!attr_set) {                                                                             \
-            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, SCHED>,                       \
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,                              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
             if (e != hipSuccess) return (int)e;                                                      \
             attr_set = true;                                                                         \
         }                                                                                            \
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCHED>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn); \
-    } while (0)
-#define DWM_LAUNCH(EPI)                                                                              \
-    do {                                                                                             \
-        switch (((a->reserved >> 9) & 3) ^ sched_default()) {                                        \
-            case 0: DWM_LAUNCH_S(EPI, 0); break;                                                     \
-            case 1: DWM_LAUNCH_S(EPI, 1); break;                                                     \
-            case 2: DWM_LAUNCH_S(EPI, 2); break;                                                     \
-            default: DWM_LAUNCH_S(EPI, 3); break;                                                    \
-        }                                                                                            \
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);      \
     } while (0)
     switch (a->epilogue) {
         case DWM_EPI_PLAIN: DWM_LAUNCH(DWM_EPI_PLAIN); break;
@@ -840,7 +803,6 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         case DWM_EPI_RESID: DWM_LAUNCH(DWM_EPI_RESID); break;
         default: DWM_LAUNCH(DWM_EPI_RMSHEAD); break;
     }
-#undef DWM_LAUNCH_S
 #undef DWM_LAUNCH
     e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;

@@ -332,6 +332,13 @@ class CTSDTrainer:
         loss = mse(x0_hat.float(), x0.float()) * coef                      :1368-1370
         loss.backward(); [clip_grad_norm_]; optimizer.step(); zero_grad    :1401-1432
 
+    With the SD 2.1 UNet as the model the trainer takes the reference's other branch (ctsd.py:1240-1253):
+
+        t ~ randint(0, num_train_timesteps) per sample (per frame with diffusion forcing), from the pipeline generator
+        x_t = train_scheduler.add_noise(x0, noise, t)          (schedulers.DDPMScheduler, tensor timesteps)
+        target = noise ("epsilon") | train_scheduler.get_velocity(x0, noise, t) ("v_prediction")
+        loss = mse(model(x_t, t, conditions).float(), target.float()) * coef
+
     `ddp=True` wraps the model in torch DistributedDataParallel (ctsd.py:1051-1054): the block Functions of
     opendwm_amd.train hand their parameter gradients to autograd block by block, so the bucketed RCCL
     all-reduce overlaps the rest of the backward.  The buckets travel as bf16 (`ddp_comm_dtype`, torch's
@@ -348,7 +355,8 @@ class CTSDTrainer:
                  shift: float = 3.0, num_train_timesteps: int = 1000, loss_coef: float = 1.0,
                  max_grad_norm: Optional[float] = None, weighting_scheme: str = "logit_normal", ddp: bool = False,
                  ddp_kwargs: Optional[dict] = None, common_config: Optional[dict] = None, training_config: Optional[dict] = None,
-                 reference_latent_count=0, lr_scheduler=None, ddp_comm_dtype: Optional[torch.dtype] = bf16):
+                 reference_latent_count=0, lr_scheduler=None, ddp_comm_dtype: Optional[torch.dtype] = bf16,
+                 train_scheduler=None):
         """common_config["frame_prediction_style"] (None | "diffusion_forcing" | "ctsd") and training_config select the
         training task mix of `make_input_for_prediction`; with "diffusion_forcing" every frame draws its own timestep
         (ctsd.py:1232-1237)."""
@@ -378,6 +386,13 @@ class CTSDTrainer:
         self.max_grad_norm = self.training_config.get("max_norm_for_grad_clip", max_grad_norm)
         self.weighting_scheme = weighting_scheme
         self.reference_latent_count = reference_latent_count
+        # SD 2.1 branch (ctsd.py:1240-1253): the model is the UNet -> DDPM noising, epsilon / v_prediction target
+        from .unet import UNetCrossviewTemporalConditionModel
+        self.is_unet = isinstance(model, UNetCrossviewTemporalConditionModel)
+        if self.is_unet and train_scheduler is None:
+            from .schedulers import DDPMScheduler
+            train_scheduler = DDPMScheduler(num_train_timesteps=num_train_timesteps)
+        self.train_scheduler = train_scheduler
 
     def draw_condition_masks(self, batch_size: int, generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
         """the per-sample condition dropout masks of the training step in the reference's draw order (ctsd.py:1278-1301):
@@ -399,7 +414,10 @@ class CTSDTrainer:
         B, T = latents_shape[:2]
         noise = torch.randn(tuple(latents_shape), generator=generator)
         per_frame = self.common_config.get("frame_prediction_style") == "diffusion_forcing"
-        idx = sample_timestep_indices((B, T) if per_frame else (B,), None, self.weighting_scheme, self.num_train_timesteps)
+        if self.is_unet:                    # :1241-1244: integer timesteps from the SAME generator, right after the noise
+            idx = torch.randint(0, self.num_train_timesteps, (B, T) if per_frame else (B,), generator=generator)
+        else:
+            idx = sample_timestep_indices((B, T) if per_frame else (B,), None, self.weighting_scheme, self.num_train_timesteps)
         return noise, idx, self.draw_condition_masks(B, generator)
 
     def make_training_pair(self, latents: torch.Tensor, generator: Optional[torch.Generator] = None,
@@ -421,8 +439,48 @@ class CTSDTrainer:
         noisy = sig_b * noise + (1.0 - sig_b) * latents.float()
         return noisy, timesteps.to(dev), sig_b, noise
 
+    def make_unet_training_pair(self, latents: torch.Tensor, generator: Optional[torch.Generator] = None,
+                                timesteps: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """SD 2.1 branch (ctsd.py:1229-1253, 1273-1276): returns (noisy_latents, timesteps [B,T,V] int64, target, noise)"""
+        B, T, V = latents.shape[:3]
+        if noise is None:
+            noise = torch.randn(latents.shape, generator=generator)
+        if timesteps is None:
+            per_frame = self.common_config.get("frame_prediction_style") == "diffusion_forcing"
+            timesteps = torch.randint(0, self.num_train_timesteps, (B, T) if per_frame else (B,), generator=generator)
+        dev = latents.device
+        noise, timesteps = noise.to(dev), timesteps.to(dev)
+        sch = self.train_scheduler
+        noisy = sch.add_noise(latents.float(), noise, timesteps)
+        pt = sch.config.prediction_type
+        if pt == "epsilon":
+            target = noise
+        elif pt == "v_prediction":
+            target = sch.get_velocity(latents.float(), noise, timesteps)
+        else:
+            raise Exception("Unknown training target of the UNet.")
+        while timesteps.dim() < 3:                                                     # :1273-1276
+            timesteps = timesteps.unsqueeze(-1).repeat_interleave(latents.shape[timesteps.dim()], -1)
+        return noisy, timesteps, target.float(), noise
+
+    def _unet_loss(self, latents, conditions, generator, timesteps, noise) -> torch.Tensor:
+        noisy, timesteps, target, _ = self.make_unet_training_pair(latents, generator, timesteps, noise)
+        noisy, timesteps, extra, reference = make_input_for_prediction(
+            noisy, latents.float(), timesteps, self.training_config, self.common_config, generator, self.reference_latent_count)
+        cond = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
+                for k, v in conditions.items()}
+        if extra is not None:
+            cond.update(extra)
+        pred = self.wrapper(noisy.to(bf16), timesteps, **cond)[0][0].float()           # :1358-1360: sd_pred[0] as it is
+        if self.training_config.get("disable_reference_frame_loss", False):          # :1363-1367
+            keep = ~reference.view(*pred.shape[:3], 1, 1, 1).to(pred.device)
+            pred, target = pred * keep, target * keep
+        return torch.nn.functional.mse_loss(pred, target, reduction="mean") * self.loss_coef
+
     def loss(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
              timestep_indices=None, noise=None) -> torch.Tensor:
+        if self.is_unet:
+            return self._unet_loss(latents, conditions, generator, timestep_indices, noise)
         noisy, timesteps, sig, _ = self.make_training_pair(latents, generator, timestep_indices, noise)
         noisy, timesteps, extra, reference = make_input_for_prediction(
             noisy, latents.float(), timesteps, self.training_config, self.common_config, generator, self.reference_latent_count)

@@ -2,7 +2,8 @@
 `dwm.models.crossview_temporal_unet.UNetCrossviewTemporalConditionModel`
 (src/dwm/models/crossview_temporal_unet.py:355-835; blocks :10-352; ResBlock / TransformerModel /
 TemporalBasicTransformerBlock src/dwm/models/crossview_temporal.py:75-514) - same constructor kwargs, forward
-signature, return structure and state-dict keys; inference only.
+signature, return structure and state-dict keys.  This file is the inference path; in train() mode the forward runs
+opendwm_amd.train_unet (block Functions with hand-written HIP backward).
 
 Activations stay token-major `[(b t v)(h w), C]` bf16 for the whole network:
   * every 3x3 convolution (ResnetBlock2D, Downsample2D stride 2, Upsample2D, conv_in / conv_out) is an implicit GEMM
@@ -469,11 +470,43 @@ class UNetCrossviewTemporalConditionModel(_Base):
         STORE.bump()
         return out
 
-    @torch.no_grad()
     def forward(self, sample: torch.Tensor, timesteps, frustum_bev_residuals=None, encoder_hidden_states=None,
                 condition_image_tensor=None, disable_crossview=None, disable_temporal=None, crossview_attention_mask=None,
                 camera_intrinsics=None, camera_transforms=None, added_time_ids=None, camera_intrinsics_norm=None,
                 camera2referego=None, return_dict=False):
+        """Reference signature (crossview_temporal_unet.py:655-675).  In train() mode with autograd enabled the prediction
+        carries a grad_fn (opendwm_amd.train_unet: checkpointed block Functions with HIP backward kernels - the SD 2.1
+        branch of the train step, ctsd.py:1240-1253); otherwise the fused inference path runs under no_grad."""
+        if self.training and torch.is_grad_enabled():
+            from . import train_unet as _tu
+            if not sample.is_cuda:
+                raise RuntimeError("opendwm_amd runs on an MI355X (HIP) device only; got a CPU tensor")
+            if isinstance(encoder_hidden_states, dict):
+                raise NotImplementedError("dict encoder_hidden_states (align projection) is not built")
+            squeeze = sample.dim() < 6
+            if squeeze:
+                sample, timesteps = sample.unsqueeze(2), timesteps.unsqueeze(2)
+                if encoder_hidden_states is not None:
+                    encoder_hidden_states = encoder_hidden_states.unsqueeze(2)
+                if disable_temporal is not None:
+                    disable_temporal = disable_temporal.unsqueeze(2)
+            out = _tu.forward_train(self, sample, timesteps, encoder_hidden_states, disable_crossview=disable_crossview,
+                                    disable_temporal=disable_temporal, crossview_attention_mask=crossview_attention_mask,
+                                    added_time_ids=added_time_ids, condition_image_tensor=condition_image_tensor)
+            if squeeze:
+                out = out.squeeze(2)
+            if return_dict:
+                return {"noise_pred": out}
+            return (out,), None, None
+        with torch.no_grad():
+            return self._forward_infer(sample, timesteps, frustum_bev_residuals, encoder_hidden_states, condition_image_tensor,
+                                       disable_crossview, disable_temporal, crossview_attention_mask, camera_intrinsics,
+                                       camera_transforms, added_time_ids, camera_intrinsics_norm, camera2referego, return_dict)
+
+    def _forward_infer(self, sample: torch.Tensor, timesteps, frustum_bev_residuals=None, encoder_hidden_states=None,
+                       condition_image_tensor=None, disable_crossview=None, disable_temporal=None, crossview_attention_mask=None,
+                       camera_intrinsics=None, camera_transforms=None, added_time_ids=None, camera_intrinsics_norm=None,
+                       camera2referego=None, return_dict=False):
         STORE.set_precision(bf16)            # the UNet runs in bf16 only (the fp32 accuracy path covers the MMDiT forward)
         if not sample.is_cuda:
             raise RuntimeError("opendwm_amd runs on an MI355X (HIP) device only; got a CPU tensor")
