@@ -415,6 +415,82 @@ def main_train(args):
     D.shutdown()
 
 
+def _unet_synth_init_(model, seed: int):
+    """the UNet's seeded synthetic initialisation (bench only)"""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("mix_factor"):
+                p.fill_(2.0)
+            elif p.dim() == 1:
+                p.normal_(0.0, 0.05, generator=g)
+                if name.endswith(".weight"):
+                    p.add_(1.0)
+            else:
+                std = p[0].numel() ** -0.5
+                if ".conv2." in name or name.endswith("proj_out.weight") or ".net.2." in name or ".to_out.0." in name:
+                    std *= 0.5
+                p.normal_(0.0, std, generator=g)
+
+
+def main_train_unet(args):
+    """SD 2.1 training step (ctsd.py:1195-1437 in its UNet branch :1240-1253) at the BASELINE configs[1] geometry: DDPM noising,
+    v-prediction target, UNet forward + recompute + backward through opendwm_amd.train_unet, HIP AdamW on fp32 masters."""
+    from opendwm_amd import dist as D
+    rank, local_rank, world = D.env_ranks()
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init("nccl", dev)
+    from opendwm_amd import _lib
+    from opendwm_amd.pipeline import CTSDTrainer
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel, unet_flops
+    from opendwm_amd.build import ensure_built
+    ensure_built()
+    _lib.load()
+    with torch.device(dev):
+        model = UNetCrossviewTemporalConditionModel(**UNET_KWARGS)          # fp32 master parameters
+    _unet_synth_init_(model, 0)                                            # same seed on every rank
+    n_all = sum(p.numel() for p in model.parameters())
+    trainer = CTSDTrainer(model, lr=1e-5, weight_decay=0.01, ddp=world > 1)
+    w = UNET_WORKLOAD
+    B, T, V = w["B"], w["T"], w["V"]
+    gi = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    ring = torch.zeros(V, V, dtype=torch.bool)
+    for i in range(V):
+        for d in (-1, 0, 1):
+            ring[i, (i + d) % V] = True
+    cond = dict(
+        encoder_hidden_states=(torch.randn(B, T, V, w["text_len"], 1024, device=dev, generator=gi) * 0.5).to(torch.bfloat16),
+        disable_crossview=torch.zeros(B, dtype=torch.bool, device=dev), disable_temporal=torch.zeros(B, dtype=torch.bool, device=dev),
+        crossview_attention_mask=ring[None].repeat(B, 1, 1).to(dev),
+        added_time_ids=torch.rand(B, T, V, 11, device=dev, generator=gi) * 2 - 1)
+    latents = torch.randn(B, T, V, w["C"], w["H"], w["W"], device=dev, generator=gi)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    losses = []
+
+    def step(i):
+        losses.append(trainer.train_step(latents, cond, generator=gen))
+
+    dt = D.timed_steps(step, args.steps, args.warmup, dev)
+    finite = bool(torch.isfinite(torch.stack(losses)).all().item())
+    if rank == 0:
+        fwd = unet_flops(UNET_KWARGS, B, T, V, w["H"], w["W"], w["text_len"])
+        step_ms = 1e3 * dt / args.steps
+        print(json.dumps({
+            "metric": "train-samples/sec (6-view x6f 448x256 per sample), SD-2.1 CTSD UNet train step", "value": world * args.steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 compute, fp32 master weights / grads / AdamW",
+            "data": "synthetic (seeded random-init weights, random latents / text embeddings)",
+            "config": {"workload": "CTSD SD-2.1 UNet train step (DDPM noising, v-prediction loss, checkpointed blocks: forward + "
+                                   "recompute + backward, AdamW), one [1,6,6,4,32,56] sample per GPU, DDP over RCCL",
+                       "parameters": n_all, "forward_flop": fwd, "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
+                       "finite": finite, "peak_memory_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30},
+            "approx_mfma_frac": (4.0 * fwd) / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+        }))
+    D.shutdown()
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): re-execute this command line
     under torch.distributed.run with one rank per GPU (one process per GPU as src/dwm/train.py:60-67 of the reference
@@ -501,6 +577,8 @@ def main():
         sys.exit(self_launch(args.gpus))
     if args.debug_cpu_launch:
         return main_debug_cpu(args)
+    if args.train and args.unet:
+        return main_train_unet(args)
     if args.train:
         return main_train(args)
     if args.unet:

@@ -749,3 +749,48 @@ def test_scheduler_oracle_and_coefficient_tables_equal_reference():
     assert sch.timesteps[0].item() == 981 and sch.timesteps[-1].item() == 1 and len(sch.timesteps) == 50      # leading + offset 1
     with pytest.raises(ValueError):
         DDIMScheduler().coefficients(torch.tensor([1]))                     # set_timesteps not called: the reference raises too
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SD 2.1 (UNet) branch of the training step: the REAL train_step with a UNet-typed model and the REAL tensor-timestep
+# DDPMScheduler methods (tests/golden/make_reference_train_unet_fixture.py)
+@pytest.mark.parametrize("name", ["v_prediction", "epsilon", "df_style", "ctsd_style"])
+def test_trainer_unet_branch_equals_reference_train_step(name):
+    """CTSDTrainer.draw_training_inputs + CTSDTrainer.loss in the SD 2.1 branch (ctsd.py:1240-1253, 1273-1276, 1358-1360): integer
+    timesteps drawn from the pipeline generator right after the noise, DDPM add_noise, epsilon / v_prediction target, the
+    (b, t, v) timestep expansion, the task mixer on the same generator, mse on the raw prediction.  The stand-in model of the
+    fixture is the `wrapper`; the train scheduler is the oracle's restatement of the tensor-timestep DDPMScheduler (itself
+    pinned by reference_schedulers.pt; the HIP form is checked against the same vectors in the GPU leg) - same model input,
+    timesteps, loss and SGD update as the REAL train_step."""
+    import types
+    from oracle import scheduler_oracle as SO
+    from opendwm_amd.pipeline import CTSDTrainer
+    fx = torch.load(os.path.join(GOLDEN, "reference_train_step_unet.pt"))
+    d, acp = fx[name], fx["alphas_cumprod"]
+    img = d["batch"]["vae_images"]
+    B, T, V = img.shape[:3]
+    lat = (torch.nn.functional.avg_pool2d((img * 2 - 1).flatten(0, 2), 8) * 0.18215).unflatten(0, (B, T, V))
+    w = torch.tensor(0.3, requires_grad=True)
+    seen = []
+
+    def wrapper(x, ts, c=None, **kw):
+        seen.append((x.detach().float(), ts.detach()))
+        return [w * (x.float() + 1e-3 * ts[..., None, None, None] + 0.05 * c[..., None, None, None])], None, None
+    tr = CTSDTrainer.__new__(CTSDTrainer)
+    tr.wrapper, tr.num_train_timesteps, tr.is_unet = wrapper, 1000, True
+    tr.train_scheduler = types.SimpleNamespace(
+        config=types.SimpleNamespace(num_train_timesteps=1000, prediction_type=d["prediction_type"]),
+        add_noise=lambda x0, n, t: SO.add_noise(acp, x0, n, t), get_velocity=lambda x0, n, t: SO.get_velocity(acp, x0, n, t))
+    tr.common_config, tr.training_config = d["common_config"], d["training_config"]
+    tr.reference_latent_count = d["training_config"].get("reference_frame_count", 0)
+    tr.loss_coef = d["training_config"].get("loss_coef_dict", {}).get("sd", 1.0)
+    gen = torch.Generator().manual_seed(d["generator_seed"])
+    noise, ts, _ = tr.draw_training_inputs(lat.shape, gen)
+    assert ts.dtype == torch.int64 and ts.shape == ((B, T) if d["common_config"].get("frame_prediction_style") == "diffusion_forcing" else (B,))
+    loss = tr.loss(lat, {"c": d["batch"]["c"]}, generator=gen, timestep_indices=ts, noise=noise)
+    x_t, t_seen = seen[0]
+    assert torch.equal(t_seen, d["timesteps"])
+    assert torch.allclose(x_t, d["noisy_latents"], atol=2e-2)                  # the model input travels as bf16
+    assert abs(loss.item() - d["loss"].item()) / d["loss"].item() < 1e-2, (loss.item(), d["loss"].item())
+    loss.backward()
+    assert abs((0.3 - d["lr"] * w.grad).item() - d["w_after"].item()) < 2e-3
