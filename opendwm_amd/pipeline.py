@@ -414,7 +414,7 @@ class CTSDTrainer:
         B, T = latents_shape[:2]
         noise = torch.randn(tuple(latents_shape), generator=generator)
         per_frame = self.common_config.get("frame_prediction_style") == "diffusion_forcing"
-        if self.is_unet:                    # :1241-1244: integer timesteps from the SAME generator, right after the noise
+        if getattr(self, "is_unet", False): # :1241-1244: integer timesteps from the SAME generator, right after the noise
             idx = torch.randint(0, self.num_train_timesteps, (B, T) if per_frame else (B,), generator=generator)
         else:
             idx = sample_timestep_indices((B, T) if per_frame else (B,), None, self.weighting_scheme, self.num_train_timesteps)
@@ -479,7 +479,7 @@ class CTSDTrainer:
 
     def loss(self, latents: torch.Tensor, conditions: Dict[str, torch.Tensor], generator=None,
              timestep_indices=None, noise=None) -> torch.Tensor:
-        if self.is_unet:
+        if getattr(self, "is_unet", False):
             return self._unet_loss(latents, conditions, generator, timestep_indices, noise)
         noisy, timesteps, sig, _ = self.make_training_pair(latents, generator, timestep_indices, noise)
         noisy, timesteps, extra, reference = make_input_for_prediction(
