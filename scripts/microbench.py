@@ -128,7 +128,7 @@ def bench_gemm(dbg_list=(0, 1)):
             else:
                 f = lambda: ops.gemm(a, w, b, _debug=dbg)
             ms = timeit(f)
-            res[{0: "w8", 1: "w8-noepi", 1 << 9: "sched1", 2 << 9: "sched2", 3 << 9: "sched3"}.get(dbg, str(dbg))] = round(fl / ms / 1e9, 1)
+            res[{0: "w8", 1: "w8-noepi", 4: "w8-general-resid"}.get(dbg, str(dbg))] = round(fl / ms / 1e9, 1)
         ms_t = timeit(lambda: torch.matmul(a, w.t()))
         print(json.dumps({"kernel": "gemm", "case": name, "M": M, "N": N, "K": K, "tflops": res,
                           "hipblaslt_plain_tflops": round(fl / ms_t / 1e9, 1)}), flush=True)
@@ -161,7 +161,7 @@ if __name__ == "__main__":
         bench_attn([1, 1 | 64, 1 | 128, 1 | 64 | 128])
     if "gemm" in what:
         bench_gemm()
-    if "gemmx" in what:                  # main-loop schedule experiments (reserved bits 9-10)
-        bench_gemm((0, 1 << 9, 2 << 9, 3 << 9, 1))
+    if "gemmx" in what:                  # reserved bit 2: the general RESID epilogue instead of its FAST form; bit 0: no epilogue
+        bench_gemm((0, 4, 1))
     if "ln" in what:
         bench_ln()
