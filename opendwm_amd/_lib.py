@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdwm_hip.so")
+LIB_PATH = os.environ.get("DWM_HIP_LIB") or os.path.join(HERE, "libdwm_hip.so")      # DWM_HIP_LIB: another build of the same ABI (A/B measurements)
 ABI_VERSION = 13
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3

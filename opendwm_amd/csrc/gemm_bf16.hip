@@ -54,14 +54,13 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + (int64_t)x * rm.xstep + rm.origin;
 }
 
-// FAST (RESID only): the common residual form of the transformer blocks - no output row map, residual row = output row,
-// no activation, every leading dimension < 2^31 - with those facts known at compile time: the per-step address arithmetic is
-// one 32 x 32 -> 64 bit multiply-add per pointer instead of the row-map / modulo chains in 64-bit arithmetic, and the
-// activation switch is gone (the general form spends ~350 instructions per 8-row step, 44 per output value).
+// FAST: the linear layers of the transformer blocks - no output row map, every leading dimension < 2^31, and for RESID:
+// residual row = output row, no activation - with those facts known at compile time: the per-step address arithmetic is
+// one 32 x 32 -> 64 bit multiply-add per pointer instead of the row-map / modulo chains in 64-bit arithmetic, and the RESID
+// activation switch is gone (the general RESID form spends ~350 instructions per 8-row step, 44 per output value).
 template <int EPI, bool FAST = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
-    static_assert(!FAST || EPI == DWM_EPI_RESID, "FAST is a form of the RESID epilogue");
     constexpr int NWN = 4;                       // wave columns of the 2 x 4 wave grid
     constexpr int NTHREADS = 128 * NWN;
     constexpr int WCOLS = BN / NWN;              // output columns per wave: 64 / 128
@@ -220,6 +219,40 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         }
         sa = sa1;
     }
+    // bias (and, RMSHEAD, per-column norm weights) of this lane's 2 x 16 columns in the MFMA layout, requested NOW so that
+    // the round trip overlaps the drain of the last MFMAs and the barrier below.  All 8 (16) loads are issued back to back,
+    // branch-free, from clamped addresses and unpacked behind counted waits: a per-load `if (n < N)` made every load its own
+    // exec-masked block with `s_waitcnt vmcnt(0)` behind it - 8 to 16 serialised L2 round trips per tile (8-14 us of a
+    // 39 us tile at K = 1536)
+    static_assert(NTW == 2, "one 64-column slab per wave");
+    const bf16_t* __restrict__ bias = (EPI == EPI_SPLITK || EPI == DWM_EPI_RESID) ? nullptr : (const bf16_t*)p.bias;
+    const bool hb = bias != nullptr;                       // wave-uniform
+    bool do_norm = false;
+    uint2 braw[2][4], rraw[2][4];
+    bool nv[2][4];
+    {
+        const int64_t nw = n0 + wn * WCOLS;
+        const bf16_t* __restrict__ bsrc = hb ? bias : (const bf16_t*)p.W;            // any valid, 8-byte aligned address
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int64_t n = nw + nt * 32 + rg * 8 + half * 4;
+                nv[nt][rg] = n < N;
+                braw[nt][rg] = *(const uint2*)(bsrc + ((hb && nv[nt][rg]) ? n : 0));
+            }
+        if constexpr (EPI == DWM_EPI_RMSHEAD) {
+            do_norm = nw < p.rms_ncols;                        // wave-uniform: this slab is a q/k head
+            const bf16_t* __restrict__ rsrc = do_norm ? (const bf16_t*)p.rms_w : (const bf16_t*)p.W;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int64_t n = nw + nt * 32 + rg * 8 + half * 4;
+                    rraw[nt][rg] = *(const uint2*)(rsrc + ((do_norm && nv[nt][rg]) ? n : 0));
+                }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the redundant last DMA must not land in the epilogue scratch
 
     // ------------------------------------------------------------------ epilogue
@@ -236,7 +269,6 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         if (sink == 123.456f) ((float*)p.C)[0] = sink;
         return;
     }
-    const bf16_t* __restrict__ bias = (EPI == EPI_SPLITK || EPI == DWM_EPI_RESID) ? nullptr : (const bf16_t*)p.bias;
     bf16_t* __restrict__ Cp = (bf16_t*)p.C;
 
     __syncthreads();                                       // every wave is done with the operand tiles
@@ -252,40 +284,21 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         // round trips per tile (measured: 8-14 us of a 39 us tile at K = 1536)
         float bv[2][16];
         float rw[2][16];                                       // RMSHEAD: per-column norm weights
-        bool do_norm = false;
         {
-            const bool hb = bias != nullptr;                   // wave-uniform
-            const bf16_t* __restrict__ bsrc = hb ? bias : (const bf16_t*)p.W;        // any valid, 8-byte aligned address
-            uint2 braw[2][4], rraw[2][4];
-            bool nv[2][4];
+            // absent values as bit masks on the raw words (0.0 for the bias, bf16 1.0 for the norm weight): no control flow
     #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
     #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int64_t n = nw + nt * 32 + rg * 8 + half * 4;
-                    nv[nt][rg] = n < N;
-                    braw[nt][rg] = *(const uint2*)(bsrc + ((hb && nv[nt][rg]) ? n : 0));
-                }
-            if constexpr (EPI == DWM_EPI_RMSHEAD) {
-                do_norm = nw < p.rms_ncols;                    // wave-uniform: this slab is a q/k head
-                const bf16_t* __restrict__ rsrc = do_norm ? (const bf16_t*)p.rms_w : (const bf16_t*)p.W;
-    #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-    #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const int64_t n = nw + nt * 32 + rg * 8 + half * 4;
-                        rraw[nt][rg] = *(const uint2*)(rsrc + ((do_norm && nv[nt][rg]) ? n : 0));
-                    }
-            }
-    #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-    #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    unpack4(braw[nt][rg], &bv[nt][rg * 4]);
-                    if (!(hb && nv[nt][rg])) bv[nt][rg * 4 + 0] = bv[nt][rg * 4 + 1] = bv[nt][rg * 4 + 2] = bv[nt][rg * 4 + 3] = 0.f;
+                    const uint32_t mb = (hb && nv[nt][rg]) ? 0xffffffffu : 0u;
+                    uint2 b = braw[nt][rg];
+                    b.x &= mb; b.y &= mb;
+                    unpack4(b, &bv[nt][rg * 4]);
                     if constexpr (EPI == DWM_EPI_RMSHEAD) {
-                        unpack4(rraw[nt][rg], &rw[nt][rg * 4]);
-                        if (!(do_norm && nv[nt][rg])) rw[nt][rg * 4 + 0] = rw[nt][rg * 4 + 1] = rw[nt][rg * 4 + 2] = rw[nt][rg * 4 + 3] = 1.f;
+                        const uint32_t mr = (do_norm && nv[nt][rg]) ? 0xffffffffu : 0u;
+                        uint2 r = rraw[nt][rg];
+                        r.x = (r.x & mr) | (~mr & 0x3f803f80u); r.y = (r.y & mr) | (~mr & 0x3f803f80u);
+                        unpack4(r, &rw[nt][rg * 4]);
                     }
                 }
         }
@@ -830,17 +843,23 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         }                                                                                            \
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI, FAST>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn); \
     } while (0)
-    // the transformer blocks' residual form (see FAST above); reserved bit 2 keeps the general kernel (A/B measurements)
+    // the transformer blocks' linear layers (see FAST above); reserved bit 2 keeps the general kernels (A/B measurements)
     const int64_t lim = 1ll << 31;
-    const bool fast = a->epilogue == DWM_EPI_RESID && !cp.c.enabled && a->res_mod == 0 && a->act == DWM_ACT_NONE && a->ldc < lim &&
-                      (a->gate == nullptr || a->ld_gate < lim) && (a->res == nullptr || a->ld_res < lim) &&
-                      (a->blend == nullptr || a->ld_blend < lim) && !(a->reserved & 4);
+    bool fast = !cp.c.enabled && a->ldc < lim && !(a->reserved & 4);
+    if (a->epilogue == DWM_EPI_RESID)
+        fast = fast && a->res_mod == 0 && a->act == DWM_ACT_NONE && (a->gate == nullptr || a->ld_gate < lim) &&
+               (a->res == nullptr || a->ld_res < lim) && (a->blend == nullptr || a->ld_blend < lim);
+#define DWM_LAUNCH2(EPI)                                                                             \
+    do {                                                                                             \
+        if (fast) DWM_LAUNCH(EPI, true); else DWM_LAUNCH(EPI, false);                                \
+    } while (0)
     switch (a->epilogue) {
-        case DWM_EPI_PLAIN: DWM_LAUNCH(DWM_EPI_PLAIN, false); break;
-        case DWM_EPI_GEGLU: DWM_LAUNCH(DWM_EPI_GEGLU, false); break;
-        case DWM_EPI_RESID: if (fast) DWM_LAUNCH(DWM_EPI_RESID, true); else DWM_LAUNCH(DWM_EPI_RESID, false); break;
-        default: DWM_LAUNCH(DWM_EPI_RMSHEAD, false); break;
+        case DWM_EPI_PLAIN: DWM_LAUNCH2(DWM_EPI_PLAIN); break;
+        case DWM_EPI_GEGLU: DWM_LAUNCH2(DWM_EPI_GEGLU); break;
+        case DWM_EPI_RESID: DWM_LAUNCH2(DWM_EPI_RESID); break;
+        default: DWM_LAUNCH2(DWM_EPI_RMSHEAD); break;
     }
+#undef DWM_LAUNCH2
 #undef DWM_LAUNCH
     e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;

@@ -113,7 +113,8 @@ def bench_gemm(dbg_list=(0, 1)):
         a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
         fl = 2.0 * M * N * K
         res = {}
-        for dbg in dbg_list:
+        for di, dbg in enumerate([dbg_list[0]] + list(dbg_list)):     # the first variant is measured twice and its first pass dropped:
+            # the first timed loop of a shape runs 10 % slower than any later one (same kernel: 958 vs 1082 TFLOP/s in r2g)
             if kind == "rms":
                 rms = rnd(2 * 1536) * 0.1 + 1
                 f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=3072, rms_eps=1e-6, _debug=dbg)
@@ -128,6 +129,8 @@ def bench_gemm(dbg_list=(0, 1)):
             else:
                 f = lambda: ops.gemm(a, w, b, _debug=dbg)
             ms = timeit(f)
+            if di == 0:
+                continue
             res[{0: "w8", 1: "w8-noepi", 4: "w8-general-resid"}.get(dbg, str(dbg))] = round(fl / ms / 1e9, 1)
         ms_t = timeit(lambda: torch.matmul(a, w.t()))
         print(json.dumps({"kernel": "gemm", "case": name, "M": M, "N": N, "K": K, "tflops": res,
