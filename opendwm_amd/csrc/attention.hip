@@ -679,6 +679,172 @@ attn_group_kernel(const AttnParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Group-masked attention, shared form: ONE WORKGROUP = one (problem, head group), ONE WAVE = one query group (view).  The
+// per-wave form above lets every wave fetch the K / V rows of the key groups it may see straight from global memory, so a
+// row is pulled through L1 / TA once per query group that sees it (3x with the ring mask of the 6-camera rigs) in 32-byte
+// pieces: the launch moves its 1.06 GB at 2.7 TB/s.  Here wave g copies the K and V rows of group g of the current head into
+// the workgroup's LDS images ONCE, by LDS-DMA (8 lanes per row: whole 128-byte row pieces, no staging registers), and after
+// one barrier every wave reads the fragments of the groups its mask row allows from LDS (K image swizzled for ds_read_b128,
+// V image for ds_read_b64_tr_b16, as in attn_fwd_kernel).  A second barrier retires the images before the next head's copy;
+// the output tile leaves through 4 KiB of wave-private LDS as whole rows.  Two workgroups share a CU (72 KiB each), so one
+// computes while the other waits for its copy.  HBM-bound: q, k, v read + o written once.
+constexpr int GRP_IMG = 32 * 128;                 // one group's K (or V) image: 32 rows x 128 B
+template <int G>
+__global__ void __launch_bounds__(G * 64, 2)
+attn_group_lds_kernel(const AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kimg = smem;                                  // [G][32][128]
+    char* const vimg = smem + G * GRP_IMG;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = query group
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    char* const sc = smem + 2 * G * GRP_IMG + wave * 4096;    // this wave's output transpose region
+
+    const uint32_t prob = fdiv(blockIdx.x, P.fd_heads);
+    const int hgrp = (int)(blockIdx.x - prob * P.fd_heads.d);
+    const int gs = P.group_size, hpb = P.hpb;
+    const int64_t hoff = (int64_t)hgrp * hpb * 64;
+    const int64_t base = seg0_base(P.rm, (int)prob);
+
+    const bool qvalid = l31 < gs;
+    const int lclamp = qvalid ? l31 : gs - 1;
+    const int64_t qrow = seg0_row(P.rm, base, wave * gs + lclamp);
+    const bf16_t* const qp = P.q0 + qrow * P.ld0 + hoff + half * 8;
+    const int64_t orow = (int64_t)(P.o0 + qrow * P.ldo0 + hoff);
+
+    uint32_t bits = 0;                     // key groups this wave's queries may attend to (wave-uniform)
+    {
+        const uint8_t* mrow = P.mask + ((int64_t)fdiv(prob, P.fd_ppm) * G + wave) * G;
+        for (int g = 0; g < G; ++g) bits |= (mrow[g] ? 1u : 0u) << g;
+        bits = __builtin_amdgcn_readfirstlane(bits);
+    }
+    uint32_t kmask = 0;                    // keys of a group this lane's 16 score registers stand for: valid = key < gs
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) + 4 * half < gs) kmask |= 1u << r;
+
+    // copy geometry: instruction i of this wave fills rows 8 i + (lane >> 3) of ITS group's image, 16 B per lane; the chunk
+    // swizzle of the image is applied on the source column (the destination of an LDS-DMA is lane-linear)
+    int64_t srow[4];
+    int kcol[4], vcol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        srow[i] = seg0_row(P.rm, base, wave * gs + (r < gs ? r : gs - 1)) * P.ld0 + hoff;      // rows past the group: clamped, masked
+        kcol[i] = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+        vcol[i] = ((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3;
+    }
+    const int kswz = (lane >> 1) & 7;
+    const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+    int vra[2], vrb[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+        const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+        vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+    }
+    char* const myrow = sc + l31 * 128;
+
+    for (int hh = 0; hh < hpb; ++hh) {
+        // ---- copy this head's K / V rows of group `wave`; Q fragments of this wave's queries
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(P.k0 + srow[i] + hh * 64 + kcol[i], kimg + wave * GRP_IMG + i * 1024);
+            glds16(P.v0 + srow[i] + hh * 64 + vcol[i], vimg + wave * GRP_IMG + i * 1024);
+        }
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + hh * 64 + ks * 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // every group of this head has landed
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(qf[ks], P.scale_log2);
+
+        f32x16 ot[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        for (uint32_t rem = bits; rem != 0; rem &= rem - 1) {
+            const int g = __builtin_ctz(rem);
+            const char* kl = kimg + g * GRP_IMG;
+            const char* vl = vimg + g * GRP_IMG;
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kl + l31 * 128 + (((2 * ks + half) ^ kswz) << 4));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!((kmask >> r) & 1u)) st[r] = -INFINITY;
+                mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // a group holds >= 1 valid key: finite
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 for the first group (m_run = -inf)
+            m_run = m_new;
+            float pv[16], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+                sum += pv[r];
+            }
+            l_run = l_run * alpha + sum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint4 pk = pack8(pv + 8 * s2);
+                pf[s2] = *reinterpret_cast<const bf16x8*>(&pk);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s2 * (16 * 128)));
+                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s2 * (16 * 128)));
+                    const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], ot[dt], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                       // every wave is done with this head's images
+        // normalise; transpose the 32 x 64 output tile through the wave's own LDS (same-wave LDS ops complete in order)
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(l_tot);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ot[dt][rg * 4 + j] * inv;
+                *(uint2*)(myrow + (((dt * 4 + rg) ^ (l31 & 7)) << 4) + half * 8) = pack4(v);
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (lane >> 3), c = lane & 7;
+            const uint4 val = *(const uint4*)(sc + r * 128 + ((c ^ (r & 7)) << 4));
+            const int64_t rp = __shfl(orow, r, 64);
+            if (r < gs && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+        }
+    }
+}
+
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
 __global__ void __launch_bounds__(64)
@@ -756,6 +922,32 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     // only the key groups its mask row allows; variant bit 5 keeps the tiled kernel (A/B measurements, tests)
     if (P.mask_mode == 1 && P.L1 == 0 && P.lse == nullptr && P.group_size >= 8 && P.group_size <= 32 && (int64_t)P.mask_G * P.group_size == L &&
         !((a->variant >> 5) & 1)) {
+        // shared form (one workgroup per (problem, head group), K / V of a head copied to LDS once): G = 6 views (the camera
+        // rigs of every shipped config) or 4 / 8; variant bit 7 keeps the per-wave form (A/B measurements, tests)
+        if ((P.mask_G == 6 || P.mask_G == 4 || P.mask_G == 8) && !((a->variant >> 7) & 1)) {
+            int hs = (a->variant >> 8) & 15;
+            if (hs == 0) { for (hs = 8; P.heads % hs != 0; --hs) {} }
+            if (P.heads % hs != 0) return DWM_EINVAL;
+            P.hpb = hs;
+            P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
+            const int64_t nblk = (int64_t)P.n_problems * (P.heads / hs);
+            if (nblk >= (1ll << 31)) return DWM_EUNSUPPORTED;
+            const int G = P.mask_G;
+            const size_t lds = (size_t)2 * G * GRP_IMG + (size_t)G * 4096;
+#define DWM_GRP(G_)                                                                                              \
+            do {                                                                                                 \
+                static bool attr_set = false;                                                                    \
+                if (!attr_set) {                                                                                 \
+                    (void)hipFuncSetAttribute((const void*)attn_group_lds_kernel<G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+                    attr_set = true;                                                                             \
+                }                                                                                                \
+                hipLaunchKernelGGL((attn_group_lds_kernel<G_>), dim3((unsigned)nblk), dim3(G_ * 64), lds, s, P); \
+            } while (0)
+            if (G == 6) DWM_GRP(6); else if (G == 4) DWM_GRP(4); else DWM_GRP(8);
+#undef DWM_GRP
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? DWM_OK : (int)e;
+        }
         int hs = (a->variant >> 8) & 15;
         if (hs == 0) { for (hs = 8; P.heads % hs != 0; --hs) {} }
         if (P.heads % hs != 0) return DWM_EINVAL;

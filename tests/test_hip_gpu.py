@@ -279,6 +279,34 @@ def test_attention_joint(dev, variant, I, N, Lc, heads):
     assert e0 < TOL_KERNEL and e1 < TOL_KERNEL
 
 
+@pytest.mark.parametrize("V,w,heads", [(6, 28, 3), (6, 32, 2), (6, 16, 8), (4, 8, 2), (8, 11, 2), (3, 28, 2), (6, 28, 24)])
+def test_attention_group_forms(dev, V, w, heads):
+    """row-wise cross-view attention whose problems are V whole groups of w <= 32 tokens: the shared form (one workgroup per
+    (problem, head group), K / V of a head copied to LDS once; V = 4 / 6 / 8), the per-wave form (variant bit 7) and the
+    tiled kernel (bit 5) against the masked reference, with a mask that differs per batch entry and per view"""
+    from opendwm_amd import ops
+    B, T, h = 2, 2, 3
+    D = heads * 64
+    rm = ops.rowmap_crossview_rowwise(B, T, V, h, w)
+    R = B * T * V * h * w
+    qkv = _rand((R, 3 * D), dev, 3)
+    gmask = O.ring_crossview_mask(B, V).to(dev)
+    gmask[1, 1, V - 1] = True
+    gmask[0, 0, 1] = False
+    p = torch.arange(rm.n_problems, device=dev)[:, None, None]
+    l = torch.arange(rm.L0, device=dev)
+    ref_mask = gmask[p // rm.p_per_mask, ((l // rm.group_size) % V)[None, :, None], ((l // rm.group_size) % V)[None, None, :]]
+    f = qkv.float()
+    r0, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads, mask=ref_mask)
+    errs = {}
+    for name, variant in (("default", 0), ("per_wave", 128), ("tiled", 32)):
+        out = torch.zeros((R, D), dtype=bf16, device=dev)
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, group_mask=gmask, variant=variant)
+        errs[name] = rel_err(out, r0)
+    _log("attention_group_forms", V=V, w=w, heads=heads, **errs)
+    assert all(e < TOL_KERNEL for e in errs.values()), errs
+
+
 @pytest.mark.parametrize("variant", ATTN_VARIANTS)
 @pytest.mark.parametrize("kind", ["crossview_rowwise", "crossview_full", "temporal_rowwise", "temporal_full",
                                   "temporal_pointwise"])
