@@ -153,7 +153,7 @@ class KernelTimer:
             L = rowmap.L0 + (kw["q1"].shape[0] // rowmap.n_problems if kw.get("q1") is not None else 0)
             fl = 4.0 * rowmap.n_problems * heads * L * L * 64
             small = L <= 32 and kw.get("q1") is None and kw.get("group_mask") is None and kw.get("dense_mask") is None
-            # attn_group_kernel: group-masked problems of G whole groups of 8..32 tokens (row-wise cross-view attention)
+            # attn_group_lds_kernel: group-masked problems of G whole groups of 8..32 tokens (row-wise cross-view attention)
             grouped = (kw.get("group_mask") is not None and kw.get("q1") is None and kw.get("lse") is None and
                        8 <= rowmap.group_size <= 32 and kw["group_mask"].shape[-1] * rowmap.group_size == L)
             timer.records.append(("attn_small" if small else "attn_group" if grouped else "attn", fl, s, e))
@@ -199,9 +199,9 @@ class KernelTimer:
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (scripts/pmc_traffic.sh -> profiles/r1_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
+    (scripts/pmc_traffic.sh -> profiles/r2_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
     Counters cannot be collected inside the timed run, so the bench line cites the committed measurement."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
     try:
         return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
     except Exception:
@@ -693,7 +693,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_bf16_kernel"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r1_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r2_pmc_traffic.json)",
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
@@ -705,8 +705,8 @@ def main():
                                    "all_attention_launches_tflops": ((at.get("flops") or 0.0) + (asm.get("flops") or 0.0) + (agr.get("flops") or 0.0)) /
                                    max((at.get("ms") or 0.0) + (asm.get("ms") or 0.0) + (agr.get("ms") or 0.0), 1e-9) / 1e9},
             "roofline_attention_crossview": None if not agr else {
-                "bound": "hbm", "kernel": "attn_group_kernel (row-wise cross-view attention, ring view mask: one wave per query view, "
-                                          "allowed key views only)",
+                "bound": "hbm", "kernel": "attn_group_lds_kernel (row-wise cross-view attention, ring view mask: one workgroup per (problem, head "
+                                          "group), one wave per query view, K / V of a head copied to LDS once, allowed key views only)",
                 "achieved": timer.group_bytes / (agr["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                 "frac": timer.group_bytes / (agr["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                 "algorithmic_bytes_per_launch": timer.group_bytes / agr["launches"], "launches": agr["launches"],

@@ -749,13 +749,17 @@ attn_group_lds_kernel(const AttnParams P) {
     }
     char* const myrow = sc + l31 * 128;
 
+    // copy of head h's K / V rows of group `wave` into the images (8 LDS-DMA instructions)
+#define DWM_GRP_COPY(h_)                                                                          \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+            glds16(P.k0 + srow[i] + (h_) * 64 + kcol[i], kimg + wave * GRP_IMG + i * 1024);       \
+            glds16(P.v0 + srow[i] + (h_) * 64 + vcol[i], vimg + wave * GRP_IMG + i * 1024);       \
+        }                                                                                         \
+    } while (0)
+    DWM_GRP_COPY(0);
     for (int hh = 0; hh < hpb; ++hh) {
-        // ---- copy this head's K / V rows of group `wave`; Q fragments of this wave's queries
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(P.k0 + srow[i] + hh * 64 + kcol[i], kimg + wave * GRP_IMG + i * 1024);
-            glds16(P.v0 + srow[i] + hh * 64 + vcol[i], vimg + wave * GRP_IMG + i * 1024);
-        }
+        // ---- Q fragments of this wave's queries; this head's copy was requested before the previous head's output phase
         bf16x8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + hh * 64 + ks * 16);
@@ -823,6 +827,7 @@ attn_group_lds_kernel(const AttnParams P) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                                       // every wave is done with this head's images
+        if (hh + 1 < hpb) DWM_GRP_COPY(hh + 1);                // the next head's rows travel under this head's output phase
         // normalise; transpose the 32 x 64 output tile through the wave's own LDS (same-wave LDS ops complete in order)
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(l_tot);
@@ -844,6 +849,8 @@ attn_group_lds_kernel(const AttnParams P) {
         }
     }
 }
+
+#undef DWM_GRP_COPY
 
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
@@ -926,7 +933,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         // rigs of every shipped config) or 4 / 8; variant bit 7 keeps the per-wave form (A/B measurements, tests)
         if ((P.mask_G == 6 || P.mask_G == 4 || P.mask_G == 8) && !((a->variant >> 7) & 1)) {
             int hs = (a->variant >> 8) & 15;
-            if (hs == 0) { for (hs = 8; P.heads % hs != 0; --hs) {} }
+            if (hs == 0) { for (hs = 4; P.heads % hs != 0; --hs) {} }      // measured at config 3: 4 >= 8 > 2 > 12 heads per workgroup
             if (P.heads % hs != 0) return DWM_EINVAL;
             P.hpb = hs;
             P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
