@@ -25,12 +25,12 @@ def rel(a, b):
 
 def attn_cases():
     H, D = 4, 256
-    for I, N, Lc in ((3, 448, 154), (2, 100, 0), (2, 64, 10), (1, 300, 3), (5, 602, 0), (2, 33, 0)):
+    for I, N, Lc in ((3, 448, 154), (2, 100, 0), (2, 64, 10), (1, 300, 3), (5, 602, 0), (2, 33, 0), (2, 129, 0), (3, 192, 0), (2, 1792, 0)):
         qkv = rnd(I * N, 3 * D)
         cqkv = rnd(max(I * Lc, 1), 3 * D)
         kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:]) if Lc else {}
         outs = {}
-        for var in (0, 64, 128, 192):
+        for var in (0, 64):
             out = torch.zeros(I * N, D, device=dev, dtype=bf16)
             cout = torch.zeros(max(I * Lc, 1), D, device=dev, dtype=bf16)
             if Lc:
@@ -38,7 +38,7 @@ def attn_cases():
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, ops.rowmap_identity(I, N), H, variant=var, **kw)
             torch.cuda.synchronize()
             outs[var] = (out.clone(), cout.clone())
-        for var in (64, 128, 192):
+        for var in (64,):
             print(json.dumps({"check": "attention", "I": I, "N": N, "Lc": Lc, "variant": var,
                               "rel_sample": rel(outs[var][0], outs[0][0]), "rel_ctx": rel(outs[var][1], outs[0][1]) if Lc else 0.0,
                               "finite": bool(torch.isfinite(outs[var][0].float()).all())}), flush=True)
@@ -66,4 +66,3 @@ def gemm_cases():
 
 if __name__ == "__main__":
     attn_cases()
-    gemm_cases()

@@ -161,7 +161,7 @@ if __name__ == "__main__":
     if "attn" in what:
         bench_attn([1])
     if "attnx" in what:                  # tile-body experiments: bit 6 = no s_setprio brackets, bit 7 = the non-default body
-        bench_attn([1, 1 | 64, 1 | 128, 1 | 64 | 128])
+        bench_attn([1, 1, 1 | 64, 1 | 64])
     if "gemm" in what:
         bench_gemm()
     if "gemmx" in what:                  # reserved bit 2: the general RESID epilogue instead of its FAST form; bit 0: no epilogue
