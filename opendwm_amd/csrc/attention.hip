@@ -32,19 +32,11 @@ using namespace dwm_attn;
 
 namespace {
 
-constexpr bool kVregDefault = false;   // V transport of the unmasked 32-queries-per-wave kernel when variant bit 6 is clear
-
 // MASK: 0 none, 1 group mask, 2 dense byte mask.  NW = 4 waves (256 threads).
 // occupancy target: 3 workgroups (waves per SIMD) for 32 queries/wave, 2 for 64 queries/wave
-// VREG (QT = 1, no mask): the V tiles travel global -> registers -> ds_write_b128 instead of by LDS-DMA (K keeps the DMA).
-// Why: with 128-query workgroups every (problem, head)'s K / V is copied 4-5 times, 6.6-6.9 TB/s of LDS-DMA traffic at
-// L = 448 / 602 - the fill rate the chip sustains for LDS-DMA (MI355X_MICROARCH.md: 6.4-6.8 TB/s), which is why no change
-// to the wave's own instruction stream moved this kernel.  One 8-register set per lane carries tile s+3's V rows from
-// the end of iteration s to the end of iteration s+1, where they are written into the ring slot tile s-1 left.
-template <int QT, int MASK, bool VREG = false>
+template <int QT, int MASK>
 __global__ void __launch_bounds__(256, QT == 1 ? 3 : 2)
 attn_fwd_kernel(const AttnParams P) {
-    static_assert(!VREG || (QT == 1 && MASK == 0), "register-staged V: one query tile per wave, no mask");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 4;
     constexpr int QB = NW * QT * 32;          // queries per block
@@ -143,30 +135,14 @@ attn_fwd_kernel(const AttnParams P) {
         char* kl_ = smem + (stage_) * STAGE_BYTES + sdst;                                   \
         glds16(kg0 + oa_ + (ho_), kl_);                                                     \
         glds16(kg1 + ob_ + (ho_), kl_ + 1024);                                              \
-        if constexpr (VREG) {                                                               \
-            /* inline asm: a compiler-visible load pending on the loop's back edge would put "s_waitcnt vmcnt(0)" in */ \
-            /* front of every tile's S MFMAs (see the Q prefetch below); the waits are the explicit ones */            \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vr0) : "v"(vg0 + oa_ + (ho_)) : "memory");            \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vr1) : "v"(vg1 + ob_ + (ho_)) : "memory");            \
-        } else {                                                                            \
-            glds16(vg0 + oa_ + (ho_), kl_ + K_TILE_BYTES);                                  \
-            glds16(vg1 + ob_ + (ho_), kl_ + K_TILE_BYTES + 1024);                           \
-        }                                                                                   \
+        glds16(vg0 + oa_ + (ho_), kl_ + K_TILE_BYTES);                                      \
+        glds16(vg1 + ob_ + (ho_), kl_ + K_TILE_BYTES + 1024);                               \
     } while (0)
-    // register-staged V rows of one tile -> the V image of ring slot `stage_` (same lane-linear positions the DMA fills)
-#define DWM_V_WRITE(stage_)                                                                 \
-    do {                                                                                    \
-        char* vl_ = smem + (stage_) * STAGE_BYTES + K_TILE_BYTES + sdst + lane * 16;        \
-        *(u32x4*)vl_ = vr0;                                                                 \
-        *(u32x4*)(vl_ + 1024) = vr1;                                                        \
-    } while (0)
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    u32x4 vr0 = {0u, 0u, 0u, 0u}, vr1 = {0u, 0u, 0u, 0u};
 
     // Softmax bookkeeping in the exponent domain: Q is pre-multiplied by scale*log2(e) and the S MFMAs
     // start from C = -m (negm holds -m_run in all 16 registers), so the accumulator already is
     // s*c - m and the exponentials need no per-score multiply-add.
-    f32x16 ot[QT][2], negm[QT];        // (VREG: only element 0 of negm is kept - the 16-register splat is rebuilt per tile)
+    f32x16 ot[QT][2], negm[QT];
     float l_run[QT];
     bool mvalid[QT];                     // m_run has been set from a finite score
 #pragma unroll
@@ -198,28 +174,12 @@ attn_fwd_kernel(const AttnParams P) {
     // prologue: tiles 0, 1, 2 requested (4 DMA instructions per wave and tile; the Q fragment loads
     // were issued before them, so "vmcnt(8)" also covers Q)
     const int NT = hpb * nkt;             // tiles of this workgroup's stream
-    if constexpr (VREG) {
-        // tiles 0 and 1: V written here; tile 2's V rows stay in the register set until the end of iteration 0
-        DWM_DMA_NEXT(0);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(vr0), "+v"(vr1) :: "memory");
-        DWM_V_WRITE(0);
-        if (NT > 1) {
-            DWM_DMA_NEXT(1);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vr0), "+v"(vr1) :: "memory");
-            DWM_V_WRITE(1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the register set is rewritten by the next request
-        if (NT > 2) DWM_DMA_NEXT(2);
-        if (NT > 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // K of tiles 0, 1 (and 2) landed; V(2) may stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
     DWM_DMA_NEXT(0);
     if (NT > 1) DWM_DMA_NEXT(1);
     if (NSTAGE > 2 && NT > 2) DWM_DMA_NEXT(2);
     if (NSTAGE > 2 && NT > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     __syncthreads();
 
     // a wave whose queries all lie past the end of the sequence (last query block) only takes part
@@ -244,13 +204,8 @@ attn_fwd_kernel(const AttnParams P) {
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    if (VREG && ks == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st[t][j][r] = negm[t][0];
-                    }
-                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], (ks == 0 && !VREG) ? negm[t] : st[t][j], 0, 0, 0);
-                }
+                for (int t = 0; t < QT; ++t)
+                    st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t][ks], ks == 0 ? negm[t] : st[t][j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
         if (fetch_q) {
@@ -315,7 +270,7 @@ attn_fwd_kernel(const AttnParams P) {
                 mvalid[t] = mvalid[t] || finite;
                 l_run[t] *= alpha;
 #pragma unroll
-                for (int r = 0; r < (VREG ? 1 : 16); ++r) negm[t][r] -= delta;
+                for (int r = 0; r < 16; ++r) negm[t][r] -= delta;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -361,23 +316,10 @@ attn_fwd_kernel(const AttnParams P) {
 
         // tile s+1 landed (tile s+2 may stay in flight), everyone is done with this tile's slot, which then
         // receives tile s+3 (loads return in order: the Q loads of this iteration are younger than tile s+2's DMA)
-        if constexpr (VREG) {
-            // the register set holds tile sidx + 2's V rows (the youngest requests apart from this iteration's Q prefetch):
-            // wait for them - everything older, K of tiles sidx + 1 and sidx + 2 included, has then landed too - and write
-            // them into the slot tile sidx - 1 left
-            if (sidx + 2 < NT) {
-                if (fetch_q) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(vr0), "+v"(vr1) : "n"(4 * QT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(vr0), "+v"(vr1) :: "memory");
-                const int s2 = stage + 2 >= NSTAGE ? stage + 2 - NSTAGE : stage + 2;
-                DWM_V_WRITE(s2);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
         if (NSTAGE > 2 && sidx + 2 < NT) {
             if (fetch_q) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * QT) : "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __syncthreads();
 
         // ---- end of a head: normalise and store its output, reset the running state, switch Q.
@@ -924,16 +866,16 @@ tr_probe_kernel(const int* __restrict__ offs, short* __restrict__ out) {
     for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
 }
 
-template <int QT, int MASK, bool VREG = false>
+template <int QT, int MASK>
 void launch_attn(const AttnParams& P, hipStream_t s) {
     const int64_t nblk = (int64_t)P.n_problems * (P.heads / P.hpb) * P.nqb;
     const size_t lds = NSTAGE * STAGE_BYTES + (size_t)((P.L + 3) & ~3) * sizeof(int32_t);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<QT, MASK, VREG>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<QT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<QT, MASK, VREG>), dim3((unsigned)nblk), dim3(256), lds, s, P);
+    hipLaunchKernelGGL((attn_fwd_kernel<QT, MASK>), dim3((unsigned)nblk), dim3(256), lds, s, P);
 }
 
 }  // namespace
@@ -1031,9 +973,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         else if (P.mask_mode == 1) launch_attn<QT_, 1>(P, s);      \
         else launch_attn<QT_, 2>(P, s);                            \
     } while (0)
-    // 32 queries per wave without a mask: V by register staging (kVregDefault; variant bit 6 selects the other form)
-    if (qt == 1 && P.mask_mode == 0 && (kVregDefault != (((a->variant >> 6) & 1) != 0))) launch_attn<1, 0, true>(P, s);
-    else if (qt == 1) DWM_ATTN(1); else DWM_ATTN(2);
+    if (qt == 1) DWM_ATTN(1); else DWM_ATTN(2);
 #undef DWM_ATTN
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
