@@ -584,34 +584,44 @@ class AdapterFn(torch.autograd.Function):
         I, _, H, W = x.shape
         r = ad.downscale_factor
         h, w = H // r, W // r
-        # ---- recompute, keeping what the backward needs
-        cur = ops.unshuffle_tokens(x, r)
+        # ---- recompute, keeping what the backward needs.  A level = one AdapterBlock; its grid changes where the block
+        # starts with AvgPool2d (the MMDiT layout adapters pool in the first block only, the SD 2.1 UNet's in blocks 1-3)
+        cur = ops.unshuffle_tokens(x, r)            # compact tokens; None while the running tensor lives on a padded grid
         levels = []
         xp, grid, idx = None, None, None
         for bi, (blk, zc) in enumerate(zip(ad.body, ad.zero_convs)):
+            lv = {"blk": blk, "zc": zc, "res": [], "pooled_from": None}
             if blk.downsample is not None:
-                if bi != 0:
-                    raise NotImplementedError("adapter backward: AvgPool2d only in the first block (every shipped DiT layout config)")
+                if cur is None:
+                    cur = xp[idx]                                                 # compact rows of the previous level's output
+                if h % 2 or w % 2:
+                    raise NotImplementedError("AvgPool2d(ceil_mode) on odd sizes")
                 cur = ops.avgpool2_tokens(cur, I, h, w)
+                lv["pooled_from"] = (h, w)
                 h, w = h // 2, w // 2
-            if grid is None:
+                xp = None
+            if xp is None:
                 grid = PaddedGrid(I, h, w)
                 idx = grid.interior_index().to(x.device)
-            lv = {"blk": blk, "zc": zc, "in": None, "res": []}
-            if xp is None:
-                if blk.in_conv is None:
-                    raise NotImplementedError("adapter backward: the first block needs an in_conv")
-                wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1)
-                if wi.shape[1] != cur.shape[1]:
-                    wpad = torch.zeros((wi.shape[0], cur.shape[1]), dtype=bf16, device=wi.device)
-                    wpad[:, :wi.shape[1]] = wi
-                    wi = wpad
-                xp = ops.gemm(cur, wi.contiguous(), _bf(blk.in_conv.bias), c_grid=grid)
-                lv["in"] = ("first", cur)
+                if blk.in_conv is not None:
+                    wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1)
+                    if wi.shape[1] != cur.shape[1]:                               # first block: K padded to 64 by unshuffle_tokens
+                        wpad = torch.zeros((wi.shape[0], cur.shape[1]), dtype=bf16, device=wi.device)
+                        wpad[:, :wi.shape[1]] = wi
+                        wi = wpad
+                    xp = ops.gemm(cur, wi.contiguous(), _bf(blk.in_conv.bias), c_grid=grid)
+                    lv["in"] = ("compact", cur)
+                else:
+                    xp = ops.pad_tokens(cur, grid)
+                    lv["in"] = ("pad", None)
+                cur = None
             elif blk.in_conv is not None:
                 wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1).contiguous()
                 lv["in"] = ("grid", xp)
                 xp = ops.gemm(xp, wi, _bf(blk.in_conv.bias), a_grid=grid, c_grid=grid)
+            else:
+                lv["in"] = ("same", None)
+            lv["grid"], lv["idx"], lv["first"] = grid, idx, bi == 0
             for res in blk.resnets:
                 pk = res.packed()
                 h1 = ops.gemm(xp, pk["w3"], _bf(res.block1.bias), act=ACT_RELU, a_grid=grid, conv3x3=True)
@@ -622,7 +632,9 @@ class AdapterFn(torch.autograd.Function):
             levels.append(lv)
         # ---- backward, last level first; dx: gradient w.r.t. the level's output grid (padded rows, zero border)
         dx = None
+        quarter = torch.full((1,), 0.25, dtype=torch.float32, device=x.device)
         for lv, df in zip(reversed(levels), reversed(dfeats)):
+            grid, idx = lv["grid"], lv["idx"]
             if df is not None:
                 df = df.to(bf16).contiguous()
                 zc = lv["zc"]
@@ -651,21 +663,38 @@ class AdapterFn(torch.autograd.Function):
                 dhp = ops.pad_tokens(dh1, grid)
                 ops.gemm(dhp, _conv3_flip(res.block1.weight), None, a_grid=grid, conv3x3=True, epilogue=EPI_RESID, res=dx,
                          out=dx, c_grid=grid)                                     # dx += conv3x3^T(dh1), in place
-            kind = lv["in"]
-            if kind is not None:
-                blk = lv["blk"]
+            kind, saved = lv["in"]
+            blk = lv["blk"]
+            dcur = None                           # gradient w.r.t. the compact tensor that entered this level (if it had one)
+            if kind == "grid":                    # in_conv on the previous level's grid (same resolution)
                 dxc = dx[idx]
-                if kind[0] == "first":
-                    dwi, dbi = T.linear_wgrad(dxc, kind[1], want_bias=True)
-                    ci = blk.in_conv.weight.shape[1]
-                    G.add(blk.in_conv.weight, dwi[:, :ci].contiguous())
-                    G.add(blk.in_conv.bias, dbi)
+                dwi, dbi = T.linear_wgrad(dxc, saved[idx], want_bias=True)
+                G.add(blk.in_conv.weight, dwi)
+                G.add(blk.in_conv.bias, dbi)
+                dx = ops.gemm(dxc, w_t(blk.in_conv.weight), None, c_grid=grid)
+            elif kind == "compact":
+                dxc = dx[idx]
+                dwi, dbi = T.linear_wgrad(dxc, saved, want_bias=True)
+                ci = blk.in_conv.weight.shape[1]
+                G.add(blk.in_conv.weight, dwi[:, :ci].contiguous())
+                G.add(blk.in_conv.bias, dbi)
+                if not lv["first"]:
+                    dcur = T.linear_dgrad(dxc, w_t(blk.in_conv.weight))
+            elif kind == "pad":
+                if not lv["first"]:
+                    dcur = dx[idx]
+            # kind == "same": the previous level's grid IS this level's input: dx carries on unchanged
+            if kind in ("compact", "pad"):
+                if lv["first"] or dcur is None:
                     dx = None                                                     # the condition images carry no gradient
                 else:
-                    dwi, dbi = T.linear_wgrad(dxc, kind[1][idx], want_bias=True)
-                    G.add(blk.in_conv.weight, dwi)
-                    G.add(blk.in_conv.bias, dbi)
-                    dx = ops.gemm(dxc, w_t(blk.in_conv.weight), None, c_grid=grid)
+                    if lv["pooled_from"] is None:
+                        raise RuntimeError("adapter backward: a level that re-grids without pooling")
+                    # AvgPool2d(2) backward: every child pixel gets a quarter of the pooled gradient - nearest 2x upsample
+                    # straight onto the previous level's padded grid
+                    hp, wp_ = lv["pooled_from"]
+                    up = ops.upsample2_padded(dcur, I, hp // 2, wp_ // 2)
+                    dx = T.rowcombine(up, coef_a=quarter, rows_per_coef_a=up.shape[0])
         ps = _params(ad)
         return (None, None) + _grads_for(G, ps, ctx.needs_input_grad[2:])
 

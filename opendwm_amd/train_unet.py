@@ -24,7 +24,7 @@ from . import ops
 from . import train_ops as T
 from .blocks import STORE, _bf
 from .ops import EPI_RESID, PaddedGrid, TimeGrid
-from .train import (Grads, SiluFn, _conv3_flip, _grads_for, _params, alpha_train, lin_bwd, lin_fwd, linear_train, mlp_train,
+from .train import (AdapterFn, AddFn, Grads, SiluFn, _conv3_flip, _grads_for, _params, alpha_train, lin_bwd, lin_fwd, linear_train, mlp_train,
                     project_qkv_train, qkv_bwd, vt_block_train, w_t)
 from . import unet as UM
 
@@ -564,11 +564,10 @@ class ConcatFn(torch.autograd.Function):
 def forward_train(model: UM.UNetCrossviewTemporalConditionModel, sample, timesteps, encoder_hidden_states=None,
                   disable_crossview=None, disable_temporal=None, crossview_attention_mask=None, added_time_ids=None,
                   condition_image_tensor=None):
-    """Autograd-enabled forward of UNetCrossviewTemporalConditionModel (crossview_temporal_unet.py:655-835).  Returns the
+    """Autograd-enabled forward of UNetCrossviewTemporalConditionModel (crossview_temporal_unet.py:655-835), layout
+    ImageAdapter included (the shipped SD 2.1 training configs, configs/ctsd/*/ctsd_21_*_tirda_bm_*.json, use it).  Returns the
     prediction [B, T, V, C_out, H, W] (bf16) with a grad_fn."""
     STORE.set_precision(bf16)
-    if condition_image_tensor is not None and model.condition_image_adapter is not None:
-        raise NotImplementedError("UNet training with the layout ImageAdapter is not built (the MMDiT branch has it)")
     B, Tn, V, _, H, W = sample.shape
     dev = sample.device
     I = B * Tn * V
@@ -591,6 +590,21 @@ def forward_train(model: UM.UNetCrossviewTemporalConditionModel, sample, timeste
     if xin.dtype not in (torch.float32, bf16):
         xin = xin.to(bf16)
     x = ConvInFn.apply(model.conv_in, xin, *_params(model.conv_in))
+    # layout residuals (crossview_temporal_unet.py:717-729, 748-750): one after conv_in, one after every down block; the
+    # block's last skip connection carries the sum, as in the reference
+    residuals: List[torch.Tensor] = []
+    if model.condition_image_adapter is not None and condition_image_tensor is not None:
+        ad = model.condition_image_adapter
+        residuals = list(AdapterFn.apply(ad, condition_image_tensor, *_params(ad)))
+
+    def add_residual(t):
+        if not residuals:
+            return t
+        f = residuals.pop(0)
+        if f.shape != t.shape:
+            raise RuntimeError(f"UNet: layout residual {tuple(f.shape)} does not match the feature map {tuple(t.shape)}")
+        return AddFn.apply(t, f)
+    x = add_residual(x)
 
     def attn(tm, x, g):
         return transformer_model_train(tm, x, ctx_rows, g, disable_crossview, disable_temporal, crossview_attention_mask)
@@ -609,6 +623,9 @@ def forward_train(model: UM.UNetCrossviewTemporalConditionModel, sample, timeste
             x = DownsampleFn.apply(conv, I, h_, w_, x, *_params(conv))
             h_, w_ = h_ // 2, w_ // 2
             skips.append((x, h_, w_))
+        if residuals:
+            x = add_residual(x)
+            skips[-1] = (x, h_, w_)
     g = g0.at(h_, w_)
     x = res_block_train(model.mid_block.resnets[0], x, silu_emb, g, disable_temporal)
     x = attn(model.mid_block.attentions[0], x, g)

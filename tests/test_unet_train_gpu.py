@@ -236,3 +236,44 @@ def test_unet_trainer_sd21_branch_loss_and_descent(dev):
         losses.append(tr.train_step(latents.to(dev), dcond, timestep_indices=ts, noise=noise).item())
     _log("unet_train_descent", losses=losses)
     assert losses[-1] < losses[0] * 0.98, losses
+
+
+def test_unet_gradients_with_layout_adapter(dev):
+    """the SD 2.1 training configs ship the layout ImageAdapter (channels [c0, c0, c1, c2, c3], AvgPool2d in blocks 1-3,
+    zero convs; configs/ctsd/multi_datasets/ctsd_21_tirda_bm_nwa.json): its residuals after conv_in and every down block in
+    train mode, gradients of every adapter parameter (incl. the pooling levels) and of the UNet against fp32 autograd"""
+    from oracle import unet_oracle as U
+    acfg = dict(in_channels=3, channels=[128, 128, 256, 512, 512], is_downblocks=[False, True, True, True, False],
+                num_res_blocks=1, downscale_factor=8, use_zero_convs=True)
+    cfg = _small_unet_cfg(condition_image_adapter_config=acfg)
+    sd = {k: v.to(bf16).float() for k, v in U.make_unet_state_dict(cfg, 0).items()}
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 8, 16, text_len=10)
+    inp["condition_image_tensor"] = torch.rand(2, 2, 3, 3, 64, 128, generator=torch.Generator().manual_seed(7))
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timesteps", "added_time_ids") else v) for k, v in inp.items()}
+    di = to_dev(inp, dev)
+    wgt = torch.randn(2, 2, 3, cfg["out_channels"], 8, 16, generator=torch.Generator().manual_seed(11)).to(dev)
+    ref, gref = _oracle_unet_grads(sd, cfg, di, wgt, dev)
+    m = _unet_model(cfg, sd, dev)
+    kw = dict(di)
+    out = m(kw.pop("sample"), kw.pop("timesteps"), **kw)[0][0]
+    assert out.grad_fn is not None
+    e_fwd = rel_err(out, ref)
+    (out.float() * wgt).sum().backward()
+    errs, num, den, missing = {}, 0.0, 0.0, []
+    for name, p in m.named_parameters():
+        if not name.startswith("condition_image_adapter") or name not in gref or gref[name] is None:
+            continue
+        if p.grad is None:
+            missing.append(name)
+            continue
+        a, b = p.grad.double().cpu(), gref[name].double().cpu()
+        errs[name] = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        num += float((a - b).pow(2).sum())
+        den += float(b.pow(2).sum())
+    glob = (num / den) ** 0.5
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _log("unet_adapter_gradients", fwd=e_fwd, adapter_global_rel=glob, worst=worst, n_adapter_params=len(errs), missing=missing)
+    assert not missing, missing
+    assert len(errs) >= 5 * 6                      # five blocks: in_conv / block1 / block2 / zero conv, weight + bias
+    assert e_fwd < 2e-2 and glob < 4e-2, (glob, worst)
+    assert all(v < 0.15 for v in errs.values()), worst
