@@ -683,25 +683,26 @@ attn_group_kernel(const AttnParams P) {
 // Group-masked attention, shared form: ONE WORKGROUP = one (problem, head group), ONE WAVE = one query group (view).  The
 // per-wave form above lets every wave fetch the K / V rows of the key groups it may see straight from global memory, so a
 // row is pulled through L1 / TA once per query group that sees it (3x with the ring mask of the 6-camera rigs) in 32-byte
-// pieces: the launch moves its 1.06 GB at 2.7 TB/s.  Here wave g copies the K and V rows of group g of the current head into
-// the workgroup's LDS images ONCE, by LDS-DMA (8 lanes per row: whole 128-byte row pieces, no staging registers), and after
-// one barrier every wave reads the fragments of the groups its mask row allows from LDS (K image swizzled for ds_read_b128,
-// V image for ds_read_b64_tr_b16, as in attn_fwd_kernel).  A second barrier retires the images before the next head's copy;
-// the output tile leaves through 4 KiB of wave-private LDS as whole rows.  Two workgroups share a CU (72 KiB each), so one
-// computes while the other waits for its copy.  HBM-bound: q, k, v read + o written once.
+// pieces: the launch moves its 1.06 GB at 2.7-3.0 TB/s.  Here wave g copies the K and V rows of group g of a head into the
+// workgroup's LDS images ONCE, by LDS-DMA (8 lanes per row: whole 128-byte row pieces, no staging registers), and every
+// wave reads the fragments of the groups its mask row allows from LDS (K image swizzled for ds_read_b128, V image for
+// ds_read_b64_tr_b16, as in attn_fwd_kernel).  The images are double buffered over the heads of the workgroup: the copy of
+// head h+2 is requested right after the ONE barrier per head - the one that says "everybody is done reading head h's images
+// and everybody's rows of head h+1 have landed" - so a copy has a whole head's compute to arrive; the next head's Q rows are
+// requested before the current head's compute; the output tile leaves through 4 KiB of wave-private LDS as whole rows.
+// One workgroup per CU (120 KiB at 6 views).  HBM-bound: q, k, v read + o written once.
 constexpr int GRP_IMG = 32 * 128;                 // one group's K (or V) image: 32 rows x 128 B
 template <int G>
-__global__ void __launch_bounds__(G * 64, 2)
+__global__ void __launch_bounds__(G * 64, 1)
 attn_group_lds_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const kimg = smem;                                  // [G][32][128]
-    char* const vimg = smem + G * GRP_IMG;
+    constexpr int STAGE = 2 * G * GRP_IMG;                    // K images [G][32][128], then V images
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = query group
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    char* const sc = smem + 2 * G * GRP_IMG + wave * 4096;    // this wave's output transpose region
+    char* const sc = smem + 2 * STAGE + wave * 4096;          // this wave's output transpose region
 
     const uint32_t prob = fdiv(blockIdx.x, P.fd_heads);
     const int hgrp = (int)(blockIdx.x - prob * P.fd_heads.d);
@@ -749,25 +750,32 @@ attn_group_lds_kernel(const AttnParams P) {
     }
     char* const myrow = sc + l31 * 128;
 
-    // copy of head h's K / V rows of group `wave` into the images (8 LDS-DMA instructions)
-#define DWM_GRP_COPY(h_)                                                                          \
-    do {                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-            glds16(P.k0 + srow[i] + (h_) * 64 + kcol[i], kimg + wave * GRP_IMG + i * 1024);       \
-            glds16(P.v0 + srow[i] + (h_) * 64 + vcol[i], vimg + wave * GRP_IMG + i * 1024);       \
-        }                                                                                         \
+    // copy of head h_'s K / V rows of group `wave` into the images of stage (h_ & 1) (8 LDS-DMA instructions)
+#define DWM_GRP_COPY(h_)                                                                                          \
+    do {                                                                                                          \
+        char* const st_ = smem + ((h_) & 1) * STAGE + wave * GRP_IMG;                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+            glds16(P.k0 + srow[i] + (h_) * 64 + kcol[i], st_ + i * 1024);                                         \
+            glds16(P.v0 + srow[i] + (h_) * 64 + vcol[i], st_ + G * GRP_IMG + i * 1024);                           \
+        }                                                                                                         \
     } while (0)
     DWM_GRP_COPY(0);
-    for (int hh = 0; hh < hpb; ++hh) {
-        // ---- Q fragments of this wave's queries; this head's copy was requested before the previous head's output phase
-        bf16x8 qf[4];
+    if (hpb > 1) DWM_GRP_COPY(1);
+    bf16x8 qf[4], qn[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + hh * 64 + ks * 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                       // every group of this head has landed
+    for (int ks = 0; ks < 4; ++ks) qn[ks] = qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // heads 0 and 1 have landed
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(qf[ks], P.scale_log2);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(qf[ks], P.scale_log2);
 
+    for (int hh = 0; hh < hpb; ++hh) {
+        const char* const kimg = smem + (hh & 1) * STAGE;
+        const char* const vimg = kimg + G * GRP_IMG;
+        if (hh + 1 < hpb) {                                    // the next head's Q rows travel under this head's compute
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qp + (hh + 1) * 64 + ks * 16);
+        }
         f32x16 ot[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -825,9 +833,11 @@ attn_group_lds_kernel(const AttnParams P) {
                     ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], ot[dt], 0, 0, 0);
                 }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                       // every wave is done with this head's images
-        if (hh + 1 < hpb) DWM_GRP_COPY(hh + 1);                // the next head's rows travel under this head's output phase
+        // ONE barrier per head: own fragment reads of this head done, own rows of the next head landed (everything this
+        // wave has requested is at least a head old here: the wait is free) - after it stage hh & 1 may be refilled
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (hh + 2 < hpb) DWM_GRP_COPY(hh + 2);
         // normalise; transpose the 32 x 64 output tile through the wave's own LDS (same-wave LDS ops complete in order)
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(l_tot);
@@ -847,9 +857,10 @@ attn_group_lds_kernel(const AttnParams P) {
             const int64_t rp = __shfl(orow, r, 64);
             if (r < gs && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
         }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(qn[ks], P.scale_log2);
     }
 }
-
 #undef DWM_GRP_COPY
 
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
@@ -933,19 +944,19 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         // rigs of every shipped config) or 4 / 8; variant bit 7 keeps the per-wave form (A/B measurements, tests)
         if ((P.mask_G == 6 || P.mask_G == 4 || P.mask_G == 8) && !((a->variant >> 7) & 1)) {
             int hs = (a->variant >> 8) & 15;
-            if (hs == 0) { for (hs = 4; P.heads % hs != 0; --hs) {} }      // measured at config 3: 4 >= 8 > 2 > 12 heads per workgroup
+            if (hs == 0) { for (hs = 8; P.heads % hs != 0; --hs) {} }      // heads per workgroup (the double-buffered copy pipeline runs over them)
             if (P.heads % hs != 0) return DWM_EINVAL;
             P.hpb = hs;
             P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
             const int64_t nblk = (int64_t)P.n_problems * (P.heads / hs);
             if (nblk >= (1ll << 31)) return DWM_EUNSUPPORTED;
             const int G = P.mask_G;
-            const size_t lds = (size_t)2 * G * GRP_IMG + (size_t)G * 4096;
+            const size_t lds = (size_t)4 * G * GRP_IMG + (size_t)G * 4096;        // two stages of K + V images, output regions
 #define DWM_GRP(G_)                                                                                              \
             do {                                                                                                 \
                 static bool attr_set = false;                                                                    \
                 if (!attr_set) {                                                                                 \
-                    (void)hipFuncSetAttribute((const void*)attn_group_lds_kernel<G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+                    (void)hipFuncSetAttribute((const void*)attn_group_lds_kernel<G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                     attr_set = true;                                                                             \
                 }                                                                                                \
                 hipLaunchKernelGGL((attn_group_lds_kernel<G_>), dim3((unsigned)nblk), dim3(G_ * 64), lds, s, P); \

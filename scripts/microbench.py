@@ -87,8 +87,8 @@ def bench_crossview():
     mask = ring[None].repeat(B, 1, 1).to(dev)
     gb = 4 * R * D * 2 / 1e9
     timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, group_mask=mask), iters=300)
-    for name, var in (("shared hs=4", 0), ("shared hs=4", 0), ("shared hs=8", 8 << 8), ("shared hs=12", 12 << 8), ("shared hs=2", 2 << 8),
-                      ("shared hs=8 nostore", 16), ("per-wave hs=8", 128), ("per-wave hs=4", 128 | (4 << 8)), ("tiled", 32), ("shared hs=4", 0)):
+    for name, var in (("shared hs=8", 0), ("shared hs=8", 0), ("shared hs=4", 4 << 8), ("shared hs=12", 12 << 8), ("shared hs=6", 6 << 8),
+                      ("shared hs=3", 3 << 8), ("shared hs=8 nostore", 16), ("per-wave hs=8", 128), ("tiled", 32), ("shared hs=8", 0)):
         ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, group_mask=mask, variant=var))
         print(json.dumps({"kernel": "attn-crossview", "case": name, "ms": round(ms, 4), "GBps": round(gb / ms * 1e3, 1)}), flush=True)
 
