@@ -782,56 +782,81 @@ attn_group_lds_kernel(const AttnParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        for (uint32_t rem = bits; rem != 0; rem &= rem - 1) {
-            const int g = __builtin_ctz(rem);
-            const char* kl = kimg + g * GRP_IMG;
-            const char* vl = vimg + g * GRP_IMG;
-            f32x16 st;
+        // the allowed key groups are taken three at a time (the ring mask of the camera rigs allows exactly three): the S
+        // MFMAs of a chunk are independent chains, the softmax runs once over the chunk's 48 scores per lane (one rescale
+        // per chunk instead of one per group) - a wave alone on its SIMD is latency-bound, this is where its ILP comes from
+        for (uint32_t rem = bits; rem != 0;) {
+            int gi[3];
+            int ng = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                gi[c] = rem ? __builtin_ctz(rem) : 0;
+                if (rem) { ++ng; rem &= rem - 1; }
+            }
+            f32x16 st[3];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kl + l31 * 128 + (((2 * ks + half) ^ kswz) << 4));
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[c][r] = 0.f;
+                if (c < ng) {
+                    const char* kl = kimg + gi[c] * GRP_IMG;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const bf16x8 kf = *(const bf16x8*)(kl + l31 * 128 + (((2 * ks + half) ^ kswz) << 4));
+                        st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[c], 0, 0, 0);
+                    }
+                }
             }
             float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (!((kmask >> r) & 1u)) st[r] = -INFINITY;
-                mx = fmaxf(mx, st[r]);
-            }
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (!((kmask >> r) & 1u) || c >= ng) st[c][r] = -INFINITY;
+                    mx = fmaxf(mx, st[c][r]);
+                }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // a group holds >= 1 valid key: finite
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 for the first group (m_run = -inf)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 for the first chunk (m_run = -inf)
             m_run = m_new;
-            float pv[16], sum = 0.f;
+            float sum = 0.f;
+            bf16x8 pf[3][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
-                sum += pv[r];
+            for (int c = 0; c < 3; ++c) {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(st[c][r] - m_new);
+                    sum += pv[r];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const uint4 pk = pack8(pv + 8 * s2);
+                    pf[c][s2] = *reinterpret_cast<const bf16x8*>(&pk);
+                }
             }
             l_run = l_run * alpha + sum;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
-            bf16x8 pf[2];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const uint4 pk = pack8(pv + 8 * s2);
-                pf[s2] = *reinterpret_cast<const bf16x8*>(&pk);
-            }
+            for (int c = 0; c < 3; ++c) {
+                if (c < ng) {
+                    const char* vl = vimg + gi[c] * GRP_IMG;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+                    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s2 * (16 * 128)));
-                    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s2 * (16 * 128)));
-                    const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], ot[dt], 0, 0, 0);
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s2 * (16 * 128)));
+                            const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s2 * (16 * 128)));
+                            const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c][s2], ot[dt], 0, 0, 0);
+                        }
                 }
+            }
         }
         // ONE barrier per head: own fragment reads of this head done, own rows of the next head landed (everything this
         // wave has requested is at least a head old here: the wait is free) - after it stage hh & 1 may be refilled

@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun call K of round 2: shared-LDS group attention after the copy / output overlap: tests, microbench, bench
-TAG=${1:-r2n}
+TAG=${1:-r2o}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
