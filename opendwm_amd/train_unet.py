@@ -327,9 +327,7 @@ class BasicBlockFn(torch.autograd.Function):
         ctx.blk, ctx.n_img, ctx.ctx_rows = blk, n_img, ctx_rows
         ctx.save_for_backward(h)
         with torch.no_grad():
-            tc = UM._TextContext.__new__(UM._TextContext)
-            tc.rows, tc._kv = ctx_rows, {}
-            return blk.run(h.clone(), tc, n_img)
+            return blk.run(h.clone(), UM._TextContext.from_rows(ctx_rows), n_img)
 
     @staticmethod
     def backward(ctx, dout):

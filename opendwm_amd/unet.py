@@ -207,6 +207,13 @@ class _TextContext:
         self.rows = ehs.reshape(ehs.shape[0] * ehs.shape[1], -1).contiguous()
         self._kv = {}
 
+    @classmethod
+    def from_rows(cls, rows: torch.Tensor) -> "_TextContext":
+        """a context over text rows that are already flattened to [images * L, cross_attention_dim] bf16 (training path)"""
+        self = cls.__new__(cls)
+        self.source, self.key, self.rows, self._kv = None, None, rows, {}
+        return self
+
     def matches(self, encoder_hidden_states: torch.Tensor) -> bool:
         t = encoder_hidden_states
         return t is self.source and self.key == (t.data_ptr(), t._version, tuple(t.shape), t.dtype, STORE.step)

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 for s in make_reference_fixtures make_reference_driver_fixtures make_reference_forward_fixture make_reference_unet_fixture \
          make_reference_train_fixture make_reference_condition_fixtures make_reference_checkpoint_fixture \
-         make_reference_scheduler_fixture; do
+         make_reference_scheduler_fixture make_reference_train_unet_fixture; do
   echo "== $s"
   python tests/golden/$s.py | tail -2
 done
