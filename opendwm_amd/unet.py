@@ -443,10 +443,19 @@ class UNetCrossviewTemporalConditionModel(_Base):
             self.condition_image_adapter = ImageAdapter(**condition_image_adapter_config)
         self._adapter_cache = (None, None)
         self.depth_net = None
+        self.gradient_checkpointing = False
         self.depth_frustum_range = depth_frustum_range
         self._scratch = _Scratch()
         self._text_ctx = None
         self._tproj_layers = None
+
+    def enable_gradient_checkpointing(self):
+        """module protocol of the pipeline (ctsd.py:867-875).  The training path keeps only each block's inputs whatever
+        this flag says (opendwm_amd.train_unet), as the reference's blocks do once it is set."""
+        self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
 
     def _time_proj_layers(self):
         """every residual block's `time_emb_proj`, in module order (the column layout of the stacked projection)"""

@@ -458,6 +458,12 @@ def test_unet_model_state_dict_keys_equal_oracle_tree():
     full = U.make_unet_config()
     n = sum(torch.Size(s).numel() for s in U.unet_param_shapes(full).values())
     assert 1.9e9 < n < 1.95e9
+    # module protocol the pipeline uses on the model (ctsd.py:867-875, 1462)
+    assert m.depth_net is None and m.gradient_checkpointing is False
+    m.enable_gradient_checkpointing()
+    assert m.gradient_checkpointing is True
+    with pytest.raises(RuntimeError):             # no CPU / PyTorch fallback, in train mode either
+        m.train()(torch.zeros(1, 1, 3, 4, 8, 16), torch.zeros(1, 1, 3), encoder_hidden_states=torch.zeros(1, 1, 3, 10, cfg["cross_attention_dim"]))
 
 
 def test_dpm_solver_tables_and_last_step():
