@@ -305,7 +305,9 @@ class DiTCrossviewTemporalConditionModel(_Base):
                                        disable_crossview=kw.get("disable_crossview"), disable_temporal=kw.get("disable_temporal"),
                                        crossview_attention_mask=kw.get("crossview_attention_mask"),
                                        added_time_ids=kw.get("added_time_ids"),
-                                       condition_image_tensor=kw.get("condition_image_tensor"))
+                                       condition_image_tensor=kw.get("condition_image_tensor"),
+                                       camera_intrinsics_norm=kw.get("camera_intrinsics_norm"),
+                                       camera2referego=kw.get("camera2referego"))
             if kw.get("return_dict"):                       # crossview_temporal_dit.py:620-630: only the dict form is squeezed
                 return {"noise_pred": out.squeeze(2) if squeeze else out}
             return [out], None, None

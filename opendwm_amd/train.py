@@ -361,8 +361,8 @@ def vt_block_backward(blk: VTSelfAttentionBlock, h: torch.Tensor, emb: torch.Ten
     dyin = lin_bwd(G, pi, y, du1)
     dxs0 = dxs1
     ln_bwd(h, blk.norm_in, dyin, dxs0, addvec=emb, rows_per_add=rows_per_emb)
-    # xs0 = h + emb[row // rows_per_emb]
-    demb = T.segsum(dxs0, rows_per_group=rows_per_emb)
+    # xs0 = h + emb[row // rows_per_emb]   (one embedding row per token - explicit perspective modelling - needs no sum)
+    demb = dxs0 if rows_per_emb == 1 else T.segsum(dxs0, rows_per_group=rows_per_emb)
     dh = T.rowcombine(dy, coef_a=alpha, rows_per_coef_a=rows_per_alpha, b=dxs0)
     return dh, demb, dalpha
 
@@ -699,9 +699,35 @@ class AdapterFn(torch.autograd.Function):
         return (None, None) + _grads_for(G, ps, ctx.needs_input_grad[2:])
 
 
+class RayEmbFn(torch.autograd.Function):
+    """Explicit perspective modelling (crossview_temporal_dit.py:440-458, 528-568): per-token embedding of a cross-view /
+    temporal block = per-image index embedding [I, D] + RayEncoder.proj(ray features [I*N, 72]).  One K = 128 GEMM with the
+    per-image row as the epilogue residual; the ray features carry no gradient, `proj.weight` and the index embedding do."""
+
+    @staticmethod
+    def forward(ctx, renc, n_tok, ray_feat, emb_img, *params):
+        ctx.renc, ctx.n_tok = renc, n_tok
+        ctx.save_for_backward(ray_feat)
+        with torch.no_grad():
+            return ops.gemm(ray_feat, renc.packed(), None, epilogue=ops.EPI_RESID, res=emb_img.contiguous(), res_mod=-n_tok)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ray_feat,) = ctx.saved_tensors
+        renc = ctx.renc
+        G = Grads()
+        dout = dout.contiguous()
+        if renc.proj.weight.requires_grad:
+            dw, _ = T.linear_wgrad(dout, ray_feat, want_bias=False)                  # [D, 128]: K was zero-padded from 72
+            G.add(renc.proj.weight, dw[:, :renc.proj.weight.shape[1]].contiguous())
+        demb = ops.cast_bf16(T.segsum(dout, rows_per_group=ctx.n_tok))
+        return (None, None, None, demb) + _grads_for(G, _params(renc), ctx.needs_input_grad[4:])
+
+
 # ------------------------------------------------------------------------------------------ model forward
 def forward_train(model, sample, timestep, encoder_hidden_states, pooled_projections, disable_crossview=None,
-                  disable_temporal=None, crossview_attention_mask=None, added_time_ids=None, condition_image_tensor=None):
+                  disable_temporal=None, crossview_attention_mask=None, added_time_ids=None, condition_image_tensor=None,
+                  camera_intrinsics_norm=None, camera2referego=None):
     """Autograd-enabled forward of DiTCrossviewTemporalConditionModel (text-conditioned configuration;
     crossview_temporal_dit.py:372-630).  Returns the prediction [B, T, V, C, H, W] (bf16) with a grad_fn."""
     STORE.set_precision(bf16)               # training runs in bf16 compute over fp32 masters
@@ -726,9 +752,18 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
     st = SiluFn.apply(temb)
 
     view_cam_emb = None
-    if model.perspective_modeling_type == "explicit":
-        raise NotImplementedError("training with perspective_modeling_type='explicit' (RayEncoder weight gradient) is not built; "
-                                  "the inference forward is (DiTCrossviewTemporalConditionModel.eval())")
+    ray_feat = None
+    if model.perspective_modeling_type == "explicit":                                              # :440-458
+        if camera_intrinsics_norm is None or camera2referego is None:
+            raise RuntimeError("perspective_modeling_type='explicit' needs camera_intrinsics_norm and camera2referego")
+        with torch.no_grad():
+            ray_feat = model.rayencoder.features(camera_intrinsics_norm, camera2referego, height, width)
+
+    def with_rays(emb_img):
+        """(embedding for the VT block, rows per embedding row): the per-image row alone, or row + ray projection per token"""
+        if ray_feat is None:
+            return emb_img, N
+        return RayEmbFn.apply(model.rayencoder, N, ray_feat, emb_img, *_params(model.rayencoder)), 1
     if model.perspective_modeling_type == "implicit":
         ve = ops.timestep_sinusoid(added_time_ids.flatten(), 256).view(I, -1)
         view_cam_emb = mlp_train(model.view_embedding, ve)
@@ -755,16 +790,20 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
             seq = ops.timestep_sinusoid(idx, D)
             use_cam = model.enable_crossview and not model.disable_view_emb_on_temporal_module and view_cam_emb is not None
             seq_emb = mlp_train(model.time_pos_embeds[k], seq, res=view_cam_emb if use_cam else None)
+            rpe = N
+            if model.enable_crossview and not model.disable_view_emb_on_temporal_module:           # :559-566
+                seq_emb, rpe = with_rays(seq_emb)
             tt = model.temporal_attention_type
             mk = ops.rowmap_temporal_full if tt == "full" else \
                 ops.rowmap_temporal_rowwise if tt == "rowwise" else ops.rowmap_temporal_pointwise
             alpha = alpha_train(model.time_mixers[k], disable_temporal, B)
-            h = vt_block_train(model.temporal_transformer_blocks[k], h, mk(B, Tn, V, height, width), seq_emb, N,
+            h = vt_block_train(model.temporal_transformer_blocks[k], h, mk(B, Tn, V, height, width), seq_emb, rpe,
                                alpha, Tn * V * N)
         if model.enable_crossview and i in model.crossview_block_layers:
             k = model.crossview_block_layers.index(i)
             idx = torch.arange(V, device=dev).view(1, 1, V).expand(B, Tn, V)
             vemb = mlp_train(model.view_pos_embeds[k], ops.timestep_sinusoid(idx, D), res=view_cam_emb)
+            vemb, rpe = with_rays(vemb)                                                             # :528-537
             ct = model.crossview_attention_type
             gmask = dmask = None
             if ct == "rowwise":
@@ -776,7 +815,7 @@ def forward_train(model, sample, timestep, encoder_hidden_states, pooled_project
             else:
                 raise NotImplementedError(f"Not support {ct}")
             alpha = alpha_train(model.view_mixers[k], disable_crossview, B)
-            h = vt_block_train(model.crossview_transformer_blocks[k], h, rm, vemb, N, alpha, Tn * V * N,
+            h = vt_block_train(model.crossview_transformer_blocks[k], h, rm, vemb, rpe, alpha, Tn * V * N,
                                group_mask=gmask, dense_mask=dmask)
 
     geom = (I, model.out_channels, height, width, p, N, D)

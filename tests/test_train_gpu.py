@@ -632,3 +632,48 @@ def test_adapter_weights_are_repacked_after_optimizer_step(dev):
          weights_moved=moved, changed=rel_err(after, before))
     assert e_now < 2e-2 and e_train < 2e-2, (e_now, e_train)
     assert e_old > 3 * e_now, (e_old, e_now)
+
+
+def test_model_gradients_explicit_perspective_vs_oracle(dev):
+    """training with perspective_modeling_type="explicit" (the UniMLVG training configs, configs/ctsd/unimlvg/*): per-token
+    embedding = index embedding + RayEncoder.proj(ray features) in front of every cross-view / temporal block
+    (crossview_temporal_dit.py:440-458, 528-568) - gradients of `rayencoder.proj.weight`, of the index-embedding MLPs and of
+    everything else against fp32 autograd through the oracle"""
+    from oracle import ctsd_oracle as O
+    from tests.common import small_config, small_inputs, to_dev
+    GOLDEN = os.path.join(ROOT, "tests", "golden")
+    fx = torch.load(os.path.join(GOLDEN, "reference_forward.pt"))["explicit"]
+    cfg = small_config(perspective_modeling_type="explicit")
+    sd = {k: v.to(bf16).float() for k, v in O.make_state_dict(cfg, 0).items()}
+    inp = small_inputs(cfg, 0)
+    inp.pop("added_time_ids")
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep",) else v) for k, v in inp.items()}
+    inp.update({k: fx[k] for k in ("camera_intrinsics_norm", "camera2referego")})
+    di = to_dev(inp, dev)
+    wgt = torch.randn(inp["sample"].shape, generator=torch.Generator().manual_seed(11)).to(dev)
+    cond = {}
+    ref, gref = _oracle_grads(sd, cfg, di, wgt, dev, mixer_cond=cond)
+    m = _train_model(cfg, sd, dev)
+    kw = dict(di)
+    out = m(kw.pop("sample"), kw.pop("timestep"), **kw)[0][0]
+    assert out.grad_fn is not None
+    e_fwd = rel_err(out, ref)
+    (out.float() * wgt).sum().backward()
+    errs, num, den, missing = {}, 0.0, 0.0, []
+    for name, p in m.named_parameters():
+        if name not in gref or gref[name] is None:
+            continue
+        if p.grad is None:
+            missing.append(name)
+            continue
+        a, b = p.grad.double().cpu(), gref[name].double().cpu()
+        errs[name] = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        num += float((a - b).pow(2).sum())
+        den += float(b.pow(2).sum())
+    glob = (num / den) ** 0.5
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _log("model_gradients_explicit", fwd=e_fwd, global_rel=glob, rayencoder=errs.get("rayencoder.proj.weight"), worst=worst, missing=missing)
+    assert not missing and "rayencoder.proj.weight" in errs, (missing, list(errs)[:5])
+    assert e_fwd < 2e-2 and glob < 3e-2, (glob, worst)
+    assert errs["rayencoder.proj.weight"] < 5e-2
+    assert all(v < 0.15 for n, v in errs.items() if n not in cond), worst
