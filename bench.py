@@ -638,10 +638,10 @@ def main():
             if args.graph:
                 den.enable_graph()
 
+            model.cache_adapter_residuals = bool(args.adapter_cache)     # default: the adapter runs inside every timed step
+
             def step(i):
                 timer.enabled = i >= warmup and not args.graph
-                if not args.adapter_cache:
-                    model._adapter_cache = (None, None)
                 den.step(i % ninf)
 
             dt = D.timed_steps(step, steps, warmup, dev)

@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 13
+#define DWM_ABI_VERSION 14
 int dwm_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -106,6 +106,11 @@ typedef struct dwm_gemm_args {
      * (>= 2 * M * N * 4 to be usable), owned by the caller, one per stream; NULL = never split.
      * split_k: 0 = automatic, 1 = never, > 1 = exactly this many ranges (DWM_EUNSUPPORTED if impossible). */
     void* workspace; int64_t workspace_bytes; int32_t split_k;
+    /* fp32 residual stream (RESID, res_mod == 0): when C32 != NULL, `res` is an fp32 matrix (ld_res in fp32 elements, rows
+     * through c_map like C), the result v is written to C32 in fp32 (in place over `res` allowed) and, rounded, to the bf16 C
+     * that the next GEMM reads.  Keeps a chain of residual blocks from accumulating one bf16 storage rounding per block (the
+     * layout ImageAdapter, src/dwm/models/adapters.py:40-60: its input - and so its error - is the same at every denoise step). */
+    void* C32; int64_t ldc32;
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
@@ -148,10 +153,13 @@ typedef struct dwm_attn_args {
     int64_t pdiv[3], pmod[3], pstride[3];
     int64_t ldiv[2], lstride[3];
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
-    int32_t variant;                           /* 0 = auto.  Tuning / test knob (attention.hip): bits 0-3 queries per wave
-                                                * (1: 32, 2: 64), bit 4 skip the output stores (benchmarks), bit 5 keep the
-                                                * tiled kernel for L <= 32 (default there: the packed short-sequence kernel),
-                                                * bits 8-11 heads per workgroup / per wave */
+    int32_t variant;                           /* 0 = auto.  Kernel selection (attention.hip): bits 0-3 query tiles per wave
+                                                * (1: 32 queries, 2: 64; the resident kernel: 12 waves x 1 tile or 8 waves x 2),
+                                                * bit 4 online softmax with a running maximum for every unit of the resident
+                                                * kernel (default: its maximum-free fast path with a checked fallback),
+                                                * bit 5 keep the tiled kernel (default for L <= 32: the packed short-sequence
+                                                * kernel; for unmasked self-attention with 64 <= L <= 608: the resident kernel),
+                                                * bit 7 per-wave form of the group-masked kernel, bits 8-11 heads per workgroup */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */
@@ -262,6 +270,9 @@ int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t w, int32_t 
 
 /* y += x, bf16, n % 8 == 0 (hidden_states + condition_residual, crossview_temporal_dit.py:491-494). */
 int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream);
+/* y (bf16) += x (fp32), the sum rounded once: layout residuals kept in fp32 across denoise steps
+ * (crossview_temporal_dit.py:491-494 with the ImageAdapter output cached) */
+int dwm_add_f32_inplace(void* y, const float* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------
  * VAE blocks (diffusers AutoencoderKL, called at src/dwm/pipelines/ctsd.py:1213-1218,1634-1640)

@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DWM_HIP_LIB") or os.path.join(HERE, "libdwm_hip.so")      # DWM_HIP_LIB: another build of the same ABI (A/B measurements)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("a_map", RowMap2D), ("c_map", RowMap2D), ("ntaps", _i32), ("k_per_tap", _i32),
         ("tap_shift", _i64 * 27),
         ("workspace", _vp), ("workspace_bytes", _i64), ("split_k", _i32),
+        ("C32", _vp), ("ldc32", _i64),
     ]
 
 
@@ -129,6 +130,7 @@ SIGNATURES = {
     "dwm_unshuffle_tokens": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "dwm_avgpool2_tokens": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dwm_add_inplace": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_add_f32_inplace": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_groupnorm_silu": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), _vp]),
     "dwm_groupnorm_silu_mapped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),

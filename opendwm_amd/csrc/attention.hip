@@ -336,7 +336,7 @@ attn_fwd_kernel(const AttnParams P) {
                 const float inv = __builtin_amdgcn_rcpf(l_tot);
                 if (P.lse != nullptr && qok[t] && half == 0)       // NEGATIVE log2-domain LSE: P = exp2(c q.k + neg_lse)
                     P.lse[((int64_t)prob * P.heads + head) * L + qb * QB + (wave * QT + t) * 32 + l31] = negm[t][0] - __builtin_amdgcn_logf(l_tot);
-                if (wave_active && !P.dbg_nostore) {
+                if (wave_active) {
                     char* const myrow = sc + (l31 >> 4) * K_TILE_BYTES + (l31 & 15) * 128;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
@@ -518,7 +518,7 @@ attn_small_kernel(const AttnParams P) {
             const uint4 val = *(const uint4*)(sc + r * 128 + ((c ^ (r & 7)) << 4));
             const int64_t rp = __shfl(orow, r, 64);
             const int okr = __shfl((int)ok, r, 64);
-            if (okr && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+            if (okr) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
         }
     }
 }
@@ -674,7 +674,7 @@ attn_group_kernel(const AttnParams P) {
             const int r = pass * 8 + (lane >> 3), c = lane & 7;
             const uint4 val = *(const uint4*)(sc + r * 128 + ((c ^ (r & 7)) << 4));
             const int64_t rp = __shfl(orow, r, 64);
-            if (r < gs && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+            if (r < gs) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
         }
     }
 }
@@ -880,13 +880,362 @@ attn_group_lds_kernel(const AttnParams P) {
             const int r = pass * 8 + (lane >> 3), c = lane & 7;
             const uint4 val = *(const uint4*)(sc + r * 128 + ((c ^ (r & 7)) << 4));
             const int64_t rp = __shfl(orow, r, 64);
-            if (r < gs && !P.dbg_nostore) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
+            if (r < gs) *(uint4*)((bf16_t*)rp + hh * 64 + c * 8) = val;
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = scale_frag(qn[ks], P.scale_log2);
     }
 }
 #undef DWM_GRP_COPY
+
+// ---------------------------------------------------------------------------------------------------------------
+// Resident form (round 3): ONE WORKGROUP = one (problem, head group); the K and V rows of one head - all L <= 608 of them,
+// 2 x 76 KiB at the joint attention's L = 602 - are copied into LDS ONCE by LDS-DMA and every query tile of the head is
+// walked against them by the workgroup's waves.  Against the tiled kernel above (128-query workgroups: every (problem,
+// head)'s K / V crosses L2 -> LDS 4-5 times; 4 LDS-DMA instructions + their address arithmetic + one workgroup barrier per
+// 16 MFMAs and wave) this removes the refills (amplification 1), the per-tile barrier and the per-tile DMA issue: a wave's
+// tile loop is fragment reads, MFMAs and the softmax only, and the waves of a workgroup run it unsynchronised (two
+// barriers per HEAD: "K / V landed", "everybody done with them").  The copy of a head is exposed (nothing else runs on the
+// CU while it lands), so the NEXT head's rows are pulled into L2 a head ahead by one 4-byte touch per 128-byte piece, and
+// the next unit's Q rows are fetched (or touched) a unit ahead.  The output tile leaves the registers as 16-byte pieces
+// after a lane <-> lane + 32 exchange (v_permlane32_swap): the LDS is full.
+//
+// Softmax without a running maximum (the fast path): softmax is shift invariant, so P' = 2^s (s = the log2-domain score,
+// scale * log2(e) folded into Q) and O = (sum_k P'_k V_k) / (sum_k P'_k) need no maximum at all as long as nothing leaves
+// the fp32 / bf16 exponent range - bf16 keeps fp32's exponent, so P' has the same RELATIVE precision as 2^(s - m).  With
+// the RMS-normalised q / k of this model |s| is a few units.  Head_dim 64 makes the forward VALU-issue bound (one
+// exponential, half a max3, half a packed add, half a convert per score against 256 MFMA flop): dropping the maximum, the
+// -m accumulator splat and the rescale branch takes ~20 % of the vector instructions and 16 registers per query tile out
+// of the tile loop.  The result of a unit is accepted if every row sum lies in [2^-64, 2^64] and every output is finite;
+// otherwise (never, on this model) the unit is redone by the textbook online softmax (res_tile_safe).
+// Fragment layouts and swizzles are attn_fwd_kernel's.
+template <int NT, int NJ>   // one tile step, fast path.  NT query tiles; NJ = 2: 64 keys, NJ = 1: 32 keys (sequence tail)
+DWM_DEVINL void res_tile_fast(const char* __restrict__ kl, const char* __restrict__ vl, int key0, int L,
+                              const bf16x8 (&qf)[NT][4], f32x16 (&ot)[NT][2], f32x2 (&lsum)[NT][2],
+                              int l31, int half, int kswz, const int (&vra)[2], const int (&vrb)[2]) {
+    f32x16 st[NT][NJ];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // all K fragments of the step are requested before the first MFMA (counted lgkmcnt waits in between): a wave's S phase
+    // is then 8 back-to-back MFMAs behind ONE LDS latency instead of 8 (read, wait, MFMA) rounds
+    bf16x8 kf[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            kf[j][ks] = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j][ks], qf[t][ks], ks == 0 ? zero : st[t][j], 0, 0, 0);
+    if (NJ == 1 && key0 + 32 > L) {                 // ragged end of the sequence (wave-uniform; full 64-key steps never are): 2^-inf = 0
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[t][j][r] = -INFINITY;
+    }
+    bf16x8 pf[NT][2 * NJ];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(st[t][j][s2 * 8 + e]);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) lsum[t][(e >> 1) & 1] += (f32x2){pv[e], pv[e + 1]};
+                const uint4 pk = pack8(pv);
+                pf[t][j * 2 + s2] = *reinterpret_cast<const bf16x8*>(&pk);
+            }
+#pragma unroll
+    for (int s = 0; s < 2 * NJ; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s * (16 * 128)));
+            const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s * (16 * 128)));
+            const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                ot[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], ot[t][dt], 0, 0, 0);
+        }
+}
+
+// the same step by the textbook online softmax (one query tile; running max m and sum l per lane, rescale every step):
+// the fallback of a unit whose fast-path sums left the safe range.  Written for few registers, not for speed.
+template <int NJ>
+DWM_DEVINL void res_tile_safe(const char* __restrict__ kl, const char* __restrict__ vl, int key0, int L,
+                              const bf16x8 (&qf)[4], f32x16 (&ot)[2], float& m_run, float& l_run,
+                              int l31, int half, int kswz, const int (&vra)[2], const int (&vrb)[2]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+        f32x16 st;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : st, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (key0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[r] = -INFINITY;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                  // finite: the first step of a sequence holds key 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 at the first step (m_run = -inf)
+        m_run = m_new;
+        float pv[16], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+            sum += pv[r];
+        }
+        l_run = l_run * alpha + sum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint4 pk = pack8(pv + 8 * s2);
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + (2 * j + s2) * (16 * 128)));
+                const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + (2 * j + s2) * (16 * 128)));
+                const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+struct ResCtx {             // launch / workgroup invariants of attn_res_kernel's helpers
+    const char *kimg, *vimg;
+    const int32_t* rowtab;
+    int L, L0, nk64, l31, half, kswz;
+    bool tail32;
+    int vra[2], vrb[2];
+};
+
+// one unit = NT query tiles of one head against the resident K / V images: tile loop, acceptance test of the fast path (or
+// the fallback), normalisation, and the stores.  qraw: this lane's raw Q fragments; op[t]: this lane's output row pointer
+// (rows past the last query are clamped to it: they then hold the same Q, compute the same output and store the same
+// bytes to the same address - unconditional stores keep the loop free of exec-masked blocks).
+template <int NT>
+DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe) {
+    bf16x8 qf[NT][4];
+    f32x16 ot[NT][2];
+    f32x2 lsum[NT][2];
+    float l_tot[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = scale_frag(qraw[t][ks], scale_log2);
+        lsum[t][0] = lsum[t][1] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
+    }
+    for (int kt = 0; kt < c.nk64; ++kt)
+        res_tile_fast<NT, 2>(c.kimg + kt * 8192, c.vimg + kt * 8192, kt * 64, c.L, qf, ot, lsum, c.l31, c.half, c.kswz, c.vra, c.vrb);
+    if (c.tail32)
+        res_tile_fast<NT, 1>(c.kimg + c.nk64 * 8192, c.vimg + c.nk64 * 8192, c.nk64 * 64, c.L, qf, ot, lsum, c.l31, c.half, c.kswz, c.vra, c.vrb);
+    bool ok = !force_safe;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float l_half = (lsum[t][0][0] + lsum[t][0][1]) + (lsum[t][1][0] + lsum[t][1][1]);
+        const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
+        l_tot[t] = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
+        float chk = 0.f;                                   // 0 * finite = 0, 0 * (inf | nan) = nan
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(ot[t][i][r], 0.f, chk);
+        ok = ok && (l_tot[t] >= 5.421010862e-20f) && (l_tot[t] <= 1.8446744e19f) && (chk == 0.f);
+    }
+    if (!__all(ok)) {                                      // wave-uniform: redo the unit by the online softmax
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
+            for (int kt = 0; kt < c.nk64; ++kt)
+                res_tile_safe<2>(c.kimg + kt * 8192, c.vimg + kt * 8192, kt * 64, c.L, qf[t], ot[t], m_run, l_run, c.l31, c.half, c.kswz, c.vra, c.vrb);
+            if (c.tail32)
+                res_tile_safe<1>(c.kimg + c.nk64 * 8192, c.vimg + c.nk64 * 8192, c.nk64 * 64, c.L, qf[t], ot[t], m_run, l_run, c.l31, c.half, c.kswz, c.vra, c.vrb);
+            l_tot[t] = l_run + __shfl_xor(l_run, 32, 64);
+        }
+    }
+    // normalise and store: lane (q, half) holds d = 32 dt + 8 g + 4 half + (0..3) in registers 4 g .. 4 g + 3 of ot[dt];
+    // after the exchange of one 8-byte piece with lane ^ 32 per pair of g, the lower lane owns the whole 16-byte chunk of
+    // the even g, the upper lane that of the odd g
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float inv = __builtin_amdgcn_rcpf(l_tot[t]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                float a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = ot[t][dt][gp * 8 + j] * inv;            // g = 2 gp
+                    b[j] = ot[t][dt][gp * 8 + 4 + j] * inv;        // g = 2 gp + 1
+                }
+                const uint2 pa = pack4(a), pb = pack4(b);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                const uint4 val = {s0[0], s1[0], s0[1], s1[1]};
+                *(uint4*)(op[t] + dt * 32 + (2 * gp + c.half) * 8) = val;
+            }
+    }
+}
+
+template <int QT, int NW>      // QT query tiles per unit (wave), NW waves
+__global__ void __launch_bounds__(NW * 64, 1)
+attn_res_kernel(const AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int L = P.L, L0 = P.L0;
+    const int Lp = (L + 31) & ~31;                        // image rows (32-key granules)
+    char* const kimg = smem;
+    char* const vimg = smem + Lp * 128;
+    int32_t* __restrict__ rowtab = (int32_t*)(smem + 2 * Lp * 128);      // see attn_fwd_kernel
+
+    const uint32_t prob = fdiv(blockIdx.x, P.fd_heads);
+    const int hgrp = (int)(blockIdx.x - prob * P.fd_heads.d);
+    const int hpb = P.hpb;
+    const int64_t hoff = (int64_t)hgrp * hpb * 64;
+    const int64_t base0 = seg0_base(P.rm, (int)prob);
+    for (int l = tid; l < L; l += NW * 64)
+        rowtab[l] = (int32_t)((l < L0 ? seg0_row(P.rm, base0, l) * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
+    __syncthreads();
+
+    ResCtx c;
+    c.kimg = kimg; c.vimg = vimg; c.rowtab = rowtab;
+    c.L = L; c.L0 = L0; c.nk64 = L >> 6; c.tail32 = Lp > (c.nk64 << 6);
+    c.l31 = l31; c.half = half; c.kswz = (lane >> 1) & 7;
+    {
+        const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+            const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+            c.vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+            c.vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        }
+    }
+
+    // copy of one head's K and V rows: instruction i (8 rows x 128 B, 16 B per lane, LDS destination lane-linear) is issued by
+    // wave i mod NW; the chunk swizzle of the images is applied on the source column (attn_fwd_kernel)
+    const int ngrp = Lp >> 3;
+    auto copy_head = [&](int hh) {
+        const int64_t ho = hoff + hh * 64;
+        for (int i = wave; i < ngrp; i += NW) {
+            const int r = i * 8 + (lane >> 3);
+            const int rc = r < L ? r : L - 1;                 // rows past the end: a copy of the last row (finite), masked as keys
+            const int64_t off = ((int64_t)rowtab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
+            glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
+            glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
+        }
+    };
+    // L2 prefetch of a head's K / V rows: one 4-byte touch per 128-byte piece, lane = row.  No wait here: the destination
+    // registers stay reserved until the vmcnt(0) at the top of the next head (they are operands of the asm there); loads
+    // return in order and these are older than every load the compiler tracks
+    uint32_t td0 = 0, td1 = 0;
+    auto touch_head = [&](int hh) {
+        const int64_t ho = hoff + hh * 64;
+        for (int r0 = wave * 64; r0 < L; r0 += NW * 64) {
+            const int r = r0 + lane < L ? r0 + lane : L - 1;
+            const int64_t off = ((int64_t)rowtab[r] << 3) + (r < L0 ? 0 : P.seg1_delta) + ho;
+            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                         : "=&v"(td0), "=&v"(td1) : "v"(P.k0 + off), "v"(P.v0 + off) : "memory");
+        }
+    };
+
+    const int nqt = (P.qend + 31) >> 5;                      // 32-query tiles of a head
+    // row offset (elements) of this lane's query of tile qt inside q0 / k0 / v0, and its output row pointer
+    auto q_off = [&](int qt) -> int64_t {
+        int lq = qt * 32 + l31;
+        lq = lq < P.qend ? lq : P.qend - 1;
+        return ((int64_t)rowtab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta);
+    };
+    auto o_ptr = [&](int qt) -> bf16_t* {
+        int lq = qt * 32 + l31;
+        lq = lq < P.qend ? lq : P.qend - 1;
+        if (lq < L0) return P.o0 + seg0_row(P.rm, base0, lq) * P.ldo0;
+        return P.o1 + ((int64_t)prob * P.L1 + (lq - L0)) * P.ldo1;
+    };
+
+    // L2 prefetch of the NEXT unit's Q rows (one touch per row; same register discipline as touch_head)
+    uint32_t tq[QT] = {};
+    auto touch_q = [&](int hh, int qt0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(tq[t]) : "v"(P.q0 + q_off(qt0 + t < nqt ? qt0 + t : nqt - 1) + hoff + hh * 64) : "memory");
+    };
+
+    copy_head(0);
+    const int qt_first = wave * QT;
+    const bool force_safe = P.safe_softmax != 0;             // dwm_attn_args.variant bit 4: online softmax for every unit
+
+    for (int hh = 0; hh < hpb; ++hh) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
+        asm volatile("" : "+v"(td0), "+v"(td1));             // (the touch destinations are free again)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) asm volatile("" : "+v"(tq[t]));
+        __syncthreads();                                     // ... and everybody else's
+        if (hh + 1 < hpb) touch_head(hh + 1);
+        const int64_t ho = hoff + hh * 64;
+        for (int qt0 = qt_first; qt0 < nqt; qt0 += NW * QT) {
+            if (qt0 + NW * QT < nqt) touch_q(hh, qt0 + NW * QT);
+            else if (hh + 1 < hpb) touch_q(hh + 1, qt_first);
+            if (QT == 2 && qt0 + 1 < nqt) {
+                bf16x8 q[2][4];
+                bf16_t* op[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16_t* qp = P.q0 + q_off(qt0 + t) + ho + half * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) q[t][ks] = *(const bf16x8*)(qp + ks * 16);
+                    op[t] = o_ptr(qt0 + t) + ho;
+                }
+                res_unit<2>(c, q, op, P.scale_log2, force_safe);
+            } else {
+                bf16x8 q[1][4];
+                bf16_t* op[1];
+                const bf16_t* qp = P.q0 + q_off(qt0) + ho + half * 8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) q[0][ks] = *(const bf16x8*)(qp + ks * 16);
+                op[0] = o_ptr(qt0) + ho;
+                res_unit<1>(c, q, op, P.scale_log2, force_safe);
+            }
+        }
+        __syncthreads();                                     // everybody is done with this head's images
+        if (hh + 1 < hpb) copy_head(hh + 1);
+    }
+}
 
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
@@ -930,7 +1279,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     P.nqb = (int)((P.qend + qblock - 1) / qblock);
     // heads per workgroup: amortises the per-workgroup fixed cost (variant bits 8..11 override: 1..15).
     // Measured on the step's shapes (L = 168 .. 602): 2 ~ 3 > 1; single-tile problems (L <= 64) take more.
-    P.dbg_nostore = (a->variant >> 4) & 1;
+    P.safe_softmax = (a->variant >> 4) & 1;
     int hpb = (a->variant >> 8) & 15;
     if (hpb == 0) {
         if (L - P.kbeg <= KT) { for (hpb = 6; P.heads % hpb != 0; --hpb) {} }
@@ -1000,6 +1349,35 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         const int64_t nblk = ((units + 3) / 4) * (P.heads / hs);
         if (nblk >= (1ll << 31) || units >= (1ll << 31)) return DWM_EUNSUPPORTED;
         hipLaunchKernelGGL(attn_group_kernel, dim3((unsigned)nblk), dim3(256), 0, s, P);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? DWM_OK : (int)e;
+    }
+    // resident form: no mask, no LSE, self-attention, the K / V rows of one head fit the LDS (L <= 608); variant bit 5 keeps
+    // the tiled kernel (A/B measurements, tests)
+    if (P.mask_mode == 0 && P.lse == nullptr && !a->cross && L <= 608 && L >= 64 && !((a->variant >> 5) & 1)) {
+        const int nqt = (P.qend + 31) / 32;
+        int rq = a->variant & 15;
+        if (rq == 0) rq = nqt <= 16 ? 2 : 1;       // 8 waves x 2 query tiles cover <= 16 tiles in one round; else 12 waves x 1
+        if (rq != 1 && rq != 2) return DWM_EINVAL;
+        int hs = (a->variant >> 8) & 15;
+        if (hs == 0) {                             // heads per workgroup: as many as leave >= 3 workgroups per CU
+            for (hs = 6; hs > 1; --hs)
+                if (P.heads % hs == 0 && (int64_t)P.n_problems * (P.heads / hs) >= 768) break;
+        }
+        if (P.heads % hs != 0) return DWM_EINVAL;
+        P.hpb = hs;
+        P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
+        const int64_t nblk = (int64_t)P.n_problems * (P.heads / hs);
+        if (nblk >= (1ll << 31)) return DWM_EUNSUPPORTED;
+        const size_t lds = (size_t)2 * ((L + 31) & ~31) * 128 + (size_t)((L + 3) & ~3) * sizeof(int32_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_res_kernel<1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_res_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        if (rq == 1) hipLaunchKernelGGL((attn_res_kernel<1, 12>), dim3((unsigned)nblk), dim3(768), lds, s, P);
+        else hipLaunchKernelGGL((attn_res_kernel<2, 8>), dim3((unsigned)nblk), dim3(512), lds, s, P);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }

@@ -300,6 +300,19 @@ add_inplace_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, int64_t
     *(uint4*)(y + i * 8) = pack8(a);
 }
 
+// y (bf16) += x (fp32): one rounding of the fp32 sum (the cached fp32 layout residuals of the ImageAdapter)
+__global__ void __launch_bounds__(256)
+add_f32_inplace_kernel(bf16_t* __restrict__ y, const float* __restrict__ x, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float a[8];
+    unpack8(*(const uint4*)(y + i * 8), a);
+    const float4 b0 = *(const float4*)(x + i * 8), b1 = *(const float4*)(x + i * 8 + 4);
+    a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w;
+    a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+    *(uint4*)(y + i * 8) = pack8(a);
+}
+
 inline int finish() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
@@ -450,6 +463,14 @@ extern "C" int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t 
     const int64_t total = I * (h / 2) * (w / 2) * (C / 8);
     hipLaunchKernelGGL(avgpool2_tokens_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, I, h, w, C / 8, (bf16_t*)out);
+    return finish();
+}
+
+extern "C" int dwm_add_f32_inplace(void* y, const float* x, int64_t n, void* stream) {
+    if (x == nullptr || y == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 8 != 0 || !dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    hipLaunchKernelGGL(add_f32_inplace_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)y, x, n / 8);
     return finish();
 }
 

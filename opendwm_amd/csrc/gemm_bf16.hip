@@ -58,7 +58,11 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
 // residual row = output row, no activation - with those facts known at compile time: the per-step address arithmetic is
 // one 32 x 32 -> 64 bit multiply-add per pointer instead of the row-map / modulo chains in 64-bit arithmetic, and the RESID
 // activation switch is gone (the general RESID form spends ~350 instructions per 8-row step, 44 per output value).
-template <int EPI, bool FAST = false>
+// RF32 (general RESID form only): the residual stream is kept in fp32 - `res` is an fp32 matrix (ld_res in fp32 elements), the
+// result is written to `C32` in fp32 (in place over `res` is fine: a lane reads exactly the elements it writes) AND, rounded, to
+// the bf16 matrix C that the next GEMM reads.  For chains of residual blocks whose bf16 storage rounding would otherwise
+// accumulate block after block (the layout ImageAdapter: 12 resnets, step-invariant input, hence a step-invariant error).
+template <int EPI, bool FAST = false, bool RF32 = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
     constexpr int NWN = 4;                       // wave columns of the 2 x 4 wave grid
@@ -319,7 +323,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         // requested into the same registers, so four steps' worth of loads are always in flight behind the math and
         // the stores.  (Plain arrays + a macro: a second set, or structs behind lambda references, end up in scratch.)
         constexpr int NSTEP = 32 / RPS;
-        uint4 gbA[NSTEP], rA[NSTEP];
+        uint4 gbA[NSTEP], rA[NSTEP], rB[RF32 ? NSTEP : 1];
         float alA[NSTEP];
         // branch-free: always two 16-byte loads and one alpha load per step (absent operands read a valid dummy row of C),
         // so the compiler's counted waits stay exact and never degrade to "everything outstanding, stores included"
@@ -350,7 +354,13 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             const int64_t rr_ = !p.res ? mr_ : p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m_, cp.fd_rmod)          \
                                              : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m_, cp.fd_rmod) : mr_;     \
             gbA[ST_] = *(const uint4*)(gb_ptr + grow_ * gb_ld + nc_);                                             \
-            rA[ST_] = *(const uint4*)(r_ptr + rr_ * r_ld + nc_);                                                  \
+            if constexpr (RF32) {                                                                                 \
+                const float* rp_ = (const float*)(p.res ? p.res : p.C32) + rr_ * (p.res ? r_ld : p.ldc32) + nc_;  \
+                rA[ST_] = *(const uint4*)rp_;                                                                     \
+                rB[ST_] = *(const uint4*)(rp_ + 4);                                                               \
+            } else {                                                                                              \
+                rA[ST_] = *(const uint4*)(r_ptr + rr_ * r_ld + nc_);                                              \
+            }                                                                                                     \
             alA[ST_] = al_ptr[p.blend ? (int64_t)fdiv((uint32_t)m_, cp.fd_rpa) : 0];                              \
         }
         if constexpr (EPI == DWM_EPI_RESID) {
@@ -453,7 +463,12 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         }
                     }
                     if (p.res) {
-                        unpack8(rA[st], t);
+                        if constexpr (RF32) {
+                            const float4 ta = *reinterpret_cast<const float4*>(&rA[st]), tb = *reinterpret_cast<const float4*>(&rB[st]);
+                            t[0] = ta.x; t[1] = ta.y; t[2] = ta.z; t[3] = ta.w; t[4] = tb.x; t[5] = tb.y; t[6] = tb.z; t[7] = tb.w;
+                        } else {
+                            unpack8(rA[st], t);
+                        }
     #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
                             const f32x2 y = (f32x2){v[j], v[j + 1]} + (f32x2){t[j], t[j + 1]};
@@ -481,6 +496,11 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     if (m < M && nok && !((p.reserved & 2) && m >= 0)) {
                         if constexpr (FAST) *(uint4*)(Cp + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc + (uint32_t)ncol)) = pack8(v);
                         else *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+                        if constexpr (RF32) {
+                            float* o32 = (float*)p.C32 + mrow * p.ldc32 + ncol;
+                            *(float4*)o32 = make_float4(v[0], v[1], v[2], v[3]);
+                            *(float4*)(o32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                     }
                 }
                 if constexpr (EPI == DWM_EPI_RESID) {
@@ -759,12 +779,15 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
             if (a->res && (a->ld_res % 8 != 0 || !dwm_aligned16(a->res))) return DWM_EALIGN;
             if (a->blend && (a->alpha == nullptr || a->rows_per_alpha <= 0 || a->ld_blend % 8 != 0 || !dwm_aligned16(a->blend))) return DWM_EINVAL;
             if (a->gate && a->blend) return DWM_EUNSUPPORTED;      // one register set carries the gate OR the blend rows
+            if (a->C32 != nullptr && ((a->res != nullptr && a->ld_res % 4 != 0) || a->ldc32 % 4 != 0 || a->ldc32 < a->N ||
+                                      !dwm_aligned16(a->C32) || a->res_mod != 0 || a->split_k > 1)) return DWM_EINVAL;
             break;
         case DWM_EPI_RMSHEAD:
             if (a->rms_w == nullptr || a->rms_ncols % 64 != 0 || a->N % 64 != 0) return DWM_EINVAL;
             break;
         default: return DWM_EINVAL;
     }
+    if (a->C32 != nullptr && a->epilogue != DWM_EPI_RESID) return DWM_EUNSUPPORTED;
     ConvParams cp;
     auto mk = [](const dwm_rowmap2d& r, DevRowMap& d) -> bool {
         d.enabled = r.rw > 0;
@@ -797,7 +820,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     {
         const int64_t tiles = (int64_t)ntm * ntn, nk = a->K / BK;
         const bool can = (a->epilogue == DWM_EPI_PLAIN || a->epilogue == DWM_EPI_RESID) && a->workspace != nullptr &&
-                         dwm_aligned16(a->workspace) && !(a->reserved & 3);
+                         dwm_aligned16(a->workspace) && !(a->reserved & 3) && a->C32 == nullptr;
         if (a->split_k > 1) {
             if (!can) return DWM_EUNSUPPORTED;
             ksplit = a->split_k;
@@ -853,6 +876,17 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     do {                                                                                             \
         if (fast) DWM_LAUNCH(EPI, true); else DWM_LAUNCH(EPI, false);                                \
     } while (0)
+    if (a->C32 != nullptr) {                 // fp32 residual stream: the general RESID form with fp32 residual / master output
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<DWM_EPI_RESID, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, false, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
+        e = hipGetLastError();
+        return e == hipSuccess ? DWM_OK : (int)e;
+    }
     switch (a->epilogue) {
         case DWM_EPI_PLAIN: DWM_LAUNCH2(DWM_EPI_PLAIN); break;
         case DWM_EPI_GEGLU: DWM_LAUNCH2(DWM_EPI_GEGLU); break;

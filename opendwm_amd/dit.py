@@ -215,6 +215,11 @@ class DiTCrossviewTemporalConditionModel(_Base):
         else:
             self.condition_image_adapter = None
         self._adapter_cache = (None, None)
+        # True: the layout residuals (step-invariant: they depend on the condition images only) are computed once, kept in
+        # fp32 and re-used while the condition tensor is the same object; False: recomputed by every forward, as the
+        # reference's forward does (crossview_temporal_dit.py:459-462) - then each zero convolution adds straight into the
+        # hidden state from its GEMM epilogue (adapters.ImageAdapter.residual_adders)
+        self.cache_adapter_residuals = True
         self.frame_shard = None             # set by CTSDDenoiser(frame_group=...): opendwm_amd.sharding.FrameShard
         self.compute_dtype = bf16           # torch.float32 selects the fp32 accuracy path of the inference forward
         self.perspective_modeling_type = perspective_modeling_type
@@ -414,14 +419,16 @@ class DiTCrossviewTemporalConditionModel(_Base):
 
         # layout residuals (crossview_temporal_dit.py:459-462).  They depend only on the condition
         # images, which do not change across denoise steps: cached on the tensor's identity.
-        condition_residuals = None
-        if self.condition_image_adapter is not None and condition_image_tensor is not None:
+        condition_residuals = residual_adders = None
+        if self.condition_image_adapter is not None and condition_image_tensor is not None and not self.cache_adapter_residuals:
+            residual_adders = self.condition_image_adapter.residual_adders(condition_image_tensor)
+        elif self.condition_image_adapter is not None and condition_image_tensor is not None:
             # the key holds the optimizer step (residuals of old adapter weights must not survive a training step) and
             # the cache keeps the tensor alive (a freed tensor's address can be handed to the next same-shape batch)
             from .blocks import STORE
             key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape), STORE.step)
             if self._adapter_cache[0] != key:
-                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor), condition_image_tensor)
+                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor, precise=True), condition_image_tensor)
             condition_residuals = list(self._adapter_cache[1])
             for f in condition_residuals:
                 if f.shape != h.shape:
@@ -429,7 +436,13 @@ class DiTCrossviewTemporalConditionModel(_Base):
 
         for i, block in enumerate(self.transformer_blocks):
             if condition_residuals:
-                ops.add_(h, condition_residuals.pop(0))                                 # :491-494
+                ops.add_(h, condition_residuals.pop(0))                                 # :491-494 (fp32 residual, one rounding)
+            elif residual_adders is not None:
+                add = next(residual_adders, None)
+                if add is None:
+                    residual_adders = None
+                else:
+                    add(h)                                                              # :491-494, fused into the zero-conv GEMM
             c, h = block.run(h, c, silu_temb, I)
 
             if self.enable_temporal and i in self.temporal_block_layers:

@@ -171,13 +171,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rows_per_alpha: int = 1,
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
          a_grid=None, conv3x3: bool = False, stride2=False, conv_taps: Optional[list] = None,
-         c_grid=None,
+         c_grid=None, out32: Optional[torch.Tensor] = None,
          rows: Optional[int] = None, split_k: int = 0, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
     a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
     axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids.
     split_k: 0 = the kernel's rule (small tile grid + long K -> K ranges, fp32 partials, ordered reduction),
-    1 = never, n > 1 = exactly n ranges."""
+    1 = never, n > 1 = exactly n ranges.
+    out32 (RESID): fp32 residual stream - `res` is then an fp32 matrix shaped like `out`, the result goes to out32 in fp32
+    (out32 may be `res` itself) and, rounded, to the bf16 `out` the next GEMM reads."""
     if a.dtype == torch.float32:            # the fp32 accuracy path (dwm_gemm_f32)
         if a_grid is not None or c_grid is not None or conv3x3 or conv_taps is not None or stride2:
             raise NotImplementedError("gemm: implicit convolutions are not part of the fp32 path")
@@ -216,7 +218,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if gate is not None:
         _chk2d(gate, "gate")
         g.gate, g.ld_gate, g.rows_per_gate = gate.data_ptr(), gate.stride(0), rows_per_gate
-    if res is not None:
+    if out32 is not None:
+        if epilogue != EPI_RESID or res_mod != 0:
+            raise RuntimeError("gemm: out32 needs the RESID epilogue (res_mod = 0; `res`, if any, in fp32)")
+        _chk2d(out32, "out32", torch.float32)
+        if out32.shape != out.shape:
+            raise RuntimeError("gemm: out32 must have the shape of out")
+        if res is not None:
+            _chk2d(res, "res", torch.float32)
+            if res.shape != out.shape:
+                raise RuntimeError("gemm: the fp32 res must have the shape of out")
+            g.res, g.ld_res, g.res_mod = res.data_ptr(), res.stride(0), 0
+        g.C32, g.ldc32 = out32.data_ptr(), out32.stride(0)
+        split_k = 1
+    elif res is not None:
         _chk2d(res, "res")
         g.res, g.ld_res, g.res_mod = res.data_ptr(), res.stride(0), res_mod
     if blend is not None:
@@ -818,10 +833,13 @@ def avgpool2_tokens(x: torch.Tensor, I: int, h: int, w: int) -> torch.Tensor:
 
 
 def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """y += x (bf16, contiguous, same shape)."""
-    if y.shape != x.shape or y.dtype != bf16 or x.dtype != bf16 or not y.is_contiguous() or not x.is_contiguous() or not y.is_cuda:
-        raise RuntimeError("add_: expected contiguous bf16 device tensors of one shape")
-    _lib.check(_lib.load().dwm_add_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_inplace")
+    """y += x (y bf16; x bf16, or fp32: the fp32 sum is rounded once; contiguous, same shape)."""
+    if y.shape != x.shape or y.dtype != bf16 or x.dtype not in (bf16, torch.float32) or not y.is_contiguous() or not x.is_contiguous() or not y.is_cuda:
+        raise RuntimeError("add_: expected contiguous device tensors of one shape (y bf16, x bf16 / fp32)")
+    if x.dtype == torch.float32:
+        _lib.check(_lib.load().dwm_add_f32_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_f32_inplace")
+    else:
+        _lib.check(_lib.load().dwm_add_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_inplace")
     return y
 
 

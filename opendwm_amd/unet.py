@@ -570,7 +570,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
         if self.condition_image_adapter is not None and condition_image_tensor is not None:
             key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape), STORE.step)
             if self._adapter_cache[0] != key:
-                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor), condition_image_tensor)
+                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor, precise=True), condition_image_tensor)
             residuals = list(self._adapter_cache[1])
 
         def add_residual(t):

@@ -66,7 +66,7 @@ def bench_pointwise():
     gb = 4 * R * D * 2 / 1e9
     timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H), iters=300)
     for name, var in (("packed hs=8", 0), ("packed hs=4", 4 << 8), ("packed hs=12", 12 << 8), ("packed hs=2", 2 << 8),
-                      ("packed hs=8 nostore", 16), ("tiled", 32), ("packed hs=8", 0)):
+                      ("tiled", 32), ("packed hs=8", 0)):
         ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var))
         print(json.dumps({"kernel": "attn-pointwise", "case": name, "ms": round(ms, 4), "GBps": round(gb / ms * 1e3, 1)}), flush=True)
 
@@ -88,7 +88,7 @@ def bench_crossview():
     gb = 4 * R * D * 2 / 1e9
     timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, group_mask=mask), iters=300)
     for name, var in (("shared hs=8", 0), ("shared hs=8", 0), ("shared hs=4", 4 << 8), ("shared hs=12", 12 << 8), ("shared hs=6", 6 << 8),
-                      ("shared hs=3", 3 << 8), ("shared hs=8 nostore", 16), ("per-wave hs=8", 128), ("tiled", 32), ("shared hs=8", 0)):
+                      ("shared hs=3", 3 << 8), ("per-wave hs=8", 128), ("tiled", 32), ("shared hs=8", 0)):
         ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, group_mask=mask, variant=var))
         print(json.dumps({"kernel": "attn-crossview", "case": name, "ms": round(ms, 4), "GBps": round(gb / ms * 1e3, 1)}), flush=True)
 
@@ -159,9 +159,9 @@ if __name__ == "__main__":
     if "cv" in what:
         bench_crossview()
     if "attn" in what:
-        bench_attn([1])
-    if "attnx" in what:                  # tile-body experiments: bit 6 = no s_setprio brackets, bit 7 = the non-default body
-        bench_attn([1, 1, 1 | 64, 1 | 64])
+        bench_attn([0])
+    if "attnx" in what:                  # resident kernel geometries (12 waves x 1 tile / 8 x 2; 6 / 3 / 2 heads per workgroup; online softmax) vs tiled
+        bench_attn([0, 1, 2, (3 << 8) | 1, (3 << 8) | 2, (2 << 8) | 1, (2 << 8) | 2, 16 | 1, 16 | 2, 32 | 1])
     if "gemm" in what:
         bench_gemm()
     if "gemmx" in what:                  # reserved bit 2: the general RESID epilogue instead of its FAST form; bit 0: no epilogue

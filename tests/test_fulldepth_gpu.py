@@ -116,6 +116,55 @@ def test_forty_step_denoise_vs_oracle_loop_on_device(dev, layout):
     assert e40 < TOL and e1 < TOL, (e1, e40)
 
 
+@pytest.mark.parametrize("layout", [False, True], ids=["text_only_rowwise", "text_layout_pointwise"])
+def test_forty_step_denoise_full_depth_full_size_vs_oracle_loop_on_device(dev, layout):
+    """What north_star bounds, on the configuration `bench.py` times: ALL 40 guided FlowMatch-Euler steps of the hot loop
+    (ctsd.py:1496-1575) through the full 24-layer model on latents [1,16,6,16,32,56] (CFG batch 2, 154 text tokens) - bf16
+    CTSDDenoiser against O.denoise in fp32 on the device (~18 PFLOP of fp32 per variant).  The error after the LAST step is
+    the tolerance's subject; steps 1 / 10 / 20 / 30 are logged to show how it accumulates."""
+    import bench
+    from opendwm_amd.pipeline import CTSDDenoiser
+    kwargs = bench.variant_kwargs(layout)
+    model = bench.build_model(kwargs, dev, seed=0)
+    wl = bench.WORKLOAD
+    cond = bench.make_conditions(dev, seed=3, layout=layout)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lat = torch.randn(1, wl["T"], wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=g)
+    marks = (1, 10, 20, 30, 40)
+    den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=40)
+    ours = {}
+    with torch.no_grad():
+        den.prepare(lat, cond)
+        for i in range(40):
+            den.step(i)
+            if i + 1 in marks:
+                ours[i + 1] = den.result().clone()
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    del model, den
+    torch.cuda.empty_cache()
+    cfg = O.make_config(**kwargs)
+    fwd0 = O.dit_forward
+    O.dit_forward = _oracle_on_device(fwd0)
+    errs = {}
+    try:
+        condf = {k: (v.float() if v.is_floating_point() else v) for k, v in cond.items()}
+        ref = lat
+        with torch.no_grad():
+            for i in range(40):
+                ref = O.denoise(sd, cfg, ref, condf, steps=40, guidance_scale=4.0, start=i, stop=i + 1)
+                if i + 1 in marks:
+                    errs[i + 1] = rel_err(ours[i + 1], ref)
+    finally:
+        O.dit_forward = fwd0
+    move = ((ours[40].double() - ref.double()).norm() / (ref.double() - lat.double()).norm()).item()
+    _log("denoise_40_steps_full_depth", variant="text+layout" if layout else "text_only", layers=kwargs["num_layers"],
+         latents=list(lat.shape), **{f"rel_step{k}": v for k, v in errs.items()}, rel_to_displacement=move,
+         finite=bool(torch.isfinite(ours[40]).all()))
+    del sd, ref
+    torch.cuda.empty_cache()
+    assert errs[40] < TOL and errs[1] < TOL, errs
+
+
 def test_unet_full_width_config1_six_frames_vs_oracle_on_device(dev):
     """BASELINE.json configs[1] as `bench.py --unet` runs it: SD 2.1 cross-view temporal UNet at full width (1.92 B
     parameters), 6 views x 6 frames x 32x56 latents, CFG batch 2, 77 text tokens, ring cross-view mask"""

@@ -252,7 +252,10 @@ def _attn_ref(q, k, v, rows, heads, mask=None, q1=None, k1=None, v1=None):
     return o0, o1
 
 
-ATTN_VARIANTS = [0, 1, 2]      # auto, 32 / 64 queries per wave
+# auto; 32 / 64 queries per wave (resident kernel where it applies: 12 waves x 1 tile / 8 waves x 2 tiles); the same with the
+# online-softmax fallback forced (bit 4); several heads per workgroup (bits 8-11: the head loop of the resident kernel - copy of the
+# next head, L2 touches); the tiled kernel (bit 5)
+ATTN_VARIANTS = [0, 1, 2, 16 | 1, 16 | 2, (3 << 8) | 1, (2 << 8) | 2, 32 | 1, 32 | 2]
 
 
 @pytest.mark.parametrize("variant", ATTN_VARIANTS)
@@ -277,6 +280,57 @@ def test_attention_joint(dev, variant, I, N, Lc, heads):
     e1 = rel_err(cout, r1) if Lc else 0.0
     _log("attention_joint", variant=variant, I=I, N=N, Lc=Lc, heads=heads, rel0=e0, rel1=e1)
     assert e0 < TOL_KERNEL and e1 < TOL_KERNEL
+
+
+@pytest.mark.parametrize("scale", [1.0, 8.0], ids=["unit_scores", "huge_scores_fallback"])
+@pytest.mark.parametrize("I,N,Lc,heads", [(2, 448, 154, 6), (2, 448, 0, 6), (2, 608, 0, 3), (2, 97, 0, 4), (1, 64, 0, 2), (2, 200, 33, 2),
+                                          (1, 575, 0, 2), (3, 33, 32, 3)])
+def test_attention_resident_forms(dev, scale, I, N, Lc, heads):
+    """attn_res_kernel (K / V of one head resident in LDS; unmasked self-attention, 64 <= L <= 608): both wave geometries
+    (12 waves x 1 query tile, 8 waves x 2), one and all heads per workgroup (head loop: the next head's copy and L2 touches),
+    one and two segments, sequence lengths that end in a ragged 32-key step / a full 64-key step / the LDS limit, two rounds of
+    query tiles per wave (L = 602 / 608: 19 tiles), the maximum-free fast path and the online-softmax fallback - forced (bit 4)
+    and taken by itself when the scores leave the safe range (inputs x 8: log2-domain scores of several hundred, where 2^s
+    overflows) - against the fp32 reference"""
+    from opendwm_amd import ops
+    D = heads * 64
+    qkv = _rand((I * N, 3 * D), dev, 11, scale)
+    cqkv = _rand((I * Lc, 3 * D), dev, 12, scale) if Lc else None
+    rm = ops.rowmap_identity(I, N)
+    kw, f, cf = {}, qkv.float(), (cqkv.float() if Lc else None)
+    r0, r1 = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads,
+                       q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
+    errs = {}
+    for variant in (1, 2, (heads << 8) | 1, (heads << 8) | 2, 16 | (heads << 8) | 1, 16 | 2):
+        out = torch.full((I * N, D), float("nan"), dtype=bf16, device=dev)
+        cout = torch.full((I * Lc, D), float("nan"), dtype=bf16, device=dev) if Lc else None
+        if Lc:
+            kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout)
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant, **kw)
+        errs[variant] = max(rel_err(out, r0), rel_err(cout, r1) if Lc else 0.0)
+    _log("attention_resident_forms", scale=scale, I=I, N=N, Lc=Lc, heads=heads, **{str(k): v for k, v in errs.items()})
+    assert all(e < TOL_KERNEL for e in errs.values()), errs
+
+
+def test_attention_resident_temporal_rowmap_multihead(dev):
+    """the resident kernel through a strided row map (row-wise temporal attention: L = frames x row width, token rows far apart),
+    24 heads in groups of 6 per workgroup, bit-equal between the two wave geometries' fast paths is NOT required - both against
+    the reference"""
+    from opendwm_amd import ops
+    B, T, V, h, w, heads = 1, 16, 2, 3, 28, 24
+    D = heads * 64
+    rm = ops.rowmap_temporal_rowwise(B, T, V, h, w)
+    R = B * T * V * h * w
+    qkv = _rand((R, 3 * D), dev, 13)
+    f = qkv.float()
+    ref, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads)
+    errs = {}
+    for variant in ((6 << 8) | 1, (6 << 8) | 2, (4 << 8) | 2):
+        out = torch.full((R, D), float("nan"), dtype=bf16, device=dev)
+        ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant)
+        errs[variant] = rel_err(out, ref)
+    _log("attention_resident_temporal_rowmap", L=rm.L0, **{str(k): v for k, v in errs.items()})
+    assert all(e < TOL_KERNEL for e in errs.values()), errs
 
 
 @pytest.mark.parametrize("V,w,heads", [(6, 28, 3), (6, 32, 2), (6, 16, 8), (4, 8, 2), (8, 11, 2), (3, 28, 2), (6, 28, 24)])
