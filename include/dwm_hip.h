@@ -153,13 +153,14 @@ typedef struct dwm_attn_args {
     int64_t pdiv[3], pmod[3], pstride[3];
     int64_t ldiv[2], lstride[3];
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
-    int32_t variant;                           /* 0 = auto.  Kernel selection (attention.hip): bits 0-3 query tiles per wave
-                                                * (1: 32 queries, 2: 64; the resident kernel: 12 waves x 1 tile or 8 waves x 2),
-                                                * bit 4 online softmax with a running maximum for every unit of the resident
-                                                * kernel (default: its maximum-free fast path with a checked fallback),
-                                                * bit 5 keep the tiled kernel (default for L <= 32: the packed short-sequence
-                                                * kernel; for unmasked self-attention with 64 <= L <= 608: the resident kernel),
-                                                * bit 7 per-wave form of the group-masked kernel, bits 8-11 heads per workgroup */
+    int32_t variant;                           /* 0 = auto.  Kernel selection (attention.hip): bits 0-3 tiled kernel: 2 = 64
+                                                * queries per wave (else 32); resident kernel: number of compute waves (1-12, the
+                                                * other waves of its 12 only copy), bit 4 online softmax with a running maximum
+                                                * for every unit of the resident kernel (default: its maximum-free fast path with
+                                                * a checked fallback), bit 5 keep the tiled kernel (default for L <= 32: the
+                                                * packed short-sequence kernel; for unmasked self-attention with 64 <= L <= 608:
+                                                * the resident kernel), bit 7 per-wave form of the group-masked kernel, bits 8-11
+                                                * heads per workgroup / item */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */

@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the
     # VALU epilogues / softmax read them without v_accvgpr_read/write copies
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
-             "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"]
+             "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"] + os.environ.get("DWM_EXTRA_FLAGS", "").split()
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

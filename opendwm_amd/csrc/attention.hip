@@ -889,135 +889,176 @@ attn_group_lds_kernel(const AttnParams P) {
 #undef DWM_GRP_COPY
 
 // ---------------------------------------------------------------------------------------------------------------
-// Resident form (round 3): ONE WORKGROUP = one (problem, head group); the K and V rows of one head - all L <= 608 of them,
-// 2 x 76 KiB at the joint attention's L = 602 - are copied into LDS ONCE by LDS-DMA and every query tile of the head is
-// walked against them by the workgroup's waves.  Against the tiled kernel above (128-query workgroups: every (problem,
-// head)'s K / V crosses L2 -> LDS 4-5 times; 4 LDS-DMA instructions + their address arithmetic + one workgroup barrier per
-// 16 MFMAs and wave) this removes the refills (amplification 1), the per-tile barrier and the per-tile DMA issue: a wave's
-// tile loop is fragment reads, MFMAs and the softmax only, and the waves of a workgroup run it unsynchronised (two
-// barriers per HEAD: "K / V landed", "everybody done with them").  The copy of a head is exposed (nothing else runs on the
-// CU while it lands), so the NEXT head's rows are pulled into L2 a head ahead by one 4-byte touch per 128-byte piece, and
-// the next unit's Q rows are fetched (or touched) a unit ahead.  The output tile leaves the registers as 16-byte pieces
-// after a lane <-> lane + 32 exchange (v_permlane32_swap): the LDS is full.
+// Resident form (round 3): the K and V rows of ONE head of one problem - all L <= 608 of them, 2 x 76 KiB at the joint
+// attention's L = 602 - are copied into LDS ONCE by LDS-DMA and every query tile of the head is walked against them by the
+// workgroup's 12 waves (tile = round * 12 + wave).  Against the tiled kernel above (128-query workgroups: every (problem,
+// head)'s K / V crosses L2 -> LDS 4-5 times - 3.2 x its bytes in 128-byte requests, profiles/r2_attn_l2_counters.json; 4 LDS-DMA
+// instructions + their address arithmetic + one workgroup barrier per 16 MFMAs and wave) this removes the refills
+// (amplification 1), the per-tile barrier and the per-tile DMA issue: a wave's tile loop is fragment reads, MFMAs and the
+// softmax only, and the waves run it unsynchronised (two barriers per HEAD: "K / V landed", "everybody done with them").
+// Workgroups are persistent (one per CU, a fixed share of the (problem, head group) items), the next unit's Q rows are
+// requested when a unit's tile loop ends, row offsets of inputs and outputs come from per-item tables in LDS, and the output
+// tile leaves the registers as 16-byte pieces after a lane <-> lane + 32 exchange (v_permlane32_swap): the LDS is full.
+// What the structure still pays (timeline in profiles/r3_attn_timeline.txt, L = 602: 54.7 k cycles per head): the copy of the
+// next head stands between two heads (7 k cycles: 304 one-KiB DMA instructions through one CU's address path), the waves of a
+// SIMD finish their tiles far apart (the oldest wave of three gets most issue slots: 15.6 / 19.7 / 34.3 k cycles for the same
+// tile loop) and 19 tiles over 12 waves leave 5 waves idle in the second round.  Tried and dropped in this round: L2
+// touches of the next head (loads return in order: the touches stall the next wait behind an HBM round trip), a refill point
+// inside the last round (its barrier costs the waves' skew), loader waves that copy behind the others' progress words (the
+// copy is hidden but the computing waves slow down by more), 8 computing + 4 loading waves, start skew between workgroups.
 //
 // Softmax without a running maximum (the fast path): softmax is shift invariant, so P' = 2^s (s = the log2-domain score,
 // scale * log2(e) folded into Q) and O = (sum_k P'_k V_k) / (sum_k P'_k) need no maximum at all as long as nothing leaves
 // the fp32 / bf16 exponent range - bf16 keeps fp32's exponent, so P' has the same RELATIVE precision as 2^(s - m).  With
-// the RMS-normalised q / k of this model |s| is a few units.  Head_dim 64 makes the forward VALU-issue bound (one
-// exponential, half a max3, half a packed add, half a convert per score against 256 MFMA flop): dropping the maximum, the
-// -m accumulator splat and the rescale branch takes ~20 % of the vector instructions and 16 registers per query tile out
-// of the tile loop.  The result of a unit is accepted if every row sum lies in [2^-64, 2^64] and every output is finite;
-// otherwise (never, on this model) the unit is redone by the textbook online softmax (res_tile_safe).
+// the RMS-normalised q / k of this model |s| is a few units.  Dropping the maximum, the -m accumulator splat and the rescale
+// branch takes ~20 % of the vector instructions and 16 registers out of the tile loop - and makes partial results over key
+// ranges plain sums.  A unit is accepted if every row sum lies in [2^-64, 2^64] (no P' overflowed, no row underflowed);
+// otherwise (never, on this model) it is redone by the textbook online softmax from global memory (res_tile_safe).
 // Fragment layouts and swizzles are attn_fwd_kernel's.
-template <int NT, int NJ>   // one tile step, fast path.  NT query tiles; NJ = 2: 64 keys, NJ = 1: 32 keys (sequence tail)
-DWM_DEVINL void res_tile_fast(const char* __restrict__ kl, const char* __restrict__ vl, int key0, int L,
-                              const bf16x8 (&qf)[NT][4], f32x16 (&ot)[NT][2], f32x2 (&lsum)[NT][2],
-                              int l31, int half, int kswz, const int (&vra)[2], const int (&vrb)[2]) {
-    f32x16 st[NT][NJ];
+// One step of the fast path's software pipeline over the 32-key sub-tiles k of a sequence:
+//     S(k+1) = K(k+1) Q^T   (4 MFMAs per query tile; accumulator starts from the inline constant 0)
+//  || E(k):  P' = 2^S(k), row sums, bf16 pack   (16 v_exp, 8 v_pk_add, 8 v_cvt_pk per query tile)
+//  || PV(k-1): O^T += V(k-1)^T P'(k-1)^T        (4 MFMAs per query tile)
+// written as ONE instruction stream in which every MFMA is followed by one slice of E - two exponentials, a packed add and a
+// convert: head_dim 64 makes the forward VALU-heavy (a vector instruction per ~50 MFMA flop), and on this chip a wave's own
+// vector instructions hide under its own MFMAs (MFMA + 4..6 VALU per 32-cycle slot: 17.8 / 19.6 ns against 17.2 ns for the
+// bare MFMA) while another wave's do not (43.8 ns for the same work split over two waves of a SIMD; scripts/probes/
+// mfma_valu_probe.hip, profiles/r3_mfma_valu_probe.txt).  The order is pinned with sched_barrier(0) between the chunks; all
+// fragment reads of a step are requested in its first chunks (the compiler's counted lgkmcnt waits follow the data).
+template <int NT, bool DO_S, bool DO_E, bool DO_PV, bool RAGGED>
+DWM_DEVINL void res_step(const char* __restrict__ kl, const char* __restrict__ vl, int key0, int L,
+                         const bf16x8 (&qf)[NT][4], f32x16 (&s_out)[NT], f32x16 (&s_in)[NT],
+                         bf16x8 (&p_out)[NT][2], const bf16x8 (&p_in)[NT][2],
+                         f32x16 (&ot)[NT][2], f32x2 (&lsum)[NT][2],
+                         int l31, int half, int kswz, const int (&vra)[2], const int (&vrb)[2]) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // all K fragments of the step are requested before the first MFMA (counted lgkmcnt waits in between): a wave's S phase
-    // is then 8 back-to-back MFMAs behind ONE LDS latency instead of 8 (read, wait, MFMA) rounds
-    bf16x8 kf[NJ][4];
+    bf16x8 kf[4], vf[2][2];
+    uint32_t pk[NT][8];
+    // slice j of E: scores 2j, 2j + 1 of every query tile
+    auto slice = [&](int j) {
+        if (!DO_E) return;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            kf[j][ks] = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                st[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j][ks], qf[t][ks], ks == 0 ? zero : st[t][j], 0, 0, 0);
-    if (NJ == 1 && key0 + 32 > L) {                 // ragged end of the sequence (wave-uniform; full 64-key steps never are): 2^-inf = 0
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[t][j][r] = -INFINITY;
-    }
-    bf16x8 pf[NT][2 * NJ];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float pv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(st[t][j][s2 * 8 + e]);
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) lsum[t][(e >> 1) & 1] += (f32x2){pv[e], pv[e + 1]};
-                const uint4 pk = pack8(pv);
-                pf[t][j * 2 + s2] = *reinterpret_cast<const bf16x8*>(&pk);
+        for (int t = 0; t < NT; ++t) {
+            float a = s_in[t][2 * j], b = s_in[t][2 * j + 1];
+            if (RAGGED) {                                   // keys past the end of the sequence: 2^-inf = 0
+                if (key0 + ((2 * j) & 3) + 8 * ((2 * j) >> 2) + 4 * half >= L) a = -INFINITY;
+                if (key0 + ((2 * j + 1) & 3) + 8 * ((2 * j + 1) >> 2) + 4 * half >= L) b = -INFINITY;
             }
+            const float pa = __builtin_amdgcn_exp2f(a), pb = __builtin_amdgcn_exp2f(b);
+            lsum[t][j & 1] += (f32x2){pa, pb};
+            // the convert is pinned to its slice by an empty volatile asm on its result (left alone it is sunk to the end of
+            // the step, eight in a row behind the last MFMA).  NOT the convert itself as inline asm: the compiler does not
+            // see the v_exp -> VALU wait state an asm operand needs and the convert then reads stale registers
+            uint32_t w = pack_bf16x2(pa, pb);
+            asm volatile("" : "+v"(w));
+            pk[t][j] = w;
+        }
+    };
+    auto vread = [&](int s2, int dt) {
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s2 * (16 * 128)));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s2 * (16 * 128)));
+        vf[s2][dt] = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // MFMA m of the step (0-3: S with K fragment m; 4-7: PV with V fragment (m-4)/2, (m-4)%2) has its fragment requested PD
+    // chunks ahead: everything up front would cost 32 fragment registers (with two query tiles the step then spills)
+    constexpr int PD = NT == 1 ? 4 : 2;
+    auto request = [&](int m) {
+        if (m < 4) { if (DO_S) kf[m] = *(const bf16x8*)(kl + l31 * 128 + (((2 * m + half) ^ kswz) << 4)); }
+        else if (m < 8) { if (DO_PV) vread((m - 4) >> 1, (m - 4) & 1); }
+    };
+    // chunk 0: the first fragment requests, first slice
 #pragma unroll
-    for (int s = 0; s < 2 * NJ; ++s)
+    for (int m = 0; m < PD; ++m) request(m);
+    slice(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // chunks 1-8: one MFMA per query tile, the request PD MFMAs ahead, one slice
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + s * (16 * 128)));
-            const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + s * (16 * 128)));
-            const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    for (int m = 0; m < 8; ++m) {
+        request(m + PD);
+        if (m < 4) {
+            if (DO_S) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    s_out[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[m], qf[t][m], m == 0 ? zero : s_out[t], 0, 0, 0);
+            }
+        } else if (DO_PV) {
+            const int i = m - 4;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                ot[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], ot[t][dt], 0, 0, 0);
+                ot[t][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i >> 1][i & 1], p_in[t][i >> 1], ot[t][i & 1], 0, 0, 0);
         }
+        if (m < 7) slice(m + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (DO_E) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint4 lo = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]}, hi = {pk[t][4], pk[t][5], pk[t][6], pk[t][7]};
+            p_out[t][0] = *reinterpret_cast<const bf16x8*>(&lo);
+            p_out[t][1] = *reinterpret_cast<const bf16x8*>(&hi);
+        }
+    }
 }
 
-// the same step by the textbook online softmax (one query tile; running max m and sum l per lane, rescale every step):
-// the fallback of a unit whose fast-path sums left the safe range.  Written for few registers, not for speed.
-template <int NJ>
-DWM_DEVINL void res_tile_safe(const char* __restrict__ kl, const char* __restrict__ vl, int key0, int L,
-                              const bf16x8 (&qf)[4], f32x16 (&ot)[2], float& m_run, float& l_run,
-                              int l31, int half, int kswz, const int (&vra)[2], const int (&vrb)[2]) {
+// One 32-key step by the textbook online softmax (running max m and sum l per lane, rescale every step): the fallback of a
+// unit whose fast-path sums left the safe range.  It reads K and V from GLOBAL memory, not from the images: by the time a unit
+// knows that it needs the fallback, the first sub-tiles of the images may already hold the NEXT head's rows (the refill point
+// of attn_res_kernel).  K fragments are the lanes' own rows (16 B per lane); V fragments are gathered element by element in the
+// MFMA A-operand layout with the key order of the P' registers.  Written for few registers and for correctness, not for speed.
+struct ResGlobal {
+    const bf16_t *k, *v;       // k0 / v0 + this head's column offset
+    const int32_t* tab;        // row table (LDS)
+    int64_t seg1_delta;
+};
+DWM_DEVINL void res_tile_safe(const ResGlobal& gm, int key0, int L, int L0, const bf16x8 (&qf)[4], f32x16 (&ot)[2], float& m_run, float& l_run,
+                              int l31, int half) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int j = 0; j < NJ; ++j) {
-        f32x16 st;
+    auto row_off = [&](int key) -> int64_t {
+        key = key < L ? key : L - 1;
+        return ((int64_t)gm.tab[key] << 3) + (key < L0 ? 0 : gm.seg1_delta);
+    };
+    f32x16 st;
+    {
+        const bf16_t* kp = gm.k + row_off(key0 + l31) + half * 8;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(kl + (j * 32 + l31) * 128 + (((2 * ks + half) ^ kswz) << 4));
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : st, 0, 0, 0);
-        }
-        float mx = -INFINITY;
+        for (int ks = 0; ks < 4; ++ks)
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + ks * 16), qf[ks], ks == 0 ? zero : st, 0, 0, 0);
+    }
+    float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (key0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[r] = -INFINITY;
-            mx = fmaxf(mx, st[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);                  // finite: the first step of a sequence holds key 0
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 at the first step (m_run = -inf)
-        m_run = m_new;
-        float pv[16], sum = 0.f;
+    for (int r = 0; r < 16; ++r) {
+        if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[r] = -INFINITY;
+        mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);                  // finite: the first step of a sequence holds key 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 at the first step (m_run = -inf)
+    m_run = m_new;
+    float pv[16], sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
-            sum += pv[r];
-        }
-        l_run = l_run * alpha + sum;
+    for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+        sum += pv[r];
+    }
+    l_run = l_run * alpha + sum;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const uint4 pk = pack8(pv + 8 * s2);
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 pk = pack8(pv + 8 * s2);
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
+        // B-operand k-slot (half, e) of pf holds P' of key (e & 3) + 8 ((8 s2 + e) >> 2) + 4 half: the A operand takes the same keys
+        int64_t voff[8];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(vl + vra[dt] + (2 * j + s2) * (16 * 128)));
-                const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(vl + vrb[dt] + (2 * j + s2) * (16 * 128)));
-                const bf16x8 vf = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-                ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
-            }
+        for (int e = 0; e < 8; ++e) voff[e] = row_off(key0 + (e & 3) + 8 * ((8 * s2 + e) >> 2) + 4 * half);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            bf16x8 vf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vf[e] = (short)gm.v[voff[e] + dt * 32 + l31];
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
         }
     }
 }
@@ -1025,8 +1066,7 @@ DWM_DEVINL void res_tile_safe(const char* __restrict__ kl, const char* __restric
 struct ResCtx {             // launch / workgroup invariants of attn_res_kernel's helpers
     const char *kimg, *vimg;
     const int32_t* rowtab;
-    int L, L0, nk64, l31, half, kswz;
-    bool tail32;
+    int L, L0, nsub, l31, half, kswz;     // nsub: 32-key sub-tiles of the sequence (the last one may be ragged)
     int vra[2], vrb[2];
 };
 
@@ -1034,8 +1074,9 @@ struct ResCtx {             // launch / workgroup invariants of attn_res_kernel'
 // the fallback), normalisation, and the stores.  qraw: this lane's raw Q fragments; op[t]: this lane's output row pointer
 // (rows past the last query are clamped to it: they then hold the same Q, compute the same output and store the same
 // bytes to the same address - unconditional stores keep the loop free of exec-masked blocks).
-template <int NT>
-DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe) {
+template <int NT, class Fetch>
+DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe,
+                         const ResGlobal& gm, Fetch&& after_loop, long long* tr = nullptr) {
     bf16x8 qf[NT][4];
     f32x16 ot[NT][2];
     f32x2 lsum[NT][2];
@@ -1043,42 +1084,73 @@ DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* c
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = scale_frag(qraw[t][ks], scale_log2);
+        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = scale_log2 == 1.f ? qraw[t][ks] : scale_frag(qraw[t][ks], scale_log2);   // (Q may arrive pre-scaled)
         lsum[t][0] = lsum[t][1] = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
     }
-    for (int kt = 0; kt < c.nk64; ++kt)
-        res_tile_fast<NT, 2>(c.kimg + kt * 8192, c.vimg + kt * 8192, kt * 64, c.L, qf, ot, lsum, c.l31, c.half, c.kswz, c.vra, c.vrb);
-    if (c.tail32)
-        res_tile_fast<NT, 1>(c.kimg + c.nk64 * 8192, c.vimg + c.nk64 * 8192, c.nk64 * 64, c.L, qf, ot, lsum, c.l31, c.half, c.kswz, c.vra, c.vrb);
+    // software pipeline over the 32-key sub-tiles k (res_step); first and last sub-tile peeled, two steps per trip so that
+    // the A / B register sets swap roles without copies
+    const int n = c.nsub;
+    const bool ragged = (n << 5) > c.L;
+    const int lastkey = (n - 1) << 5;
+    f32x16 sa[NT], sb[NT];
+    bf16x8 pa[NT][2], pb[NT][2];
+#define DWM_RES_STEP(S_, E_, PV_, RG_, kl_, vl_, so_, si_, po_, pi_) \
+    res_step<NT, S_, E_, PV_, RG_>(kl_, vl_, lastkey, c.L, qf, so_, si_, po_, pi_, ot, lsum, c.l31, c.half, c.kswz, c.vra, c.vrb)
+    DWM_RES_STEP(true, false, false, false, c.kimg, c.vimg, sa, sa, pa, pa);                          // S(0)
+    if (n == 1) {
+        if (ragged) DWM_RES_STEP(false, true, false, true, c.kimg, c.vimg, sa, sa, pa, pa);           // E(0)
+        else DWM_RES_STEP(false, true, false, false, c.kimg, c.vimg, sa, sa, pa, pa);
+        DWM_RES_STEP(false, false, true, false, c.kimg, c.vimg, sa, sa, pa, pa);                      // PV(0)
+    } else {
+        DWM_RES_STEP(true, true, false, false, c.kimg + 4096, c.vimg, sb, sa, pa, pa);                // S(1) || E(0)
+        // invariant at the top of step k: S(k) is in sb, P'(k-1) in pa
+        int k = 1;
+#ifdef DWM_ATTN_TRACE
+        if (tr != nullptr) tr[4] = (long long)__builtin_readcyclecounter();
+#endif
+        for (; k + 2 < n; k += 2) {
+            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 1) * 4096, c.vimg + (k - 1) * 4096, sa, sb, pb, pa);
+            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 2) * 4096, c.vimg + k * 4096, sb, sa, pa, pb);
+        }
+        if (k + 1 < n) {                                                   // step k, then the last sub-tile k + 1
+            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 1) * 4096, c.vimg + (k - 1) * 4096, sa, sb, pb, pa);
+            if (ragged) DWM_RES_STEP(false, true, true, true, c.kimg, c.vimg + k * 4096, sa, sa, pa, pb);
+            else DWM_RES_STEP(false, true, true, false, c.kimg, c.vimg + k * 4096, sa, sa, pa, pb);
+            DWM_RES_STEP(false, false, true, false, c.kimg, c.vimg + (k + 1) * 4096, sa, sa, pa, pa);
+        } else {                                                           // k is the last sub-tile
+            if (ragged) DWM_RES_STEP(false, true, true, true, c.kimg, c.vimg + (k - 1) * 4096, sb, sb, pb, pa);
+            else DWM_RES_STEP(false, true, true, false, c.kimg, c.vimg + (k - 1) * 4096, sb, sb, pb, pa);
+            DWM_RES_STEP(false, false, true, false, c.kimg, c.vimg + k * 4096, sb, sb, pb, pb);
+        }
+    }
+#undef DWM_RES_STEP
+#ifdef DWM_ATTN_TRACE
+    if (tr != nullptr) tr[5] = (long long)__builtin_readcyclecounter();
+#endif
+    after_loop();
     bool ok = !force_safe;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float l_half = (lsum[t][0][0] + lsum[t][0][1]) + (lsum[t][1][0] + lsum[t][1][1]);
         const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
         l_tot[t] = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
-        float chk = 0.f;                                   // 0 * finite = 0, 0 * (inf | nan) = nan
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(ot[t][i][r], 0.f, chk);
-        ok = ok && (l_tot[t] >= 5.421010862e-20f) && (l_tot[t] <= 1.8446744e19f) && (chk == 0.f);
+        // the row sum in range: no P' overflowed (an infinite or NaN P' makes the sum infinite or NaN) and the row did not
+        // underflow; O' <= sum * max|V| then stays finite for |V| < 2^63
+        ok = ok && (l_tot[t] >= 5.421010862e-20f) && (l_tot[t] <= 1.8446744e19f);
     }
     if (!__all(ok)) {                                      // wave-uniform: redo the unit by the online softmax
-#pragma unroll 1
+#pragma unroll                                             // (a runtime t would put qf / ot into scratch)
         for (int t = 0; t < NT; ++t) {
             float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ot[t][i][r] = 0.f;
-            for (int kt = 0; kt < c.nk64; ++kt)
-                res_tile_safe<2>(c.kimg + kt * 8192, c.vimg + kt * 8192, kt * 64, c.L, qf[t], ot[t], m_run, l_run, c.l31, c.half, c.kswz, c.vra, c.vrb);
-            if (c.tail32)
-                res_tile_safe<1>(c.kimg + c.nk64 * 8192, c.vimg + c.nk64 * 8192, c.nk64 * 64, c.L, qf[t], ot[t], m_run, l_run, c.l31, c.half, c.kswz, c.vra, c.vrb);
+            for (int k = 0; k < c.nsub; ++k) res_tile_safe(gm, k << 5, c.L, c.L0, qf[t], ot[t], m_run, l_run, c.l31, c.half);
             l_tot[t] = l_run + __shfl_xor(l_run, 32, 64);
         }
     }
@@ -1107,7 +1179,7 @@ DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* c
     }
 }
 
-template <int QT, int NW>      // QT query tiles per unit (wave), NW waves
+template <int NW>      // NW waves; one query tile (32 queries) per unit
 __global__ void __launch_bounds__(NW * 64, 1)
 attn_res_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1119,22 +1191,16 @@ attn_res_kernel(const AttnParams P) {
 
     const int L = P.L, L0 = P.L0;
     const int Lp = (L + 31) & ~31;                        // image rows (32-key granules)
+    const int Lt = (L + 3) & ~3;                          // table pitch
     char* const kimg = smem;
     char* const vimg = smem + Lp * 128;
-    int32_t* __restrict__ rowtab = (int32_t*)(smem + 2 * Lp * 128);      // see attn_fwd_kernel
-
-    const uint32_t prob = fdiv(blockIdx.x, P.fd_heads);
-    const int hgrp = (int)(blockIdx.x - prob * P.fd_heads.d);
-    const int hpb = P.hpb;
-    const int64_t hoff = (int64_t)hgrp * hpb * 64;
-    const int64_t base0 = seg0_base(P.rm, (int)prob);
-    for (int l = tid; l < L; l += NW * 64)
-        rowtab[l] = (int32_t)((l < L0 ? seg0_row(P.rm, base0, l) * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
-    __syncthreads();
+    // tables: input row offsets (see attn_fwd_kernel) of this item and of the next one, output row offsets of this item
+    int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
+    int32_t* const otab = tabs + 2 * Lt;
 
     ResCtx c;
-    c.kimg = kimg; c.vimg = vimg; c.rowtab = rowtab;
-    c.L = L; c.L0 = L0; c.nk64 = L >> 6; c.tail32 = Lp > (c.nk64 << 6);
+    c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
+    c.L = L; c.L0 = L0; c.nsub = Lp >> 5;
     c.l31 = l31; c.half = half; c.kswz = (lane >> 1) & 7;
     {
         const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
@@ -1147,93 +1213,145 @@ attn_res_kernel(const AttnParams P) {
         }
     }
 
-    // copy of one head's K and V rows: instruction i (8 rows x 128 B, 16 B per lane, LDS destination lane-linear) is issued by
-    // wave i mod NW; the chunk swizzle of the images is applied on the source column (attn_fwd_kernel)
-    const int ngrp = Lp >> 3;
-    auto copy_head = [&](int hh) {
-        const int64_t ho = hoff + hh * 64;
-        for (int i = wave; i < ngrp; i += NW) {
-            const int r = i * 8 + (lane >> 3);
-            const int rc = r < L ? r : L - 1;                 // rows past the end: a copy of the last row (finite), masked as keys
-            const int64_t off = ((int64_t)rowtab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
-            glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
-            glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
+    // Work: item = (problem, head group of hpb heads); the workgroups are PERSISTENT (one per CU, items blockIdx.x,
+    // blockIdx.x + gridDim.x, ...): only the very first head of a workgroup is loaded cold, the copy pipeline below runs across
+    // item seams.  g = running head index of this workgroup.
+    const int hpb = P.hpb;
+    const int n_items = P.n_problems * (int)P.fd_heads.d;
+    const int n_my = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int G = n_my * hpb;
+    auto item_of = [&](int g, uint32_t& prob, int64_t& hoff) {       // head g of this workgroup: its problem and column offset
+        const int it = g / hpb, hh = g - it * hpb;
+        const uint32_t item = blockIdx.x + (uint32_t)it * gridDim.x;
+        prob = fdiv(item, P.fd_heads);
+        hoff = ((int64_t)(item - prob * P.fd_heads.d) * hpb + hh) * 64;
+    };
+    auto build_tab = [&](int32_t* tab, int32_t* ot, uint32_t prob) {
+        const int64_t base0 = seg0_base(P.rm, (int)prob);
+        for (int l = tid; l < L; l += NW * 64) {
+            const int64_t r0 = l < L0 ? seg0_row(P.rm, base0, l) : 0;
+            if (tab != nullptr) tab[l] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
+            if (ot != nullptr)      // offset inside the token's output segment in 16-byte units (segment 1 adds oseg1_delta: the two
+                                    // allocations may be > 32 GiB apart)
+                ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
         }
     };
-    // L2 prefetch of a head's K / V rows: one 4-byte touch per 128-byte piece, lane = row.  No wait here: the destination
-    // registers stay reserved until the vmcnt(0) at the top of the next head (they are operands of the asm there); loads
-    // return in order and these are older than every load the compiler tracks
-    uint32_t td0 = 0, td1 = 0;
-    auto touch_head = [&](int hh) {
-        const int64_t ho = hoff + hh * 64;
-        for (int r0 = wave * 64; r0 < L; r0 += NW * 64) {
-            const int r = r0 + lane < L ? r0 + lane : L - 1;
-            const int64_t off = ((int64_t)rowtab[r] << 3) + (r < L0 ? 0 : P.seg1_delta) + ho;
-            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                         : "=&v"(td0), "=&v"(td1) : "v"(P.k0 + off), "v"(P.v0 + off) : "memory");
+    // copy of the 32-key sub-tiles [s0, s1) of one head's K or V rows into its image: instruction i (8 rows x 128 B, 16 B per
+    // lane, LDS destination lane-linear) belongs to participant i mod np; the chunk swizzle of the images is applied on the source
+    // column (attn_fwd_kernel)
+    auto copy_rows = [&](const int32_t* tab, int64_t ho, int s0, int s1, bool is_v, int me, int np) {
+        int i = s0 * 4;
+        i += (me - i % np + np) % np;
+        for (; i < s1 * 4; i += np) {
+            const int r = i * 8 + (lane >> 3);
+            const int rc = r < L ? r : L - 1;                 // rows past the end: a copy of the last row (finite), masked as keys
+            const int64_t off = ((int64_t)tab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
+            if (!is_v) glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
+            else glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
         }
     };
 
     const int nqt = (P.qend + 31) >> 5;                      // 32-query tiles of a head
-    // row offset (elements) of this lane's query of tile qt inside q0 / k0 / v0, and its output row pointer
-    auto q_off = [&](int qt) -> int64_t {
-        int lq = qt * 32 + l31;
-        lq = lq < P.qend ? lq : P.qend - 1;
-        return ((int64_t)rowtab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta);
-    };
-    auto o_ptr = [&](int qt) -> bf16_t* {
-        int lq = qt * 32 + l31;
-        lq = lq < P.qend ? lq : P.qend - 1;
-        if (lq < L0) return P.o0 + seg0_row(P.rm, base0, lq) * P.ldo0;
-        return P.o1 + ((int64_t)prob * P.L1 + (lq - L0)) * P.ldo1;
-    };
-
-    // L2 prefetch of the NEXT unit's Q rows (one touch per row; same register discipline as touch_head)
-    uint32_t tq[QT] = {};
-    auto touch_q = [&](int hh, int qt0) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(tq[t]) : "v"(P.q0 + q_off(qt0 + t < nqt ? qt0 + t : nqt - 1) + hoff + hh * 64) : "memory");
-    };
-
-    copy_head(0);
-    const int qt_first = wave * QT;
+    const int nwc = P.nwc;                                   // compute waves (<= NW): tile = round * nwc + wave
+    const int rounds = (nqt + nwc - 1) / nwc;
     const bool force_safe = P.safe_softmax != 0;             // dwm_attn_args.variant bit 4: online softmax for every unit
+    const int n = c.nsub;
 
-    for (int hh = 0; hh < hpb; ++hh) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
-        asm volatile("" : "+v"(td0), "+v"(td1));             // (the touch destinations are free again)
+    // development aid (-DDWM_ATTN_TRACE): shader-clock timestamps of wave w of workgroup b < 8 at 8 points of every head,
+    // written to the (otherwise unused) lse buffer as int64 [8 workgroups][NW][64 heads][8]
+#ifdef DWM_ATTN_TRACE
+#define DWM_TR(slot_) do { if (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) \
+        ((long long*)P.lse)[(((int)blockIdx.x * NW + wave) * 64 + g) * 8 + (slot_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DWM_TR(slot_) do {} while (0)
+#endif
+    if (G == 0) return;
+    uint32_t prob; int64_t hoff;
+    item_of(0, prob, hoff);
+    build_tab(tabs, otab, prob);
+    __syncthreads();
+    copy_rows(tabs, hoff, 0, n, false, wave, NW);            // the first head: nothing to hide it under
+    copy_rows(tabs, hoff, 0, n, true, wave, NW);
+    bf16x8 qn[4];                                            // raw Q fragments of this wave's next unit
+    if (wave < nwc && wave < nqt) {
+        int lq = wave * 32 + l31;
+        lq = lq < P.qend ? lq : P.qend - 1;
+        const bf16_t* qp = P.q0 + ((int64_t)tabs[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + hoff + half * 8;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) asm volatile("" : "+v"(tq[t]));
-        __syncthreads();                                     // ... and everybody else's
-        if (hh + 1 < hpb) touch_head(hh + 1);
-        const int64_t ho = hoff + hh * 64;
-        for (int qt0 = qt_first; qt0 < nqt; qt0 += NW * QT) {
-            if (qt0 + NW * QT < nqt) touch_q(hh, qt0 + NW * QT);
-            else if (hh + 1 < hpb) touch_q(hh + 1, qt_first);
-            if (QT == 2 && qt0 + 1 < nqt) {
-                bf16x8 q[2][4];
-                bf16_t* op[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bf16_t* qp = P.q0 + q_off(qt0 + t) + ho + half * 8;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) q[t][ks] = *(const bf16x8*)(qp + ks * 16);
-                    op[t] = o_ptr(qt0 + t) + ho;
-                }
-                res_unit<2>(c, q, op, P.scale_log2, force_safe);
-            } else {
-                bf16x8 q[1][4];
-                bf16_t* op[1];
-                const bf16_t* qp = P.q0 + q_off(qt0) + ho + half * 8;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) q[0][ks] = *(const bf16x8*)(qp + ks * 16);
-                op[0] = o_ptr(qt0) + ho;
-                res_unit<1>(c, q, op, P.scale_log2, force_safe);
+        for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+
+    for (int g = 0; g < G; ++g) {
+        const int it = g / hpb;
+        const int32_t* const tab = tabs + (it & 1) * Lt;
+        item_of(g, prob, hoff);
+        // the next head (same item: same table; next item: its table is built now, it becomes visible at the barrier below)
+        const bool has_next = g + 1 < G;
+        uint32_t nprob = prob; int64_t nhoff = hoff;
+        const int32_t* ntab = tab;
+        const bool new_item_next = has_next && (g + 1) / hpb != it;
+        if (has_next) {
+            item_of(g + 1, nprob, nhoff);
+            if (new_item_next) {
+                ntab = tabs + ((it + 1) & 1) * Lt;
+                build_tab((int32_t*)ntab, nullptr, nprob);
             }
         }
+        DWM_TR(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
+        DWM_TR(1);
+        __syncthreads();                                     // ... and everybody else's
+        DWM_TR(2);
+        c.rowtab = tab;
+
+        for (int r = 0; r < rounds; ++r) {
+            const int qt = r * nwc + wave;
+            if (wave < nwc && qt < nqt) {
+                bf16x8 q[1][4];
+                bf16_t* op[1];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) q[0][ks] = qn[ks];
+                // this wave's NEXT unit (next round of this head, or its first tile of the next head): its Q rows are requested
+                // when this unit's tile loop is over (the loop's registers are free then) and travel under the normalisation, the
+                // stores and - across a head seam - the barriers
+                auto fetch_next_q = [&]() {
+                    const bool same = qt + nwc < nqt;
+                    if (!same && !(has_next && wave < nqt)) {      // no next unit: still define qn (it must not stay live across the tile loop)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) qn[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        return;
+                    }
+                    int lq = (same ? qt + nwc : wave) * 32 + l31;
+                    lq = lq < P.qend ? lq : P.qend - 1;
+                    const int32_t* const t2 = same ? tab : ntab;
+                    const bf16_t* qp = P.q0 + ((int64_t)t2[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + (same ? hoff : nhoff) + half * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qp + ks * 16);
+                };
+                {
+                    int lq = qt * 32 + l31;
+                    lq = lq < P.qend ? lq : P.qend - 1;
+                    op[0] = P.o0 + ((int64_t)otab[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + hoff;
+                }
+                ResGlobal gm;
+                gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
+#ifdef DWM_ATTN_TRACE
+                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q,
+                            (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64 && r == 0) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
+#else
+                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+#endif
+                if (r == 0) DWM_TR(3);
+            }
+        }
+        DWM_TR(6);
         __syncthreads();                                     // everybody is done with this head's images
-        if (hh + 1 < hpb) copy_head(hh + 1);
+        DWM_TR(7);
+        if (new_item_next) build_tab(nullptr, otab, nprob);  // the output row table of the next item (this item's is no longer read)
+        if (has_next) {
+            copy_rows(ntab, nhoff, 0, n, false, wave, NW);
+            copy_rows(ntab, nhoff, 0, n, true, wave, NW);
+        }
     }
 }
 
@@ -1271,10 +1389,9 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     if (rc != DWM_OK) return rc;
     const int64_t L = P.L;
 
-    // variant: 0 = auto; 1 / 2 = 32 / 64 queries per wave (128 / 256 per workgroup)
-    int qt = a->variant & 15;
-    if (qt == 0) qt = 1;   // 32 queries per wave (3 workgroups per CU) measured faster in the full step than 64
-    if (qt != 1 && qt != 2) return DWM_EINVAL;
+    // variant bits 0-3, tiled kernel: 2 = 64 queries per wave (256 per workgroup); anything else = 32 (3 workgroups per CU:
+    // measured faster in the full step).  The resident kernel reads the same bits as its number of compute waves.
+    const int qt = (a->variant & 15) == 2 ? 2 : 1;
     const int qblock = qt * 128;
     P.nqb = (int)((P.qend + qblock - 1) / qblock);
     // heads per workgroup: amortises the per-workgroup fixed cost (variant bits 8..11 override: 1..15).
@@ -1354,30 +1471,44 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     }
     // resident form: no mask, no LSE, self-attention, the K / V rows of one head fit the LDS (L <= 608); variant bit 5 keeps
     // the tiled kernel (A/B measurements, tests)
-    if (P.mask_mode == 0 && P.lse == nullptr && !a->cross && L <= 608 && L >= 64 && !((a->variant >> 5) & 1)) {
-        const int nqt = (P.qend + 31) / 32;
-        int rq = a->variant & 15;
-        if (rq == 0) rq = nqt <= 16 ? 2 : 1;       // 8 waves x 2 query tiles cover <= 16 tiles in one round; else 12 waves x 1
-        if (rq != 1 && rq != 2) return DWM_EINVAL;
+#ifdef DWM_ATTN_TRACE
+    const bool res_lse_ok = true;              // the lse buffer is the trace buffer in this build
+#else
+    const bool res_lse_ok = P.lse == nullptr;
+#endif
+    if (P.mask_mode == 0 && res_lse_ok && !a->cross && L <= 608 && L >= 64 && !((a->variant >> 5) & 1)) {
         int hs = (a->variant >> 8) & 15;
-        if (hs == 0) {                             // heads per workgroup: as many as leave >= 3 workgroups per CU
+        if (hs == 0) {                             // heads per item: as many as leave >= 3 items per CU
             for (hs = 6; hs > 1; --hs)
                 if (P.heads % hs == 0 && (int64_t)P.n_problems * (P.heads / hs) >= 768) break;
         }
         if (P.heads % hs != 0) return DWM_EINVAL;
         P.hpb = hs;
         P.fd_heads = make_fastdiv((uint32_t)(P.heads / hs));
-        const int64_t nblk = (int64_t)P.n_problems * (P.heads / hs);
-        if (nblk >= (1ll << 31)) return DWM_EUNSUPPORTED;
-        const size_t lds = (size_t)2 * ((L + 31) & ~31) * 128 + (size_t)((L + 3) & ~3) * sizeof(int32_t);
+        const int64_t nitems = (int64_t)P.n_problems * (P.heads / hs);
+        if (nitems >= (1ll << 31)) return DWM_EUNSUPPORTED;
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DWM_EINVAL;
+            ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const unsigned nblk = (unsigned)(nitems < ncu ? nitems : ncu);           // persistent: one workgroup per CU
+        const size_t lds = (size_t)2 * ((L + 31) & ~31) * 128 + (size_t)3 * ((L + 3) & ~3) * sizeof(int32_t);
+        // compute waves (variant bits 0-3 override; 12 = all)
+        {
+            int nwc = a->variant & 15;
+            if (nwc == 0) nwc = 12;
+            if (nwc < 1 || nwc > 12) return DWM_EINVAL;
+            P.nwc = nwc;
+        }
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_res_kernel<1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)attn_res_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_res_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if (rq == 1) hipLaunchKernelGGL((attn_res_kernel<1, 12>), dim3((unsigned)nblk), dim3(768), lds, s, P);
-        else hipLaunchKernelGGL((attn_res_kernel<2, 8>), dim3((unsigned)nblk), dim3(512), lds, s, P);
+        hipLaunchKernelGGL((attn_res_kernel<12>), dim3(nblk), dim3(768), lds, s, P);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }

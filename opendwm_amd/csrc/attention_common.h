@@ -39,6 +39,7 @@ struct AttnParams {
     float* delta;                        // [n_problems, heads, L] -rowsum(dO * O)
     float scale;
     int n_problems, heads, nqb;
+    int nwc;                 // attn_res_kernel: compute waves
     int safe_softmax;        // attn_res_kernel: online softmax (running max) for every unit instead of the max-free fast path
     int hpb;                 // heads per workgroup (forward); fd_heads then divides by heads / hpb
     FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;
