@@ -37,6 +37,10 @@ extern "C" {
 /* ABI version; bump on any struct change. */
 #define DWM_ABI_VERSION 14
 int dwm_abi_version(void);
+/* SHA-256 (hex) of the sources this library was built from (csrc .hip and .h files + this header, in sorted order), as
+ * computed by opendwm_amd/build.py; the Python binding compares it with the sources it finds next to itself and refuses a
+ * stale binary. */
+const char* dwm_source_hash(void);
 
 /* ------------------------------------------------------------------------
  * GEMM:  C[M,Nout] = epilogue( A[M,K] · W[N,K]^T )
@@ -93,7 +97,7 @@ typedef struct dwm_gemm_args {
     const float* alpha; int64_t rows_per_alpha;                 /* fp32 alpha[row/rows_per_alpha]           */
     /* RMSHEAD */
     const void* rms_w; int64_t rms_ncols; float rms_eps;        /* bf16 rms_w[rms_ncols]                    */
-    int32_t reserved;                                           /* tuning / ablation knobs, 0 in production  */
+    int32_t reserved;                                           /* ignored (ablation knobs of -DDWM_DEV_HOOKS builds) */
     /* implicit-GEMM convolution (all zero / rw == 0 for a plain GEMM):
      * K = ntaps * k_per_tap; K index (t, c) reads A[a_map(m) + tap_shift[t]][c].  W is [N, ntaps*k_per_tap]. */
     dwm_rowmap2d a_map;                                         /* A rows                                    */

@@ -102,6 +102,7 @@ class LayerNormBwdArgs(C.Structure):
 # name -> (restype, argtypes); every symbol include/dwm_hip.h declares
 SIGNATURES = {
     "dwm_abi_version": (_i32, []),
+    "dwm_source_hash": (C.c_char_p, []),
     "dwm_gemm_bf16": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dwm_attention_fwd": (_i32, [C.POINTER(AttnArgs), _vp]),
     "dwm_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
@@ -186,6 +187,17 @@ def load():
     v = lib.dwm_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libdwm_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    # a binary older than the sources next to it must not pass silently (ensure_built() never rebuilds an existing .so)
+    if os.environ.get("DWM_SKIP_SOURCE_HASH") != "1":
+        from .build import source_hash
+        try:
+            want = source_hash()
+        except OSError:
+            want = None                      # sources not shipped next to the binding: nothing to compare
+        have = (lib.dwm_source_hash() or b"").decode()
+        if want is not None and have != want:
+            raise RuntimeError(f"libdwm_hip.so was built from other sources (hash {have[:12]}..., tree {want[:12]}...): "
+                               "run `python -m opendwm_amd.build`")
     _lib = lib
     return lib
 

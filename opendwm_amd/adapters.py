@@ -29,11 +29,19 @@ class AdapterResnetBlock(nn.Module):
         self.block2 = nn.Conv2d(channels, channels, kernel_size=1)
 
     def packed(self):
-        """tap-major 3x3 weight [N, 9*C] and the 1x1 weight [N, C]; rebuilt after every optimizer step / state-dict load
-        (STORE.derived keys on the optimizer step and the parameter version, as every other packed weight does)"""
+        """tap-major 3x3 weight [N, 9*C] and the 1x1 weight [N, C] in the store's precision (bf16, or fp32 for the accuracy
+        path); rebuilt after every optimizer step / state-dict load (STORE.derived keys on the optimizer step and the
+        parameter version, as every other packed weight does)"""
         w3, w1 = self.block1.weight, self.block2.weight
         return {"w3": STORE.derived(w3, "c3tap", lambda: _bf(w3).permute(0, 2, 3, 1).reshape(w3.shape[0], -1).contiguous()),
                 "w1": STORE.derived(w1, "c1", lambda: _bf(w1).reshape(w1.shape[0], -1).contiguous())}
+
+    def run_f32(self, x_pad: torch.Tensor, grid: PaddedGrid) -> torch.Tensor:
+        """the fp32 accuracy path: x_pad fp32 padded grid, updated in place (dwm_gemm_f32 with the 3x3 taps)"""
+        pk = self.packed()
+        h1 = ops.gemm(x_pad, pk["w3"], _bf(self.block1.bias), act=ACT_RELU, a_grid=grid, conv3x3=True)
+        ops.gemm(h1, pk["w1"], _bf(self.block2.bias), epilogue=EPI_RESID, res=x_pad, out=x_pad, c_grid=grid)
+        return x_pad
 
     def run(self, x_pad: torch.Tensor, grid: PaddedGrid, x32_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_pad: padded token grid [grid.rows, C] (zero border), updated in place.  With x32_pad (the fp32 master of the same
@@ -149,12 +157,67 @@ class ImageAdapter(nn.Module):
                 res.run(cur_pad, grid, cur32)
             yield cur_pad, grid, zc
 
+    def _levels_f32(self, x: torch.Tensor):
+        """the fp32 accuracy path of the body (model.compute_dtype = torch.float32): every activation and weight in fp32, the
+        convolutions by dwm_gemm_f32; PixelUnshuffle / AvgPool2d / the padded-grid scatter are plain data movement in torch"""
+        if self.zero_gates is not None:
+            raise NotImplementedError("zero_gates (zero_gate_coef) is not used by any shipped CTSD config")
+        import torch.nn.functional as F
+        f32 = torch.float32
+        x = x.flatten(0, -4).to(f32)
+        I, _, H, W = x.shape
+        r = self.downscale_factor
+        h, w = H // r, W // r
+        cur = F.pixel_unshuffle(x, r)                        # [I, C r r, h, w]
+        cur_pad, grid = None, None
+
+        def to_pad(img, g):                                  # [I, C, h, w] -> padded token grid [g.rows, Cpad] (K granularity 64)
+            Cc = img.shape[1]
+            Cp = (Cc + 63) // 64 * 64
+            p = torch.zeros((g.I, g.h + 2, g.w + 2, Cp), dtype=f32, device=img.device)
+            p[:, 1:-1, 1:-1, :Cc] = img.permute(0, 2, 3, 1)
+            return p.view(g.rows, Cp)
+
+        def from_pad(p, g):                                  # -> [I, C, h, w]
+            return p.view(g.I, g.h + 2, g.w + 2, -1)[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
+
+        for blk, zc in zip(self.body, self.zero_convs):
+            if blk.downsample is not None:
+                if cur is None:
+                    cur = from_pad(cur_pad, grid)
+                if h % 2 or w % 2:
+                    raise NotImplementedError("AvgPool2d(ceil_mode) on odd sizes")
+                cur = F.avg_pool2d(cur, 2)
+                h, w = h // 2, w // 2
+                cur_pad = None
+            if cur_pad is None:
+                grid = PaddedGrid(I, h, w)
+                cur_pad = to_pad(cur, grid)
+                cur = None
+            if blk.in_conv is not None:
+                wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1)
+                if wi.shape[1] != cur_pad.shape[1]:          # input channels padded to a multiple of 64
+                    wp = torch.zeros((wi.shape[0], cur_pad.shape[1]), dtype=f32, device=wi.device)
+                    wp[:, :wi.shape[1]] = wi
+                    wi = wp
+                cur_pad = ops.gemm(cur_pad, wi.contiguous(), _bf(blk.in_conv.bias), a_grid=grid, c_grid=grid)
+            for res in blk.resnets:
+                res.run_f32(cur_pad, grid)
+            yield cur_pad, grid, zc
+
     @torch.no_grad()
     def run(self, x: torch.Tensor, precise: bool = False) -> List[torch.Tensor]:
         """x [..., C, H, W] -> list of token-major features [I*h_i*w_i, channels[i]], I = prod(leading): bf16, or - precise -
         fp32 (fp32 skip path inside the adapter, fp32 output of the zero convolutions: what the inference forwards cache
         across denoise steps and add with ops.add_)."""
         feats = []
+        if STORE.precision == torch.float32:                 # the fp32 accuracy path: fp32 residuals
+            for cur_pad, grid, zc in self._levels_f32(x):
+                if zc is not None:
+                    feats.append(ops.gemm(cur_pad, _bf(zc.weight).reshape(zc.weight.shape[0], -1).contiguous(), _bf(zc.bias), a_grid=grid))
+                else:
+                    feats.append(cur_pad[grid.interior_index().to(cur_pad.device)].contiguous())
+            return feats
         for cur_pad, grid, zc in self._levels(x, precise):
             if zc is not None:
                 wz = _bf(zc.weight).reshape(zc.weight.shape[0], -1).contiguous()
@@ -176,7 +239,7 @@ class ImageAdapter(nn.Module):
         i-th feature to the token-major hidden state h [I*h_i*w_i, C] IN PLACE - the zero convolution runs as a GEMM whose
         epilogue adds h in fp32 (h <- bf16(h + W x + b): no residual tensor, no separate add, one rounding).  Each add must
         be called before the next item is drawn (the next level overwrites the grid the zero convolution reads)."""
-        for cur_pad, grid, zc in self._levels(x, True):
+        for cur_pad, grid, zc in (self._levels_f32(x) if STORE.precision == torch.float32 else self._levels(x, True)):
             if zc is not None:
                 wz = _bf(zc.weight).reshape(zc.weight.shape[0], -1).contiguous()
 

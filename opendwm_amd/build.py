@@ -35,9 +35,22 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash() -> str:
+    """SHA-256 over the HIP sources and headers (sorted by name); baked into the library as dwm_source_hash()"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(INCLUDE, "dwm_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attention_common.h"), os.path.join(INCLUDE, "dwm_hip.h")]
+    shash = source_hash()
+    stamp = os.path.join(CSRC, "build", ".source_hash")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the
@@ -45,15 +58,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
              "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"] + os.environ.get("DWM_EXTRA_FLAGS", "").split()
     jobs = []
+    old_hash = open(stamp).read().strip() if os.path.exists(stamp) else ""
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        # elementwise.hip carries the source hash: it is rebuilt whenever any source changed
+        if force or _stale(o, [s] + headers) or (src == "elementwise.hip" and old_hash != shash):
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
         fl = [f for f in flags if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")] if os.path.basename(s) in AGPR_SOURCES else flags
+        if os.path.basename(s) == "elementwise.hip":
+            fl = fl + [f'-DDWM_SOURCE_HASH="{shash}"']
         cmd = [hipcc] + fl + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -71,12 +88,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(shash)
     return LIB
 
 
 def ensure_built() -> str:
     """Build the library if it is missing (sources newer than the .so do NOT trigger a rebuild here: a snapshot copy may
-    reorder mtimes).  Serialised with a file lock so the ranks of one node do not compile concurrently."""
+    reorder mtimes; a stale binary is caught by _lib.load(), which compares dwm_source_hash() with the sources).  Serialised
+    with a file lock so the ranks of one node do not compile concurrently."""
     if os.path.exists(LIB):
         return LIB
     import fcntl

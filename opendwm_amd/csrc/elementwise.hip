@@ -322,6 +322,10 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 extern "C" int dwm_abi_version(void) { return DWM_ABI_VERSION; }
+#ifndef DWM_SOURCE_HASH
+#define DWM_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* dwm_source_hash(void) { return DWM_SOURCE_HASH; }
 
 extern "C" int dwm_silu(const void* x, void* y, int64_t n, void* stream) {
     if (x == nullptr || y == nullptr || n <= 0) return DWM_EINVAL;

@@ -23,6 +23,14 @@
 
 namespace {
 
+// dwm_gemm_args.reserved carries ablation / tuning knobs of development builds (-DDWM_DEV_HOOKS: bit 0 main loop without
+// epilogue, bit 1 no stores, bit 2 general instead of FAST kernels, bits 4-8 group height); the shipped object ignores it
+#ifdef DWM_DEV_HOOKS
+#define DWM_RESERVED(x_) (x_)
+#else
+#define DWM_RESERVED(x_) 0
+#endif
+
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;            // 32 KiB per operand tile
 constexpr int A_STAGES = 3, W_STAGES = 2;          // the activation operand is requested two K steps ahead, the weights one
@@ -91,7 +99,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     }
     // group height: 8 row tiles share a W panel in the XCD's L2 for K ~ 1.5 k; a long K (FF2: 6144) makes the A panel of
     // 8 rows (25 MB) stream through it, 4 rows measured 3 % faster there
-    int gm_ = (p.reserved >> 4) & 31;
+    int gm_ = (DWM_RESERVED(p.reserved) >> 4) & 31;
     if (gm_ == 0) gm_ = p.K >= 4096 ? 4 : 8;
     const int per_group = gm_ * ntn;
     const int grp_id = id / per_group, in_grp = id - grp_id * per_group;
@@ -264,7 +272,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // per-head RMSNorm.  Stage B: each wave transposes its tile through a private, XOR-swizzled
     // 8 KiB LDS region (32 rows x 64 fp32 per pass) so that gate / residual / blend loads and
     // the bf16 stores are row-major 16-B accesses (8 rows x 128 B per wave instruction).
-    if (p.reserved & 1) {        // ablation knob (benchmarks only): main loop without the epilogue
+    if (DWM_RESERVED(p.reserved) & 1) {        // ablation knob (development builds only): main loop without the epilogue
         float sink = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -493,7 +501,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         *(float4*)(wp + 4) = x1;
                     }
                 } else {
-                    if (m < M && nok && !((p.reserved & 2) && m >= 0)) {
+                    if (m < M && nok && !((DWM_RESERVED(p.reserved) & 2) && m >= 0)) {
                         if constexpr (FAST) *(uint4*)(Cp + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc + (uint32_t)ncol)) = pack8(v);
                         else *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
                         if constexpr (RF32) {
@@ -682,11 +690,23 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr || a->workspace == nullptr) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 30) || a->N >= (1ll << 31)) return DWM_EINVAL;
     if (a->K % BK != 0 || a->N % 8 != 0) return DWM_EUNSUPPORTED;
-    if (a->ntaps > 0 || a->a_map.rw > 0 || a->c_map.rw > 0) return DWM_EUNSUPPORTED;         // no implicit convolution in this mode
+    // implicit convolution (a_map / c_map / taps as in dwm_gemm_bf16): every tap is walked as three plane taps (A_hi x W_hi, A_hi x
+    // W_lo, A_lo x W_hi), so at most 9 taps (a 3x3 kernel) fit the 27 tap slots; W is [N, ntaps * 3 * k_per_tap] (ops.split_weight)
+    const int ctaps = a->ntaps > 0 ? a->ntaps : 1;
+    if (ctaps > 9) return DWM_EUNSUPPORTED;
+    const int64_t kpt = a->ntaps > 0 ? a->k_per_tap : a->K;
+    if (kpt <= 0 || kpt % BK != 0 || kpt * ctaps != a->K) return DWM_EINVAL;
+    // rows of the A buffer (both planes cover all of them: taps reach into the padded border)
+    int64_t a_rows = a->M;
+    if (a->a_map.rw > 0) {
+        const int64_t ppi = a->a_map.rw * a->a_map.rh;
+        if (a->a_map.rh <= 0 || a->M % ppi != 0) return DWM_EINVAL;
+        a_rows = (a->M / ppi) * a->a_map.ipitch;
+    } else if (a->ntaps > 0) return DWM_EUNSUPPORTED;            // taps need the padded-grid map
     if (a->lda % 4 != 0 || a->ldc % 4 != 0 || !dwm_aligned16(a->A) || !dwm_aligned16(a->W) || !dwm_aligned16(a->C) ||
         !dwm_aligned16(a->workspace)) return DWM_EALIGN;
     const int64_t nout = a->epilogue == DWM_EPI_GEGLU ? a->N / 2 : a->N;
-    if (a->ldc < nout || a->lda < a->K) return DWM_EINVAL;
+    if (a->ldc < nout || a->lda < kpt) return DWM_EINVAL;
     switch (a->epilogue) {
         case DWM_EPI_PLAIN: break;
         case DWM_EPI_GEGLU: if (a->N % 64 != 0) return DWM_EUNSUPPORTED; break;
@@ -701,7 +721,7 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     }
     if (a->rows_per_gate > (1ll << 30) || a->res_mod > (1ll << 30) || a->res_mod < -(1ll << 30) || a->rows_per_alpha > (1ll << 30)) return DWM_EINVAL;
     // workspace: [A_hi ; A_lo] bf16 planes, then the fp32 partial sums
-    const int64_t plane_bytes = ((2 * a->M * a->K * 2 + 255) / 256) * 256;
+    const int64_t plane_bytes = ((2 * a_rows * kpt * 2 + 255) / 256) * 256;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
     const int64_t tiles = (int64_t)ntm * ntn, nk = 3 * a->K / BK, slice_bytes = a->M * a->N * 4;
     int ksplit = 1;
@@ -716,24 +736,33 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     bf16_t* planes = (bf16_t*)a->workspace;
     {
-        const int64_t nthr = a->M * (a->K >> 3);
-        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)a->A, a->lda, a->M,
-                           a->K, planes);
+        const int64_t nthr = a_rows * (kpt >> 3);
+        hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)a->A, a->lda, a_rows,
+                           kpt, planes);
     }
     dwm_gemm_args g = *a;
-    g.A = planes; g.lda = a->K; g.K = 3 * a->K;
+    g.A = planes; g.lda = kpt; g.K = 3 * a->K;
     ConvParams cp;
-    cp.a.enabled = cp.c.enabled = 0;
-    cp.a.xstep = cp.c.xstep = 1;
-    cp.a.rw = cp.a.rh = cp.c.rw = cp.c.rh = make_fastdiv(1);
-    cp.a.rpitch = cp.a.ipitch = cp.a.origin = cp.c.rpitch = cp.c.ipitch = cp.c.origin = 0;
-    cp.steps_per_tap = (int)(a->K / BK);
+    auto mk = [](const dwm_rowmap2d& r, DevRowMap& d) -> bool {
+        d.enabled = r.rw > 0;
+        d.xstep = r.xstep > 0 ? (int)r.xstep : 1;
+        if (!d.enabled) { d.rw = make_fastdiv(1); d.rh = make_fastdiv(1); d.rpitch = d.ipitch = d.origin = 0; return true; }
+        if (r.rh <= 0 || r.rw >= (1ll << 30) || r.rh >= (1ll << 30)) return false;
+        d.rw = make_fastdiv((uint32_t)r.rw); d.rh = make_fastdiv((uint32_t)r.rh);
+        d.rpitch = r.rpitch; d.ipitch = r.ipitch; d.origin = r.origin;
+        return true;
+    };
+    if (!mk(a->a_map, cp.a) || !mk(a->c_map, cp.c)) return DWM_EINVAL;
+    cp.steps_per_tap = (int)(kpt / BK);
     cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
     cp.fd_rpg = make_fastdiv((uint32_t)(a->rows_per_gate > 0 ? a->rows_per_gate : 1));
     cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : a->res_mod < 0 ? -a->res_mod : 1));
     cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
     for (int t = 0; t < 27; ++t) cp.tap_shift[t] = 0;
-    cp.tap_shift[2] = a->M;                           // taps: A_hi (x W_hi), A_hi (x W_lo), A_lo (x W_hi)
+    for (int t = 0; t < ctaps; ++t) {                 // per tap: A_hi (x W_hi), A_hi (x W_lo), A_lo (x W_hi)
+        const int64_t sh = a->ntaps > 0 ? a->tap_shift[t] : 0;
+        cp.tap_shift[3 * t] = sh; cp.tap_shift[3 * t + 1] = sh; cp.tap_shift[3 * t + 2] = sh + a_rows;
+    }
     cp.ksplit = ksplit;
     cp.ws = (float*)((char*)a->workspace + plane_bytes);
     cp.ws_slice = a->M * a->N;
@@ -820,7 +849,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     {
         const int64_t tiles = (int64_t)ntm * ntn, nk = a->K / BK;
         const bool can = (a->epilogue == DWM_EPI_PLAIN || a->epilogue == DWM_EPI_RESID) && a->workspace != nullptr &&
-                         dwm_aligned16(a->workspace) && !(a->reserved & 3) && a->C32 == nullptr;
+                         dwm_aligned16(a->workspace) && !(DWM_RESERVED(a->reserved) & 3) && a->C32 == nullptr;
         if (a->split_k > 1) {
             if (!can) return DWM_EUNSUPPORTED;
             ksplit = a->split_k;
@@ -868,7 +897,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     } while (0)
     // the transformer blocks' linear layers (see FAST above); reserved bit 2 keeps the general kernels (A/B measurements)
     const int64_t lim = 1ll << 31;
-    bool fast = !cp.c.enabled && a->ldc < lim && !(a->reserved & 4);
+    bool fast = !cp.c.enabled && a->ldc < lim && !(DWM_RESERVED(a->reserved) & 4);
     if (a->epilogue == DWM_EPI_RESID)
         fast = fast && a->res_mod == 0 && a->act == DWM_ACT_NONE && (a->gate == nullptr || a->ld_gate < lim) &&
                (a->res == nullptr || a->ld_res < lim) && (a->blend == nullptr || a->ld_blend < lim);

@@ -374,10 +374,9 @@ class DiTCrossviewTemporalConditionModel(_Base):
         from .blocks import STORE
         cd = self.compute_dtype
         STORE.set_precision(cd)           # reset to bf16 by `forward` on the way out
-        if cd == torch.float32 and (fs is not None or (self.condition_image_adapter is not None and condition_image_tensor is not None)
-                                    or self.perspective_modeling_type == "explicit"):
-            raise NotImplementedError("the fp32 accuracy path covers the text-conditioned model (no ImageAdapter, no explicit "
-                                      "perspective modelling, no frame sharding)")
+        if cd == torch.float32 and (fs is not None or self.perspective_modeling_type == "explicit"):
+            raise NotImplementedError("the fp32 accuracy path covers the text / text+layout models with implicit perspective "
+                                      "modelling (no explicit perspective modelling, no frame sharding)")
 
         def as_bf16(t):
             if cd == torch.float32:
@@ -420,7 +419,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
         # layout residuals (crossview_temporal_dit.py:459-462).  They depend only on the condition
         # images, which do not change across denoise steps: cached on the tensor's identity.
         condition_residuals = residual_adders = None
-        if self.condition_image_adapter is not None and condition_image_tensor is not None and not self.cache_adapter_residuals:
+        if self.condition_image_adapter is not None and condition_image_tensor is not None and \
+                (not self.cache_adapter_residuals or cd == torch.float32):      # (the fp32 accuracy path always recomputes)
             residual_adders = self.condition_image_adapter.residual_adders(condition_image_tensor)
         elif self.condition_image_adapter is not None and condition_image_tensor is not None:
             # the key holds the optimizer step (residuals of old adapter weights must not survive a training step) and

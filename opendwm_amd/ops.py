@@ -177,15 +177,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
     axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids.
     split_k: 0 = the kernel's rule (small tile grid + long K -> K ranges, fp32 partials, ordered reduction),
-    1 = never, n > 1 = exactly n ranges.
+    1 = never, n > 1 = exactly n ranges.  _debug: ablation knobs, honoured only by -DDWM_DEV_HOOKS builds of the library.
     out32 (RESID): fp32 residual stream - `res` is then an fp32 matrix shaped like `out`, the result goes to out32 in fp32
     (out32 may be `res` itself) and, rounded, to the bf16 `out` the next GEMM reads."""
     if a.dtype == torch.float32:            # the fp32 accuracy path (dwm_gemm_f32)
-        if a_grid is not None or c_grid is not None or conv3x3 or conv_taps is not None or stride2:
-            raise NotImplementedError("gemm: implicit convolutions are not part of the fp32 path")
+        if conv_taps is not None or stride2:
+            raise NotImplementedError("gemm: of the implicit convolutions only the dense 3x3 / 1x1 forms on a padded grid are part of the fp32 path")
         return _gemm_f32(a, w, bias, out=out, epilogue=epilogue, act=act, gate=gate, rows_per_gate=rows_per_gate, res=res,
                          res_mod=res_mod, blend=blend, alpha=alpha, rows_per_alpha=rows_per_alpha, rms_w=rms_w,
-                         rms_ncols=rms_ncols, rms_eps=rms_eps, rows=rows)
+                         rms_ncols=rms_ncols, rms_eps=rms_eps, rows=rows, a_grid=a_grid, conv3x3=conv3x3, c_grid=c_grid)
     _chk2d(a, "a")
     _chk2d(w, "w")
     if not w.is_contiguous():
@@ -272,18 +272,29 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 
 _SPLIT_WEIGHTS: dict = {}
+SPLIT_WEIGHT_CACHE_MAX = 2048        # > the ~1300 weight matrices of the largest model on the path
 
 
-def split_weight(w: torch.Tensor) -> torch.Tensor:
-    """fp32 [N, K] -> the pre-split bf16 operand [N, 3K] = [hi | lo | hi] of dwm_gemm_f32 (hi = bf16(w), lo = bf16(w - hi)).
-    Cached on the tensor's storage / version (weights and packed weights are long-lived); `clear_split_weights()` drops it."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    hit = _SPLIT_WEIGHTS.get(key)
+def split_weight(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
+    """fp32 [N, K] -> the pre-split bf16 operand [N, 3K] of dwm_gemm_f32 (hi = bf16(w), lo = bf16(w - hi)): [hi | lo | hi], or -
+    `taps` > 1, K = taps x C tap-major (implicit convolution) - [hi_t | lo_t | hi_t] per tap t.
+    Cached on the tensor's storage / version (weights and packed weights are long-lived), at most SPLIT_WEIGHT_CACHE_MAX entries
+    (least recently used first out: per-call temporaries must not pile up); `clear_split_weights()` drops everything."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), taps)
+    hit = _SPLIT_WEIGHTS.pop(key, None)
     if hit is None:
         hi = w.to(bf16)
         lo = (w - hi.float()).to(bf16)
-        hit = (torch.cat([hi, lo, hi], 1).contiguous(), w)          # keeps `w` alive: its address is the key
-        _SPLIT_WEIGHTS[key] = hit
+        if taps > 1:
+            N, K = w.shape
+            h3, l3 = hi.view(N, taps, K // taps), lo.view(N, taps, K // taps)
+            ws = torch.stack([h3, l3, h3], 2).reshape(N, 3 * K).contiguous()
+        else:
+            ws = torch.cat([hi, lo, hi], 1).contiguous()
+        hit = (ws, w)                                               # keeps `w` alive: its address is the key
+    _SPLIT_WEIGHTS[key] = hit                                       # (re-)inserted last: dict order = recency
+    while len(_SPLIT_WEIGHTS) > SPLIT_WEIGHT_CACHE_MAX:
+        _SPLIT_WEIGHTS.pop(next(iter(_SPLIT_WEIGHTS)))
     return hit[0]
 
 
@@ -292,27 +303,50 @@ def clear_split_weights() -> None:
 
 
 def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_mod, blend, alpha, rows_per_alpha, rms_w, rms_ncols,
-              rms_eps, rows):
+              rms_eps, rows, a_grid=None, conv3x3=False, c_grid=None):
     f32 = torch.float32
     _chk2d(a, "a", f32)
     _chk2d(w, "w", f32)
     if not w.is_contiguous():
         raise RuntimeError("w must be contiguous [N, K]")
     N, K = w.shape
-    M = a.shape[0] if rows is None else rows
-    if a.shape[1] != K:
-        raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
+    taps = 9 if conv3x3 else 1
+    if a_grid is not None:
+        if a.shape[0] != a_grid.rows or a.shape[1] * taps != K or not a.is_contiguous():
+            raise RuntimeError(f"gemm: padded A {tuple(a.shape)} does not match grid / weight {tuple(w.shape)}")
+        M, a_rows = a_grid.pixels, a_grid.rows
+    else:
+        if conv3x3:
+            raise RuntimeError("gemm: conv3x3 needs a_grid")
+        M = a.shape[0] if rows is None else rows
+        a_rows = M
+        if a.shape[1] != K:
+            raise RuntimeError(f"gemm: K mismatch {a.shape} x {w.shape}")
     nout = N // 2 if epilogue == EPI_GEGLU else N
+    orow = c_grid.rows if c_grid is not None else M
+    if c_grid is not None and c_grid.pixels != M:
+        raise RuntimeError("gemm: c_grid pixel count != M")
     if out is None:
-        out = torch.empty((M, nout), dtype=f32, device=a.device)
+        out = (torch.zeros if c_grid is not None else torch.empty)((orow, nout), dtype=f32, device=a.device)
     _chk2d(out, "out", f32)
-    if out.shape != (M, nout):
-        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(M, nout)}")
+    if out.shape != (orow, nout):
+        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(orow, nout)}")
     _chkvec(bias, "bias", f32)
-    ws = split_weight(w)
+    ws = split_weight(w, taps)
     g = _lib.GemmArgs()
     g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), ws.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)
     g.M, g.N, g.K, g.epilogue, g.act = M, N, K, epilogue, act
+    if a_grid is not None:
+        a_grid.fill(g.a_map)
+        if conv3x3:
+            g.ntaps, g.k_per_tap = 9, a.shape[1]
+            for t, sh in enumerate(a_grid.tap_shifts()):
+                g.tap_shift[t] = sh
+    if c_grid is not None:
+        c_grid.fill(g.c_map)
+        for name, t in (("res", res), ("blend", blend)):
+            if t is not None and t.shape[0] != c_grid.rows:
+                raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     if gate is not None:
         _chk2d(gate, "gate", f32)
         g.gate, g.ld_gate, g.rows_per_gate = gate.data_ptr(), gate.stride(0), rows_per_gate
@@ -326,7 +360,7 @@ def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_m
     if rms_w is not None:
         _chkvec(rms_w, "rms_w", f32)
         g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
-    need = 4 * M * K + 256 + 4 * M * N
+    need = 4 * a_rows * (K // taps) + 256 + 4 * M * N
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     if tiles <= 128:
         need += 4 * M * N * min(32, 256 // tiles)          # room for the kernel's own split-K rule

@@ -220,6 +220,66 @@ def test_model_forward_fp32_vs_cpu_oracle(dev, tt):
     assert out16[0].dtype == torch.bfloat16 and 1e-4 < e16 < 2e-2
 
 
+def test_gemm_f32_implicit_conv3x3(dev):
+    """dwm_gemm_f32 as an implicit 3x3 convolution on a padded token grid (9 taps x 3 plane taps = the 27 tap slots), plain
+    and with the in-place residual on the padded grid, against F.conv2d in fp64"""
+    import torch.nn.functional as F
+    from opendwm_amd import ops
+    I, h, w, Cc, N = 3, 6, 10, 128, 192
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(I, Cc, h, w, generator=g)
+    wt = torch.randn(N, Cc, 3, 3, generator=g) * (9 * Cc) ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, N)
+    grid = ops.PaddedGrid(I, h, w)
+    idx = grid.interior_index().to(dev)
+    xp = torch.zeros((grid.rows, Cc), dtype=f32, device=dev)
+    xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, Cc).to(dev)
+    wp = wt.permute(0, 2, 3, 1).reshape(N, 9 * Cc).contiguous().to(dev)
+    out = ops.gemm(xp, wp, b.to(dev), a_grid=grid, conv3x3=True)
+    e0 = rel_err(out, ref)
+    act = ops.gemm(xp, wp, b.to(dev), act=ops.ACT_RELU, a_grid=grid, conv3x3=True)
+    e1 = rel_err(act, ref.clamp_min(0))
+    # 1x1 convolution back onto the padded grid, residual in place (AdapterResnetBlock.block2)
+    w1 = (torch.randn(Cc, N, generator=g) * N ** -0.5).to(dev)
+    res = xp.clone()
+    ops.gemm(out, w1, None, epilogue=ops.EPI_RESID, res=res, out=res, c_grid=grid)
+    want = x.permute(0, 2, 3, 1).reshape(-1, Cc).double() + ref @ w1.double().cpu().T
+    border = torch.ones(grid.rows, dtype=torch.bool, device=dev)
+    border[idx] = False
+    e2 = rel_err(res[idx], want)
+    _log("gemm_f32_conv3x3", plain=e0, relu=e1, resid_on_grid=e2)
+    assert max(e0, e1, e2) < 1e-4 and torch.count_nonzero(res[border]) == 0
+
+
+def test_model_with_layout_adapter_fp32_vs_cpu_oracle(dev):
+    """the text+layout model (ImageAdapter residuals + point-wise temporal attention, the headline variant of bench.py) in
+    the fp32 mode: fp32 convolutions of the adapter by dwm_gemm_f32, zero convolutions adding into the fp32 hidden state"""
+    ac = dict(in_channels=6, channels=[128, 128, 128], is_downblocks=[True, False, False], num_res_blocks=2, downscale_factor=8,
+              use_zero_convs=True)
+    cfg = small_config(temporal_attention_type="pointwise", condition_image_adapter_config=ac)
+    sd = O.make_state_dict(cfg, 0)
+    inp = small_inputs(cfg, 0)
+    g = torch.Generator().manual_seed(21)
+    inp["condition_image_tensor"] = torch.rand(2, 3, 3, 6, 64, 96, generator=g)
+    ref = O.dit_forward(sd, cfg, **inp)
+    m = _fp32_model(cfg, sd, dev)
+    di = to_dev(inp, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e = rel_err(out[0], ref)
+    # and the adapter alone
+    feats = O.image_adapter(sd, cfg, inp["condition_image_tensor"])
+    from opendwm_amd.blocks import STORE
+    STORE.set_precision(f32)
+    try:
+        mine = m.condition_image_adapter.run(di["condition_image_tensor"])
+    finally:
+        STORE.set_precision(torch.bfloat16)
+    ea = max(rel_err(a, f.flatten(0, -4).permute(0, 2, 3, 1).reshape(-1, f.shape[-3])) for a, f in zip(mine, feats))
+    _log("model_forward_fp32_layout", rel_fp32=e, adapter_rel=ea)
+    assert out[0].dtype == f32 and e < TOL_F32 and ea < 1e-4, (e, ea)
+
+
 def test_denoise_fp32_vs_cpu_oracle(dev):
     """four guided FlowMatch-Euler steps in the fp32 mode (fp32 model input, fp32 prediction, fp32 CFG + Euler kernel)"""
     from opendwm_amd.pipeline import CTSDDenoiser

@@ -339,7 +339,7 @@ def test_oracle_vae_round_trip_shapes():
 # ---------------------------------------------------------------------------- C ABI
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|int64_t)\s+(dwm_[a-z0-9_]+)\s*\(", hdr, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(dwm_[a-z0-9_]+)\s*\(", hdr, flags=re.M)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -352,6 +352,8 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert set(_lib.SIGNATURES) == set(declared)
     assert lib.dwm_abi_version() == _lib.ABI_VERSION
+    lib.dwm_source_hash.restype = ctypes.c_char_p
+    assert lib.dwm_source_hash().decode() == build.source_hash()      # the binary is the one of these sources
 
 
 def test_ctypes_structs_match_header_field_order():
