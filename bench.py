@@ -360,6 +360,7 @@ def main_train(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     D.init("nccl", dev)
+    pre = D.preflight(dev) if (world > 1 or args.preflight) else None
     from opendwm_amd import _lib
     from opendwm_amd.dit import DiTCrossviewTemporalConditionModel, model_flops
     from opendwm_amd.pipeline import CTSDTrainer
@@ -393,6 +394,24 @@ def main_train(args):
 
     dt = D.timed_steps(step, args.steps, args.warmup, dev)
     finite = bool(torch.isfinite(torch.stack(losses)).all().item())
+    # gradient exchange (ctsd.py:1051-1054: DDP all-reduce), outside the timed region: the same step without synchronisation
+    # (DDP no_sync) and one all-reduce of the gradient bytes on its own -> how much of the exchange hides behind the backward
+    ddp_extra = None
+    if world > 1:
+        import contextlib
+        nosync = trainer.wrapper.no_sync if trainer.ddp else contextlib.nullcontext
+
+        def step_nosync(i):
+            with nosync():
+                trainer.train_step(latents, cond, generator=gen)
+        dt_ns = D.timed_steps(step_nosync, 2, 1, dev)
+        wire = torch.bfloat16 if getattr(trainer, "ddp_comm_dtype", None) == torch.bfloat16 else torch.float32
+        nbytes = n_train * (2 if wire == torch.bfloat16 else 4)
+        ar_ms = D.measure_allreduce(nbytes, dev, wire)
+        exposed = max(0.0, 1e3 * dt / args.steps - 1e3 * dt_ns / 2)
+        ddp_extra = dict(allreduce_ms=ar_ms, allreduce_bytes=nbytes, wire_dtype=str(wire).replace("torch.", ""),
+                         step_ms_without_gradient_sync=1e3 * dt_ns / 2, exposed_allreduce_ms=exposed,
+                         backward_overlap_frac=(1.0 - min(1.0, exposed / ar_ms)) if ar_ms > 0 else None)
     if rank == 0:
         fwd = model_flops(kwargs, w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])["total"]
         step_ms = 1e3 * dt / args.steps
@@ -410,8 +429,7 @@ def main_train(args):
                        "peak_memory_GiB": mem,
                        # DDP: one bucketed all-reduce of the trainable gradients per step, bf16 on the wire (bf16_compress_hook,
                        # 200 MB buckets), overlapped with the rest of the backward; a ring over N GPUs moves 2 (N-1)/N of it per GPU
-                       "ddp_allreduce_GB_per_step": (2.0 * n_train / 1e9) if world > 1 else 0.0, "ddp_bucket_dtype": "bf16",
-                       "ddp_bucket_cap_mb": 200},
+                       "ddp": ddp_extra, "preflight": pre},
             # forward + recompute + 2x backward GEMMs (input + weight gradients); frozen weights skip their wgrad
             "approx_mfma_frac": (4.0 * fwd) / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12) if not args.freeze_base else None,
         }))
@@ -520,6 +538,8 @@ def main_debug_cpu(args):
     rank, local_rank, world = D.env_ranks()
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     D.init("gloo")
+    pre = D.preflight(None, mbytes=1)            # the same preflight and gradient-exchange probes the GPU paths run
+    ar_ms = D.measure_allreduce(1 << 20, None)
     x = torch.randn(64, 64)
 
     def step(i):
@@ -532,7 +552,8 @@ def main_debug_cpu(args):
         print(json.dumps({"metric": "DEBUG launch-path check (no kernels) - INVALID as a bench line", "value": world * args.steps / dt,
                           "unit": "stand-in steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "debug-cpu-launch"}}))
+                          "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "debug-cpu-launch"},
+                          "preflight": pre, "allreduce_ms": ar_ms}))
     D.shutdown()
 
 
@@ -542,6 +563,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preflight", action="store_true",
+                    help="run the launch preflight (device / RCCL facts, checked all-reduce) also with one rank; always on for N > 1")
     ap.add_argument("--gemm-shapes", action="store_true", help="diagnostics: per-shape GEMM totals on stderr")
     ap.add_argument("--cfg-split", action="store_true",
                     help="pairs of ranks share one sample: CFG halves on two GPUs, one all-gather per step (per-sample latency "
@@ -593,6 +616,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     D.init("nccl", dev)          # "nccl" == RCCL on ROCm; no-op for a single process
+    pre = D.preflight(dev) if (world > 1 or args.preflight) else None     # fails loudly (rc != 0) before anything is timed
 
     from opendwm_amd import _lib
     from opendwm_amd.dit import model_flops
@@ -722,6 +746,8 @@ def main():
                 "avg_launch_us": asm["avg_us"], "share_of_step_time": (asm["ms"] / args.steps) / step_ms},
             "whole_step_mfma_frac": step_flop / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
         }
+        if pre is not None:
+            line["preflight"] = pre
         if other is not None:
             k2, dt2, t2, fin2 = other
             fl2, ks2 = model_flops(k2, 2 * w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"]), t2.summary()

@@ -71,6 +71,64 @@ def timed_steps(step: Callable[[int], None], steps: int, warmup: int, device: to
     return max_over_ranks(time.perf_counter() - t0, device)
 
 
+def preflight(device: torch.device = None, mbytes: int = 64) -> dict:
+    """Run BEFORE any timed region of a multi-rank job: every rank reports its device, all ranks all-reduce a known `mbytes`
+    buffer (rank r contributes r + 1 everywhere) and check the sum - a wrong transport set-up (IPC mode, visible devices, a rank
+    on the wrong GPU) fails loudly here instead of inside the measurement.  Returns the facts rank 0 puts into its JSON line;
+    raises RuntimeError on any mismatch.  Works on every backend (gloo in the CPU tests, nccl = RCCL on the GPUs)."""
+    rank, local_rank, world = env_ranks()
+    on_gpu = device is not None and device.type == "cuda"
+    info = dict(world_size=world, backend=dist.get_backend() if dist.is_initialized() else None,
+                hsa_enable_ipc_mode_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+    if on_gpu:
+        info.update(device=torch.cuda.get_device_name(device), device_index=device.index, visible_devices=torch.cuda.device_count())
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            info["rccl_version"] = None
+        if world > 1 and torch.cuda.device_count() < 1:
+            raise RuntimeError("preflight: no visible GPU on this rank")
+    if not dist.is_initialized():
+        return info
+    dev = device if on_gpu else torch.device("cpu")
+    n = mbytes * (1 << 20) // 4
+    buf = torch.full((n,), float(rank + 1), dtype=torch.float32, device=dev)
+    sync(device)
+    t0 = time.perf_counter()
+    dist.all_reduce(buf)
+    sync(device)
+    dt = time.perf_counter() - t0
+    want = world * (world + 1) / 2
+    lo, hi = buf.min().item(), buf.max().item()
+    if lo != want or hi != want:
+        raise RuntimeError(f"preflight: all_reduce over {world} ranks gave [{lo}, {hi}], expected {want} on rank {rank}")
+    # every rank on its own device: the (device index, host pid) pairs must be distinct
+    ids = [None] * world
+    dist.all_gather_object(ids, (local_rank if on_gpu else -1 - rank, os.getpid()))
+    if on_gpu and len({i for i, _ in ids}) != world:
+        raise RuntimeError(f"preflight: ranks share a GPU: {ids}")
+    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True)
+    return info
+
+
+def measure_allreduce(nbytes: int, device: torch.device = None, dtype: torch.dtype = torch.float32, repeat: int = 3) -> float:
+    """milliseconds of ONE all-reduce of `nbytes` (MAX over ranks, best of `repeat`): the gradient exchange of a DDP step on its
+    own, to set beside the step time with and without gradient synchronisation (bench.py --train)"""
+    if not dist.is_initialized():
+        return 0.0
+    dev = device if device is not None and device.type == "cuda" else torch.device("cpu")
+    buf = torch.zeros(max(1, nbytes // torch.empty((), dtype=dtype).element_size()), dtype=dtype, device=dev)
+    best = None
+    for _ in range(repeat):
+        sync(device)
+        t0 = time.perf_counter()
+        dist.all_reduce(buf)
+        sync(device)
+        dt = max_over_ranks(time.perf_counter() - t0, device)
+        best = dt if best is None else min(best, dt)
+    return 1e3 * best
+
+
 def shutdown() -> None:
     if dist.is_initialized():
         dist.destroy_process_group()

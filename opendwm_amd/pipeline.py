@@ -341,9 +341,10 @@ class CTSDTrainer:
 
     `ddp=True` wraps the model in torch DistributedDataParallel (ctsd.py:1051-1054): the block Functions of
     opendwm_amd.train hand their parameter gradients to autograd block by block, so the bucketed RCCL
-    all-reduce overlaps the rest of the backward.  The buckets travel as bf16 (`ddp_comm_dtype`, torch's
-    bf16_compress_hook: 7.6 GB instead of 15.1 GB per step at 3.78 B parameters - the ring all-reduce is bound by the
-    xGMI links) in 200 MB buckets; `ddp_comm_dtype=None` keeps fp32 buckets.
+    all-reduce overlaps the rest of the backward.  The buckets are fp32 by default, as the reference's DDP all-reduces them
+    (ctsd.py:1051-1054), 200 MB each; `ddp_comm_dtype=torch.bfloat16` is the opt-in throughput mode (torch's
+    bf16_compress_hook: 7.6 GB instead of 15.1 GB per step at 3.78 B parameters - the ring all-reduce is bound by the xGMI
+    links, SURVEY.md s5 - at the price of a bf16 rounding of every averaged gradient, accumulated micro-steps included).
 
     training_config keys honoured as the reference does: "freezing_pattern" (regex over module names, ctsd.py:1014-1022),
     "gradient_accumulation_steps" (optimizer step every k-th call, :1401-1432; the micro-steps in between run under DDP's
@@ -355,7 +356,7 @@ class CTSDTrainer:
                  shift: float = 3.0, num_train_timesteps: int = 1000, loss_coef: float = 1.0,
                  max_grad_norm: Optional[float] = None, weighting_scheme: str = "logit_normal", ddp: bool = False,
                  ddp_kwargs: Optional[dict] = None, common_config: Optional[dict] = None, training_config: Optional[dict] = None,
-                 reference_latent_count=0, lr_scheduler=None, ddp_comm_dtype: Optional[torch.dtype] = bf16,
+                 reference_latent_count=0, lr_scheduler=None, ddp_comm_dtype: Optional[torch.dtype] = None,
                  train_scheduler=None):
         """common_config["frame_prediction_style"] (None | "diffusion_forcing" | "ctsd") and training_config select the
         training task mix of `make_input_for_prediction`; with "diffusion_forcing" every frame draws its own timestep
@@ -367,6 +368,7 @@ class CTSDTrainer:
         self.frozen_modules = freeze_modules(model, self.training_config["freezing_pattern"]) \
             if "freezing_pattern" in self.training_config else []
         self.ddp = bool(ddp)
+        self.ddp_comm_dtype = ddp_comm_dtype
         if ddp:
             dev = next(model.parameters()).device
             kw = dict(device_ids=[dev.index] if dev.type == "cuda" else None, gradient_as_bucket_view=True, bucket_cap_mb=200)
@@ -512,7 +514,11 @@ class CTSDTrainer:
         torch.save(osd, os.path.join(output_path, "optimizer", f"{steps}.pth"))
 
     def load_checkpoint(self, output_path: str, resume_from: int) -> None:
+        """model + optimizer state of step `resume_from`; the call counter continues there, so the gradient-accumulation
+        phase `(global_step + 1) % k` lines up with the reference loop, which passes the resumed global_step
+        (ctsd.py:1401-1404).  The lr_scheduler is NOT restored: the reference re-creates it on every start too."""
         import os
+        self.global_step = int(resume_from)
         self.model.load_state_dict(torch.load(os.path.join(output_path, "checkpoints", f"{resume_from}.pth"),
                                               map_location="cpu", weights_only=True))
         self.optimizer.load_state_dict(torch.load(os.path.join(output_path, "optimizer", f"{resume_from}.pth"),
@@ -593,6 +599,9 @@ class UNetDenoiser:
         self.prediction_type = prediction_type
         self.scheduler = scheduler
         if scheduler is not None:
+            if scheduler.config.prediction_type != prediction_type:
+                raise ValueError(f"UNetDenoiser: prediction_type {prediction_type!r} disagrees with the scheduler's "
+                                 f"{scheduler.config.prediction_type!r}")
             scheduler.set_timesteps(inference_steps)
             self.timesteps, self.sigmas = scheduler.timesteps.cpu(), None
         else:
@@ -610,6 +619,11 @@ class UNetDenoiser:
         self.conditions = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
                            for k, v in conditions.items()}
         self._ts = self.timesteps.to(dev).float()
+        # DDIM: the [steps, 6] coefficient rows of every step, on the device, once per prepare() (no host-to-device copy and
+        # no fp64 table gather inside the loop: the step is a plain index, as in the DPM-Solver path)
+        self._ddim_coef = None
+        if self.scheduler is not None:
+            self._ddim_coef = self.scheduler.coefficients(self.timesteps.to(dev))
         return self
 
     def step(self, i: int):
@@ -620,8 +634,8 @@ class UNetDenoiser:
         if self.scheduler is not None:
             from .schedulers import PREDICTION_TYPES
             sc = self.scheduler
-            coef = sc.coefficients(self.timesteps[i].to(self.latents.device).expand(B, T, V))
-            ops.cfg_ddim_step(pred, self.latents, coef.view(-1, 6), self.latents[0, 0, 0].numel(), PREDICTION_TYPES[sc.config.prediction_type],
+            coef = self._ddim_coef[i].expand(B * T * V, 6).contiguous()
+            ops.cfg_ddim_step(pred, self.latents, coef, self.latents[0, 0, 0].numel(), PREDICTION_TYPES[sc.config.prediction_type],
                               guidance=self.guidance_scale, clip_range=sc.config.clip_sample_range if sc.config.clip_sample else 0.0,
                               model_in=self.model_in)
             return

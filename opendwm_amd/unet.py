@@ -499,6 +499,17 @@ class UNetCrossviewTemporalConditionModel(_Base):
                 raise RuntimeError("opendwm_amd runs on an MI355X (HIP) device only; got a CPU tensor")
             if isinstance(encoder_hidden_states, dict):
                 raise NotImplementedError("dict encoder_hidden_states (align projection) is not built")
+            if encoder_hidden_states is None:
+                raise ValueError("UNet training forward: encoder_hidden_states (the text condition) is required")
+            # inputs the reference's forward consumes (crossview_temporal_unet.py:730-755: the frustum BEV residuals are added to
+            # the down path; the camera inputs feed the depth net) but the training graph here does not: refuse, do not drop
+            dropped = {"frustum_bev_residuals": frustum_bev_residuals, "camera_intrinsics": camera_intrinsics,
+                       "camera_transforms": camera_transforms, "camera_intrinsics_norm": camera_intrinsics_norm,
+                       "camera2referego": camera2referego}
+            used = [k for k, v in dropped.items() if v is not None]
+            if used:
+                raise NotImplementedError(f"UNet training forward: {', '.join(used)} (depth net / frustum BEV branch) is not built; "
+                                          "no shipped CTSD config enables it")
             squeeze = sample.dim() < 6
             if squeeze:
                 sample, timesteps = sample.unsqueeze(2), timesteps.unsqueeze(2)

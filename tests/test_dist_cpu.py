@@ -238,6 +238,11 @@ def test_bench_self_launches_ranks_when_started_plainly():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert line["ms_per_step"] >= 20.0                       # the slow rank's sleep: MAX over ranks
     assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]   # whole-job aggregate
+    # the preflight every N > 1 launch runs before its timed region (checked all-reduce, distinct ranks) and the
+    # gradient-exchange probe of the --train line
+    pre = line["preflight"]
+    assert pre["world_size"] == 2 and pre["backend"] == "gloo" and pre["allreduce_sum_ok"] is True and pre["allreduce_ms"] > 0
+    assert line["allreduce_ms"] > 0
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
                         "--warmup", "0", "--debug-cpu-launch"], env=env, capture_output=True, text=True, timeout=300)
