@@ -45,3 +45,43 @@ def to_dev(d, device, float_dtype=None):
                 v = v.to(float_dtype)
         out[k] = v
     return out
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def capture_segsum_diff():
+    """records every dwm_segsum_diff call of a backward (the d(alpha) sums of the AlphaBlender mixers): the kernel's total, the
+    fp64 total of ITS OWN inputs and the fp64 sum of the absolute terms - what separates the kernel's arithmetic from the bf16
+    rounding of the activations / gradients it is handed"""
+    from opendwm_amd import train_ops as T
+    calls, f0 = [], T.segsum_diff
+
+    def wrapped(a, b, b2, rows_per_group=None):
+        out = f0(a, b, b2, rows_per_group=rows_per_group)
+        t = a.double() * (b.double() - b2.double())
+        calls.append(dict(kernel=out.double().sum().item(), exact=t.sum().item(), abs=t.abs().sum().item()))
+        return out
+    T.segsum_diff = wrapped
+    try:
+        yield calls
+    finally:
+        T.segsum_diff = f0
+
+
+def check_mixer_gradients(mixers: dict, calls: list, flat_tol: float):
+    """mixers: name -> dict(rel = error of mix_factor.grad against fp32 autograd, cond = sum|terms| / |sum| of its d(alpha)).
+    (1) every captured kernel call equals the fp64 sum of its own inputs to fp32 accumulation accuracy, measured against the
+    sum of the absolute terms (so the statement holds at any conditioning); (2) where the sum is reasonably conditioned
+    (cond < 400) the gradient meets the flat tolerance.  For the badly conditioned sums (a -9.7 out of +-1e4 terms) what is
+    left beyond (1) is the bf16 rounding of the activations and incoming gradients, which have their own tolerances."""
+    worst_kernel = max((abs(c["kernel"] - c["exact"]) / max(c["abs"], 1e-300) for c in calls), default=0.0)
+    assert len(calls) >= len(mixers) and worst_kernel < 2e-6, (len(calls), len(mixers), worst_kernel)
+    for c in calls:
+        if c["abs"] < 50 * abs(c["exact"]):
+            assert abs(c["kernel"] - c["exact"]) < 1e-4 * abs(c["exact"]), c
+    for n, v in mixers.items():
+        if v["cond"] < 400:
+            assert v["rel"] < flat_tol, (n, v)
+    return worst_kernel

@@ -328,6 +328,30 @@ def _oracle_grads(sd, cfg, inp, wgt, dev, mixer_cond=None):
     return ref.detach(), {k: v.grad for k, v in sdo.items() if torch.is_tensor(v) and v.requires_grad}
 
 
+def test_segsum_diff_kernel_exact_on_its_own_inputs(dev):
+    """dwm_segsum_diff (per-group column sums of dy * (a - b): the d(alpha) of the AlphaBlender mixers) against the fp64 sum
+    of the SAME bf16 inputs: a well conditioned case (every term positive: relative error <= 1e-4) and a heavily cancelling one
+    (error measured against the sum of the absolute terms, which is what fp32 accumulation can promise)"""
+    from opendwm_amd import train_ops as T
+    g = torch.Generator().manual_seed(3)
+    rows, cols, rpg = 4 * 448, 1536, 448
+    a = torch.randn(rows, cols, generator=g).to(dev).to(bf16)
+    b = torch.randn(rows, cols, generator=g).to(dev).to(bf16)
+    dy_mag = torch.rand(rows, cols, generator=g).to(dev)
+    res = {}
+    for name, dy in (("aligned", (dy_mag * torch.sign(a.float() - b.float())).to(bf16)),
+                     ("cancelling", (torch.randn(rows, cols, generator=g).to(dev) * 1e-2).to(bf16))):
+        out = T.segsum_diff(dy, a, b, rows_per_group=rpg).double()
+        t = (dy.double() * (a.double() - b.double())).view(rows // rpg, rpg, cols)
+        exact, tabs = t.sum(1), t.abs().sum(1)
+        res[name] = dict(rel_to_sum=((out - exact).abs().sum() / exact.abs().sum()).item(),
+                         rel_to_abs_terms=((out - exact).abs().max() / tabs.max()).item(),
+                         conditioning=(tabs.sum() / exact.sum().abs()).item())
+    _log("segsum_diff_exactness", **res)
+    assert res["aligned"]["rel_to_sum"] < 1e-4 and res["aligned"]["rel_to_abs_terms"] < 2e-6
+    assert res["cancelling"]["rel_to_abs_terms"] < 2e-6
+
+
 @pytest.mark.parametrize("tt", ["rowwise", "pointwise"])
 def test_model_gradients_vs_oracle(dev, tt):
     """d(loss)/d(every parameter) of the HIP training path (checkpointed block Functions, bf16) against fp32 autograd
@@ -350,7 +374,9 @@ def test_model_gradients_vs_oracle(dev, tt):
     out = train.forward_train(m, kw.pop("sample"), kw.pop("timestep"), kw.pop("encoder_hidden_states"), kw.pop("pooled_projections"),
                               crossview_attention_mask=kw.get("crossview_attention_mask"), added_time_ids=kw.get("added_time_ids"))
     e_fwd = rel_err(out, ref)
-    (out.float() * wgt).sum().backward()
+    from tests.common import capture_segsum_diff, check_mixer_gradients
+    with capture_segsum_diff() as seg_calls:
+        (out.float() * wgt).sum().backward()
     errs, num, den, missing = {}, 0.0, 0.0, []
     for name, p in m.named_parameters():
         if name not in gref or gref[name] is None:
@@ -365,16 +391,15 @@ def test_model_gradients_vs_oracle(dev, tt):
     glob = (num / den) ** 0.5
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     mixers = {n: dict(rel=errs[n], cond=cond[n]) for n in cond}
-    _log("model_gradients", temporal=tt, fwd=e_fwd, global_rel=glob, worst=worst, n_params=len(errs), missing=missing, mixers=mixers)
+    # scalar mixer parameters: d(alpha) = <dy, h - block(h)> is ONE heavily cancelling sum over every activation of the block
+    # (fp32 difference and accumulation in dwm_segsum_diff): the kernel is held against the fp64 sum of its own inputs (at any
+    # conditioning), the gradient against the flat 5e-2 where the sum is reasonably conditioned
+    wk = check_mixer_gradients(mixers, seg_calls, 5e-2)
+    _log("model_gradients", temporal=tt, fwd=e_fwd, global_rel=glob, worst=worst, n_params=len(errs), missing=missing, mixers=mixers,
+         segsum_kernel_vs_own_inputs=wk)
     assert not missing, missing
     assert e_fwd < 2e-2 and glob < 3e-2, (glob, worst)
     assert all(v < 0.15 for n, v in errs.items() if n not in cond), worst
-    # scalar mixer parameters: d(alpha) = <dy, h - block(h)> is ONE heavily cancelling sum over every activation of the block
-    # (fp32 difference and accumulation in dwm_segsum_diff).  Held to 5e-2 where the sum is reasonably conditioned
-    # (sum|terms| / |sum| <= 400); beyond that the bf16 rounding of dy alone - everything else exact - moves the value by
-    # ~1.3e-5 x the conditioning (scripts/alpha_grad_conditioning.py: 3.9e-2 at 2900), so the bound scales with it
-    for n, v in mixers.items():
-        assert v["rel"] < max(5e-2, 1.25e-4 * v["cond"]), (n, v)
 
 
 def test_adamw_step_updates_shadows(dev):
