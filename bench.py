@@ -199,13 +199,24 @@ class KernelTimer:
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (scripts/pmc_traffic.sh -> profiles/r2_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
+    (scripts/pmc_traffic.sh -> profiles/r3_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
     Counters cannot be collected inside the timed run, so the bench line cites the committed measurement."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-    try:
-        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for name in PMC_FILES:
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
+
+
+PMC_FILES = ("r3_pmc_traffic.json", "r2_pmc_traffic.json")
+
+
+def pmc_source() -> str:
+    for name in PMC_FILES:
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            return "profiles/" + name
+    return "none"
 
 
 def cpu_baseline(threads: int, full_flops: float = None):
@@ -341,7 +352,7 @@ def main_unet(args):
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": None, "launches": gm.get("launches"),
                          "avg_launch_us": gm.get("avg_us"), "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
-            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel (self / row-wise)", "achieved": at.get("tflops"),
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_res_kernel / attn_fwd_kernel (self / row-wise)", "achieved": at.get("tflops"),
                                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
                                    "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms},
@@ -720,11 +731,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_bf16_kernel"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r2_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, " + pmc_source() + ")",
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
-            "roofline_attention": {"bound": "mfma", "kernel": "attn_fwd_kernel (joint L=602, dual L=448, row-wise temporal L=448)",
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_res_kernel (K / V of a head resident in LDS; joint L=602, dual L=448, row-wise temporal L=448)",
                                    "achieved": at.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),

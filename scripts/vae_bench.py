@@ -25,3 +25,22 @@ for chunk in (8, 12, 24):
     dt = time.perf_counter() - t0
     print(json.dumps({"vae_decode_96img_256x448": round(dt, 4), "chunk": chunk, "img_per_s": round(96 / dt, 1),
                       "finite": bool(torch.isfinite(y.float()).all())}))
+# roofline line: the convolutions (implicit GEMMs of dwm_gemm_bf16) timed with HIP events inside one decode, the rest of the
+# decode (GroupNorm / SiLU / upsampling: HBM-bound passes over the activations) as the remainder
+timer = bench.KernelTimer().install()
+timer.enabled = True
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+vae.decode(z96, chunk=12)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+timer.enabled = False
+g = timer.summary().get("gemm", {})
+timer.uninstall()
+print(json.dumps({"roofline": {"workload": "SD 3.5 VAE decode, 96 images of 256x448 (one 6-view x 16-frame sample), chunk 12",
+                               "bound": "mfma", "kernel": "gemm_bf16_kernel (3x3 convolutions as implicit GEMMs, 1x1 convolutions, attention projections)",
+                               "achieved": g.get("tflops"), "peak": bench.PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": (g.get("tflops") or 0.0) / bench.PEAK_BF16_TFLOPS, "launches": g.get("launches"),
+                               "gemm_ms": g.get("ms"), "decode_ms_with_event_overhead": 1e3 * dt,
+                               "gemm_share_of_decode": (g.get("ms") or 0.0) / (1e3 * dt),
+                               "whole_decode_mfma_frac": (g.get("flops") or 0.0) / dt / (bench.PEAK_BF16_TFLOPS * 1e12)}}))
