@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 14
+#define DWM_ABI_VERSION 15
 int dwm_abi_version(void);
 /* SHA-256 (hex) of the sources this library was built from (csrc .hip and .h files + this header, in sorted order), as
  * computed by opendwm_amd/build.py; the Python binding compares it with the sources it finds next to itself and refuses a
@@ -115,6 +115,10 @@ typedef struct dwm_gemm_args {
      * that the next GEMM reads.  Keeps a chain of residual blocks from accumulating one bf16 storage rounding per block (the
      * layout ImageAdapter, src/dwm/models/adapters.py:40-60: its input - and so its error - is the same at every denoise step). */
     void* C32; int64_t ldc32;
+    /* tile configuration: 0 = automatic, 1 = 256 x 256 x 64 tiles (one 8-wave workgroup per CU), 2 = 256 x 128 x 32 tiles
+     * (two 4-wave workgroups per CU; chosen automatically where it cuts the padded columns, e.g. N = 320 / 640; not with
+     * C32; split-K grids keep the 256 x 256 tile) */
+    int32_t tile;
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);

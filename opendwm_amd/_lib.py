@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DWM_HIP_LIB") or os.path.join(HERE, "libdwm_hip.so")      # DWM_HIP_LIB: another build of the same ABI (A/B measurements)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("tap_shift", _i64 * 27),
         ("workspace", _vp), ("workspace_bytes", _i64), ("split_k", _i32),
         ("C32", _vp), ("ldc32", _i64),
+        ("tile", _i32),
     ]
 
 

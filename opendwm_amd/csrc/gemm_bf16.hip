@@ -37,6 +37,21 @@ constexpr int A_STAGES = 3, W_STAGES = 2;          // the activation operand is 
 constexpr int W_BASE = A_STAGES * TILE_BYTES;
 constexpr int LDS_BYTES = (A_STAGES + W_STAGES) * TILE_BYTES;   // 160 KiB: the whole LDS of a CU
 
+// Tile configurations of gemm_bf16_kernel (template parameter TC).
+//   0: the 256 x 256 x 64 tile described above (the constants above), one 8-wave workgroup per CU.
+//   1: 256 x 128 x 32, four waves laid out 2 x 2 with the SAME 128 x 64 wave tile (so the epilogues are shared line for line),
+//      three stages of each operand = 72 KiB and 256 VGPRs per wave: TWO workgroups per CU.  They run out of phase, so one
+//      workgroup's epilogue (VALU / LDS transpose / stores, no MFMA) sits under the other one's main loop, and a workgroup
+//      waiting at its K-step barrier leaves the matrix pipe to the other.  Costs: 1.5 x the LDS-DMA bytes per flop and
+//      one barrier per 16 instead of 32 MFMAs.  LDS image: [rows][4 x 16-B chunks], chunk XOR-swizzled by ((row >> 2) & 3)
+//      (16 consecutive rows x one logical chunk cover the 64 banks exactly once).  Also the better fit for N = 320 / 640
+//      (SD 2.1 UNet levels): 17 % / 0 % padded columns instead of 37 % / 17 %.
+template <int TC> struct TileCfg;
+template <> struct TileCfg<0> { static constexpr int bm = 256, bn = 256, bk = 64, nwn = 4, nwaves = 8, ast = A_STAGES, wst = W_STAGES; };
+template <> struct TileCfg<1> { static constexpr int bm = 256, bn = 128, bk = 32, nwn = 2, nwaves = 4, ast = 3, wst = 3; };
+template <int TC> constexpr int tile_lds_bytes() { return (TileCfg<TC>::ast * TileCfg<TC>::bm + TileCfg<TC>::wst * TileCfg<TC>::bn) * TileCfg<TC>::bk * 2; }
+static_assert(tile_lds_bytes<0>() == LDS_BYTES && 2 * tile_lds_bytes<1>() <= 160 * 1024, "LDS budget");
+
 struct DevRowMap {
     FastDiv rw, rh;
     int64_t rpitch, ipitch, origin;
@@ -70,14 +85,19 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
 // result is written to `C32` in fp32 (in place over `res` is fine: a lane reads exactly the elements it writes) AND, rounded, to
 // the bf16 matrix C that the next GEMM reads.  For chains of residual blocks whose bf16 storage rounding would otherwise
 // accumulate block after block (the layout ImageAdapter: 12 resnets, step-invariant input, hence a step-invariant error).
-template <int EPI, bool FAST = false, bool RF32 = false>
-__global__ void __launch_bounds__(512, 2)
+template <int EPI, bool FAST = false, bool RF32 = false, int TC = 0>
+__global__ void __launch_bounds__(TileCfg<TC>::nwaves * 64, 2)
 gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
-    constexpr int NWN = 4;                       // wave columns of the 2 x 4 wave grid
-    constexpr int NTHREADS = 128 * NWN;
-    constexpr int WCOLS = BN / NWN;              // output columns per wave: 64 / 128
-    constexpr int NTW = WCOLS / 32;              // 32-column accumulator tiles per wave: 2 / 4
-    constexpr int NJ = BM / (NTHREADS / 8);      // staging rounds per operand tile: 4 / 8
+    using T = TileCfg<TC>;
+    constexpr int BM = T::bm, BN = T::bn, BK = T::bk;        // (shadow the file-level constants of configuration 0)
+    constexpr int NWN = T::nwn;                  // wave columns of the 2 x NWN wave grid
+    constexpr int WCOLS = BN / NWN;              // output columns per wave: 64
+    constexpr int NTW = WCOLS / 32;              // 32-column accumulator tiles per wave: 2
+    constexpr int ROWB = BK * 2;                 // bytes per row of an LDS operand tile: 128 / 64
+    constexpr int A_TILE = BM * ROWB, W_TILE = BN * ROWB;
+    constexpr int A_STAGES = T::ast, W_BASE = A_STAGES * A_TILE;
+    constexpr int NJA = A_TILE / (T::nwaves * 1024), NJW = W_TILE / (T::nwaves * 1024);   // 1-KiB LDS-DMA requests per wave and stage
+    constexpr int RPG = 1024 / ROWB, CPR = ROWB / 16;        // rows per request, 16-B chunks per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -112,15 +132,21 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // ---- staging addresses: wave w copies row groups (w*NJ + j)*8 .. +8, j = 0..NJ-1
     const bf16_t* __restrict__ Ap = (const bf16_t*)p.A;
     const bf16_t* __restrict__ Wp = (const bf16_t*)p.W;
-    const char* a_src[NJ];
-    const char* w_src[NJ];
+    const char* a_src[NJA];
+    const char* w_src[NJW];
+    auto chunk_swz = [](int row) { return TC == 0 ? (row >> 1) & 7 : (row >> 2) & 3; };
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int row = (wave * NJ + j) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);          // logical 16-B chunk this lane fetches
+    for (int j = 0; j < NJA; ++j) {
+        const int row = (wave * NJA + j) * RPG + lane / CPR;
+        const int c = (lane % CPR) ^ chunk_swz(row);          // logical 16-B chunk this lane fetches
         int64_t gm = m0 + row; gm = gm < M ? gm : M - 1;
-        int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
         a_src[j] = (const char*)(Ap + map_row(cp.a, gm) * p.lda + c * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+        const int row = (wave * NJW + j) * RPG + lane / CPR;
+        const int c = (lane % CPR) ^ chunk_swz(row);
+        int64_t gn = n0 + row; gn = gn < N ? gn : N - 1;
         w_src[j] = (const char*)(Wp + gn * K + c * 8);
     }
     // K step kt covers tap t = kt / steps_per_tap and channels (kt % steps_per_tap)*64.. of it; the A
@@ -145,12 +171,13 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment read offsets (bytes) inside a tile: row*128 + ((chunk ^ swz) << 4)
-    const int swz = (lane >> 1) & 7;       // ((row >> 1) & 7) with row = 32*t + (lane & 31)
-    const int a_row_off = (wm * 128 + l31) * 128;
-    const int w_row_off = (wn * WCOLS + l31) * 128;
-    int coff[4];
+    const int swz = chunk_swz(l31);        // rows of a fragment are 32*t + (lane & 31)
+    const int a_row_off = (wm * 128 + l31) * ROWB;
+    const int w_row_off = (wn * WCOLS + l31) * ROWB;
+    constexpr int NKS = BK / 16;           // MFMA K steps per tile: 4 / 2
+    int coff[NKS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + half) ^ swz) << 4;
+    for (int ks = 0; ks < NKS; ++ks) coff[ks] = ((2 * ks + half) ^ swz) << 4;
 
 
     // ---- main loop.  Per K tile: 4 sub-steps x 8 chunks of { NTW/2 MFMAs, one fragment read for the
@@ -160,76 +187,140 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // kt&1 is free for tile kt+2) and its shares of tile kt+1 have landed, so the fragment reads of
     // tile kt+1's first sub-step and the barrier skew hide under the MFMAs of sub-step 3.
     auto stage_a = [&](int buf, int64_t aoff, int j) {
-        glds16(a_src[j] + aoff, smem + buf * TILE_BYTES + ((wave * NJ + j) * 8) * 128);
+        glds16(a_src[j] + aoff, smem + buf * A_TILE + (wave * NJA + j) * 1024);
     };
     auto stage_w = [&](int buf, int64_t koff, int j) {
-        glds16(w_src[j] + koff, smem + W_BASE + buf * TILE_BYTES + ((wave * NJ + j) * 8) * 128);
+        glds16(w_src[j] + koff, smem + W_BASE + buf * W_TILE + (wave * NJW + j) * 1024);
     };
     constexpr int MPC = NTW / 2;                       // MFMAs per chunk
     constexpr int NDS = 4 + NTW;                       // fragment reads per sub-step
     bf16x8 af[2][4], wf[2][NTW];
-    // Request order per wave (loads return in order, so the barrier's counted wait follows it):
-    //   ... A(kt+1) [sub-step 0 of step kt-1], W(kt+1) [sub-step 3 of step kt-1], A(kt+2) [sub-step 0 of step kt] ...
-    // The barrier of step kt needs A(kt+1) and W(kt+1): vmcnt(NJ) leaves exactly the NJ requests of A(kt+2) in flight,
-    // which therefore have almost two K steps to arrive (the activation panel is the operand that streams from HBM);
-    // the weights have one step (they are shared by every row tile and sit in L2).
-    int sa = 0;                                        // A stage of tile kt (kt % 3)
-    {
-        int64_t aoff, koff;
-        tile_offsets(0, aoff, koff);
+    if constexpr (TC == 0) {
+        // Request order per wave (loads return in order, so the barrier's counted wait follows it):
+        //   ... A(kt+1) [sub-step 0 of step kt-1], W(kt+1) [sub-step 3 of step kt-1], A(kt+2) [sub-step 0 of step kt] ...
+        // The barrier of step kt needs A(kt+1) and W(kt+1): vmcnt(NJA) leaves exactly the NJA requests of A(kt+2) in flight,
+        // which therefore have almost two K steps to arrive (the activation panel is the operand that streams from HBM);
+        // the weights have one step (they are shared by every row tile and sit in L2).
+        int sa = 0;                                        // A stage of tile kt (kt % 3)
+        {
+            int64_t aoff, koff;
+            tile_offsets(0, aoff, koff);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { stage_a(0, aoff, j); stage_w(0, koff, j); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        tile_offsets(nk > 1 ? 1 : 0, aoff, koff);
+            for (int j = 0; j < NJA; ++j) { stage_a(0, aoff, j); stage_w(0, koff, j); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            tile_offsets(nk > 1 ? 1 : 0, aoff, koff);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) stage_a(1, aoff, j);
+            for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) stage_w(1, koff, j);
+            for (int j = 0; j < NJA; ++j) stage_w(1, koff, j);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * 128) + coff[0]);
+            for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * 128) + coff[0]);
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + W_BASE + w_row_off + nt * (32 * 128) + coff[0]);
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        const int sa1 = sa == A_STAGES - 1 ? 0 : sa + 1, sa2 = sa1 == A_STAGES - 1 ? 0 : sa1 + 1;
-        const char* la = smem + sa * TILE_BYTES;
-        const char* lb = smem + W_BASE + (kt & 1) * TILE_BYTES;
-        const char* lan = smem + sa1 * TILE_BYTES;                  // tile kt+1
-        const char* lbn = smem + W_BASE + ((kt + 1) & 1) * TILE_BYTES;
-        int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
-        tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (ks == 3 && c == 0) {
-                    // own last fragments read; own shares of A(kt+1) and W(kt+1) landed (A(kt+2) may stay in flight)
-                    // bare s_barrier, not __syncthreads(): the workgroup-scope release fence of __syncthreads() makes the
-                    // compiler append "s_waitcnt vmcnt(0)" (LDS-DMA writes LDS and is tracked by vmcnt), which drains
-                    // A(kt+2) at every K step; the counted wait above is the ordering this barrier needs
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-#pragma unroll
-                for (int u = 0; u < MPC; ++u) {
-                    const int idx = c * MPC + u, mt = idx / NTW, nt = idx % NTW;
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
-                }
-                if (c < NDS) {
-                    const char* fa = ks < 3 ? la : lan;
-                    const char* fb = ks < 3 ? lb : lbn;
-                    const int kn = ks < 3 ? ks + 1 : 0;
-                    if (c < 4) af[(ks + 1) & 1][c] = *(const bf16x8*)(fa + a_row_off + c * (32 * 128) + coff[kn]);
-                    else wf[(ks + 1) & 1][c - 4] = *(const bf16x8*)(fb + w_row_off + (c - 4) * (32 * 128) + coff[kn]);
-                }
-                if (ks == 0 && c < NJ) stage_a(sa2, aoff2, c);                       // A(kt+2): the slot tile kt-1 left
-                if (ks == 3 && c >= 1 && c <= NJ) stage_w(kt & 1, koff2, c - 1);     // W(kt+2): the slot of this tile
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + W_BASE + w_row_off + nt * (32 * 128) + coff[0]);
         }
-        sa = sa1;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int sa1 = sa == A_STAGES - 1 ? 0 : sa + 1, sa2 = sa1 == A_STAGES - 1 ? 0 : sa1 + 1;
+            const char* la = smem + sa * A_TILE;
+            const char* lb = smem + W_BASE + (kt & 1) * A_TILE;
+            const char* lan = smem + sa1 * A_TILE;                  // tile kt+1
+            const char* lbn = smem + W_BASE + ((kt + 1) & 1) * A_TILE;
+            int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
+            tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (ks == 3 && c == 0) {
+                        // own last fragments read; own shares of A(kt+1) and W(kt+1) landed (A(kt+2) may stay in flight)
+                        // bare s_barrier, not __syncthreads(): the workgroup-scope release fence of __syncthreads() makes the
+                        // compiler append "s_waitcnt vmcnt(0)" (LDS-DMA writes LDS and is tracked by vmcnt), which drains
+                        // A(kt+2) at every K step; the counted wait above is the ordering this barrier needs
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJA) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+#pragma unroll
+                    for (int u = 0; u < MPC; ++u) {
+                        const int idx = c * MPC + u, mt = idx / NTW, nt = idx % NTW;
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
+                    }
+                    if (c < NDS) {
+                        const char* fa = ks < 3 ? la : lan;
+                        const char* fb = ks < 3 ? lb : lbn;
+                        const int kn = ks < 3 ? ks + 1 : 0;
+                        if (c < 4) af[(ks + 1) & 1][c] = *(const bf16x8*)(fa + a_row_off + c * (32 * 128) + coff[kn]);
+                        else wf[(ks + 1) & 1][c - 4] = *(const bf16x8*)(fb + w_row_off + (c - 4) * (32 * 128) + coff[kn]);
+                    }
+                    if (ks == 0 && c < NJA) stage_a(sa2, aoff2, c);                       // A(kt+2): the slot tile kt-1 left
+                    if (ks == 3 && c >= 1 && c <= NJA) stage_w(kt & 1, koff2, c - 1);     // W(kt+2): the slot of this tile
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            sa = sa1;
+        }
+    } else {
+        // Configuration 1 (BK = 32: two MFMA K steps per tile).  Per K step and wave: sub-step 0 = 8 MFMAs on the first
+        // half of tile kt while the second-half fragments are read and the 6 requests of tile kt+2 are issued (into the slot
+        // tile kt-1 left: every wave passed the barrier of step kt-1 after its last reads of it); sub-step 1 = counted wait
+        // (own shares of tile kt+1 landed, tile kt+2 stays in flight) + barrier, then 8 MFMAs on the second half while the
+        // first-half fragments of tile kt+1 are read.  Both operands are requested two steps ahead (3 + 3 stages).
+        // Fragment read order = first use: W0 A0 W1 A1 A2 A3 (MFMA c uses A[c / 2], W[c % 2]).
+        static_assert(TC == 0 || (NJA + NJW <= 8 && NKS == 2 && T::wst == T::ast), "configuration 1 main loop");
+        int sa = 0;
+        {
+            int64_t aoff, koff;
+            tile_offsets(0, aoff, koff);
+#pragma unroll
+            for (int j = 0; j < NJA; ++j) stage_a(0, aoff, j);
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) stage_w(0, koff, j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            tile_offsets(nk > 1 ? 1 : 0, aoff, koff);
+#pragma unroll
+            for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) stage_w(1, koff, j);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * ROWB) + coff[0]);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + W_BASE + w_row_off + nt * (32 * ROWB) + coff[0]);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int sa1 = sa == A_STAGES - 1 ? 0 : sa + 1, sa2 = sa1 == A_STAGES - 1 ? 0 : sa1 + 1;
+            const char* la = smem + sa * A_TILE;
+            const char* lb = smem + W_BASE + sa * W_TILE;
+            const char* lan = smem + sa1 * A_TILE;                      // tile kt+1
+            const char* lbn = smem + W_BASE + sa1 * W_TILE;
+            int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
+            tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (ks == 1 && c == 0) {
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJA + NJW) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                    acc[c >> 1][c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][c & 1], af[ks][c >> 1], acc[c >> 1][c & 1], 0, 0, 0);
+                    if (c < 6) {
+                        const char* fa = ks == 0 ? la : lan;
+                        const char* fb = ks == 0 ? lb : lbn;
+                        const int kn = ks ^ 1;                         // sub-step 0 reads the second half of this tile, 1 the first half of the next
+                        const bool is_w = c == 0 || c == 2;
+                        const int fi = c == 0 ? 0 : c == 1 ? 0 : c == 2 ? 1 : c - 2;
+                        if (is_w) wf[kn][fi] = *(const bf16x8*)(fb + w_row_off + fi * (32 * ROWB) + coff[kn]);
+                        else af[kn][fi] = *(const bf16x8*)(fa + a_row_off + fi * (32 * ROWB) + coff[kn]);
+                    }
+                    if (ks == 0 && c < NJA) stage_a(sa2, aoff2, c);
+                    if (ks == 0 && c >= NJA && c < NJA + NJW) stage_w(sa2, koff2, c - NJA);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            sa = sa1;
+        }
     }
     // bias (and, RMSHEAD, per-column norm weights) of this lane's 2 x 16 columns in the MFMA layout, requested NOW so that
     // the round trip overlaps the drain of the last MFMAs and the barrier below.  All 8 (16) loads are issued back to back,
@@ -840,7 +931,8 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
     for (int t = 0; t < 27; ++t) cp.tap_shift[t] = (a->ntaps > 0 && t < ntaps) ? a->tap_shift[t] : 0;
     if (a->lda < kpt) return DWM_EINVAL;
-    const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
+    if (a->tile < 0 || a->tile > 2) return DWM_EINVAL;
+    int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     // ---- split-K: a grid that fills less than half of the 256 CUs and a long K.  One K range per workgroup,
@@ -883,17 +975,35 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }
-    const dim3 grid((unsigned)(ntm * ntn)), block(512);
-#define DWM_LAUNCH(EPI, FAST)                                                                        \
+    // ---- tile configuration (TileCfg): 256 x 128 tiles (two workgroups per CU) on request, or automatically where they
+    // cut the padded columns (N = 320 -> 384 instead of 512, N = 640 -> 640 instead of 768: the SD 2.1 UNet levels)
+    int tc = a->tile == 2 ? 1 : 0;
+    if (a->tile == 0 && a->C32 == nullptr) {
+        const int64_t c256 = (a->N + 255) / 256 * 256, c128 = (a->N + 127) / 128 * 128;
+        if (c128 < c256) tc = 1;
+    }
+    if (DWM_RESERVED(a->reserved) & 0x200) tc = 1;
+    if (tc == 1 && a->C32 != nullptr) return DWM_EUNSUPPORTED;
+    if (tc == 1) {
+        ntn = (int)((a->N + TileCfg<1>::bn - 1) / TileCfg<1>::bn);
+        cp.steps_per_tap = (int)(kpt / TileCfg<1>::bk);
+        cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
+    }
+    const dim3 grid((unsigned)(ntm * ntn)), block(tc == 1 ? TileCfg<1>::nwaves * 64 : 512);
+#define DWM_LAUNCH_TC(EPI, FAST, TC_)                                                                \
     do {                                                                                             \
         static bool attr_set = false;                                                                \
         if (!attr_set) {                                                                             \
-            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, FAST>,                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);          \
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, FAST, false, TC_>,            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, tile_lds_bytes<TC_>()); \
             if (e != hipSuccess) return (int)e;                                                      \
             attr_set = true;                                                                         \
         }                                                                                            \
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, FAST>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn); \
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, FAST, false, TC_>), grid, block, tile_lds_bytes<TC_>(), s, *a, cp, ntm, ntn); \
+    } while (0)
+#define DWM_LAUNCH(EPI, FAST)                                                                        \
+    do {                                                                                             \
+        if (tc == 1) DWM_LAUNCH_TC(EPI, FAST, 1); else DWM_LAUNCH_TC(EPI, FAST, 0);                  \
     } while (0)
     // the transformer blocks' linear layers (see FAST above); reserved bit 2 keeps the general kernels (A/B measurements)
     const int64_t lim = 1ll << 31;
@@ -924,6 +1034,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     }
 #undef DWM_LAUNCH2
 #undef DWM_LAUNCH
+#undef DWM_LAUNCH_TC
     e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }

@@ -4,6 +4,7 @@ function raises if its tensors are not bf16 CUDA(HIP) tensors — there is no fa
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -163,6 +164,10 @@ def _overlaps(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a0 < b1 and b0 < a1
 
 
+# tuning knob (A/B measurements of whole models): the tile configuration of GEMM calls that do not name one
+_DEFAULT_TILE = int(os.environ.get("DWM_GEMM_TILE", "0"))
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, epilogue: int = EPI_PLAIN, act: int = ACT_NONE,
          gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
@@ -172,8 +177,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
          a_grid=None, conv3x3: bool = False, stride2=False, conv_taps: Optional[list] = None,
          c_grid=None, out32: Optional[torch.Tensor] = None,
-         rows: Optional[int] = None, split_k: int = 0, _debug: int = 0) -> torch.Tensor:
+         rows: Optional[int] = None, split_k: int = 0, tile: int = 0, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
+    tile: 0 = the kernel's choice, 1 = 256 x 256 tiles, 2 = 256 x 128 tiles (two workgroups per CU).
     a_grid: A is a padded token grid (PaddedGrid.rows x C); M = its pixel count; with conv3x3 the K
     axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids.
     split_k: 0 = the kernel's rule (small tile grid + long K -> K ranges, fp32 partials, ordered reduction),
@@ -263,6 +269,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                 raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
     g.split_k = split_k
+    g.tile = tile or _DEFAULT_TILE
     # split-K scratch (fp32 partial tiles): only handed over when the kernel's own rule can take it
     if split_k != 1 and epilogue in (EPI_PLAIN, EPI_RESID) and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and K >= 1024:
         ws = _gemm_workspace(a.device)

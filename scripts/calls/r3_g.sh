@@ -1,0 +1,21 @@
+#!/bin/bash
+# gpurun call G of round 3: the 256 x 128 GEMM tile (two workgroups per CU) - parity, per-shape A/B, whole-step A/B
+TAG=${1:-r3g}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+echo "== pytest gemm"; date
+timeout 900 python -m pytest tests/test_hip_gpu.py -m gpu -q -x -k "gemm" -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest.log | cut -c1-300
+echo "== microbench tiles"; date
+timeout 600 python scripts/microbench.py gemmt > $OUT/gemm_tiles.log 2>&1; echo "exit $?"; cat $OUT/gemm_tiles.log | cut -c1-250
+echo "== bench A/B"; date
+for t in 0 2 0 2; do
+  DWM_GEMM_TILE=$t timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-text-only-leg 2>> $OUT/bench.err | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('tile $t', d['ms_per_step'], d['roofline']['achieved'], d['config']['finite'])
+" | tee -a $OUT/bench_ab.log
+done
+date

@@ -137,6 +137,41 @@ def bench_gemm(dbg_list=(0, 1)):
                           "hipblaslt_plain_tflops": round(fl / ms_t / 1e9, 1)}), flush=True)
 
 
+def bench_gemm_tiles():
+    """256 x 256 (one workgroup per CU) against 256 x 128 (two per CU) on the headline shapes and the UNet's N = 320 / 640"""
+    from opendwm_amd.blocks import geglu_pack
+    shapes = [("qkv rmshead", 86016, 4608, 1536, "rms"), ("out-proj resid", 86016, 1536, 1536, "resid"),
+              ("ff1 gelu", 86016, 6144, 1536, "gelu"), ("ff2 resid", 86016, 1536, 6144, "resid"),
+              ("vt geglu", 86016, 12288, 1536, "geglu"), ("ctx qkv", 29568, 4608, 1536, "rms"),
+              ("adapter conv K=13824", 86016, 1536, 13824, "plain"),
+              ("unet N=320 K=2880", 129024, 320, 2880, "plain"), ("unet N=320 K=320", 129024, 320, 320, "resid"),
+              ("unet geglu N=2560 K=320", 129024, 2560, 320, "geglu"), ("unet N=640 K=5760", 32256, 640, 5760, "plain"),
+              ("unet N=1280 K=1280", 8064, 1280, 1280, "plain")]
+    for name, M, N, K, kind in shapes:
+        a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+        fl = 2.0 * M * N * K
+        res = {}
+        for di, tile in enumerate((1, 1, 2, 1, 2)):
+            if kind == "rms":
+                rms = rnd(2 * N // 3) * 0.1 + 1
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=2 * N // 3, rms_eps=1e-6, tile=tile, split_k=1)
+            elif kind == "resid":
+                gate, res_t = rnd(M // 448 + 1, N), rnd(M, N)
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=res_t, out=res_t, tile=tile, split_k=1)
+            elif kind == "gelu":
+                f = lambda: ops.gemm(a, w, b, act=ops.ACT_GELU_TANH, tile=tile, split_k=1)
+            elif kind == "geglu":
+                wp, bp = geglu_pack(w), geglu_pack(b)
+                f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU, tile=tile, split_k=1)
+            else:
+                f = lambda: ops.gemm(a, w, b, tile=tile, split_k=1)
+            ms = timeit(f)
+            if di == 0:
+                continue
+            res.setdefault("256x256" if tile == 1 else "256x128", []).append(round(fl / ms / 1e9, 1))
+        print(json.dumps({"kernel": "gemm_tiles", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -166,5 +201,7 @@ if __name__ == "__main__":
         bench_gemm()
     if "gemmx" in what:                  # reserved bit 2: the general RESID epilogue instead of its FAST form; bit 0: no epilogue
         bench_gemm((0, 4, 1))
+    if "gemmt" in what:
+        bench_gemm_tiles()
     if "ln" in what:
         bench_ln()

@@ -138,6 +138,74 @@ def test_gemm_rmshead(dev, M, heads, K, biased):
     assert rel_err(qk, ref[:, :2 * D]) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (700, 320, 128), (1000, 1536, 1536), (2048, 640, 2880), (77, 8, 64), (4096, 4608, 1536),
+                                   (513, 1160, 6144)])
+def test_gemm_tile_256x128_equals_256x256(dev, M, N, K):
+    """Tile configuration 2 (256 x 128 x 32, two 4-wave workgroups per CU) accumulates every output element in the same
+    order as the 256 x 256 x 64 tile (the same MFMA K steps one after the other), so all epilogues must agree BIT FOR BIT;
+    the plain form is also held against the fp32 product."""
+    from opendwm_amd import ops as ops_
+    from opendwm_amd.blocks import geglu_pack
+    import functools, types
+    # split_k = 1: small grids with a long K would otherwise take the split-K path (always 256 x 256 tiles) in both calls
+    ops = types.SimpleNamespace(**{k: getattr(ops_, k) for k in dir(ops_) if k.isupper()}, gemm=functools.partial(ops_.gemm, split_k=1))
+    a, w, b = _rand((M, K), dev, 1), _rand((N, K), dev, 2, K ** -0.5), _rand((N,), dev, 3)
+    ref = a.float() @ w.float().T + b.float()
+    o2 = ops.gemm(a, w, b, tile=2)
+    e = rel_err(o2, ref)
+    _log("gemm_tile2_plain", M=M, N=N, K=K, rel=e)
+    assert e < TOL_KERNEL
+    assert torch.equal(o2, ops.gemm(a, w, b, tile=1))
+    for act in (ops.ACT_GELU_TANH, ops.ACT_SILU):
+        assert torch.equal(ops.gemm(a, w, b, act=act, tile=2), ops.gemm(a, w, b, act=act, tile=1))
+    rpg = 100
+    groups = (M + rpg - 1) // rpg
+    gate, res, blend = _rand((groups, N), dev, 4), _rand((M, N), dev, 5), _rand((M, N), dev, 6)
+    alpha = torch.rand(groups, device=dev)
+    pos = _rand((rpg, N), dev, 7)
+    for kw in (dict(gate=gate, rows_per_gate=rpg, res=res), dict(res=res, blend=blend, alpha=alpha, rows_per_alpha=rpg),
+               dict(res=pos, res_mod=rpg), dict(res=res, act=ops.ACT_SILU)):
+        o1 = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, tile=1, **kw)
+        assert torch.equal(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, tile=2, **kw), o1), kw.keys()
+    r2 = res.clone()                                # in place over the residual
+    ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=rpg, res=r2, out=r2, tile=2)
+    assert torch.equal(r2, ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=rpg, res=res, tile=1))
+    if N % 128 == 0:
+        wg, bg = geglu_pack(w), geglu_pack(b)
+        assert torch.equal(ops.gemm(a, wg, bg, epilogue=ops.EPI_GEGLU, tile=2), ops.gemm(a, wg, bg, epilogue=ops.EPI_GEGLU, tile=1))
+    if N % 192 == 0:
+        D = N // 3
+        rms = (_rand((2 * D,), dev, 8) * 0.2 + 1).contiguous()
+        kw = dict(epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=2 * D, rms_eps=1e-6)
+        assert torch.equal(ops.gemm(a, w, b, tile=2, **kw), ops.gemm(a, w, b, tile=1, **kw))
+
+
+@pytest.mark.parametrize("I,h,w,C,N", [(3, 16, 28, 128, 320), (2, 4, 6, 64, 192), (7, 9, 5, 320, 640)])
+def test_gemm_tile_256x128_implicit_conv(dev, I, h, w, C, N):
+    """the implicit 3x3 convolution (tap-shifted LDS-DMA sources, K steps of 32 inside a tap) and the padded output grid on
+    the 256 x 128 tile; N = 320 / 640 take it automatically (fewer padded columns)"""
+    from opendwm_amd import ops
+    grid = ops.PaddedGrid(I, h, w)
+    x = _rand((I, C, h, w), dev, 1)
+    wt, b = _rand((N, C, 3, 3), dev, 2, (9 * C) ** -0.5), _rand((N,), dev, 3)
+    ref = F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).permute(0, 2, 3, 1).reshape(-1, N)
+    idx = grid.interior_index().to(dev)
+    xp = torch.zeros((grid.rows, C), dtype=bf16, device=dev)
+    xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    wp = wt.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    o2 = ops.gemm(xp, wp, b, act=ops.ACT_SILU, a_grid=grid, conv3x3=True, tile=2)
+    e = rel_err(o2, ref)
+    _log("gemm_tile2_conv3x3", I=I, h=h, w=w, C=C, N=N, rel=e)
+    assert e < TOL_KERNEL
+    assert torch.equal(o2, ops.gemm(xp, wp, b, act=ops.ACT_SILU, a_grid=grid, conv3x3=True, tile=1, split_k=1))
+    assert torch.equal(o2, ops.gemm(xp, wp, b, act=ops.ACT_SILU, a_grid=grid, conv3x3=True, split_k=1))       # automatic choice
+    w1 = _rand((C, N), dev, 4, N ** -0.5)
+    r1, r2 = xp.clone(), xp.clone()
+    ops.gemm(o2, w1, None, epilogue=ops.EPI_RESID, res=r1, out=r1, c_grid=grid, tile=1, split_k=1)
+    ops.gemm(o2, w1, None, epilogue=ops.EPI_RESID, res=r2, out=r2, c_grid=grid, tile=2)
+    assert torch.equal(r1, r2)
+
+
 @pytest.mark.parametrize("M,N,K,split", [(300, 1280, 4096, 0), (72, 1280, 5120, 0), (512, 512, 2048, 5), (1536, 1536, 8192, 0),
                                          (77, 8, 1024, 2)])
 def test_gemm_split_k(dev, M, N, K, split):
