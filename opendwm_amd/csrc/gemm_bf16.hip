@@ -24,11 +24,13 @@
 namespace {
 
 // dwm_gemm_args.reserved carries ablation / tuning knobs of development builds (-DDWM_DEV_HOOKS: bit 0 main loop without
-// epilogue, bit 1 no stores, bit 2 general instead of FAST kernels, bits 4-8 group height); the shipped object ignores it
+// epilogue, bit 1 no stores, bit 2 general instead of FAST kernels, bits 4-8 group height, bit 9 the 256 x 128 tile, bit 10 pad its LDS); the shipped object ignores it
 #ifdef DWM_DEV_HOOKS
 #define DWM_RESERVED(x_) (x_)
+#define DWM_DEV_LDS_PAD 16384      /* bit 10: this much unused LDS on top, so that only ONE 256 x 128 workgroup fits a CU */
 #else
 #define DWM_RESERVED(x_) 0
+#define DWM_DEV_LDS_PAD 0
 #endif
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -155,11 +157,28 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     const int nk_all = (int)(K / BK);
     const int kt0 = EPI == EPI_SPLITK ? (int)((int64_t)slice * nk_all / cp.ksplit) : 0;
     const int nk = EPI == EPI_SPLITK ? (int)((int64_t)(slice + 1) * nk_all / cp.ksplit) - kt0 : nk_all;
-    auto tile_offsets = [&](int kt, int64_t& aoff, int64_t& koff) {
-        kt += kt0;
-        koff = (int64_t)kt * (BK * 2);
-        const uint32_t tap = fdiv((uint32_t)kt, cp.fd_steps);
-        aoff = cp.tap_shift[tap] * lda_bytes + (int64_t)(kt - tap * cp.steps_per_tap) * (BK * 2);
+    // The walk over K: wave-uniform byte offsets of the A / W sources of one K step, advanced step by step.  Inside a tap both
+    // simply move on by one tile; the tap table is read at tap boundaries only (a plain GEMM has none), so no K step waits
+    // for a scalar load and the per-lane source address is ONE 64-bit add per request.
+    int64_t walk_a, walk_w;
+    int walk_left, walk_tap;                           // K steps left in this tap (this one included), tap index
+    auto walk_init = [&]() {
+        const uint32_t tap = fdiv((uint32_t)kt0, cp.fd_steps);
+        const int r = kt0 - (int)tap * cp.steps_per_tap;
+        walk_tap = (int)tap;
+        walk_left = cp.steps_per_tap - r;
+        walk_w = (int64_t)kt0 * (BK * 2);
+        walk_a = cp.tap_shift[tap] * lda_bytes + (int64_t)r * (BK * 2);
+    };
+    auto walk_next = [&]() {
+        walk_w += BK * 2;
+        if (--walk_left == 0) {
+            ++walk_tap;
+            walk_left = cp.steps_per_tap;
+            walk_a = cp.tap_shift[walk_tap] * lda_bytes;
+        } else {
+            walk_a += BK * 2;
+        }
     };
 
     f32x16 acc[4][NTW];
@@ -203,13 +222,14 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         // the weights have one step (they are shared by every row tile and sit in L2).
         int sa = 0;                                        // A stage of tile kt (kt % 3)
         {
-            int64_t aoff, koff;
-            tile_offsets(0, aoff, koff);
+            walk_init();
+            int64_t aoff = walk_a, koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) { stage_a(0, aoff, j); stage_w(0, koff, j); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            tile_offsets(nk > 1 ? 1 : 0, aoff, koff);
+            if (nk > 1) walk_next();
+            aoff = walk_a; koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
 #pragma unroll
@@ -225,8 +245,8 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             const char* lb = smem + W_BASE + (kt & 1) * A_TILE;
             const char* lan = smem + sa1 * A_TILE;                  // tile kt+1
             const char* lbn = smem + W_BASE + ((kt + 1) & 1) * A_TILE;
-            int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
-            tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
+            if (kt + 2 < nk) walk_next();                              // tile kt+2 (past the end: a redundant reload nobody reads)
+            const int64_t aoff2 = walk_a, koff2 = walk_w;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -269,15 +289,16 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         static_assert(TC == 0 || (NJA + NJW <= 8 && NKS == 2 && T::wst == T::ast), "configuration 1 main loop");
         int sa = 0;
         {
-            int64_t aoff, koff;
-            tile_offsets(0, aoff, koff);
+            walk_init();
+            int64_t aoff = walk_a, koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) stage_a(0, aoff, j);
 #pragma unroll
             for (int j = 0; j < NJW; ++j) stage_w(0, koff, j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            tile_offsets(nk > 1 ? 1 : 0, aoff, koff);
+            if (nk > 1) walk_next();
+            aoff = walk_a; koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
 #pragma unroll
@@ -293,8 +314,8 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             const char* lb = smem + W_BASE + sa * W_TILE;
             const char* lan = smem + sa1 * A_TILE;                      // tile kt+1
             const char* lbn = smem + W_BASE + sa1 * W_TILE;
-            int64_t aoff2, koff2;                                      // tile kt+2 (clamped: a redundant reload nobody reads)
-            tile_offsets(kt + 2 < nk ? kt + 2 : nk - 1, aoff2, koff2);
+            if (kt + 2 < nk) walk_next();                              // tile kt+2 (past the end: a redundant reload nobody reads)
+            const int64_t aoff2 = walk_a, koff2 = walk_w;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -976,11 +997,13 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         return e == hipSuccess ? DWM_OK : (int)e;
     }
     // ---- tile configuration (TileCfg): 256 x 128 tiles (two workgroups per CU) on request, or automatically where they
-    // cut the padded columns (N = 320 -> 384 instead of 512, N = 640 -> 640 instead of 768: the SD 2.1 UNet levels)
+    // cut the padded columns (N = 320 -> 384 instead of 512: the SD 2.1 UNet's first level) AND K is short, i.e. the
+    // epilogue's share is large (measured, profiles/README.md: N = 320, K = 320: 1.17 x; with K >= 2880 the 256 x 256
+    // main loop wins although it pads more)
     int tc = a->tile == 2 ? 1 : 0;
     if (a->tile == 0 && a->C32 == nullptr) {
         const int64_t c256 = (a->N + 255) / 256 * 256, c128 = (a->N + 127) / 128 * 128;
-        if (c128 < c256) tc = 1;
+        if (c128 < c256 && a->K <= 640) tc = 1;
     }
     if (DWM_RESERVED(a->reserved) & 0x200) tc = 1;
     if (tc == 1 && a->C32 != nullptr) return DWM_EUNSUPPORTED;
@@ -995,11 +1018,12 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         static bool attr_set = false;                                                                \
         if (!attr_set) {                                                                             \
             e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, FAST, false, TC_>,            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, tile_lds_bytes<TC_>()); \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, tile_lds_bytes<TC_>() + (TC_ ? DWM_DEV_LDS_PAD : 0)); \
             if (e != hipSuccess) return (int)e;                                                      \
             attr_set = true;                                                                         \
         }                                                                                            \
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, FAST, false, TC_>), grid, block, tile_lds_bytes<TC_>(), s, *a, cp, ntm, ntn); \
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, FAST, false, TC_>), grid, block,                   \
+                           tile_lds_bytes<TC_>() + ((TC_ && (DWM_RESERVED(a->reserved) & 0x400)) ? DWM_DEV_LDS_PAD : 0), s, *a, cp, ntm, ntn); \
     } while (0)
 #define DWM_LAUNCH(EPI, FAST)                                                                        \
     do {                                                                                             \

@@ -172,6 +172,32 @@ def bench_gemm_tiles():
         print(json.dumps({"kernel": "gemm_tiles", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
 
 
+def bench_gemm_tiles_dev():
+    """development library only (DWM_HIP_LIB = a -DDWM_DEV_HOOKS build): the 256 x 128 tile with one / two workgroups per CU
+    and both tiles without their epilogue"""
+    from opendwm_amd.blocks import geglu_pack
+    names = {0: "256x256", 1: "256x256 no epilogue", 0x200: "256x128", 0x201: "256x128 no epilogue",
+             0x600: "256x128 one workgroup per CU", 0x601: "256x128 one workgroup per CU, no epilogue"}
+    for name, M, N, K, kind in [("vt geglu", 86016, 12288, 1536, "geglu"), ("ff2 resid", 86016, 1536, 6144, "resid"),
+                                ("plain K=13824", 86016, 1536, 13824, "plain"), ("qkv plain", 86016, 4608, 1536, "plain")]:
+        a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+        fl = 2.0 * M * N * K
+        res = {}
+        for di, dbg in enumerate([0] + list(names)):
+            if kind == "resid":
+                gate, res_t = rnd(M // 448 + 1, N), rnd(M, N)
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=res_t, out=res_t, _debug=dbg, split_k=1)
+            elif kind == "geglu":
+                wp, bp = geglu_pack(w), geglu_pack(b)
+                f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU, _debug=dbg, split_k=1)
+            else:
+                f = lambda: ops.gemm(a, w, b, _debug=dbg, split_k=1)
+            ms = timeit(f)
+            if di:
+                res[names[dbg]] = round(fl / ms / 1e9, 1)
+        print(json.dumps({"kernel": "gemm_tiles_dev", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -203,5 +229,7 @@ if __name__ == "__main__":
         bench_gemm((0, 4, 1))
     if "gemmt" in what:
         bench_gemm_tiles()
+    if "gemmd" in what:
+        bench_gemm_tiles_dev()
     if "ln" in what:
         bench_ln()
