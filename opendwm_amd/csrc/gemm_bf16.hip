@@ -162,20 +162,29 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // for a scalar load and the per-lane source address is ONE 64-bit add per request.
     int64_t walk_a, walk_w;
     int walk_left, walk_tap;                           // K steps left in this tap (this one included), tap index
+    // lane t keeps the byte shift of tap t; a tap boundary fetches it with v_readlane.  (A scalar load anywhere in the loop -
+    // even on this rare path - makes the compiler wait for ALL outstanding LDS reads at every use of a fragment: scalar
+    // loads return out of order on the counter they share with the LDS, so no counted lgkmcnt wait is possible any more.)
+    const int64_t tap_bytes = cp.tap_shift[lane < 27 ? lane : 0] * lda_bytes;
+    auto tap_offset = [&](int tap) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tap_bytes, tap);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)tap_bytes >> 32), tap);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
     auto walk_init = [&]() {
         const uint32_t tap = fdiv((uint32_t)kt0, cp.fd_steps);
         const int r = kt0 - (int)tap * cp.steps_per_tap;
         walk_tap = (int)tap;
         walk_left = cp.steps_per_tap - r;
         walk_w = (int64_t)kt0 * (BK * 2);
-        walk_a = cp.tap_shift[tap] * lda_bytes + (int64_t)r * (BK * 2);
+        walk_a = tap_offset(walk_tap) + (int64_t)r * (BK * 2);
     };
     auto walk_next = [&]() {
         walk_w += BK * 2;
         if (--walk_left == 0) {
             ++walk_tap;
             walk_left = cp.steps_per_tap;
-            walk_a = cp.tap_shift[walk_tap] * lda_bytes;
+            walk_a = tap_offset(walk_tap);
         } else {
             walk_a += BK * 2;
         }
@@ -205,11 +214,21 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // last sub-step: by then every wave holds its last fragments of tile kt in registers (the weight slot
     // kt&1 is free for tile kt+2) and its shares of tile kt+1 have landed, so the fragment reads of
     // tile kt+1's first sub-step and the barrier skew hide under the MFMAs of sub-step 3.
+    // The LDS-DMA requests go through inline asm.  The compiler models global_load_lds as a FLAT access that may touch the LDS,
+    // and with one of those "pending" it degrades every later LDS wait to lgkmcnt(0): each sub-step then began by draining all
+    // six fragment reads, the newest issued two MFMAs earlier.  Opaque requests keep its LDS bookkeeping exact (counted
+    // lgkmcnt waits); their vmcnt bookkeeping is done by hand here anyway (the counted waits at the barriers), and the
+    // compiler's own vmcnt waits stay safe because loads return in order and no tracked load is older than an untracked one
+    // that it must not wait for.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    auto glds = [&](const char* src, uint32_t lds_off) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + lds_off) : "memory", "m0");
+    };
     auto stage_a = [&](int buf, int64_t aoff, int j) {
-        glds16(a_src[j] + aoff, smem + buf * A_TILE + (wave * NJA + j) * 1024);
+        glds(a_src[j] + aoff, (uint32_t)(buf * A_TILE + (wave * NJA + j) * 1024));
     };
     auto stage_w = [&](int buf, int64_t koff, int j) {
-        glds16(w_src[j] + koff, smem + W_BASE + buf * W_TILE + (wave * NJW + j) * 1024);
+        glds(w_src[j] + koff, (uint32_t)(W_BASE + buf * W_TILE + (wave * NJW + j) * 1024));
     };
     constexpr int MPC = NTW / 2;                       // MFMAs per chunk
     constexpr int NDS = 4 + NTW;                       // fragment reads per sub-step
@@ -266,11 +285,15 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
                     }
                     if (c < NDS) {
+                        // order of first use in the next sub-step (MFMA c uses A[c / 2], W[c % 2]): W0 A0 W1 A1 A2 A3 - every
+                        // read then has eight MFMAs to land and the compiler's counted lgkmcnt waits never drain the queue
                         const char* fa = ks < 3 ? la : lan;
                         const char* fb = ks < 3 ? lb : lbn;
                         const int kn = ks < 3 ? ks + 1 : 0;
-                        if (c < 4) af[(ks + 1) & 1][c] = *(const bf16x8*)(fa + a_row_off + c * (32 * 128) + coff[kn]);
-                        else wf[(ks + 1) & 1][c - 4] = *(const bf16x8*)(fb + w_row_off + (c - 4) * (32 * 128) + coff[kn]);
+                        const bool is_w = c == 0 || c == 2;
+                        const int fi = c == 0 ? 0 : c == 1 ? 0 : c == 2 ? 1 : c - 2;
+                        if (is_w) wf[(ks + 1) & 1][fi] = *(const bf16x8*)(fb + w_row_off + fi * (32 * 128) + coff[kn]);
+                        else af[(ks + 1) & 1][fi] = *(const bf16x8*)(fa + a_row_off + fi * (32 * 128) + coff[kn]);
                     }
                     if (ks == 0 && c < NJA) stage_a(sa2, aoff2, c);                       // A(kt+2): the slot tile kt-1 left
                     if (ks == 3 && c >= 1 && c <= NJA) stage_w(kt & 1, koff2, c - 1);     // W(kt+2): the slot of this tile
