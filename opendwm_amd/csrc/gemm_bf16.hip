@@ -566,15 +566,29 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
 #undef DWM_ACT_PASS
             }
 #undef DWM_PAIR
-            // ---- transpose: row l31, 16-B chunk c = (nt*32 + rg*8 + half*4) / 4, swizzled by the row
+            // ---- transpose.  PLAIN / GEGLU / RMSHEAD: the values are final after stage A, so they cross the LDS as bf16
+            // (half the LDS bytes, one 16-byte read per lane and step, no conversion after it): row l31 of [32][CW] bf16, a
+            // lane's 4 consecutive columns = 8 bytes at 16-B chunk (nt*4 + rg), half `half` of it, chunk swizzled by the row.
+            // RESID / split-K: fp32 (the gate / residual / blend math follows the transpose): row l31, 16-B chunk
+            // c = (nt*32 + rg*8 + half*4) / 4, swizzled by the row
+            constexpr bool kT16 = EPI != DWM_EPI_RESID && EPI != EPI_SPLITK;
+            constexpr int RB16 = CW * 2;                                           // bytes per bf16 row: 128 (64 for GEGLU)
+            auto swz16 = [](int r) { return RB16 == 128 ? (r >> 1) & 7 : (r >> 2) & 3; };
     #pragma unroll
             for (int nt = 0; nt < (kGeglu ? 1 : 2); ++nt)
     #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int c = nt * 8 + rg * 2 + half;
-                    const float4 v = make_float4(acc[mt][ch * 2 + nt][rg * 4], acc[mt][ch * 2 + nt][rg * 4 + 1],
-                                                 acc[mt][ch * 2 + nt][rg * 4 + 2], acc[mt][ch * 2 + nt][rg * 4 + 3]);
-                    *(float4*)(scr + l31 * (CW * 4) + ((c ^ (l31 & (CW / 4 - 1))) << 4)) = v;
+                    if constexpr (kT16) {
+                        uint2 w;
+                        w.x = pack_bf16x2(acc[mt][ch * 2 + nt][rg * 4], acc[mt][ch * 2 + nt][rg * 4 + 1]);
+                        w.y = pack_bf16x2(acc[mt][ch * 2 + nt][rg * 4 + 2], acc[mt][ch * 2 + nt][rg * 4 + 3]);
+                        *(uint2*)(scr + l31 * RB16 + (((nt * 4 + rg) ^ swz16(l31)) << 4) + half * 8) = w;
+                    } else {
+                        const int c = nt * 8 + rg * 2 + half;
+                        const float4 v = make_float4(acc[mt][ch * 2 + nt][rg * 4], acc[mt][ch * 2 + nt][rg * 4 + 1],
+                                                     acc[mt][ch * 2 + nt][rg * 4 + 2], acc[mt][ch * 2 + nt][rg * 4 + 3]);
+                        *(float4*)(scr + l31 * (CW * 4) + ((c ^ (l31 & (CW / 4 - 1))) << 4)) = v;
+                    }
                 }
             // same-wave LDS ops complete in order; the reads below see the writes above
             // ---- stage B.  RESID: the gate / residual / blend rows were requested one pass ahead (see above)
@@ -582,11 +596,19 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 const int r = st * RPS + brow;                 // row inside this 32-row pass
+                const int64_t m = m0 + wm * 128 + mt * 32 + r;
+                const int64_t mrow = FAST ? (m < M ? m : M - 1) : map_row(cp.c, m < M ? m : M - 1);
+                if constexpr (kT16) {
+                    const uint4 o = *(const uint4*)(scr + r * RB16 + ((bc8 ^ swz16(r)) << 4));
+                    if (m < M && nok && !((DWM_RESERVED(p.reserved) & 2) && m >= 0)) {
+                        if constexpr (FAST) *(uint4*)(Cp + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc + (uint32_t)ncol)) = o;
+                        else *(uint4*)(Cp + mrow * p.ldc + ncol) = o;
+                    }
+                    continue;
+                }
                 const float4 x0 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8) ^ (r & (CW / 4 - 1))) << 4));
                 const float4 x1 = *(const float4*)(scr + r * (CW * 4) + (((2 * bc8 + 1) ^ (r & (CW / 4 - 1))) << 4));
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                const int64_t m = m0 + wm * 128 + mt * 32 + r;
-                const int64_t mrow = FAST ? (m < M ? m : M - 1) : map_row(cp.c, m < M ? m : M - 1);
                 if constexpr (EPI == DWM_EPI_RESID) {
                     float t[8];
     #pragma unroll
