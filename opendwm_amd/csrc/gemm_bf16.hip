@@ -70,7 +70,19 @@ struct ConvParams {
     int ksplit;
     float* ws;
     int64_t ws_slice;
+    // tile rasterisation: groups of `gm` row tiles x all column tiles (fast divisors prepared on the host)
+    int gm;
+    FastDiv fd_pergroup, fd_gm;
 };
+// group height: 8 row tiles share a W panel in the XCD's L2 for K ~ 1.5 k; a long K (FF2: 6144) makes the A panel of
+// 8 rows (25 MB) stream through it, 4 rows measured 3 % faster there
+static inline void set_raster(ConvParams& cp, const dwm_gemm_args& a, int ntn) {
+    int gm = (DWM_RESERVED(a.reserved) >> 4) & 31;
+    if (gm == 0) gm = a.K >= 4096 ? 4 : 8;
+    cp.gm = gm;
+    cp.fd_pergroup = make_fastdiv((uint32_t)(gm * ntn));
+    cp.fd_gm = make_fastdiv((uint32_t)gm);
+}
 constexpr int EPI_SPLITK = 100;     // internal epilogue id: fp32 partials to the workspace
 DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
     if (!rm.enabled) return m;
@@ -109,6 +121,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     const int wn = wave % NWN;             // column slab of WCOLS
     const int half = lane >> 5;
     const int l31 = lane & 31;
+    const int64_t tap_raw = cp.tap_shift[lane < 27 ? lane : 0];        // lane t: row shift of tap t (see the K walk below)
 
     // XCD-contiguous ids, then grouped rasterisation: consecutive ids walk GM row-tiles down a
     // column before moving to the next column, so the ~32 tiles resident on one XCD at a time form
@@ -119,15 +132,19 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         slice = id / (ntm * ntn);
         id -= slice * (ntm * ntn);
     }
-    // group height: 8 row tiles share a W panel in the XCD's L2 for K ~ 1.5 k; a long K (FF2: 6144) makes the A panel of
-    // 8 rows (25 MB) stream through it, 4 rows measured 3 % faster there
-    int gm_ = (DWM_RESERVED(p.reserved) >> 4) & 31;
-    if (gm_ == 0) gm_ = p.K >= 4096 ? 4 : 8;
+    const int gm_ = cp.gm;
     const int per_group = gm_ * ntn;
-    const int grp_id = id / per_group, in_grp = id - grp_id * per_group;
+    const int grp_id = (int)fdiv((uint32_t)id, cp.fd_pergroup), in_grp = id - grp_id * per_group;
     const int first_m = grp_id * gm_;
     const int gsize = ntm - first_m < gm_ ? ntm - first_m : gm_;
-    const int tm = first_m + in_grp % gsize, tn = in_grp / gsize;
+    int tm, tn;
+    if (gsize == gm_) {                                  // (all groups but a ragged last one)
+        tn = (int)fdiv((uint32_t)in_grp, cp.fd_gm);
+        tm = first_m + in_grp - tn * gm_;
+    } else {
+        tn = in_grp / gsize;
+        tm = first_m + in_grp % gsize;
+    }
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t M = p.M, N = p.N, K = p.K;
 
@@ -165,7 +182,10 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // lane t keeps the byte shift of tap t; a tap boundary fetches it with v_readlane.  (A scalar load anywhere in the loop -
     // even on this rare path - makes the compiler wait for ALL outstanding LDS reads at every use of a fragment: scalar
     // loads return out of order on the counter they share with the LDS, so no counted lgkmcnt wait is possible any more.)
-    const int64_t tap_bytes = cp.tap_shift[lane < 27 ? lane : 0] * lda_bytes;
+    int64_t tap_bytes = tap_raw * lda_bytes;
+    // (the table load was issued at the top of the kernel; it is consumed HERE, before the first LDS-DMA request, so that
+    // the compiler's wait for it cannot end up behind those requests - loads return in order, it would drain them)
+    asm volatile("" : "+v"(tap_bytes));
     auto tap_offset = [&](int tap) {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tap_bytes, tap);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)tap_bytes >> 32), tap);
@@ -177,7 +197,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         walk_tap = (int)tap;
         walk_left = cp.steps_per_tap - r;
         walk_w = (int64_t)kt0 * (BK * 2);
-        walk_a = tap_offset(walk_tap) + (int64_t)r * (BK * 2);
+        walk_a = cp.tap_shift[tap] * lda_bytes + (int64_t)r * (BK * 2);     // (scalar load: the per-lane table may still be in flight)
     };
     auto walk_next = [&]() {
         walk_w += BK * 2;
@@ -245,14 +265,23 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             int64_t aoff = walk_a, koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) { stage_a(0, aoff, j); stage_w(0, koff, j); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // tile 1 is requested right behind tile 0, before the first wait: it then has the whole round trip of tile 0 plus
+            // most of K step 0 to arrive, instead of starting its own round trip only after tile 0 has landed
             if (nk > 1) walk_next();
             aoff = walk_a; koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
 #pragma unroll
             for (int j = 0; j < NJA; ++j) stage_w(1, koff, j);
+            // (the accumulators are zeroed HERE, under the round trip of the first requests: left to itself the compiler
+            // sinks the 128 moves behind the barrier, ~1 us of a 45 us tile with nothing else to run)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(acc[i][j]));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJA) : "memory");          // tile 0 landed (loads return in order)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * 128) + coff[0]);
 #pragma unroll
@@ -318,14 +347,19 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             for (int j = 0; j < NJA; ++j) stage_a(0, aoff, j);
 #pragma unroll
             for (int j = 0; j < NJW; ++j) stage_w(0, koff, j);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (nk > 1) walk_next();
+            if (nk > 1) walk_next();                                   // (tile 1 right behind tile 0, as in configuration 0)
             aoff = walk_a; koff = walk_w;
 #pragma unroll
             for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
 #pragma unroll
             for (int j = 0; j < NJW; ++j) stage_w(1, koff, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(acc[i][j]));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJA + NJW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const bf16x8*)(smem + a_row_off + mt * (32 * ROWB) + coff[0]);
 #pragma unroll
@@ -933,6 +967,7 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
         }
     }
     g.reserved = 0;
+    set_raster(cp, g, ntn);
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI_SPLITK>, dim3((unsigned)(ntm * ntn * ksplit)), dim3(512), LDS_BYTES, s, g, cp, ntm, ntn);
     const int64_t nthr = a->M * (nout >> 3);
     const dim3 fg((unsigned)((nthr + 255) / 256));
@@ -999,6 +1034,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a->lda < kpt) return DWM_EINVAL;
     if (a->tile < 0 || a->tile > 2) return DWM_EINVAL;
     int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
+    set_raster(cp, *a, ntn);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     // ---- split-K: a grid that fills less than half of the 256 CUs and a long K.  One K range per workgroup,
@@ -1056,6 +1092,7 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         ntn = (int)((a->N + TileCfg<1>::bn - 1) / TileCfg<1>::bn);
         cp.steps_per_tap = (int)(kpt / TileCfg<1>::bk);
         cp.fd_steps = make_fastdiv((uint32_t)cp.steps_per_tap);
+        set_raster(cp, *a, ntn);
     }
     const dim3 grid((unsigned)(ntm * ntn)), block(tc == 1 ? TileCfg<1>::nwaves * 64 : 512);
 #define DWM_LAUNCH_TC(EPI, FAST, TC_)                                                                \

@@ -6,7 +6,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OLD=$GRAFT_REPO_ROOT/opendwm_amd/libdwm_hip_old.so
-echo "== LDS-DMA offset probe"; ./scripts/probes/lds_dma_offset_probe
+
 echo "== pytest gemm / conv"; date
 timeout 900 python -m pytest tests/test_hip_gpu.py tests/test_fp32_gpu.py -m gpu -q -x -k "gemm or conv or adapter or vae or split" -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest exit $?"; tail -4 $OUT/pytest.log | cut -c1-300
 echo "== microbench new / old / new / old"; date

@@ -198,6 +198,33 @@ def bench_gemm_tiles_dev():
         print(json.dumps({"kernel": "gemm_tiles_dev", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
 
 
+def bench_gemm_epilogue_dev():
+    """development library only: the 256 x 256 tile complete / without its output stores / without its epilogue"""
+    from opendwm_amd.blocks import geglu_pack
+    names = {0: "complete", 2: "no stores", 1: "no epilogue"}
+    for name, M, N, K, kind in [("qkv rmshead", 86016, 4608, 1536, "rms"), ("ff1 gelu", 86016, 6144, 1536, "gelu"), ("vt geglu", 86016, 12288, 1536, "geglu"),
+                                ("out-proj resid", 86016, 1536, 1536, "resid"), ("ff2 resid", 86016, 1536, 6144, "resid")]:
+        a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+        fl = 2.0 * M * N * K
+        res = {}
+        for di, dbg in enumerate([0] + list(names) + list(names)):
+            if kind == "rms":
+                rms = rnd(2 * N // 3) * 0.1 + 1
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=2 * N // 3, rms_eps=1e-6, _debug=dbg, split_k=1)
+            elif kind == "resid":
+                gate, res_t = rnd(M // 448 + 1, N), rnd(M, N)
+                f = lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=res_t, out=res_t, _debug=dbg, split_k=1)
+            elif kind == "gelu":
+                f = lambda: ops.gemm(a, w, b, act=ops.ACT_GELU_TANH, _debug=dbg, split_k=1)
+            else:
+                wp, bp = geglu_pack(w), geglu_pack(b)
+                f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU, _debug=dbg, split_k=1)
+            ms = timeit(f)
+            if di:
+                res.setdefault(names[dbg], []).append(round(fl / ms / 1e9, 1))
+        print(json.dumps({"kernel": "gemm_epilogue_dev", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -231,5 +258,7 @@ if __name__ == "__main__":
         bench_gemm_tiles()
     if "gemmd" in what:
         bench_gemm_tiles_dev()
+    if "gemme" in what:
+        bench_gemm_epilogue_dev()
     if "ln" in what:
         bench_ln()
