@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 15
+#define DWM_ABI_VERSION 16
 int dwm_abi_version(void);
 /* SHA-256 (hex) of the sources this library was built from (csrc .hip and .h files + this header, in sorted order), as
  * computed by opendwm_amd/build.py; the Python binding compares it with the sources it finds next to itself and refuses a
@@ -122,6 +122,27 @@ typedef struct dwm_gemm_args {
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Weight-gradient GEMM, both operands row-major with the contraction index as their ROW (gemm_tn.hip):
+ *     out[n, t*C + c] = sum_{m < M} A[m, n] * B[clamp(m + tap_shift[t], 0, b_rows - 1), c]       (bf16, fp32 accumulate)
+ * A = dY [M, N], B = X: dW = dY^T X of torch.nn.Linear (ntaps = 0) - autograd's weight gradient under loss.backward(),
+ * src/dwm/pipelines/ctsd.py:1401-1404 - and, with dY and X on the same zero-bordered padded token grid, the weight gradient of a
+ * 3x3 / (3,1,1) / 3x3x3 convolution in one launch (tap t reads the rows shifted by tap_shift[t]; the border rows of A are zero).
+ * M % 64 == 0, N % 8 == 0, C % 8 == 0; out is [N, max(ntaps,1)*C] with leading dimension ldo.  The contraction is cut into K
+ * ranges (split_k: 0 = automatic, > 0 = exactly this many), fp32 partials go to `workspace` (>= split_k * N * ntaps*C * 4 bytes,
+ * 16-byte aligned, owned by the caller, one per stream) and are reduced in range order.
+ * ---------------------------------------------------------------------- */
+typedef struct dwm_gemm_tn_args {
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb; int64_t b_rows;
+    void* out; int64_t ldo;
+    int64_t M, N, C;
+    int32_t ntaps; int32_t split_k;
+    int64_t tap_shift[27];
+    void* workspace; int64_t workspace_bytes;
+} dwm_gemm_tn_args;
+int dwm_gemm_tn(const dwm_gemm_tn_args* args, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused multi-head attention forward, head_dim 64, bf16, flash-style online

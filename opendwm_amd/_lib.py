@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DWM_HIP_LIB") or os.path.join(HERE, "libdwm_hip.so")      # DWM_HIP_LIB: another build of the same ABI (A/B measurements)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -17,6 +17,14 @@ _i64, _i32, _f32, _vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
 class RowMap2D(C.Structure):
     _fields_ = [("rw", _i64), ("rh", _i64), ("rpitch", _i64), ("ipitch", _i64), ("origin", _i64), ("xstep", _i64)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("b_rows", _i64), ("out", _vp), ("ldo", _i64),
+        ("M", _i64), ("N", _i64), ("C", _i64), ("ntaps", _i32), ("split_k", _i32), ("tap_shift", _i64 * 27),
+        ("workspace", _vp), ("workspace_bytes", _i64),
+    ]
 
 
 class GemmArgs(C.Structure):
@@ -105,6 +113,7 @@ SIGNATURES = {
     "dwm_abi_version": (_i32, []),
     "dwm_source_hash": (C.c_char_p, []),
     "dwm_gemm_bf16": (_i32, [C.POINTER(GemmArgs), _vp]),
+    "dwm_gemm_tn": (_i32, [C.POINTER(GemmTnArgs), _vp]),
     "dwm_attention_fwd": (_i32, [C.POINTER(AttnArgs), _vp]),
     "dwm_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
     "dwm_debug_tr_probe": (_i32, [_vp, _vp, _vp]),

@@ -542,15 +542,8 @@ class OutFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------ layout ImageAdapter
 def _conv3_wgrad(dh: torch.Tensor, x_pad: torch.Tensor, grid, idx: torch.Tensor) -> torch.Tensor:
     """dW [N, 9*C] (tap-major, bf16) of h = conv3x3(x): dW[n, t, c] = sum_pixels dh[pixel, n] * x_pad[row(pixel) + shift_t, c].
-    One weight-gradient GEMM per tap; its activation operand is the tap-shifted gather of the padded grid, transposed so
-    that the pixel contraction runs along rows (as in train_ops.linear_wgrad)."""
-    N, Cc = dh.shape[1], x_pad.shape[1]
-    dw = torch.empty((N, 9 * Cc), dtype=bf16, device=dh.device)
-    dht = T.transpose(dh)                                              # [N, Pp]
-    for t, sh in enumerate(grid.tap_shifts()):
-        xt = T.transpose(x_pad[idx + sh])                              # [C, Pp]: rows of tap t for every pixel
-        ops.gemm(dht, xt, None, out=dw[:, t * Cc:(t + 1) * Cc])
-    return dw
+    (train_ops.conv_wgrad: dh scattered onto the padded grid, all nine taps one dwm_gemm_tn launch)"""
+    return T.conv_wgrad(dh, x_pad, idx, grid.tap_shifts())
 
 
 def _conv3_flip(w: torch.Tensor) -> torch.Tensor:

@@ -4,7 +4,8 @@ conventions as opendwm_amd.ops: bf16 CUDA tensors, current stream, no fallback."
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+import os
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -12,6 +13,8 @@ from . import _lib, ops
 from .ops import _p, _stream, ACT_GELU_TANH, ACT_SILU  # noqa: F401
 
 bf16 = torch.bfloat16
+# weight gradients by dwm_gemm_tn (operands as they are); "0": the transposes + NT GEMM path (A/B measurements)
+WGRAD_TN = os.environ.get("DWM_WGRAD_TN", "1") != "0"
 
 
 def _rows2d(t: torch.Tensor, name: str, dtype=bf16) -> None:
@@ -199,14 +202,69 @@ def linear_dgrad(dy: torch.Tensor, w_t: torch.Tensor, out: Optional[torch.Tensor
     return ops.gemm(dy, w_t, None, out=out, **epi)
 
 
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, tap_shifts: Optional[Sequence[int]] = None, split_k: int = 0,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out [N, taps*C] (bf16) = sum over rows m of dy[m, n] * x[clamp(m + shift_t, 0, rows(x) - 1), c] (dwm_gemm_tn): the weight
+    gradient of a linear layer (no taps) or - dy and x on the same padded token grid, dy zero on its border rows - of a
+    convolution with those taps, from the row-major operands as they are (no transposes, no per-tap gathers).
+    dy [M, N], M % 64 == 0; x [rows, C]."""
+    _rows2d(dy, "dy")
+    _rows2d(x, "x")
+    M, N = dy.shape
+    Cc = x.shape[1]
+    ntaps = len(tap_shifts) if tap_shifts is not None else 0
+    if ntaps > 27:
+        raise RuntimeError("gemm_tn: at most 27 taps")
+    if tap_shifts is None and x.shape[0] < M:
+        raise RuntimeError("gemm_tn: x has fewer rows than dy")
+    cols = max(ntaps, 1) * Cc
+    if out is None:
+        out = torch.empty((N, cols), dtype=bf16, device=dy.device)
+    _rows2d(out, "out")
+    if out.shape != (N, cols):
+        raise RuntimeError(f"gemm_tn: out must be [{N}, {cols}]")
+    ws = ops._gemm_workspace(dy.device)
+    g = _lib.GemmTnArgs()
+    g.A, g.lda, g.B, g.ldb, g.b_rows = _p(dy), dy.stride(0), _p(x), x.stride(0), x.shape[0]
+    g.out, g.ldo, g.M, g.N, g.C = _p(out), out.stride(0), M, N, Cc
+    g.ntaps, g.split_k = ntaps, split_k
+    for t in range(ntaps):
+        g.tap_shift[t] = int(tap_shifts[t])
+    g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    _lib.check(_lib.load().dwm_gemm_tn(C.byref(g), _stream()), "dwm_gemm_tn")
+    return out
+
+
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """dW [N, K] (bf16) = dY^T X and db [N] (fp32) = column sums of dY; dY [M, N], X [M, K].
     Both operands are transposed so the contraction (over the M tokens) runs along rows."""
-    dyt = transpose(dy)                    # [N, Mp]
-    xt = transpose(x)                      # [K, Mp]
-    dw = ops.gemm(dyt, xt, None)           # [N, K]
+    if WGRAD_TN and dy.shape[0] % 64 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+        dw = gemm_tn(dy, x)                # both operands as they are (gemm_tn.hip)
+    else:
+        dyt = transpose(dy)                # [N, Mp]
+        xt = transpose(x)                  # [K, Mp]
+        dw = ops.gemm(dyt, xt, None)       # [N, K]
     db = segsum(dy)[0] if want_bias else None
     return dw, db
+
+
+def conv_wgrad(dy: torch.Tensor, x_pad: torch.Tensor, idx: torch.Tensor, shifts) -> torch.Tensor:
+    """dW [N, taps*C] (tap-major, bf16): dW[n, t, c] = sum_pixels dy[pixel, n] * x_pad[idx[pixel] + shift_t, c].
+    dy is scattered onto x_pad's row space (zeros elsewhere) and ALL taps are one dwm_gemm_tn launch over those rows; where
+    that does not pay (an output grid much sparser than the input grid: stride-2 convolutions) or does not apply, one
+    weight-gradient GEMM per tap on the transposed operands (gather of the tap-shifted rows + transpose, per tap)."""
+    N, Cc = dy.shape[1], x_pad.shape[1]
+    rows = x_pad.shape[0]
+    if WGRAD_TN and N % 8 == 0 and Cc % 8 == 0 and 2 * dy.shape[0] >= rows:
+        dyp = torch.zeros(((rows + 63) // 64 * 64, N), dtype=bf16, device=dy.device)
+        dyp.index_copy_(0, idx, dy)
+        return gemm_tn(dyp, x_pad, tap_shifts=[int(s) for s in shifts])
+    dw = torch.empty((N, len(shifts) * Cc), dtype=bf16, device=dy.device)
+    dyt = transpose(dy)
+    for t, sh in enumerate(shifts):
+        xt = transpose(x_pad[idx + sh])
+        ops.gemm(dyt, xt, None, out=dw[:, t * Cc:(t + 1) * Cc])
+    return dw
 
 
 def groupnorm_bwd(x: torch.Tensor, dz: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,

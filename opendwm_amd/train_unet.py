@@ -45,15 +45,9 @@ def _time_interior(tg: TimeGrid, dev) -> torch.Tensor:
 
 
 def conv_wgrad(dy: torch.Tensor, x_pad: torch.Tensor, idx: torch.Tensor, shifts) -> torch.Tensor:
-    """dW [N, taps*C] (tap-major, bf16): dW[n, t, c] = sum_pixels dy[pixel, n] * x_pad[idx[pixel] + shift_t, c] - one
-    weight-gradient GEMM per tap on the transposed operands (the pixel contraction runs along rows)."""
-    N, Cc = dy.shape[1], x_pad.shape[1]
-    dw = torch.empty((N, len(shifts) * Cc), dtype=bf16, device=dy.device)
-    dyt = T.transpose(dy)
-    for t, sh in enumerate(shifts):
-        xt = T.transpose(x_pad[idx + sh])
-        ops.gemm(dyt, xt, None, out=dw[:, t * Cc:(t + 1) * Cc])
-    return dw
+    """dW [N, taps*C] (tap-major, bf16): dW[n, t, c] = sum_pixels dy[pixel, n] * x_pad[idx[pixel] + shift_t, c]
+    (train_ops.conv_wgrad: one dwm_gemm_tn launch for all taps)."""
+    return T.conv_wgrad(dy, x_pad, idx, shifts)
 
 
 def _conv3_w_to_param(dw: torch.Tensor, n: int, c: int) -> torch.Tensor:

@@ -185,6 +185,52 @@ def test_linear_backward(dev, M, N, K):
     assert e["dx"] < TOL_KERNEL and e["dw"] < TOL_KERNEL and e["db"] < TOL_REDUCE
 
 
+@pytest.mark.parametrize("M,N,C,ks", [(1024, 256, 256, 1), (2048, 1536, 1536, 0), (4096, 320, 2880, 0), (8192, 1536, 3072, 4), (1280, 72, 8, 2),
+                                      (86016, 1536, 1536, 0)])
+def test_gemm_tn_equals_transposed_path(dev, M, N, C, ks):
+    """dwm_gemm_tn (both operands as they are, transposing LDS reads) against the path it replaces - two explicit transposes + the NT
+    GEMM: the same products in the same order over the same K ranges, so BIT-identical; and against the fp32 product."""
+    from opendwm_amd import ops, train_ops as T
+    dy, x = _rand((M, N), dev, 1), _rand((M, C), dev, 2, M ** -0.5)
+    got = T.gemm_tn(dy, x, split_k=ks)
+    e = rel_err(got, dy.float().t() @ x.float())
+    _log("gemm_tn", M=M, N=N, C=C, split_k=ks, rel=e)
+    assert got.shape == (N, C) and e < TOL_KERNEL
+    old = ops.gemm(T.transpose(dy), T.transpose(x), None, split_k=ks)
+    assert torch.equal(got, old)
+    # strided operands (column slices of wider buffers)
+    wide_dy, wide_x = _rand((M, N + 64), dev, 3), _rand((M, C + 8), dev, 4, M ** -0.5)
+    got2 = T.gemm_tn(wide_dy[:, 64:], wide_x[:, :C], split_k=ks)
+    assert rel_err(got2, wide_dy[:, 64:].float().t() @ wide_x[:, :C].float()) < TOL_KERNEL
+
+
+@pytest.mark.parametrize("I,h,w,C,N", [(3, 16, 28, 128, 320), (2, 5, 7, 64, 72), (6, 32, 56, 320, 320)])
+def test_conv_wgrad_tn_vs_autograd(dev, I, h, w, C, N):
+    """the 3x3 weight gradient as ONE dwm_gemm_tn launch over the padded grid (dy scattered onto it, nine row shifts) against fp32
+    autograd of F.conv2d and against the per-tap path it replaces"""
+    from opendwm_amd import ops, train_ops as T
+    grid = ops.PaddedGrid(I, h, w)
+    x = _rand((I, C, h, w), dev, 1)
+    dy = _rand((I, N, h, w), dev, 2, (I * h * w) ** -0.5)
+    wt = torch.zeros((N, C, 3, 3), device=dev, requires_grad=True)
+    F.conv2d(x.float(), wt, None, padding=1).backward(dy.float())
+    ref = wt.grad.permute(0, 2, 3, 1).reshape(N, 9 * C)                   # tap-major [N, 9*C]
+    idx = grid.interior_index().to(dev)
+    xp = torch.zeros((grid.rows, C), dtype=bf16, device=dev)
+    xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    dyc = dy.permute(0, 2, 3, 1).reshape(-1, N).contiguous()
+    got = T.conv_wgrad(dyc, xp, idx, grid.tap_shifts())
+    e = rel_err(got, ref)
+    tn0 = T.WGRAD_TN
+    try:
+        T.WGRAD_TN = False
+        old = T.conv_wgrad(dyc, xp, idx, grid.tap_shifts())
+    finally:
+        T.WGRAD_TN = tn0
+    _log("conv_wgrad_tn", I=I, h=h, w=w, C=C, N=N, rel=e, rel_old_path=rel_err(old, ref), rel_vs_old=rel_err(got, old))
+    assert e < TOL_KERNEL and rel_err(old, ref) < TOL_KERNEL
+
+
 def test_adamw_matches_torch(dev):
     from opendwm_amd import train_ops as T
     n = 100_003
