@@ -67,8 +67,8 @@ gemm_tn_kernel(const TnParams p) {
 
     // ---- staging: request j of this wave fills rows (wave*4 + j)*2 + {0, 1} of a tile; lane -> row half, physical 16-B chunk
     const char* a_src[NJ];
-    int64_t b_row[NJ];                         // row of B for K step 0 of this range, before the clamp
-    int64_t b_col_bytes[NJ];
+    const char* b_base[NJ];                    // B + this lane's column
+    int b_row[NJ];                             // row of B for K step 0 of this range, before the clamp (rows < 2^31)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int r = (wave * NJ + j) * 2 + (lane >> 5);
@@ -76,11 +76,12 @@ gemm_tn_kernel(const TnParams p) {
         const int64_t acol = n0 + lc * 8 < p.N ? n0 + lc * 8 : 0;           // columns past the matrix: any valid address (never stored)
         const int64_t bcol = c0 + lc * 8 < p.C ? c0 + lc * 8 : 0;
         a_src[j] = (const char*)(p.A + ((int64_t)kt0 * TBK + r) * p.lda + acol);
-        b_row[j] = (int64_t)kt0 * TBK + r + shift;
-        b_col_bytes[j] = bcol * 2;
+        b_base[j] = (const char*)(p.B + bcol);
+        b_row[j] = (int)((int64_t)kt0 * TBK + r + shift);
     }
     const int64_t a_step = (int64_t)TBK * p.lda * 2;                       // bytes per K step
-    const int64_t ldb_bytes = p.ldb * 2, b_last = p.b_rows - 1;
+    const uint32_t ldb_bytes = (uint32_t)(p.ldb * 2);
+    const int b_last = (int)(p.b_rows - 1);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
     auto glds = [&](const char* src, uint32_t lds_off) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + lds_off) : "memory", "m0");
@@ -89,9 +90,11 @@ gemm_tn_kernel(const TnParams p) {
         glds(a_src[j] + (int64_t)kt * a_step, (uint32_t)(buf * TILE + (wave * NJ + j) * 1024));
     };
     auto stage_b = [&](int buf, int kt, int j) {
-        int64_t row = b_row[j] + (int64_t)kt * TBK;
-        row = row < 0 ? 0 : row > b_last ? b_last : row;
-        glds((const char*)p.B + row * ldb_bytes + b_col_bytes[j], (uint32_t)(B_BASE + buf * TILE + (wave * NJ + j) * 1024));
+        // one v_med3 (clamp: tap shifts reach before / behind the grid only in the first / last K step) + one 32 x 32 -> 64-bit multiply-add
+        int row = b_row[j] + kt * TBK;
+        row = row < 0 ? 0 : row;
+        row = row > b_last ? b_last : row;                     // (max + min: the compiler folds them into one v_med3_i32)
+        glds(b_base[j] + (uint64_t)(uint32_t)row * ldb_bytes, (uint32_t)(B_BASE + buf * TILE + (wave * NJ + j) * 1024));
     };
 
     // ---- transposing fragment reads: 16-lane group (g1 = column half of the 32-column fragment, `half` = which 8 of the 16 rows),
@@ -221,7 +224,7 @@ extern "C" int dwm_gemm_tn(const dwm_gemm_tn_args* a, void* stream) {
     if (a->M % TBK != 0 || a->N % 8 != 0 || a->C % 8 != 0) return DWM_EUNSUPPORTED;
     const int ntaps = a->ntaps > 0 ? a->ntaps : 1;
     if (ntaps > 27) return DWM_EINVAL;
-    if (a->lda < a->N || a->ldb < a->C || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldo % 8 != 0 || a->ldo < (int64_t)ntaps * a->C) return DWM_EALIGN;
+    if (a->lda < a->N || a->ldb < a->C || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldb >= (1ll << 30) || a->ldo % 8 != 0 || a->ldo < (int64_t)ntaps * a->C) return DWM_EALIGN;
     if (!dwm_aligned16(a->A) || !dwm_aligned16(a->B) || !dwm_aligned16(a->out) || !dwm_aligned16(a->workspace)) return DWM_EALIGN;
     TnParams p;
     p.A = (const bf16_t*)a->A; p.lda = a->lda;

@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for w in "unet --unet" "train --train" "train_unet --train --unet"; do
+for w in "train --train" "train_unet --train --unet"; do
   set -- $w; name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$name -o p -- python $GRAFT_REPO_ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_$name.log 2> $OUT/bench_$name.err
   echo "$name exit $?"; grep '^{' $OUT/bench_$name.log | cut -c1-200
