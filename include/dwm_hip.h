@@ -35,7 +35,7 @@ extern "C" {
 #define DWM_EUNSUPPORTED (-3)
 
 /* ABI version; bump on any struct change. */
-#define DWM_ABI_VERSION 16
+#define DWM_ABI_VERSION 17
 int dwm_abi_version(void);
 /* SHA-256 (hex) of the sources this library was built from (csrc .hip and .h files + this header, in sorted order), as
  * computed by opendwm_amd/build.py; the Python binding compares it with the sources it finds next to itself and refuses a
@@ -473,6 +473,16 @@ int dwm_rmsnorm_heads_bwd(const void* y, int64_t ldy, const float* rinv, const v
 int dwm_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
               float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
               void* stream);
+
+/* The same step for many tensors in ONE launch.  items / block_item / block_start are DEVICE arrays: block b updates elements
+ * [block_start[b], min(block_start[b] + chunk, items[block_item[b]].n)) of tensor block_item[b]; every tensor needs
+ * ceil(n / chunk) consecutive-start blocks.  All tensors share the hyper-parameters and the step count (bias corrections). */
+typedef struct dwm_adamw_item {
+    float* p; const float* g; float* m; float* v; void* p_bf16; int64_t n;
+} dwm_adamw_item;
+int dwm_adamw_multi(const dwm_adamw_item* items, const int32_t* block_item, const int64_t* block_start, int64_t n_blocks,
+                    int64_t chunk, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                    float bias_corr2, float grad_scale, void* stream);
 
 /* Backward of dwm_groupnorm_silu / dwm_groupnorm_silu_mapped (the UNet's ResnetBlock2D / TemporalResnetBlock / TransformerModel
  * norms in the SD 2.1 training branch, src/dwm/pipelines/ctsd.py:1240-1253): x = the forward input (compact rows, through

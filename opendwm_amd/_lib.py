@@ -7,7 +7,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DWM_HIP_LIB") or os.path.join(HERE, "libdwm_hip.so")      # DWM_HIP_LIB: another build of the same ABI (A/B measurements)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EPI_PLAIN, EPI_GEGLU, EPI_RESID, EPI_RMSHEAD = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_SILU, ACT_RELU = 0, 1, 2, 3
@@ -164,6 +164,7 @@ SIGNATURES = {
     "dwm_rmsnorm_heads_train": (_i32, [_vp, _i64, _i64, _i64, _vp, _f32, _vp, _vp]),
     "dwm_rmsnorm_heads_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dwm_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "dwm_adamw_multi": (_i32, [_vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "dwm_cast_bf16_to_f32": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
     "dwm_groupnorm_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
                                  C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),

@@ -444,6 +444,31 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
     }
 }
 
+// The same update for MANY tensors in one launch: block b works on elements [block_start[b], block_start[b] + chunk) of tensor
+// block_item[b] (a model has 1.4-1.7 k parameter tensors: per-tensor launches made the optimizer step launch-bound).
+__global__ void __launch_bounds__(256)
+adamw_multi_kernel(const dwm_adamw_item* __restrict__ items, const int32_t* __restrict__ block_item,
+                   const int64_t* __restrict__ block_start, int64_t chunk, float lr, float b1, float b2, float eps, float wd,
+                   float bc1, float bc2, float gscale) {
+    const dwm_adamw_item it = items[block_item[blockIdx.x]];
+    const int64_t i0 = block_start[blockIdx.x];
+    const int64_t i1 = i0 + chunk < it.n ? i0 + chunk : it.n;
+    float* __restrict__ p = it.p;
+    const float* __restrict__ g = it.g;
+    float* __restrict__ m = it.m;
+    float* __restrict__ v = it.v;
+    bf16_t* __restrict__ pb = (bf16_t*)it.p_bf16;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (pb) pb[i] = f32_to_bf16(pi);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 cast_bf16_to_f32_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                         int64_t rows, int64_t cols, int accumulate) {
@@ -611,6 +636,16 @@ extern "C" int dwm_adamw(float* p, const float* g, float* m, float* v, void* p_b
     if (!p || !g || !m || !v || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return DWM_EINVAL;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr,
                        beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale);
+    DWM_RET();
+}
+
+extern "C" int dwm_adamw_multi(const dwm_adamw_item* items, const int32_t* block_item, const int64_t* block_start, int64_t n_blocks,
+                               int64_t chunk, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                               float bias_corr2, float grad_scale, void* stream) {
+    if (!items || !block_item || !block_start || n_blocks <= 0 || n_blocks >= (1ll << 31) || chunk <= 0 || bias_corr1 <= 0.f ||
+        bias_corr2 <= 0.f) return DWM_EINVAL;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, items, block_item, block_start,
+                       chunk, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale);
     DWM_RET();
 }
 

@@ -853,6 +853,7 @@ class AdamW(torch.optim.Optimizer):
             if group.get("amsgrad") or group.get("maximize"):
                 raise NotImplementedError("AdamW: amsgrad / maximize")
             b1, b2 = group["betas"]
+            batches: dict = {}                  # step count -> lists for ONE dwm_adamw_multi launch (normally a single batch)
             for p in group["params"]:
                 if p.grad is None:              # frozen, or unused in this step: no state, no step (as torch)
                     continue
@@ -868,7 +869,16 @@ class AdamW(torch.optim.Optimizer):
                 shadow = STORE.bf(p) if (p.is_cuda and p.numel() % 4 == 0 and p.is_contiguous()) else None
                 if shadow is None:
                     STORE._shadow.pop(id(p), None)      # re-cast on next use
-                T.adamw_(p.data, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], shadow, lr=float(group["lr"]), beta1=b1, beta2=b2,
-                         eps=group["eps"], weight_decay=group["weight_decay"], step=int(st["step"].item()), grad_scale=grad_scale)
+                step = int(st["step"].item())
+                if p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous():
+                    b = batches.setdefault(step, ([], [], [], [], []))
+                    for lst, t in zip(b, (p.data, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], shadow)):
+                        lst.append(t)
+                else:
+                    T.adamw_(p.data, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], shadow, lr=float(group["lr"]), beta1=b1, beta2=b2,
+                             eps=group["eps"], weight_decay=group["weight_decay"], step=step, grad_scale=grad_scale)
+            for step, (ps, gs, ms, vs, shs) in batches.items():
+                T.adamw_multi_(ps, gs, ms, vs, shs, lr=float(group["lr"]), beta1=b1, beta2=b2, eps=group["eps"],
+                               weight_decay=group["weight_decay"], step=step, grad_scale=grad_scale)
         STORE.bump(keep_shadows=True)
         return loss

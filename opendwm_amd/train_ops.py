@@ -182,6 +182,39 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, p
                                      1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, _stream()), "dwm_adamw")
 
 
+ADAMW_CHUNK = 1 << 16            # elements per workgroup of the multi-tensor AdamW
+_ADAMW_BLOCKS: dict = {}         # (device, tuple of numels) -> (block_item, block_start) on the device: static per parameter list
+
+
+def adamw_multi_(ps, gs, ms, vs, shadows, *, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
+                 grad_scale: float = 1.0) -> None:
+    """dwm_adamw_multi: one launch for the whole list (fp32 contiguous p / g / m / v of equal numel per entry; shadows: bf16 copy or
+    None).  All entries share the hyper-parameters and `step`."""
+    if not ps:
+        return
+    dev = ps[0].device
+    rows = []
+    for p, g, m, v, sh in zip(ps, gs, ms, vs, shadows):
+        for t in (p, g, m, v):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel() or t.device != dev:
+                raise RuntimeError("adamw_multi_: fp32 contiguous tensors of one shape on one device expected")
+        rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 0 if sh is None else sh.data_ptr(), p.numel()))
+    items = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)          # [n, 6] = dwm_adamw_item[n]
+    key = (dev.index, tuple(r[5] for r in rows))
+    tab = _ADAMW_BLOCKS.get(key)
+    if tab is None:
+        bi, bs = [], []
+        for i, r in enumerate(rows):
+            nb = (r[5] + ADAMW_CHUNK - 1) // ADAMW_CHUNK
+            bi.append(torch.full((nb,), i, dtype=torch.int32))
+            bs.append(torch.arange(nb, dtype=torch.int64) * ADAMW_CHUNK)
+        _ADAMW_BLOCKS.clear()                                                           # one parameter list at a time
+        tab = _ADAMW_BLOCKS[key] = (torch.cat(bi).to(dev), torch.cat(bs).to(dev))
+    _lib.check(_lib.load().dwm_adamw_multi(_p(items), _p(tab[0]), _p(tab[1]), tab[0].numel(), ADAMW_CHUNK, lr, beta1, beta2, eps,
+                                           weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, _stream()),
+               "dwm_adamw_multi")
+
+
 def cast_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """fp32 (+)= bf16 matrix / vector."""
     x2 = x if x.dim() == 2 else x.reshape(1, -1)

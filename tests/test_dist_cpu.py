@@ -284,6 +284,7 @@ def _trainer_worker(rank, world, port, comm, q):
     from opendwm_amd import train_ops
     from opendwm_amd.pipeline import CTSDTrainer
     train_ops.adamw_ = _adamw_cpu                      # the HIP kernel needs a GPU; the host logic around it is what runs here
+    train_ops.adamw_multi_ = lambda ps, gs, ms, vs, shs, **kw: [_adamw_cpu(*t, **kw) for t in zip(ps, gs, ms, vs, shs)]
     calls = []
     hook0 = default_hooks.bf16_compress_hook
 
