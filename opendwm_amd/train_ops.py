@@ -268,10 +268,15 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, tap_shifts: Optional[Sequence[int
     return out
 
 
+def _tn_fits(n: int, cols: int) -> bool:
+    """one fp32 partial tile set [n, cols] of dwm_gemm_tn must fit the shared GEMM workspace"""
+    return n * cols * 4 <= ops.GEMM_WORKSPACE_BYTES
+
+
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """dW [N, K] (bf16) = dY^T X and db [N] (fp32) = column sums of dY; dY [M, N], X [M, K].
     Both operands are transposed so the contraction (over the M tokens) runs along rows."""
-    if WGRAD_TN and dy.shape[0] % 64 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+    if WGRAD_TN and dy.shape[0] % 64 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and _tn_fits(dy.shape[1], x.shape[1]):
         dw = gemm_tn(dy, x)                # both operands as they are (gemm_tn.hip)
     else:
         dyt = transpose(dy)                # [N, Mp]
@@ -288,7 +293,7 @@ def conv_wgrad(dy: torch.Tensor, x_pad: torch.Tensor, idx: torch.Tensor, shifts)
     weight-gradient GEMM per tap on the transposed operands (gather of the tap-shifted rows + transpose, per tap)."""
     N, Cc = dy.shape[1], x_pad.shape[1]
     rows = x_pad.shape[0]
-    if WGRAD_TN and N % 8 == 0 and Cc % 8 == 0 and 2 * dy.shape[0] >= rows:
+    if WGRAD_TN and N % 8 == 0 and Cc % 8 == 0 and 2 * dy.shape[0] >= rows and _tn_fits(N, len(shifts) * Cc):
         dyp = torch.zeros(((rows + 63) // 64 * 64, N), dtype=bf16, device=dy.device)
         dyp.index_copy_(0, idx, dy)
         return gemm_tn(dyp, x_pad, tap_shifts=[int(s) for s in shifts])
