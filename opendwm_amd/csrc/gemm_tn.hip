@@ -16,9 +16,12 @@
 // split over K ranges (one workgroup per (tile, range)): fp32 partial tiles to the workspace, tn_finish_kernel reduces them in a
 // fixed order.  Same K order and ranges as the transposed path => bit-identical results.
 //
-// LDS image of a tile: row r at r*512, its 32-byte granule index XORed with swz(r) = (r & 3) | (((r >> 3) & 1) << 2): the 4 rows of a
-// 16-lane group and the two 8-row halves of an instruction then fall on different banks.  Applied on the SOURCE chunk of the
-// lane-linear LDS-DMA and again on the transposing reads.
+// LDS image of a tile: row r at r*512, its 64-byte slot index XORed with (r & 3).  The LDS serves 256 bytes (64 banks) per cycle,
+// i.e. 32 lanes of a ds_read_b64_tr_b16: two 16-lane groups = the same 4 rows x 64 contiguous bytes; the rows are 512 bytes
+// apart (the same banks), the XOR puts them into the four 64-byte slots of the 256-byte bank space.  (A first version XORed the
+// 32-byte granule instead: conflict-free per 16-lane group, but the two groups of a cycle then met in the same 128 bytes - the
+// counters showed one conflict cycle per active cycle, profiles/README.md.)  Applied on the SOURCE chunk of the lane-linear
+// LDS-DMA and again on the transposing reads.
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -42,7 +45,7 @@ struct TnParams {
     int ksplit, nk_all, ntm, ntn;
 };
 
-DWM_DEVINL int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+DWM_DEVINL int tn_swz(int r) { return r & 3; }
 
 __global__ void __launch_bounds__(512, 2)
 gemm_tn_kernel(const TnParams p) {
@@ -72,7 +75,7 @@ gemm_tn_kernel(const TnParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int r = (wave * NJ + j) * 2 + (lane >> 5);
-        const int lc = (lane & 31) ^ (tn_swz(r) << 1);                       // logical chunk this lane fetches
+        const int lc = (lane & 31) ^ (tn_swz(r) << 2);                       // logical 16-B chunk this lane fetches (64-B slot XOR)
         const int64_t acol = n0 + lc * 8 < p.N ? n0 + lc * 8 : 0;           // columns past the matrix: any valid address (never stored)
         const int64_t bcol = c0 + lc * 8 < p.C ? c0 + lc * 8 : 0;
         a_src[j] = (const char*)(p.A + ((int64_t)kt0 * TBK + r) * p.lda + acol);
@@ -100,7 +103,7 @@ gemm_tn_kernel(const TnParams p) {
     // ---- transposing fragment reads: 16-lane group (g1 = column half of the 32-column fragment, `half` = which 8 of the 16 rows),
     // lane u: address of row (u >> 2), 8-byte piece (u & 3) of the group's 32-byte column segment; receives column u, 4 rows
     const int u = lane & 15, g1 = (lane >> 4) & 1;
-    const int sw = ((u >> 2) | (half << 2)) << 5;                           // swz(row) << 5: the same for every row this lane addresses
+    const int sw = (u >> 2) << 6;                                           // swz(row) << 6: row & 3 = u >> 2 for every row this lane addresses
     const int row_off = half * 4096 + (u >> 2) * 512;                       // + ks * 8192 + rd * 2048
     int a_off[4], b_off[2];
 #pragma unroll
@@ -238,12 +241,34 @@ extern "C" int dwm_gemm_tn(const dwm_gemm_tn_args* a, void* stream) {
     p.nk_all = (int)(a->M / TBK);
     const int64_t tiles = (int64_t)p.ntm * p.ntn;
     const int64_t slice_floats = a->N * (int64_t)ntaps * a->C;
-    int ksplit = a->split_k > 0 ? a->split_k : (int)(256 / tiles);
-    if (ksplit > p.nk_all / 8) ksplit = p.nk_all / 8;
-    if (ksplit > 32) ksplit = 32;
-    if (ksplit < 1) ksplit = 1;
-    if ((int64_t)ksplit * slice_floats * 4 > a->workspace_bytes) ksplit = (int)(a->workspace_bytes / (slice_floats * 4));
-    if (ksplit < 1 || (a->split_k > 0 && ksplit != a->split_k)) return DWM_EINVAL;
+    // K ranges: every (tile, range) is one workgroup and a CU holds one, so the launch runs in ceil(tiles * ranges / CUs) rounds.
+    // Automatic choice: the range count (ranges of >= 8 K steps, <= 32, within the workspace) with the smallest modelled time
+    //     rounds * (K steps per range * 1.5 us + 25 us per workgroup) + ranges * partial bytes / 4 TB/s   (the ordered reduction)
+    // - e.g. the 144 tiles of a 6144 x 1536 weight gradient: 1 range = 144 of 256 CUs busy for 1344 steps, 7 ranges = 1008
+    // workgroups = 3.94 rounds of 192 steps; but 108 tiles over 462 steps stay at 2 ranges (26 ranges would fill the last round
+    // better and pay 11 rounds of fixed costs for it; measured).
+    int kmax = p.nk_all / 8;
+    if (kmax > 32) kmax = 32;
+    if ((int64_t)kmax * slice_floats * 4 > a->workspace_bytes) kmax = (int)(a->workspace_bytes / (slice_floats * 4));
+    if (kmax < 1) kmax = slice_floats * 4 <= a->workspace_bytes ? 1 : 0;
+    if (kmax < 1) return DWM_EINVAL;
+    int ksplit = a->split_k;
+    if (ksplit <= 0) {
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        }
+        double best = 0.0;
+        for (int k = 1; k <= kmax; ++k) {
+            const int64_t rounds = (tiles * k + ncu - 1) / ncu;
+            const double steps = (double)((p.nk_all + k - 1) / k);
+            const double us = (double)rounds * (steps * 1.5 + 25.0) + (double)k * (double)slice_floats * 4.0 / 4.0e6;
+            if (k == 1 || us < best) { best = us; ksplit = k; }
+        }
+    } else if (ksplit > kmax) {
+        return DWM_EINVAL;
+    }
     p.ksplit = ksplit;
     p.ws = (float*)a->workspace;
     p.ws_slice = slice_floats;

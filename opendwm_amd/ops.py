@@ -390,7 +390,7 @@ def _f32_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 
 
 _WORKSPACES: dict = {}
-GEMM_WORKSPACE_BYTES = 256 << 20
+GEMM_WORKSPACE_BYTES = 1 << 30          # 1 GiB per (device, stream): up to ~8 K ranges of the largest weight gradient (12288 x 1536 fp32)
 
 
 def _gemm_workspace(device: torch.device) -> torch.Tensor:

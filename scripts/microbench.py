@@ -225,6 +225,21 @@ def bench_gemm_epilogue_dev():
         print(json.dumps({"kernel": "gemm_epilogue_dev", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
 
 
+def bench_gemm_tn():
+    """weight-gradient GEMM from the row-major operands (dwm_gemm_tn) against the path it replaces (two transposes + NT GEMM)"""
+    from opendwm_amd import train_ops as T
+    for name, M, N, Cc in [("dW out-proj", 86016, 1536, 1536), ("dW ff1", 86016, 6144, 1536), ("dW ff2", 86016, 1536, 6144),
+                           ("dW geglu", 86016, 12288, 1536), ("dW ctx qkv", 29568, 4608, 1536)]:
+        dy, x = rnd(M, N), rnd(M, Cc, scale=M ** -0.5)
+        fl = 2.0 * M * N * Cc
+        ms_tn = min(timeit(lambda: T.gemm_tn(dy, x)) for _ in range(2))
+        ms_old = min(timeit(lambda: ops.gemm(T.transpose(dy), T.transpose(x), None)) for _ in range(2))
+        dyt, xt = T.transpose(dy), T.transpose(x)
+        ms_nt = min(timeit(lambda: ops.gemm(dyt, xt, None)) for _ in range(2))
+        print(json.dumps({"kernel": "gemm_tn", "case": name, "M": M, "N": N, "C": Cc, "tn_tflops": round(fl / ms_tn / 1e9, 1),
+                          "transposes_plus_nt_tflops": round(fl / ms_old / 1e9, 1), "nt_alone_tflops": round(fl / ms_nt / 1e9, 1)}), flush=True)
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -256,6 +271,8 @@ if __name__ == "__main__":
         bench_gemm((0, 4, 1))
     if "gemmt" in what:
         bench_gemm_tiles()
+    if "gemmtn" in what:
+        bench_gemm_tn()
     if "gemmd" in what:
         bench_gemm_tiles_dev()
     if "gemme" in what:

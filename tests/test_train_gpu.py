@@ -185,8 +185,8 @@ def test_linear_backward(dev, M, N, K):
     assert e["dx"] < TOL_KERNEL and e["dw"] < TOL_KERNEL and e["db"] < TOL_REDUCE
 
 
-@pytest.mark.parametrize("M,N,C,ks", [(1024, 256, 256, 1), (2048, 1536, 1536, 0), (4096, 320, 2880, 0), (8192, 1536, 3072, 4), (1280, 72, 8, 2),
-                                      (86016, 1536, 1536, 0)])
+@pytest.mark.parametrize("M,N,C,ks", [(1024, 256, 256, 1), (2048, 1536, 1536, 4), (4096, 320, 2880, 8), (8192, 1536, 3072, 4), (1280, 72, 8, 2),
+                                      (86016, 1536, 1536, 7)])
 def test_gemm_tn_equals_transposed_path(dev, M, N, C, ks):
     """dwm_gemm_tn (both operands as they are, transposing LDS reads) against the path it replaces - two explicit transposes + the NT
     GEMM: the same products in the same order over the same K ranges, so BIT-identical; and against the fp32 product."""
@@ -198,6 +198,8 @@ def test_gemm_tn_equals_transposed_path(dev, M, N, C, ks):
     assert got.shape == (N, C) and e < TOL_KERNEL
     old = ops.gemm(T.transpose(dy), T.transpose(x), None, split_k=ks)
     assert torch.equal(got, old)
+    auto = T.gemm_tn(dy, x)                          # automatic range count (fills the last round of workgroups): another summation order
+    assert rel_err(auto, dy.float().t() @ x.float()) < TOL_KERNEL
     # strided operands (column slices of wider buffers)
     wide_dy, wide_x = _rand((M, N + 64), dev, 3), _rand((M, C + 8), dev, 4, M ** -0.5)
     got2 = T.gemm_tn(wide_dy[:, 64:], wide_x[:, :C], split_k=ks)
