@@ -103,11 +103,14 @@ def preflight(device: torch.device = None, mbytes: int = 64) -> dict:
     if lo != want or hi != want:
         raise RuntimeError(f"preflight: all_reduce over {world} ranks gave [{lo}, {hi}], expected {want} on rank {rank}")
     # every rank on its own device: the (device index, host pid) pairs must be distinct
-    ids = [None] * world
-    dist.all_gather_object(ids, (local_rank if on_gpu else -1 - rank, os.getpid()))
+    # (a tensor all-gather, not all_gather_object: no pickling through the backend's device path)
+    mine = torch.tensor([local_rank if on_gpu else -1 - rank, os.getpid()], dtype=torch.int64, device=dev)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    ids = [tuple(int(v) for v in t.tolist()) for t in got]
     if on_gpu and len({i for i, _ in ids}) != world:
         raise RuntimeError(f"preflight: ranks share a GPU: {ids}")
-    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True)
+    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True, distinct_devices=on_gpu)
     return info
 
 
