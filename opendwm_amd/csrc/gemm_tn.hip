@@ -227,6 +227,7 @@ extern "C" int dwm_gemm_tn(const dwm_gemm_tn_args* a, void* stream) {
     if (a->M % TBK != 0 || a->N % 8 != 0 || a->C % 8 != 0) return DWM_EUNSUPPORTED;
     const int ntaps = a->ntaps > 0 ? a->ntaps : 1;
     if (ntaps > 27) return DWM_EINVAL;
+    if (a->ntaps <= 0 && a->b_rows < a->M) return DWM_EINVAL;      // no taps: row m of B pairs with row m of A, nothing may be clamped
     if (a->lda < a->N || a->ldb < a->C || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldb >= (1ll << 30) || a->ldo % 8 != 0 || a->ldo < (int64_t)ntaps * a->C) return DWM_EALIGN;
     if (!dwm_aligned16(a->A) || !dwm_aligned16(a->B) || !dwm_aligned16(a->out) || !dwm_aligned16(a->workspace)) return DWM_EALIGN;
     TnParams p;
