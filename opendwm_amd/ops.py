@@ -4,7 +4,6 @@ function raises if its tensors are not bf16 CUDA(HIP) tensors — there is no fa
 from __future__ import annotations
 
 import ctypes as C
-import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -164,10 +163,6 @@ def _overlaps(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a0 < b1 and b0 < a1
 
 
-# tuning knob (A/B measurements of whole models): the tile configuration of GEMM calls that do not name one
-_DEFAULT_TILE = int(os.environ.get("DWM_GEMM_TILE", "0"))
-
-
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, epilogue: int = EPI_PLAIN, act: int = ACT_NONE,
          gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1,
@@ -269,7 +264,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                 raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
     g.split_k = split_k
-    g.tile = tile or _DEFAULT_TILE
+    g.tile = tile
     # split-K scratch (fp32 partial tiles): only handed over when the kernel's own rule can take it
     if split_k != 1 and epilogue in (EPI_PLAIN, EPI_RESID) and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and K >= 1024:
         ws = _gemm_workspace(a.device)
