@@ -439,7 +439,8 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
     // ------------------------------------------------------------------ epilogue
     // Stage A (MFMA layout, lane = one row x 4-column groups): bias, activation, GEGLU product,
     // per-head RMSNorm.  Stage B: each wave transposes its tile through a private, XOR-swizzled
-    // 8 KiB LDS region (32 rows x 64 fp32 per pass) so that gate / residual / blend loads and
+    // 8 KiB LDS region (32 rows per pass: 64 fp32 for RESID / split-K, whose arithmetic follows the
+    // transpose; 64 bf16 for the other epilogues) so that gate / residual / blend loads and
     // the bf16 stores are row-major 16-B accesses (8 rows x 128 B per wave instruction).
     if (DWM_RESERVED(p.reserved) & 1) {        // ablation knob (development builds only): main loop without the epilogue
         float sink = 0.f;
