@@ -240,6 +240,27 @@ def bench_gemm_tn():
                           "transposes_plus_nt_tflops": round(fl / ms_old / 1e9, 1), "nt_alone_tflops": round(fl / ms_nt / 1e9, 1)}), flush=True)
 
 
+def bench_gemm_raster_dev():
+    """development library only: group height of the tile rasterisation (reserved bits 4-8) per shape"""
+    from opendwm_amd.blocks import geglu_pack
+    for name, M, N, K, kind in [("qkv", 86016, 4608, 1536, "plain"), ("ff1", 86016, 6144, 1536, "plain"), ("vt geglu", 86016, 12288, 1536, "geglu"),
+                                ("out-proj", 86016, 1536, 1536, "plain"), ("ff2", 86016, 1536, 6144, "plain")]:
+        a, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+        fl = 2.0 * M * N * K
+        res = {}
+        for di, gm in enumerate([8, 2, 4, 8, 16, 24, 2, 4, 8, 16, 24]):
+            dbg = gm << 4
+            if kind == "geglu":
+                wp, bp = geglu_pack(w), geglu_pack(b)
+                f = lambda: ops.gemm(a, wp, bp, epilogue=ops.EPI_GEGLU, _debug=dbg, split_k=1)
+            else:
+                f = lambda: ops.gemm(a, w, b, _debug=dbg, split_k=1)
+            ms = timeit(f)
+            if di:
+                res.setdefault(f"gm={gm}", []).append(round(fl / ms / 1e9, 1))
+        print(json.dumps({"kernel": "gemm_raster_dev", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -277,5 +298,7 @@ if __name__ == "__main__":
         bench_gemm_tiles_dev()
     if "gemme" in what:
         bench_gemm_epilogue_dev()
+    if "gemmr" in what:
+        bench_gemm_raster_dev()
     if "ln" in what:
         bench_ln()
