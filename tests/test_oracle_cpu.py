@@ -361,7 +361,7 @@ def test_ctypes_structs_match_header_field_order():
     from opendwm_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "dwm_hip.h")).read()
     for cname, cls in (("dwm_gemm_args", _lib.GemmArgs), ("dwm_attn_args", _lib.AttnArgs),
-                       ("dwm_layernorm_args", _lib.LayerNormArgs)):
+                       ("dwm_layernorm_args", _lib.LayerNormArgs), ("dwm_gemm_tn_args", _lib.GemmTnArgs)):
         body = hdr[hdr.index(f"typedef struct {cname}"):hdr.index(f"}} {cname};")]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         pos = -1
@@ -369,6 +369,47 @@ def test_ctypes_structs_match_header_field_order():
             m = re.search(rf"[\s\*,]{fname}\s*(\[\d+\])?\s*[,;]", body[pos + 1:])
             assert m, (cname, fname)
             pos = pos + 1 + m.start()
+
+
+def test_entry_points_validate_their_arguments_before_touching_the_device():
+    """Argument checks of the C ABI run on the host, before any HIP call: they can be exercised without a GPU (fake, aligned
+    device addresses; every call below must return its error code, not launch)."""
+    from opendwm_amd import _lib, build
+    lib = ctypes.CDLL(build.build())
+    lib.dwm_gemm_tn.restype = ctypes.c_int
+    lib.dwm_gemm_bf16.restype = ctypes.c_int
+    fake = 1 << 20                                             # 16-byte aligned, never dereferenced on these paths
+
+    def tn(**kw):
+        g = _lib.GemmTnArgs()
+        g.A = g.B = g.out = g.workspace = fake
+        g.lda, g.ldb, g.ldo, g.M, g.N, g.C, g.b_rows = 256, 256, 256, 128, 256, 256, 128
+        g.workspace_bytes = 1 << 30
+        for k, v in kw.items():
+            setattr(g, k, v)
+        return lib.dwm_gemm_tn(ctypes.byref(g), None)
+
+    assert tn(M=100, b_rows=100) != 0                          # contraction rows must be a multiple of 64
+    assert tn(N=252) != 0 and tn(C=12) != 0                    # 16-byte rows
+    assert tn(b_rows=64) != 0                                  # no taps: B must have a row for every row of A
+    assert tn(ntaps=28) != 0
+    assert tn(lda=128) != 0 and tn(ldo=128) != 0               # leading dimensions shorter than the rows
+    assert tn(workspace_bytes=1024) != 0                       # not even one K range of partial tiles fits
+    assert tn(split_k=64) != 0                                 # more ranges than the rule allows (>= 8 K steps each, <= 32)
+    assert tn(A=fake + 2) != 0                                 # misaligned
+
+    def nt(**kw):
+        g = _lib.GemmArgs()
+        g.A = g.W = g.C = fake
+        g.lda, g.ldc, g.M, g.N, g.K = 256, 256, 256, 256, 256
+        for k, v in kw.items():
+            setattr(g, k, v)
+        return lib.dwm_gemm_bf16(ctypes.byref(g), None)
+
+    assert nt(tile=3) != 0 and nt(tile=-1) != 0                # tile configuration: 0 / 1 / 2
+    assert nt(K=100) != 0 and nt(N=100) != 0
+    assert nt(tile=2, C32=fake, epilogue=_lib.EPI_RESID, ldc32=256) != 0     # the fp32 residual stream has no 256 x 128 form
+    assert nt(epilogue=99) != 0
 
 
 def test_train_pair_construction_matches_oracle():
