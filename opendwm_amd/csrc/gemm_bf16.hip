@@ -18,6 +18,8 @@
 // stages for the activation tile (requested two K steps ahead: it is the operand that streams from HBM
 // when K is long) and two for the weight tile (one step ahead, L2-resident); one barrier per K step with a
 // counted vmcnt that leaves the newest activation requests in flight.
+#include <type_traits>
+
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -267,19 +269,22 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             for (int j = 0; j < NJA; ++j) { stage_a(0, aoff, j); stage_w(0, koff, j); }
             // tile 1 is requested right behind tile 0, before the first wait: it then has the whole round trip of tile 0 plus
             // most of K step 0 to arrive, instead of starting its own round trip only after tile 0 has landed
-            if (nk > 1) walk_next();
-            aoff = walk_a; koff = walk_w;
+            if (nk > 1) {
+                walk_next();
+                aoff = walk_a; koff = walk_w;
 #pragma unroll
-            for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
+                for (int j = 0; j < NJA; ++j) stage_a(1, aoff, j);
 #pragma unroll
-            for (int j = 0; j < NJA; ++j) stage_w(1, koff, j);
+                for (int j = 0; j < NJA; ++j) stage_w(1, koff, j);
+            }
             // (the accumulators are zeroed HERE, under the round trip of the first requests: left to itself the compiler
             // sinks the 128 moves behind the barrier, ~1 us of a 45 us tile with nothing else to run)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(acc[i][j]));
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJA) : "memory");          // tile 0 landed (loads return in order)
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJA) : "memory");   // tile 0 landed (loads return in order)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -287,24 +292,32 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) wf[0][nt] = *(const bf16x8*)(smem + W_BASE + w_row_off + nt * (32 * 128) + coff[0]);
         }
-        for (int kt = 0; kt < nk; ++kt) {
+        // One K step.  MODE 0: tiles kt+1 and kt+2 exist (the steady state described above).  MODE 1: the second-to-last step -
+        // nothing is requested any more, so the barrier's wait is vmcnt(0) (tile kt+1, the last, must have landed).  MODE 2: the
+        // last step - no requests, no barrier, no fragment reads of a next tile.  (Until round 3 the tail re-requested the last
+        // tile twice to keep the counted waits uniform: 8 % of a K = 1536 tile's LDS-DMA traffic for nothing, and the wait for the
+        // final redundant request - a full L2 round trip - sat between the last MFMA and the epilogue.)
+        int kt = 0;
+        auto k_step = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
             const int sa1 = sa == A_STAGES - 1 ? 0 : sa + 1, sa2 = sa1 == A_STAGES - 1 ? 0 : sa1 + 1;
             const char* la = smem + sa * A_TILE;
             const char* lb = smem + W_BASE + (kt & 1) * A_TILE;
             const char* lan = smem + sa1 * A_TILE;                  // tile kt+1
             const char* lbn = smem + W_BASE + ((kt + 1) & 1) * A_TILE;
-            if (kt + 2 < nk) walk_next();                              // tile kt+2 (past the end: a redundant reload nobody reads)
+            if constexpr (MODE == 0) walk_next();                      // tile kt+2
             const int64_t aoff2 = walk_a, koff2 = walk_w;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    if (ks == 3 && c == 0) {
+                    if (ks == 3 && c == 0 && MODE != 2) {
                         // own last fragments read; own shares of A(kt+1) and W(kt+1) landed (A(kt+2) may stay in flight)
                         // bare s_barrier, not __syncthreads(): the workgroup-scope release fence of __syncthreads() makes the
                         // compiler append "s_waitcnt vmcnt(0)" (LDS-DMA writes LDS and is tracked by vmcnt), which drains
                         // A(kt+2) at every K step; the counted wait above is the ordering this barrier needs
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJA) : "memory");
+                        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJA) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                     }
@@ -313,7 +326,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         const int idx = c * MPC + u, mt = idx / NTW, nt = idx % NTW;
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][nt], af[ks & 1][mt], acc[mt][nt], 0, 0, 0);
                     }
-                    if (c < NDS) {
+                    if (c < NDS && !(MODE == 2 && ks == 3)) {
                         // order of first use in the next sub-step (MFMA c uses A[c / 2], W[c % 2]): W0 A0 W1 A1 A2 A3 - every
                         // read then has eight MFMAs to land and the compiler's counted lgkmcnt waits never drain the queue
                         const char* fa = ks < 3 ? la : lan;
@@ -324,13 +337,17 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         if (is_w) wf[(ks + 1) & 1][fi] = *(const bf16x8*)(fb + w_row_off + fi * (32 * 128) + coff[kn]);
                         else af[(ks + 1) & 1][fi] = *(const bf16x8*)(fa + a_row_off + fi * (32 * 128) + coff[kn]);
                     }
-                    if (ks == 0 && c < NJA) stage_a(sa2, aoff2, c);                       // A(kt+2): the slot tile kt-1 left
-                    if (ks == 3 && c >= 1 && c <= NJA) stage_w(kt & 1, koff2, c - 1);     // W(kt+2): the slot of this tile
+                    if (MODE == 0 && ks == 0 && c < NJA) stage_a(sa2, aoff2, c);                       // A(kt+2): the slot tile kt-1 left
+                    if (MODE == 0 && ks == 3 && c >= 1 && c <= NJA) stage_w(kt & 1, koff2, c - 1);     // W(kt+2): the slot of this tile
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             sa = sa1;
-        }
+            ++kt;
+        };
+        while (kt + 2 < nk) k_step(std::integral_constant<int, 0>{});
+        if (nk > 1) k_step(std::integral_constant<int, 1>{});
+        k_step(std::integral_constant<int, 2>{});
     } else {
         // Configuration 1 (BK = 32: two MFMA K steps per tile).  Per K step and wave: sub-step 0 = 8 MFMAs on the first
         // half of tile kt while the second-half fragments are read and the 6 requests of tile kt+2 are issued (into the slot
