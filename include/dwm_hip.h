@@ -110,10 +110,12 @@ typedef struct dwm_gemm_args {
      * (>= 2 * M * N * 4 to be usable), owned by the caller, one per stream; NULL = never split.
      * split_k: 0 = automatic, 1 = never, > 1 = exactly this many ranges (DWM_EUNSUPPORTED if impossible). */
     void* workspace; int64_t workspace_bytes; int32_t split_k;
-    /* fp32 residual stream (RESID, res_mod == 0): when C32 != NULL, `res` is an fp32 matrix (ld_res in fp32 elements, rows
-     * through c_map like C), the result v is written to C32 in fp32 (in place over `res` allowed) and, rounded, to the bf16 C
-     * that the next GEMM reads.  Keeps a chain of residual blocks from accumulating one bf16 storage rounding per block (the
-     * layout ImageAdapter, src/dwm/models/adapters.py:40-60: its input - and so its error - is the same at every denoise step). */
+    /* fp32 residual stream (RESID, res_mod == 0): when C32 != NULL, `res` and `blend` are fp32 matrices (ld_res / ld_blend in
+     * fp32 elements, rows through c_map like C), the result v is written to C32 in fp32 (in place over `res` or `blend` allowed)
+     * and - unless C is NULL, which is allowed only here - rounded to the bf16 C as well.  Keeps a chain of residual blocks from
+     * accumulating one bf16 storage rounding per block: the layout ImageAdapter (src/dwm/models/adapters.py:40-60: its input -
+     * and so its error - is the same at every denoise step) and the hidden / context streams of the MMDiT forward
+     * (src/dwm/models/crossview_temporal_dit.py:486-598: ~130 residual adds per forward). */
     void* C32; int64_t ldc32;
     /* tile configuration: 0 = automatic, 1 = 256 x 256 x 64 tiles (one 8-wave workgroup per CU), 2 = 256 x 128 x 32 tiles
      * (two 4-wave workgroups per CU; chosen automatically where it cuts the padded columns, e.g. N = 320 / 640; not with
@@ -188,8 +190,9 @@ typedef struct dwm_attn_args {
                                                 * for every unit of the resident kernel (default: its maximum-free fast path with
                                                 * a checked fallback), bit 5 keep the tiled kernel (default for L <= 32: the
                                                 * packed short-sequence kernel; for unmasked self-attention with 64 <= L <= 608:
-                                                * the resident kernel), bit 7 per-wave form of the group-masked kernel, bits 8-11
-                                                * heads per workgroup / item */
+                                                * the resident kernel), bit 6 resident kernel without the register prefetch of
+                                                * the next head's K / V rows (A/B measurements), bit 7 per-wave form of the
+                                                * group-masked kernel, bits 8-11 heads per workgroup / item */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */
@@ -245,6 +248,10 @@ typedef struct dwm_layernorm_args {
 } dwm_layernorm_args;
 
 int dwm_layernorm(const dwm_layernorm_args* args, void* stream);
+/* The same with x (and xsum) in fp32 - ldx / ldxsum in fp32 elements - and everything else as above: the LayerNorms of
+ * the bf16 forward when the hidden state is kept as an fp32 residual stream (dwm_gemm_args.C32); the reference keeps the
+ * stream in the module dtype (diffusers JointTransformerBlock / crossview_temporal.py:562-582), fp32 on its CPU path. */
+int dwm_layernorm_x32(const dwm_layernorm_args* args, void* stream);
 
 /* Stand-alone per-head RMSNorm (in place) over 64-wide heads of x[rows, ncols]:
  * x[r, c] = x[r, c] * rsqrt(mean_head(x^2) + eps) * w[c]; (fallback for shapes the
@@ -303,6 +310,8 @@ int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream);
 /* y (bf16) += x (fp32), the sum rounded once: layout residuals kept in fp32 across denoise steps
  * (crossview_temporal_dit.py:491-494 with the ImageAdapter output cached) */
 int dwm_add_f32_inplace(void* y, const float* x, int64_t n, void* stream);
+/* y (fp32) += x (fp32), n % 4 == 0: cached layout residuals onto the fp32 hidden stream (crossview_temporal_dit.py:491-494) */
+int dwm_add_f32_f32_inplace(float* y, const float* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------
  * VAE blocks (diffusers AutoencoderKL, called at src/dwm/pipelines/ctsd.py:1213-1218,1634-1640)

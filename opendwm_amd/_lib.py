@@ -118,6 +118,7 @@ SIGNATURES = {
     "dwm_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
     "dwm_debug_tr_probe": (_i32, [_vp, _vp, _vp]),
     "dwm_layernorm": (_i32, [C.POINTER(LayerNormArgs), _vp]),
+    "dwm_layernorm_x32": (_i32, [C.POINTER(LayerNormArgs), _vp]),
     "dwm_rmsnorm_heads": (_i32, [_vp, _i64, _i64, _i64, _vp, _f32, _vp]),
     "dwm_silu": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_timestep_sinusoid": (_i32, [_vp, _i64, _i32, _vp, _vp]),
@@ -142,6 +143,7 @@ SIGNATURES = {
     "dwm_avgpool2_tokens": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dwm_add_inplace": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_add_f32_inplace": (_i32, [_vp, _vp, _i64, _vp]),
+    "dwm_add_f32_f32_inplace": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_groupnorm_silu": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), _vp]),
     "dwm_groupnorm_silu_mapped": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
     "dwm_upsample2_padded": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .blocks import STORE, _bf
+from .blocks import STORE, _bf, stream32
 from .ops import ACT_RELU, EPI_RESID, PaddedGrid
 
 bf16 = torch.bfloat16
@@ -246,10 +246,13 @@ class ImageAdapter(nn.Module):
                 def add(h, cur_pad=cur_pad, grid=grid, wz=wz, zc=zc):
                     if h.shape != (grid.pixels, wz.shape[0]):
                         raise RuntimeError(f"condition residual {(grid.pixels, wz.shape[0])} does not match hidden states {tuple(h.shape)}")
-                    ops.gemm(cur_pad, wz, _bf(zc.bias), a_grid=grid, epilogue=EPI_RESID, res=h, out=h)
+                    if stream32(h):        # the fp32 hidden stream of the bf16 forward: fp32 in, fp32 out, no bf16 copy
+                        ops.gemm(cur_pad, wz, _bf(zc.bias), a_grid=grid, epilogue=EPI_RESID, res=h, out32=h, mirror=False)
+                    else:
+                        ops.gemm(cur_pad, wz, _bf(zc.bias), a_grid=grid, epilogue=EPI_RESID, res=h, out=h)
             else:
                 def add(h, cur_pad=cur_pad, grid=grid):
-                    ops.add_(h, cur_pad[grid.interior_index().to(cur_pad.device)])
+                    ops.add_(h, cur_pad[grid.interior_index().to(cur_pad.device)].contiguous())      # (any bf16 / fp32 pairing)
             yield add
 
     def forward(self, x: torch.Tensor, return_features: bool = False):

@@ -104,6 +104,25 @@ def _bf(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else STORE.bf(t)
 
 
+def stream32(h: torch.Tensor) -> bool:
+    """is `h` the fp32 residual stream of a bf16 forward?  (In the fp32 accuracy path every tensor is fp32 and the ops
+    dispatch on the dtype; here only the hidden / context streams are: the residual adds - ~130 per forward, each a rounding
+    of the whole stream when it is kept in bf16 - accumulate in fp32, everything a GEMM reads stays bf16.)"""
+    return h.dtype == torch.float32 and STORE.precision == bf16
+
+
+def _act_like(h: torch.Tensor) -> torch.Tensor:
+    """an activation buffer shaped like the stream h, in the compute dtype"""
+    return torch.empty(h.shape, dtype=bf16 if stream32(h) else h.dtype, device=h.device)
+
+
+def _resid_into(stream: torch.Tensor, a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], **kw) -> torch.Tensor:
+    """stream <- stream + gate * (a @ w^T + b): the RESID GEMM in place on a residual stream (bf16, or the fp32 stream)"""
+    if stream32(stream):
+        return ops.gemm(a, w, b, epilogue=EPI_RESID, res=stream, out32=stream, mirror=False, **kw)
+    return ops.gemm(a, w, b, epilogue=EPI_RESID, res=stream, out=stream, **kw)
+
+
 def geglu_pack(w: torch.Tensor) -> torch.Tensor:
     """Reorder the rows of a GEGLU projection ([value rows ; gate rows]) into 64-row groups
     [32 value rows | 32 gate rows] — the layout DWM_EPI_GEGLU expects."""
@@ -265,50 +284,50 @@ class JointTransformerBlock(nn.Module):
             self.ff_context = FeedForward(dim, dim, activation_fn="gelu-approximate")
 
     def run(self, h: torch.Tensor, c: torch.Tensor, silu_temb: torch.Tensor, n_img: int):
-        """h [I*N, D], c [I*Lc, D] bf16 (updated in place), silu_temb [I, D].  Returns (c, h)."""
+        """h [I*N, D], c [I*Lc, D] (updated in place): bf16, or the fp32 residual streams of a bf16 forward (`stream32`);
+        silu_temb [I, D].  Returns (c, h)."""
         D = self.dim
         N, Lc = h.shape[0] // n_img, c.shape[0] // n_img
+        x32 = stream32(h)
         mod = ops.gemm(silu_temb, _bf(self.norm1.linear.weight), _bf(self.norm1.linear.bias))
         cmod = ops.gemm(silu_temb, _bf(self.norm1_context.linear.weight), _bf(self.norm1_context.linear.bias))
         sl = lambda m, i: m[:, i * D:(i + 1) * D]
         # AdaLayerNormZero(X) chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
-        nh2 = torch.empty_like(h) if self.use_dual_attention else None
+        nh2 = _act_like(h) if self.use_dual_attention else None
         nh = ops.layernorm(h, eps=1e-6, scale=sl(mod, 1), shift=sl(mod, 0), rows_per_mod=N,
                            scale2=sl(mod, 7) if nh2 is not None else None,
-                           shift2=sl(mod, 6) if nh2 is not None else None, out2=nh2)
+                           shift2=sl(mod, 6) if nh2 is not None else None, out2=nh2, x32=x32)
         if self.context_pre_only:      # AdaLayerNormContinuous: scale first
-            nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 0), shift=sl(cmod, 1), rows_per_mod=Lc)
+            nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 0), shift=sl(cmod, 1), rows_per_mod=Lc, x32=x32)
         else:
-            nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 1), shift=sl(cmod, 0), rows_per_mod=Lc)
+            nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 1), shift=sl(cmod, 0), rows_per_mod=Lc, x32=x32)
 
         qkv = self.attn.project_qkv(nh)
         cqkv = self.attn.project_qkv(nc, added=True)
-        ao = torch.empty_like(h)
-        cao = torch.empty_like(c)
+        ao = _act_like(h)
+        cao = _act_like(c)
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, ops.rowmap_identity(n_img, N), self.heads,
                       q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cao)
         to_out = self.attn.to_out[0]
-        ops.gemm(ao, _bf(to_out.weight), _bf(to_out.bias), epilogue=EPI_RESID, gate=sl(mod, 2), rows_per_gate=N,
-                 res=h, out=h)
+        _resid_into(h, ao, _bf(to_out.weight), _bf(to_out.bias), gate=sl(mod, 2), rows_per_gate=N)
         if self.use_dual_attention:
             qkv2 = self.attn2.project_qkv(nh2)
             ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], ao, ops.rowmap_identity(n_img, N), self.heads)
             to_out2 = self.attn2.to_out[0]
-            ops.gemm(ao, _bf(to_out2.weight), _bf(to_out2.bias), epilogue=EPI_RESID, gate=sl(mod, 8),
-                     rows_per_gate=N, res=h, out=h)
-        nh = ops.layernorm(h, eps=1e-6, scale=sl(mod, 4), shift=sl(mod, 3), rows_per_mod=N, out=nh)
+            _resid_into(h, ao, _bf(to_out2.weight), _bf(to_out2.bias), gate=sl(mod, 8), rows_per_gate=N)
+        nh = ops.layernorm(h, eps=1e-6, scale=sl(mod, 4), shift=sl(mod, 3), rows_per_mod=N, out=nh, x32=x32)
         f1, f2 = self.ff.net[0].proj, self.ff.net[2]
         ffh = ops.gemm(nh, _bf(f1.weight), _bf(f1.bias), act=ACT_GELU_TANH)
-        ops.gemm(ffh, _bf(f2.weight), _bf(f2.bias), epilogue=EPI_RESID, gate=sl(mod, 5), rows_per_gate=N, res=h, out=h)
+        _resid_into(h, ffh, _bf(f2.weight), _bf(f2.bias), gate=sl(mod, 5), rows_per_gate=N)
 
         if self.context_pre_only:
             return None, h
         ta = self.attn.to_add_out
-        ops.gemm(cao, _bf(ta.weight), _bf(ta.bias), epilogue=EPI_RESID, gate=sl(cmod, 2), rows_per_gate=Lc, res=c, out=c)
-        nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 4), shift=sl(cmod, 3), rows_per_mod=Lc, out=nc)
+        _resid_into(c, cao, _bf(ta.weight), _bf(ta.bias), gate=sl(cmod, 2), rows_per_gate=Lc)
+        nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 4), shift=sl(cmod, 3), rows_per_mod=Lc, out=nc, x32=x32)
         c1, c2 = self.ff_context.net[0].proj, self.ff_context.net[2]
         cff = ops.gemm(nc, _bf(c1.weight), _bf(c1.bias), act=ACT_GELU_TANH)
-        ops.gemm(cff, _bf(c2.weight), _bf(c2.bias), epilogue=EPI_RESID, gate=sl(cmod, 5), rows_per_gate=Lc, res=c, out=c)
+        _resid_into(c, cff, _bf(c2.weight), _bf(c2.bias), gate=sl(cmod, 5), rows_per_gate=Lc)
         return c, h
 
 
@@ -377,12 +396,14 @@ class VTSelfAttentionBlock(nn.Module):
             dense_mask: Optional[torch.Tensor] = None,
             blend_alpha: Optional[torch.Tensor] = None, rows_per_alpha: int = 1,
             blend_into: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """h [rows, D] bf16.  x = h + emb[row // rows_per_emb]; y = block(x); if blend_alpha is
+        """h [rows, D] bf16 (or the fp32 residual stream of a bf16 forward, `stream32`: the block's own stream x is then fp32
+        as well).  x = h + emb[row // rows_per_emb]; y = block(x); if blend_alpha is
         given the result alpha*blend_into + (1-alpha)*y is written into blend_into (the mixer of
         crossview_temporal_dit.py:320-327 / :363-370)."""
         D = self.dim
         pk = self.packed()
-        ln = lambda x, n, **kw: ops.layernorm(x, eps=1e-5, weight=_bf(n.weight), bias=_bf(n.bias), **kw)
+        x32 = stream32(h)
+        ln = lambda x, n, **kw: ops.layernorm(x, eps=1e-5, weight=_bf(n.weight), bias=_bf(n.bias), x32=stream32(x), **kw)
         if emb is not None:
             xs = torch.empty_like(h)
             y = ln(h, self.norm_in, addvec=emb, rows_per_add=rows_per_emb, xsum=xs)
@@ -391,7 +412,7 @@ class VTSelfAttentionBlock(nn.Module):
             y = ln(h, self.norm_in)
         g = ops.gemm(y, pk["ff_in_w"], pk["ff_in_b"], epilogue=EPI_GEGLU)
         l2 = self.ff_in.net[2]
-        ops.gemm(g, _bf(l2.weight), _bf(l2.bias), epilogue=EPI_RESID, res=xs, out=xs)
+        _resid_into(xs, g, _bf(l2.weight), _bf(l2.bias))
 
         y = ln(xs, self.norm1, out=y)
         qkv = self.attn1.project_qkv(y)
@@ -399,14 +420,19 @@ class VTSelfAttentionBlock(nn.Module):
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, rowmap, self.heads,
                       group_mask=group_mask, dense_mask=dense_mask)
         to_out = self.attn1.to_out[0]
-        ops.gemm(ao, _bf(to_out.weight), _bf(to_out.bias), epilogue=EPI_RESID, res=xs, out=xs)
+        _resid_into(xs, ao, _bf(to_out.weight), _bf(to_out.bias))
 
         y = ln(xs, self.norm3, out=y)
         g = ops.gemm(y, pk["ff_w"], pk["ff_b"], epilogue=EPI_GEGLU, out=g)
         l2 = self.ff.net[2]
         if blend_alpha is None:
-            ops.gemm(g, _bf(l2.weight), _bf(l2.bias), epilogue=EPI_RESID, res=xs, out=xs)
-            return xs
+            return _resid_into(xs, g, _bf(l2.weight), _bf(l2.bias))
+        if x32:
+            if not stream32(blend_into):
+                raise RuntimeError("VTSelfAttentionBlock.run: an fp32 stream blends into an fp32 stream")
+            ops.gemm(g, _bf(l2.weight), _bf(l2.bias), epilogue=EPI_RESID, res=xs, blend=blend_into,
+                     alpha=blend_alpha, rows_per_alpha=rows_per_alpha, out32=blend_into, mirror=False)
+            return blend_into
         ops.gemm(g, _bf(l2.weight), _bf(l2.bias), epilogue=EPI_RESID, res=xs, blend=blend_into,
                  alpha=blend_alpha, rows_per_alpha=rows_per_alpha, out=blend_into)
         return blend_into

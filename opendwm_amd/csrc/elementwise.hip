@@ -313,6 +313,17 @@ add_f32_inplace_kernel(bf16_t* __restrict__ y, const float* __restrict__ x, int6
     *(uint4*)(y + i * 8) = pack8(a);
 }
 
+// y (fp32) += x (fp32): cached layout residuals onto the fp32 hidden stream
+__global__ void __launch_bounds__(256)
+add_f32_f32_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = *(const float4*)(y + i * 4);
+    const float4 b = *(const float4*)(x + i * 4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *(float4*)(y + i * 4) = a;
+}
+
 inline int finish() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
@@ -475,6 +486,13 @@ extern "C" int dwm_add_f32_inplace(void* y, const float* x, int64_t n, void* str
     if (n % 8 != 0 || !dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
     hipLaunchKernelGGL(add_f32_inplace_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)y, x, n / 8);
+    return finish();
+}
+
+extern "C" int dwm_add_f32_f32_inplace(float* y, const float* x, int64_t n, void* stream) {
+    if (x == nullptr || y == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 4 != 0 || !dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
+    hipLaunchKernelGGL(add_f32_f32_inplace_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4);
     return finish();
 }
 

@@ -97,10 +97,12 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
 // residual row = output row, no activation - with those facts known at compile time: the per-step address arithmetic is
 // one 32 x 32 -> 64 bit multiply-add per pointer instead of the row-map / modulo chains in 64-bit arithmetic, and the RESID
 // activation switch is gone (the general RESID form spends ~350 instructions per 8-row step, 44 per output value).
-// RF32 (general RESID form only): the residual stream is kept in fp32 - `res` is an fp32 matrix (ld_res in fp32 elements), the
-// result is written to `C32` in fp32 (in place over `res` is fine: a lane reads exactly the elements it writes) AND, rounded, to
-// the bf16 matrix C that the next GEMM reads.  For chains of residual blocks whose bf16 storage rounding would otherwise
-// accumulate block after block (the layout ImageAdapter: 12 resnets, step-invariant input, hence a step-invariant error).
+// RF32 (RESID, both forms): the residual stream is kept in fp32 - `res` (and `blend`) are fp32 matrices (leading dimensions in
+// fp32 elements), the result is written to `C32` in fp32 (in place over `res` / `blend` is fine: a lane reads exactly the
+// elements it writes) and, when C is given, rounded to the bf16 matrix C as well.  For chains of residual blocks whose bf16
+// storage rounding would otherwise accumulate block after block: the layout ImageAdapter (12 resnets, step-invariant input,
+// hence a step-invariant error) and - round 4 - the hidden state of the MMDiT itself (~130 residual adds per forward, each a
+// bf16 rounding of the whole stream: 1.1e-3 rms x sqrt(130) = the 1.3e-2 the bf16 forward showed against the fp32 oracle).
 template <int EPI, bool FAST = false, bool RF32 = false, int TC = 0>
 __global__ void __launch_bounds__(TileCfg<TC>::nwaves * 64, 2)
 gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
@@ -465,7 +467,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) sink += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
-        if (sink == 123.456f) ((float*)p.C)[0] = sink;
+        if (sink == 123.456f) ((float*)(p.C ? p.C : p.C32))[0] = sink;
         return;
     }
     bf16_t* __restrict__ Cp = (bf16_t*)p.C;
@@ -518,15 +520,22 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         // requested into the same registers, so four steps' worth of loads are always in flight behind the math and
         // the stores.  (Plain arrays + a macro: a second set, or structs behind lambda references, end up in scratch.)
         constexpr int NSTEP = 32 / RPS;
-        uint4 gbA[NSTEP], rA[NSTEP], rB[RF32 ? NSTEP : 1];
+        uint4 gbA[NSTEP], gbB[RF32 ? NSTEP : 1], rA[NSTEP], rB[RF32 ? NSTEP : 1];      // (gbB / rB: second half of an fp32 row piece)
         float alA[NSTEP];
         // branch-free: always two 16-byte loads and one alpha load per step (absent operands read a valid dummy row of C),
         // so the compiler's counted waits stay exact and never degrade to "everything outstanding, stores included"
-        const bf16_t* const gb_ptr = p.gate ? (const bf16_t*)p.gate : p.blend ? (const bf16_t*)p.blend : (const bf16_t*)p.C;
-        const int64_t gb_ld = p.gate ? p.ld_gate : p.blend ? p.ld_blend : p.ldc;
-        const bf16_t* const r_ptr = p.res ? (const bf16_t*)p.res : (const bf16_t*)p.C;
-        const int64_t r_ld = p.res ? p.ld_res : p.ldc;
-        const float* const al_ptr = p.blend ? p.alpha : (const float*)p.C;
+        // (RF32: C may be absent - the dummy is then C32 with its own pitch, read as if it were bf16: in bounds a fortiori;
+        //  the blend rows are fp32 and travel as two 16-byte pieces, gbA / gbB; the gate stays bf16)
+        const bf16_t* const dummy = (RF32 && p.C == nullptr) ? (const bf16_t*)p.C32 : (const bf16_t*)p.C;
+        const int64_t dummy_ld = (RF32 && p.C == nullptr) ? p.ldc32 : p.ldc;
+        const bool blend32 = RF32 && p.blend != nullptr;
+        const bf16_t* const gb_ptr = p.gate ? (const bf16_t*)p.gate : (p.blend && !RF32) ? (const bf16_t*)p.blend : dummy;
+        const int64_t gb_ld = p.gate ? p.ld_gate : (p.blend && !RF32) ? p.ld_blend : dummy_ld;
+        const float* const bl32_ptr = blend32 ? (const float*)p.blend : (const float*)p.C32;
+        const int64_t bl32_ld = blend32 ? p.ld_blend : p.ldc32;
+        const bf16_t* const r_ptr = p.res ? (const bf16_t*)p.res : dummy;
+        const int64_t r_ld = p.res ? p.ld_res : dummy_ld;
+        const float* const al_ptr = p.blend ? p.alpha : (const float*)dummy;
         float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // RESID: bias of this lane's 8 output columns
         if constexpr (EPI == DWM_EPI_RESID) {
             if (p.bias != nullptr && nok) unpack8(*(const uint4*)((const bf16_t*)p.bias + ncol), b8);
@@ -537,8 +546,18 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             m_ = m_ < (uint32_t)M ? m_ : (uint32_t)(M - 1);                                                       \
             const uint32_t nc_ = nok ? (uint32_t)ncol : 0u;                                                       \
             const uint32_t grow_ = p.gate ? fdiv(m_, cp.fd_rpg) : m_;                                             \
-            gbA[ST_] = *(const uint4*)(gb_ptr + ((uint64_t)grow_ * (uint32_t)gb_ld + nc_));                       \
-            rA[ST_] = *(const uint4*)(r_ptr + ((uint64_t)m_ * (uint32_t)r_ld + nc_));                             \
+            if constexpr (RF32) {       /* (selects, no branches: the load count per step stays fixed) */           \
+                const char* g0_ = blend32 ? (const char*)(bl32_ptr + ((uint64_t)m_ * (uint32_t)bl32_ld + nc_))    \
+                                          : (const char*)(gb_ptr + ((uint64_t)grow_ * (uint32_t)gb_ld + nc_));    \
+                gbA[ST_] = *(const uint4*)g0_;                                                                    \
+                gbB[ST_] = *(const uint4*)(g0_ + (blend32 ? 16 : 0));                                             \
+                const float* rp_ = (const float*)(p.res ? p.res : p.C32) + ((uint64_t)m_ * (uint32_t)(p.res ? r_ld : p.ldc32) + nc_); \
+                rA[ST_] = *(const uint4*)rp_;                                                                     \
+                rB[ST_] = *(const uint4*)(rp_ + 4);                                                               \
+            } else {                                                                                              \
+                gbA[ST_] = *(const uint4*)(gb_ptr + ((uint64_t)grow_ * (uint32_t)gb_ld + nc_));                   \
+                rA[ST_] = *(const uint4*)(r_ptr + ((uint64_t)m_ * (uint32_t)r_ld + nc_));                         \
+            }                                                                                                     \
             alA[ST_] = al_ptr[p.blend ? fdiv(m_, cp.fd_rpa) : 0u];                                                \
         } else {                                                                                                  \
             int64_t m_ = m0 + wm * 128 + (MT_) * 32 + (ST_) * RPS + brow;                                         \
@@ -548,12 +567,16 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             const int64_t grow_ = p.gate ? (int64_t)fdiv((uint32_t)m_, cp.fd_rpg) : mr_;                          \
             const int64_t rr_ = !p.res ? mr_ : p.res_mod > 0 ? (int64_t)fmod_u((uint32_t)m_, cp.fd_rmod)          \
                                              : p.res_mod < 0 ? (int64_t)fdiv((uint32_t)m_, cp.fd_rmod) : mr_;     \
-            gbA[ST_] = *(const uint4*)(gb_ptr + grow_ * gb_ld + nc_);                                             \
             if constexpr (RF32) {                                                                                 \
+                const char* g0_ = blend32 ? (const char*)(bl32_ptr + mr_ * bl32_ld + nc_)                         \
+                                          : (const char*)(gb_ptr + grow_ * gb_ld + nc_);                          \
+                gbA[ST_] = *(const uint4*)g0_;                                                                    \
+                gbB[ST_] = *(const uint4*)(g0_ + (blend32 ? 16 : 0));                                             \
                 const float* rp_ = (const float*)(p.res ? p.res : p.C32) + rr_ * (p.res ? r_ld : p.ldc32) + nc_;  \
                 rA[ST_] = *(const uint4*)rp_;                                                                     \
                 rB[ST_] = *(const uint4*)(rp_ + 4);                                                               \
             } else {                                                                                              \
+                gbA[ST_] = *(const uint4*)(gb_ptr + grow_ * gb_ld + nc_);                                         \
                 rA[ST_] = *(const uint4*)(r_ptr + rr_ * r_ld + nc_);                                              \
             }                                                                                                     \
             alA[ST_] = al_ptr[p.blend ? (int64_t)fdiv((uint32_t)m_, cp.fd_rpa) : 0];                              \
@@ -693,7 +716,12 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         }
                     }
                     if (p.blend) {
-                        unpack8(gbA[st], t);             // (gate and blend together are rejected by the entry point)
+                        if constexpr (RF32) {            // (gate and blend together are rejected by the entry point)
+                            const float4 ta = *reinterpret_cast<const float4*>(&gbA[st]), tb = *reinterpret_cast<const float4*>(&gbB[st]);
+                            t[0] = ta.x; t[1] = ta.y; t[2] = ta.z; t[3] = ta.w; t[4] = tb.x; t[5] = tb.y; t[6] = tb.z; t[7] = tb.w;
+                        } else {
+                            unpack8(gbA[st], t);
+                        }
                         const float al = alA[st];
                         const f32x2 a2 = splat2(al), b2 = splat2(1.f - al);
     #pragma unroll
@@ -711,10 +739,13 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     }
                 } else {
                     if (m < M && nok && !((DWM_RESERVED(p.reserved) & 2) && m >= 0)) {
-                        if constexpr (FAST) *(uint4*)(Cp + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc + (uint32_t)ncol)) = pack8(v);
-                        else *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+                        if (!RF32 || Cp != nullptr) {          // (RF32: the bf16 mirror is optional)
+                            if constexpr (FAST) *(uint4*)(Cp + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc + (uint32_t)ncol)) = pack8(v);
+                            else *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
+                        }
                         if constexpr (RF32) {
-                            float* o32 = (float*)p.C32 + mrow * p.ldc32 + ncol;
+                            float* o32 = FAST ? (float*)p.C32 + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc32 + (uint32_t)ncol)
+                                              : (float*)p.C32 + mrow * p.ldc32 + ncol;
                             *(float4*)o32 = make_float4(v[0], v[1], v[2], v[3]);
                             *(float4*)(o32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                         }
@@ -1000,14 +1031,14 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
 }
 
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
-    if (a == nullptr || a->A == nullptr || a->W == nullptr || a->C == nullptr) return DWM_EINVAL;
+    if (a == nullptr || a->A == nullptr || a->W == nullptr || (a->C == nullptr && a->C32 == nullptr)) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 31) || a->N >= (1ll << 31)) return DWM_EINVAL;
     if (a->K % BK != 0 || a->N % 8 != 0) return DWM_EUNSUPPORTED;
-    if (a->lda % 8 != 0 || a->ldc % 8 != 0) return DWM_EALIGN;
+    if (a->lda % 8 != 0 || (a->C != nullptr && a->ldc % 8 != 0)) return DWM_EALIGN;
     if (!dwm_aligned16(a->A) || !dwm_aligned16(a->W) || !dwm_aligned16(a->C)) return DWM_EALIGN;
     if (a->bias && (((uintptr_t)a->bias) & 7u)) return DWM_EALIGN;
     const int64_t nout = a->epilogue == DWM_EPI_GEGLU ? a->N / 2 : a->N;
-    if (a->ldc < nout) return DWM_EINVAL;
+    if (a->C != nullptr && a->ldc < nout) return DWM_EINVAL;
     switch (a->epilogue) {
         case DWM_EPI_PLAIN: break;
         case DWM_EPI_GEGLU:
@@ -1015,8 +1046,8 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
             break;
         case DWM_EPI_RESID:
             if (a->gate && (a->rows_per_gate <= 0 || a->ld_gate % 8 != 0 || !dwm_aligned16(a->gate))) return DWM_EINVAL;
-            if (a->res && (a->ld_res % 8 != 0 || !dwm_aligned16(a->res))) return DWM_EALIGN;
-            if (a->blend && (a->alpha == nullptr || a->rows_per_alpha <= 0 || a->ld_blend % 8 != 0 || !dwm_aligned16(a->blend))) return DWM_EINVAL;
+            if (a->res && (a->ld_res % (a->C32 ? 4 : 8) != 0 || !dwm_aligned16(a->res))) return DWM_EALIGN;
+            if (a->blend && (a->alpha == nullptr || a->rows_per_alpha <= 0 || a->ld_blend % (a->C32 ? 4 : 8) != 0 || !dwm_aligned16(a->blend))) return DWM_EINVAL;
             if (a->gate && a->blend) return DWM_EUNSUPPORTED;      // one register set carries the gate OR the blend rows
             if (a->C32 != nullptr && ((a->res != nullptr && a->ld_res % 4 != 0) || a->ldc32 % 4 != 0 || a->ldc32 < a->N ||
                                       !dwm_aligned16(a->C32) || a->res_mod != 0 || a->split_k > 1)) return DWM_EINVAL;
@@ -1139,14 +1170,20 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     do {                                                                                             \
         if (fast) DWM_LAUNCH(EPI, true); else DWM_LAUNCH(EPI, false);                                \
     } while (0)
-    if (a->C32 != nullptr) {                 // fp32 residual stream: the general RESID form with fp32 residual / master output
+    if (a->C32 != nullptr) {                 // fp32 residual stream: RESID with fp32 residual / blend rows and fp32 output
         static bool attr_set = false;
         if (!attr_set) {
             e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<DWM_EPI_RESID, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<DWM_EPI_RESID, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, false, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
+        // the transformer blocks' hidden-state stream takes the FAST form (32-bit row arithmetic, no row map, no activation)
+        if (fast && a->ldc32 < lim)
+            hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, true, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
+        else
+            hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, false, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
         e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }

@@ -1,20 +1,22 @@
 // LayerNorm family + per-head RMSNorm for gfx950.  HBM-bound: one wave per row, the
 // row lives in registers (16-B bf16x8 loads/stores), fp32 two-pass statistics via
 // wave64 butterfly shuffles; optional fused "x + per-image embedding" prologue and up
-// to two modulated outputs (AdaLN-Zero-X) from one read of x.
+// to two modulated outputs (AdaLN-Zero-X) from one read of x.  XF32: the input row (and the optional `x + embedding`
+// output) is the fp32 residual stream of the bf16 forward (dwm_layernorm_x32); outputs and parameters stay bf16.
 #include "common.h"
 #include "dwm_hip.h"
 
 namespace {
 
-template <int NI>   // NI = ceil(D / 512): 16-B chunks per lane
+template <int NI, bool XF32 = false>   // NI = ceil(D / 512): 8-element chunks per lane
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const dwm_layernorm_args p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int D = p.D;
-    const bf16_t* __restrict__ x = (const bf16_t*)p.x + row * p.ldx;
+    const bf16_t* __restrict__ x = (const bf16_t*)p.x + (XF32 ? 0 : row * p.ldx);
+    const float* __restrict__ x32 = (const float*)p.x + (XF32 ? row * p.ldx : 0);
 
     float v[NI][8];
     bool ok[NI];
@@ -25,16 +27,29 @@ layernorm_kernel(const dwm_layernorm_args p) {
         const int c = (i * 64 + lane) * 8;
         ok[i] = c < D;
         if (ok[i]) {
-            unpack8(*(const uint4*)(x + c), v[i]);
+            if constexpr (XF32) {
+                const float4 a0 = *(const float4*)(x32 + c), a1 = *(const float4*)(x32 + c + 4);
+                v[i][0] = a0.x; v[i][1] = a0.y; v[i][2] = a0.z; v[i][3] = a0.w;
+                v[i][4] = a1.x; v[i][5] = a1.y; v[i][6] = a1.z; v[i][7] = a1.w;
+            } else {
+                unpack8(*(const uint4*)(x + c), v[i]);
+            }
             if (addv) {
                 float a[8];
                 unpack8(*(const uint4*)(addv + c), a);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[i][j] += a[j];
-                // the sum is the VT block's residual stream: round it to bf16 once, here
-                const uint4 r = pack8(v[i]);
-                unpack8(r, v[i]);
-                if (p.xsum) *(uint4*)((bf16_t*)p.xsum + row * p.ldxsum + c) = r;
+                if constexpr (XF32) {       // the sum is the VT block's residual stream: kept in fp32
+                    if (p.xsum) {
+                        float* xs = (float*)p.xsum + row * p.ldxsum + c;
+                        *(float4*)xs = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                        *(float4*)(xs + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+                    }
+                } else {                    // ... or rounded to bf16 once, here
+                    const uint4 r = pack8(v[i]);
+                    unpack8(r, v[i]);
+                    if (p.xsum) *(uint4*)((bf16_t*)p.xsum + row * p.ldxsum + c) = r;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[i][j];
@@ -126,10 +141,10 @@ rmsnorm_heads_kernel(bf16_t* __restrict__ x, int64_t ldx, int64_t rows, int64_t 
 
 }  // namespace
 
-extern "C" int dwm_layernorm(const dwm_layernorm_args* a, void* stream) {
+static int layernorm_launch(const dwm_layernorm_args* a, void* stream, bool x32) {
     if (a == nullptr || a->x == nullptr || a->y == nullptr || a->rows <= 0 || a->D <= 0) return DWM_EINVAL;
     if (a->D % 8 != 0 || a->D > 2048) return DWM_EUNSUPPORTED;
-    if (a->ldx % 8 != 0 || a->ldy % 8 != 0 || !dwm_aligned16(a->x) || !dwm_aligned16(a->y)) return DWM_EALIGN;
+    if (a->ldx % (x32 ? 4 : 8) != 0 || a->ldy % 8 != 0 || !dwm_aligned16(a->x) || !dwm_aligned16(a->y)) return DWM_EALIGN;
     if ((a->scale == nullptr) != (a->shift == nullptr)) return DWM_EINVAL;
     if (a->scale && (a->rows_per_mod <= 0 || a->ld_mod % 8 != 0 || !dwm_aligned16(a->scale) || !dwm_aligned16(a->shift)))
         return DWM_EALIGN;
@@ -137,20 +152,32 @@ extern "C" int dwm_layernorm(const dwm_layernorm_args* a, void* stream) {
                   !dwm_aligned16(a->y2) || !dwm_aligned16(a->scale2) || !dwm_aligned16(a->shift2)))
         return DWM_EALIGN;
     if (a->addvec && (a->rows_per_add <= 0 || a->ld_add % 8 != 0 || !dwm_aligned16(a->addvec))) return DWM_EALIGN;
-    if (a->xsum && (a->addvec == nullptr || a->ldxsum % 8 != 0 || !dwm_aligned16(a->xsum))) return DWM_EALIGN;
+    if (a->xsum && (a->addvec == nullptr || a->ldxsum % (x32 ? 4 : 8) != 0 || !dwm_aligned16(a->xsum))) return DWM_EALIGN;
     if ((a->weight && !dwm_aligned16(a->weight)) || (a->bias && !dwm_aligned16(a->bias))) return DWM_EALIGN;
     const dim3 grid((unsigned)((a->rows + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int ni = (a->D + 511) / 512;
-    switch (ni) {
-        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, *a); break;
-        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, *a); break;
-        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, *a); break;
-        default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, *a); break;
+    if (x32) {
+        switch (ni) {
+            case 1: hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, *a); break;
+            case 2: hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, *a); break;
+            case 3: hipLaunchKernelGGL((layernorm_kernel<3, true>), grid, block, 0, s, *a); break;
+            default: hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, *a); break;
+        }
+    } else {
+        switch (ni) {
+            case 1: hipLaunchKernelGGL((layernorm_kernel<1, false>), grid, block, 0, s, *a); break;
+            case 2: hipLaunchKernelGGL((layernorm_kernel<2, false>), grid, block, 0, s, *a); break;
+            case 3: hipLaunchKernelGGL((layernorm_kernel<3, false>), grid, block, 0, s, *a); break;
+            default: hipLaunchKernelGGL((layernorm_kernel<4, false>), grid, block, 0, s, *a); break;
+        }
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }
+
+extern "C" int dwm_layernorm(const dwm_layernorm_args* a, void* stream) { return layernorm_launch(a, stream, false); }
+extern "C" int dwm_layernorm_x32(const dwm_layernorm_args* a, void* stream) { return layernorm_launch(a, stream, true); }
 
 extern "C" int dwm_rmsnorm_heads(void* x, int64_t ldx, int64_t rows, int64_t ncols, const void* w,
                                  float eps, void* stream) {

@@ -9,10 +9,11 @@ forward signature and 3-tuple return (:372-391, :623-630), same state-dict keys
 (SURVEY.md §8b), so `"_class_name": "opendwm_amd.dit.DiTCrossviewTemporalConditionModel"`
 in a pipeline JSON is the whole integration (src/dwm/common.py:133-179).
 
-The forward is inference-only in this round (no autograd graph is recorded); all
-arithmetic runs in bf16 storage / fp32 accumulation through libdwm_hip.so.  There is no
-eager-PyTorch fallback: on a machine without the built library or without a GPU the
-forward raises.
+Inference (`model.eval()` or no autograd): bf16 operands / fp32 accumulation through libdwm_hip.so, the hidden and
+context streams kept in fp32 across the residual adds (`residual_dtype`), or everything in fp32
+(`compute_dtype = torch.float32`, the accuracy path).  Training (`model.train()` with autograd enabled) routes the same
+`forward` through opendwm_amd.train.forward_train (hand-written HIP backward).  There is no eager-PyTorch fallback: on a
+machine without the built library or without a GPU the forward raises.
 """
 from __future__ import annotations
 
@@ -24,7 +25,7 @@ from torch import nn
 
 from . import ops
 from .blocks import (AlphaBlender, CombinedTimestepTextProjEmbeddings, JointTransformerBlock,
-                     TimestepEmbedding, VTSelfAttentionBlock, _AdaNorm, _bf)
+                     TimestepEmbedding, VTSelfAttentionBlock, _AdaNorm, _bf, stream32)
 from .ops import EPI_RESID
 
 bf16 = torch.bfloat16
@@ -222,6 +223,12 @@ class DiTCrossviewTemporalConditionModel(_Base):
         self.cache_adapter_residuals = True
         self.frame_shard = None             # set by CTSDDenoiser(frame_group=...): opendwm_amd.sharding.FrameShard
         self.compute_dtype = bf16           # torch.float32 selects the fp32 accuracy path of the inference forward
+        # dtype of the hidden / context streams of the bf16 inference forward.  fp32 (default): the ~130 residual adds of a
+        # forward accumulate in fp32 (GEMM RESID epilogues with dwm_gemm_args.C32, LayerNorms reading fp32) - each add into a
+        # bf16 stream is a rounding of the whole stream (1.1e-3 rms each; they add up to the 1.3e-2 a bf16-stream forward
+        # shows against the fp32 oracle).  bf16: the round-1..3 behaviour (half the stream traffic).
+        self.residual_dtype = torch.float32
+        self._index_sinusoids = {}
         self.perspective_modeling_type = perspective_modeling_type
         if perspective_modeling_type == "implicit":
             self.view_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, inner_dim)
@@ -322,6 +329,37 @@ class DiTCrossviewTemporalConditionModel(_Base):
         finally:
             STORE.set_precision(bf16)       # the fp32 accuracy path is scoped to this forward (compute_dtype = torch.float32)
 
+    def _index_sinusoid(self, kind: str, B: int, T: int, V: int, D: int, device, dtype) -> torch.Tensor:
+        """sinusoid features [B*T*V, D] of the frame ("t") or view ("v") index of every image (crossview_temporal_dit.py:
+        528-531, 553-556): input-independent, kept on the model"""
+        key = (kind, B, T, V, D, str(device), dtype)
+        hit = self._index_sinusoids.get(key)
+        if hit is None:
+            if kind == "t":
+                idx = torch.arange(T, device=device).view(1, T, 1).expand(B, T, V)
+            else:
+                idx = torch.arange(V, device=device).view(1, 1, V).expand(B, T, V)
+            hit = ops.timestep_sinusoid(idx, D, dtype=dtype)
+            if len(self._index_sinusoids) > 8:
+                self._index_sinusoids.clear()
+            self._index_sinusoids[key] = hit
+        return hit
+
+    @staticmethod
+    def _mixer_alphas(mixers, image_only_indicator, batch: int):
+        """alpha[batch] of every AlphaBlender of a list (crossview_temporal.py:33-51) from ONE stacked evaluation when they
+        share a learned strategy; rows of the result = mixers"""
+        strategies = {m.merge_strategy for m in mixers}
+        if len(strategies) != 1 or "fixed" in strategies:
+            return [m.get_alpha(image_only_indicator, batch) for m in mixers]
+        sig = torch.sigmoid(torch.cat([m.mix_factor.detach().float().reshape(1) for m in mixers]))[:, None]      # [mixers, 1]
+        if strategies == {"learned"}:
+            return list(sig.expand(len(mixers), batch).contiguous())
+        if image_only_indicator is None:
+            raise ValueError("Please provide image_only_indicator to use learned_with_images merge strategy")
+        flag = image_only_indicator.reshape(1, batch).to(device=sig.device, dtype=torch.bool)
+        return list(torch.where(flag, torch.ones((), device=sig.device), sig).contiguous())
+
     @torch.no_grad()
     def _forward_infer(
         self,
@@ -395,6 +433,10 @@ class DiTCrossviewTemporalConditionModel(_Base):
         pooled = as_bf16(pooled_projections.flatten(0, 2)).contiguous()
         temb = self.time_text_embed.run(timestep.flatten(), pooled)                    # [I, D]
         silu_temb = ops.silu(temb)
+        if cd == bf16 and self.residual_dtype == torch.float32:                        # fp32 residual streams (blocks.stream32)
+            h, c = ops.cast_f32(h), ops.cast_f32(c)
+        elif self.residual_dtype not in (bf16, torch.float32):
+            raise ValueError("residual_dtype must be torch.float32 or torch.bfloat16")
 
         view_cam_emb = None
         ray_feat = None
@@ -434,6 +476,16 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 if f.shape != h.shape:
                     raise RuntimeError(f"condition residual {tuple(f.shape)} does not match hidden states {tuple(h.shape)}")
 
+        # per-block constants that do not depend on the hidden state, prepared once: the frame / view index sinusoids
+        # (input-independent: cached on the model) and the mixers' alpha vectors (one stacked sigmoid instead of one per block)
+        seq_sin = view_sin = None
+        if self.enable_temporal and self.temporal_block_layers:
+            seq_sin = self._index_sinusoid("t", B, Tg, V, D, h.device, cd)
+            t_alpha = self._mixer_alphas(self.time_mixers, disable_temporal, B)
+        if self.enable_crossview and self.crossview_block_layers:
+            view_sin = self._index_sinusoid("v", B, T, V, D, h.device, cd)
+            v_alpha = self._mixer_alphas(self.view_mixers, disable_crossview, B)
+
         for i, block in enumerate(self.transformer_blocks):
             if condition_residuals:
                 ops.add_(h, condition_residuals.pop(0))                                 # :491-494 (fp32 residual, one rounding)
@@ -447,8 +499,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
 
             if self.enable_temporal and i in self.temporal_block_layers:
                 k = self.temporal_block_layers.index(i)
-                idx = torch.arange(Tg, device=h.device).view(1, Tg, 1).expand(B, Tg, V)
-                seq = ops.timestep_sinusoid(idx, D, dtype=cd)
+                seq = seq_sin
                 use_cam = self.enable_crossview and not self.disable_view_emb_on_temporal_module \
                     and view_cam_emb is not None
                 if use_cam and fs is not None and cam_all is None:
@@ -461,7 +512,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 tt = self.temporal_attention_type
                 mk = ops.rowmap_temporal_full if tt == "full" else \
                     ops.rowmap_temporal_rowwise if tt == "rowwise" else ops.rowmap_temporal_pointwise
-                alpha = self.time_mixers[k].get_alpha(disable_temporal, B)
+                alpha = t_alpha[k]
                 if fs is None:
                     self.temporal_transformer_blocks[k].run(
                         h, mk(B, T, V, height, width), emb=seq_emb, rows_per_emb=rpe,
@@ -477,8 +528,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
 
             if self.enable_crossview and i in self.crossview_block_layers:
                 k = self.crossview_block_layers.index(i)
-                idx = torch.arange(V, device=h.device).view(1, 1, V).expand(B, T, V)
-                ve = ops.timestep_sinusoid(idx, D, dtype=cd)
+                ve = view_sin
                 view_emb = self.view_pos_embeds[k].run(ve, res=view_cam_emb)
                 rpe = N
                 if ray_feat is not None:
@@ -494,14 +544,14 @@ class DiTCrossviewTemporalConditionModel(_Base):
                     dmask = crossview_attention_mask       # reference passes it through un-expanded
                 else:
                     raise NotImplementedError(f"Not support {ct}")
-                alpha = self.view_mixers[k].get_alpha(disable_crossview, B)
+                alpha = v_alpha[k]
                 self.crossview_transformer_blocks[k].run(
                     h, rm, emb=view_emb, rows_per_emb=rpe, group_mask=gmask, dense_mask=dmask,
                     blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
 
         # norm_out (AdaLayerNormContinuous: scale first) + proj_out + unpatchify
         mod = ops.gemm(silu_temb, _bf(self.norm_out.linear.weight), _bf(self.norm_out.linear.bias))
-        nh = ops.layernorm(h, eps=1e-6, scale=mod[:, :D], shift=mod[:, D:], rows_per_mod=N)
+        nh = ops.layernorm(h, eps=1e-6, scale=mod[:, :D], shift=mod[:, D:], rows_per_mod=N, x32=stream32(h))
         y = ops.gemm(nh, _bf(self.proj_out.weight), _bf(self.proj_out.bias))
         out = ops.unpatchify(y, I, self.out_channels, height, width, p)
         output = out.view(B, T, V, self.out_channels, height * p, width * p)

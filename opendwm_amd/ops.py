@@ -171,7 +171,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rows_per_alpha: int = 1,
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
          a_grid=None, conv3x3: bool = False, stride2=False, conv_taps: Optional[list] = None,
-         c_grid=None, out32: Optional[torch.Tensor] = None,
+         c_grid=None, out32: Optional[torch.Tensor] = None, mirror: bool = True,
          rows: Optional[int] = None, split_k: int = 0, tile: int = 0, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
     tile: 0 = the kernel's choice, 1 = 256 x 256 tiles, 2 = 256 x 128 tiles (two workgroups per CU).
@@ -179,8 +179,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     axis is 9 taps x C (w is [N, 9*C], tap-major).  c_grid: out / res / blend are padded grids.
     split_k: 0 = the kernel's rule (small tile grid + long K -> K ranges, fp32 partials, ordered reduction),
     1 = never, n > 1 = exactly n ranges.  _debug: ablation knobs, honoured only by -DDWM_DEV_HOOKS builds of the library.
-    out32 (RESID): fp32 residual stream - `res` is then an fp32 matrix shaped like `out`, the result goes to out32 in fp32
-    (out32 may be `res` itself) and, rounded, to the bf16 `out` the next GEMM reads."""
+    out32 (RESID): fp32 residual stream - `res` and `blend` are then fp32 matrices shaped like the output, the result goes to
+    out32 in fp32 (out32 may be `res` or `blend` itself) and, rounded, to the bf16 `out`; mirror=False: no bf16 copy at all
+    (`out` must be None; the call returns out32) - the hidden / context streams of the bf16 MMDiT forward."""
     if a.dtype == torch.float32:            # the fp32 accuracy path (dwm_gemm_f32)
         if conv_taps is not None or stride2:
             raise NotImplementedError("gemm: of the implicit convolutions only the dense 3x3 / 1x1 forms on a padded grid are part of the fp32 path")
@@ -205,16 +206,22 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     orow = c_grid.rows if c_grid is not None else M
     if c_grid is not None and c_grid.pixels != M:
         raise RuntimeError("gemm: c_grid pixel count != M")
-    if out is None:
-        out = (torch.zeros if c_grid is not None else torch.empty)((orow, nout), dtype=bf16, device=a.device)
-    _chk2d(out, "out")
-    if out.shape != (orow, nout):
-        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(orow, nout)}")
-    if _overlaps(a, out):
-        raise RuntimeError("gemm: `out` overlaps the A operand (a tile's output would overwrite rows other tiles still read)")
+    if not mirror:
+        if out32 is None or out is not None:
+            raise RuntimeError("gemm: mirror=False needs out32 and no `out`")
+    else:
+        if out is None:
+            out = (torch.zeros if c_grid is not None else torch.empty)((orow, nout), dtype=bf16, device=a.device)
+        _chk2d(out, "out")
+        if out.shape != (orow, nout):
+            raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(orow, nout)}")
+        if _overlaps(a, out):
+            raise RuntimeError("gemm: `out` overlaps the A operand (a tile's output would overwrite rows other tiles still read)")
     _chkvec(bias, "bias")
     g = _lib.GemmArgs()
-    g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)
+    g.A, g.lda, g.W, g.bias = a.data_ptr(), a.stride(0), w.data_ptr(), _p(bias)
+    if out is not None:
+        g.C, g.ldc = out.data_ptr(), out.stride(0)
     g.M, g.N, g.K, g.epilogue, g.act = M, N, K, epilogue, act
     if gate is not None:
         _chk2d(gate, "gate")
@@ -223,12 +230,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if epilogue != EPI_RESID or res_mod != 0:
             raise RuntimeError("gemm: out32 needs the RESID epilogue (res_mod = 0; `res`, if any, in fp32)")
         _chk2d(out32, "out32", torch.float32)
-        if out32.shape != out.shape:
-            raise RuntimeError("gemm: out32 must have the shape of out")
+        if out32.shape != (orow, nout):
+            raise RuntimeError("gemm: out32 must have the shape of the output")
         if res is not None:
             _chk2d(res, "res", torch.float32)
-            if res.shape != out.shape:
-                raise RuntimeError("gemm: the fp32 res must have the shape of out")
+            if res.shape != out32.shape:
+                raise RuntimeError("gemm: the fp32 res must have the shape of the output")
             g.res, g.ld_res, g.res_mod = res.data_ptr(), res.stride(0), 0
         g.C32, g.ldc32 = out32.data_ptr(), out32.stride(0)
         split_k = 1
@@ -236,7 +243,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _chk2d(res, "res")
         g.res, g.ld_res, g.res_mod = res.data_ptr(), res.stride(0), res_mod
     if blend is not None:
-        _chk2d(blend, "blend")
+        _chk2d(blend, "blend", torch.float32 if out32 is not None else bf16)
         _chkvec(alpha, "alpha", torch.float32)
         g.blend, g.ld_blend, g.alpha, g.rows_per_alpha = blend.data_ptr(), blend.stride(0), alpha.data_ptr(), rows_per_alpha
     if rms_w is not None:
@@ -270,7 +277,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         ws = _gemm_workspace(a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
-    return out
+    return out if mirror else out32
 
 
 _SPLIT_WEIGHTS: dict = {}
@@ -637,9 +644,13 @@ def layernorm(x: torch.Tensor, *, eps: float, out: Optional[torch.Tensor] = None
               scale2: Optional[torch.Tensor] = None, shift2: Optional[torch.Tensor] = None,
               out2: Optional[torch.Tensor] = None,
               addvec: Optional[torch.Tensor] = None, rows_per_add: int = 0,
-              xsum: Optional[torch.Tensor] = None):
+              xsum: Optional[torch.Tensor] = None, x32: bool = False):
     """See dwm_layernorm.  scale/shift (and scale2/shift2) are 2-D views sharing one row
-    stride (column slices of the AdaLN modulation matrix)."""
+    stride (column slices of the AdaLN modulation matrix).  x32: x (and xsum) are the fp32 residual stream of the bf16
+    forward, everything else bf16 (dwm_layernorm_x32)."""
+    if x32:
+        return _layernorm_x32(x, eps=eps, out=out, weight=weight, bias=bias, scale=scale, shift=shift, rows_per_mod=rows_per_mod,
+                              scale2=scale2, shift2=shift2, out2=out2, addvec=addvec, rows_per_add=rows_per_add, xsum=xsum)
     dt = x.dtype if x.dtype == torch.float32 else bf16             # fp32: the accuracy path (dwm_layernorm_f32)
     _chk2d(x, "x", dt)
     rows, D = x.shape
@@ -675,6 +686,41 @@ def layernorm(x: torch.Tensor, *, eps: float, out: Optional[torch.Tensor] = None
         _lib.check(_lib.load().dwm_layernorm_f32(C.byref(a), _stream()), "dwm_layernorm_f32")
         return out
     _lib.check(_lib.load().dwm_layernorm(C.byref(a), _stream()), "dwm_layernorm")
+    return out
+
+
+def _layernorm_x32(x, *, eps, out, weight, bias, scale, shift, rows_per_mod, scale2, shift2, out2, addvec, rows_per_add, xsum):
+    _chk2d(x, "x", torch.float32)
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), dtype=bf16, device=x.device)
+    _chk2d(out, "out")
+    a = _lib.LayerNormArgs()
+    a.x, a.ldx, a.y, a.ldy = x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0)
+    a.rows, a.D, a.eps = rows, D, eps
+    _chkvec(weight, "weight")
+    _chkvec(bias, "bias")
+    a.weight, a.bias = _p(weight), _p(bias)
+    if scale is not None:
+        _chk2d(scale, "scale")
+        _chk2d(shift, "shift")
+        if scale.stride(0) != shift.stride(0):
+            raise RuntimeError("scale/shift must share a row stride")
+        a.scale, a.shift, a.ld_mod, a.rows_per_mod = scale.data_ptr(), shift.data_ptr(), scale.stride(0), rows_per_mod
+    if out2 is not None:
+        _chk2d(out2, "out2")
+        _chk2d(scale2, "scale2")
+        _chk2d(shift2, "shift2")
+        if scale2.stride(0) != a.ld_mod or shift2.stride(0) != a.ld_mod:
+            raise RuntimeError("scale2/shift2 must share the row stride of scale/shift")
+        a.y2, a.ldy2, a.scale2, a.shift2 = out2.data_ptr(), out2.stride(0), scale2.data_ptr(), shift2.data_ptr()
+    if addvec is not None:
+        _chk2d(addvec, "addvec")
+        a.addvec, a.ld_add, a.rows_per_add = addvec.data_ptr(), addvec.stride(0), rows_per_add
+        if xsum is not None:
+            _chk2d(xsum, "xsum", torch.float32)
+            a.xsum, a.ldxsum = xsum.data_ptr(), xsum.stride(0)
+    _lib.check(_lib.load().dwm_layernorm_x32(C.byref(a), _stream()), "dwm_layernorm_x32")
     return out
 
 
@@ -869,10 +915,17 @@ def avgpool2_tokens(x: torch.Tensor, I: int, h: int, w: int) -> torch.Tensor:
 
 
 def add_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """y += x (y bf16; x bf16, or fp32: the fp32 sum is rounded once; contiguous, same shape)."""
-    if y.shape != x.shape or y.dtype != bf16 or x.dtype not in (bf16, torch.float32) or not y.is_contiguous() or not x.is_contiguous() or not y.is_cuda:
-        raise RuntimeError("add_: expected contiguous device tensors of one shape (y bf16, x bf16 / fp32)")
-    if x.dtype == torch.float32:
+    """y += x (contiguous device tensors of one shape).  y bf16: x bf16, or fp32 (the fp32 sum is rounded once).  y fp32 (the
+    fp32 residual stream): x fp32 or bf16."""
+    if y.shape != x.shape or y.dtype not in (bf16, torch.float32) or x.dtype not in (bf16, torch.float32) \
+            or not y.is_contiguous() or not x.is_contiguous() or not y.is_cuda:
+        raise RuntimeError("add_: expected contiguous device tensors of one shape (bf16 / fp32)")
+    if y.dtype == torch.float32:
+        if x.dtype == torch.float32:
+            _lib.check(_lib.load().dwm_add_f32_f32_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_f32_f32_inplace")
+        else:
+            cast_f32(x, out=y, accumulate=True)
+    elif x.dtype == torch.float32:
         _lib.check(_lib.load().dwm_add_f32_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_f32_inplace")
     else:
         _lib.check(_lib.load().dwm_add_inplace(y.data_ptr(), x.data_ptr(), y.numel(), _stream()), "dwm_add_inplace")
@@ -990,6 +1043,24 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=bf16, device=x.device)
     _lib.check(_lib.load().dwm_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()),
                "dwm_cast_f32_to_bf16")
+    return out
+
+
+def cast_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """fp32 (+)= bf16, 2-D row-strided or contiguous (dwm_cast_bf16_to_f32): the entry of the fp32 residual stream"""
+    if x.dtype != bf16 or not x.is_cuda:
+        raise RuntimeError("cast_f32: expected a bf16 device tensor")
+    x2 = x if x.dim() == 2 else x.reshape(1, -1)
+    _chk2d(x2, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        accumulate = False
+    o2 = out if out.dim() == 2 else out.reshape(1, -1)
+    _chk2d(o2, "out", torch.float32)
+    if o2.shape != x2.shape:
+        raise RuntimeError("cast_f32: shape mismatch")
+    _lib.check(_lib.load().dwm_cast_bf16_to_f32(x2.data_ptr(), x2.stride(0), o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1],
+                                                int(accumulate), _stream()), "dwm_cast_bf16_to_f32")
     return out
 
 
