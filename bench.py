@@ -596,6 +596,9 @@ def main():
     ap.add_argument("--layout", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-text-only-leg", action="store_true",
                     help="skip the secondary leg that times the text-only variant after the headline (reported as 'text_only')")
+    ap.add_argument("--residual-bf16", action="store_true",
+                    help="A/B: keep the hidden / context streams in bf16 (model.residual_dtype; default: fp32 streams, the "
+                         "setting the parity tests hold to the oracle)")
     ap.add_argument("--adapter-cache", action="store_true",
                     help="keep the ImageAdapter residuals across denoise steps (its input does not change from step to step); "
                          "the default recomputes the adapter inside every step as the reference's forward does")
@@ -668,6 +671,8 @@ def main():
         timer = KernelTimer().install()
         try:
             model = build_model(kwargs, dev, seed=0)
+            if args.residual_bf16:
+                model.residual_dtype = torch.bfloat16
             cond = make_conditions(dev, seed=sample_id, layout=layout)
             g = torch.Generator(device="cuda").manual_seed(sample_id)
             latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)
@@ -725,6 +730,7 @@ def main():
                                     "CFG halves of one sample on two GPUs" if args.cfg_split else "one replica per GPU"),
                        "layers": kwargs["num_layers"], "flop_per_step": step_flop, "flop_model": fl["total"], "flop_adapter": fl["adapter"],
                        "baseline_config": "BASELINE.json configs[2]", "finite": finite,
+                       "residual_stream": "bf16" if args.residual_bf16 else "fp32 (GEMM operands and activations bf16)",
                        "variant": ("text+layout (ImageAdapter recomputed every step, pointwise temporal)" if not args.adapter_cache else
                                    "text+layout (ImageAdapter residuals cached across steps, pointwise temporal)")
                        if args.layout else "text only (rowwise temporal, no adapter)"},

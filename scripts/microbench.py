@@ -30,7 +30,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).to(bf16)
 
 
-def bench_attn(variants):
+def bench_attn(variants, only=None):
     H, D = 24, 1536
     B, T, V, h, w = 2, 16, 6, 16, 28
     I, N, Lc = B * T * V, h * w, 154
@@ -49,6 +49,8 @@ def bench_attn(variants):
     rm0 = ops.rowmap_identity(I, N)
     timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm0, H), iters=300)   # clocks up
     for name, (rm, kw, L) in cases.items():
+        if only is not None and name not in only:
+            continue
         fl = 4.0 * rm.n_problems * H * L * L * 64
         for var in list(variants) * 2:
             ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var, **kw))
@@ -261,6 +263,30 @@ def bench_gemm_raster_dev():
         print(json.dumps({"kernel": "gemm_raster_dev", "case": name, "M": M, "N": N, "K": K, "tflops": res}), flush=True)
 
 
+def bench_stream32():
+    """the residual-stream forms of round 4: RESID GEMM into a bf16 stream vs into the fp32 stream (fp32 residual in, fp32 out,
+    no bf16 copy), LayerNorm from bf16 vs from fp32, at the hidden-state size of config 3"""
+    M, D = 86016, 1536
+    h16, h32 = rnd(M, D), torch.randn(M, D, device=dev)
+    gate = rnd(192, D)
+    for name, K in (("out-proj K=1536", 1536), ("ff2 K=6144", 6144)):
+        a, w, b = rnd(M, K), rnd(D, K, scale=K ** -0.5), rnd(D)
+        fl = 2.0 * M * D * K
+        for rep in range(2):
+            ms = timeit(lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=h16, out=h16))
+            print(json.dumps({"kernel": "gemm-resid", "case": name, "stream": "bf16", "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
+            ms = timeit(lambda: ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=h32, out32=h32, mirror=False))
+            print(json.dumps({"kernel": "gemm-resid", "case": name, "stream": "fp32", "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
+    mod = rnd(192, 9 * D)
+    y, y2 = torch.empty_like(h16), torch.empty_like(h16)
+    for x, nm in ((h16, "bf16"), (h32, "fp32")):
+        ms = timeit(lambda: ops.layernorm(x, eps=1e-6, scale=mod[:, D:2 * D], shift=mod[:, :D], rows_per_mod=448, out=y, x32=x.dtype == torch.float32))
+        print(json.dumps({"kernel": "ln-mod", "stream": nm, "ms": round(ms, 4), "GBps": round((x.numel() * x.element_size() + y.numel() * 2) / ms / 1e6, 1)}))
+        ms = timeit(lambda: ops.layernorm(x, eps=1e-6, scale=mod[:, D:2 * D], shift=mod[:, :D], rows_per_mod=448, out=y,
+                                          scale2=mod[:, 7 * D:8 * D], shift2=mod[:, 6 * D:7 * D], out2=y2, x32=x.dtype == torch.float32))
+        print(json.dumps({"kernel": "ln-mod-dual", "stream": nm, "ms": round(ms, 4), "GBps": round((x.numel() * x.element_size() + 2 * y.numel() * 2) / ms / 1e6, 1)}))
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -286,6 +312,10 @@ if __name__ == "__main__":
         bench_attn([0])
     if "attnx" in what:                  # resident kernel geometries (12 waves x 1 tile / 8 x 2; 6 / 3 / 2 heads per workgroup; online softmax) vs tiled
         bench_attn([0, 32 | 1])
+    if "attnr" in what:                  # resident kernel with / without its refill points (variant bit 6)
+        bench_attn([0, 64], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
+    if "s32" in what:
+        bench_stream32()
     if "gemm" in what:
         bench_gemm()
     if "gemmx" in what:                  # reserved bit 2: the general RESID epilogue instead of its FAST form; bit 0: no epilogue

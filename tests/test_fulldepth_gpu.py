@@ -116,8 +116,18 @@ def test_forty_step_denoise_vs_oracle_loop_on_device(dev, layout):
     assert e40 < TOL and e1 < TOL, (e1, e40)
 
 
-@pytest.mark.parametrize("layout", [False, True], ids=["text_only_rowwise", "text_layout_pointwise"])
-def test_forty_step_denoise_full_depth_full_size_vs_oracle_loop_on_device(dev, layout):
+# (layout, seed, frames): the two models of the headline configuration at full size, and two more seeds (weights, conditions,
+# noise) of the text+layout model - the one the metric is quoted on - on 4 of the 16 frames (the fp32 oracle loop costs ~170 s
+# per full-size case on the device; depth, width, views, resolution, text length and the 40 steps are the full ones)
+FULL_DEPTH_CASES = [(False, 0, 16), (True, 0, 16), (True, 1, 4), (True, 2, 4)]
+# fp32 residual streams (round 4): the headline variant went 1.63e-2 -> see profiles/r4_gpu_parity.log; the assertion keeps half
+# of north_star's 2e-2 as margin for other seeds / trained weights
+TOL_40_STEPS = 1.0e-2
+
+
+@pytest.mark.parametrize("layout,seed,frames", FULL_DEPTH_CASES,
+                         ids=["text_only_rowwise", "text_layout_pointwise", "text_layout_seed1_4f", "text_layout_seed2_4f"])
+def test_forty_step_denoise_full_depth_full_size_vs_oracle_loop_on_device(dev, layout, seed, frames):
     """What north_star bounds, on the configuration `bench.py` times: ALL 40 guided FlowMatch-Euler steps of the hot loop
     (ctsd.py:1496-1575) through the full 24-layer model on latents [1,16,6,16,32,56] (CFG batch 2, 154 text tokens) - bf16
     CTSDDenoiser against O.denoise in fp32 on the device (~18 PFLOP of fp32 per variant).  The error after the LAST step is
@@ -125,10 +135,10 @@ def test_forty_step_denoise_full_depth_full_size_vs_oracle_loop_on_device(dev, l
     import bench
     from opendwm_amd.pipeline import CTSDDenoiser
     kwargs = bench.variant_kwargs(layout)
-    model = bench.build_model(kwargs, dev, seed=0)
-    wl = bench.WORKLOAD
-    cond = bench.make_conditions(dev, seed=3, layout=layout)
-    g = torch.Generator(device="cuda").manual_seed(9)
+    model = bench.build_model(kwargs, dev, seed=seed)
+    wl = dict(bench.WORKLOAD, T=frames)
+    cond = bench.make_conditions(dev, seed=3 + seed, w=wl, layout=layout)
+    g = torch.Generator(device="cuda").manual_seed(9 + seed)
     lat = torch.randn(1, wl["T"], wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=g)
     marks = (1, 10, 20, 30, 40)
     den = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=40)
@@ -157,12 +167,77 @@ def test_forty_step_denoise_full_depth_full_size_vs_oracle_loop_on_device(dev, l
     finally:
         O.dit_forward = fwd0
     move = ((ours[40].double() - ref.double()).norm() / (ref.double() - lat.double()).norm()).item()
-    _log("denoise_40_steps_full_depth", variant="text+layout" if layout else "text_only", layers=kwargs["num_layers"],
+    _log("denoise_40_steps_full_depth", variant="text+layout" if layout else "text_only", seed=seed, layers=kwargs["num_layers"],
          latents=list(lat.shape), **{f"rel_step{k}": v for k, v in errs.items()}, rel_to_displacement=move,
          finite=bool(torch.isfinite(ours[40]).all()))
     del sd, ref
     torch.cuda.empty_cache()
-    assert errs[40] < TOL and errs[1] < TOL, errs
+    assert errs[40] < TOL_40_STEPS and errs[1] < TOL_40_STEPS, errs
+
+
+def _heavy_tailed_init_(model, seed: int):
+    """A hostile weight regime for the bf16 path (trained SD 3.5 weights are not Gaussian: heavy tails, and a few hidden
+    channels that carry activations tens of times larger than the rest): Student-t (4 degrees of freedom) matrices at the
+    variance of bench.synth_init_, and 6 outlier channels - the patch embedding and every residual-writing projection
+    (attention out-projections, feed-forward second layers) produce them 16 x larger"""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    hot = torch.tensor([7, 130, 517, 802, 1111, 1490], device="cuda")
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("mix_factor"):
+                p.fill_(2.0)
+            elif p.dim() == 1:
+                p.normal_(0.0, 0.05, generator=g)
+                if name.endswith(".weight"):
+                    p.add_(1.0)
+            else:
+                fan_in = p[0].numel()
+                std = fan_in ** -0.5
+                if ".norm1.linear" in name or ".norm1_context.linear" in name or name.startswith("norm_out.linear"):
+                    std *= 0.5
+                z = torch.randn(p.shape, device=p.device, generator=g)
+                chi = torch.randn((4,) + tuple(p.shape), device=p.device, generator=g).square().sum(0)
+                t = z / (chi / 4).sqrt() / 2 ** 0.5                    # Student-t(4), unit variance
+                p.copy_((t * std).to(p.dtype))
+                writes_stream = name.endswith(("to_out.0.weight", "to_add_out.weight", "net.2.weight")) or name.startswith("pos_embed.proj.weight")
+                if writes_stream and p.shape[0] == 1536 and "condition_image_adapter" not in name:
+                    p[hot] *= 16.0
+
+
+@pytest.mark.parametrize("layout", [False, True], ids=["text_only_rowwise", "text_layout_pointwise"])
+def test_forty_step_denoise_heavy_tailed_weights_with_outlier_channels(dev, layout):
+    """the 40-step loop in the stress regime of _heavy_tailed_init_, full width, 8 layers, 6 views x 4 frames: the tolerance must
+    hold when the hidden state has channels 16 x larger than the rest (LayerNorm statistics dominated by them) and the weights
+    have heavy tails"""
+    import bench
+    from opendwm_amd.pipeline import CTSDDenoiser
+    kwargs = bench.variant_kwargs(layout)
+    n = 8
+    kwargs.update(num_layers=n, dual_attention_layers=list(range(n)), crossview_block_layers=[1, 5], temporal_block_layers=[2, 3, 6, 7])
+    model = bench.build_model(kwargs, dev, seed=0)
+    _heavy_tailed_init_(model, 5)
+    wl = dict(bench.WORKLOAD, T=4)
+    cond = bench.make_conditions(dev, seed=4, w=wl, layout=layout)
+    lat = torch.randn(1, wl["T"], wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=torch.Generator(device="cuda").manual_seed(12))
+    with torch.no_grad():
+        out = CTSDDenoiser(model, guidance_scale=4.0, inference_steps=40).run(lat, cond).clone()
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    del model
+    torch.cuda.empty_cache()
+    cfg = O.make_config(**kwargs)
+    fwd0 = O.dit_forward
+    O.dit_forward = _oracle_on_device(fwd0)
+    try:
+        condf = {k: (v.float() if v.is_floating_point() else v) for k, v in cond.items()}
+        with torch.no_grad():
+            ref = O.denoise(sd, cfg, lat, condf, steps=40, guidance_scale=4.0)
+    finally:
+        O.dit_forward = fwd0
+    e40 = rel_err(out, ref)
+    move = ((out.double() - ref.double()).norm() / (ref.double() - lat.double()).norm()).item()
+    _log("denoise_40_steps_heavy_tailed", variant="text+layout" if layout else "text_only", layers=n, latents=list(lat.shape),
+         rel_step40=e40, rel_to_displacement=move, finite=bool(torch.isfinite(out).all()))
+    assert e40 < TOL, e40
 
 
 def test_unet_full_width_config1_six_frames_vs_oracle_on_device(dev):
