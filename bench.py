@@ -219,43 +219,74 @@ def pmc_source() -> str:
     return "none"
 
 
-def cpu_baseline(threads: int, full_flops: float = None):
-    """The fp32 CPU oracle (the restated reference path) on the host cores, on a bounded sample of
-    the same workload; reported in denoise-steps/s by FLOP ratio (`full_flops` = the timed step's FLOPs)."""
+def _tiled_state_dict(cfg: dict, seed: int = 0) -> dict:
+    """fp32 weights for TIMING the CPU oracle: the value rule of oracle.synth_param (matrices ~ N(0, 1 / fan_in), damped AdaLN
+    linears, norm weights near 1) with the normal draws of the matrices taken from ONE seeded 4 M-element block, tiled - drawing
+    the 4.3 G normals of the full model costs ~90 s of host time, tiling them a few seconds, and a forward's run time does
+    not depend on the values"""
+    from oracle import ctsd_oracle as O
+    gen = torch.Generator().manual_seed(seed)
+    block = torch.randn(1 << 22, generator=gen)
+    sd = {}
+    for name, shape in O.param_shapes(cfg).items():
+        n = 1
+        for d in shape:
+            n *= d
+        if len(shape) < 2 or name == "pos_embed.pos_embed" or name.endswith("mix_factor") or n <= block.numel():
+            sd[name] = O.synth_param(name, shape, cfg, gen)
+            continue
+        fan_in = n // shape[0]
+        std = fan_in ** -0.5
+        if ".norm1.linear" in name or ".norm1_context.linear" in name or name.startswith("norm_out.linear"):
+            std *= 0.5
+        out = torch.empty(n)
+        k = n // block.numel()
+        out[:k * block.numel()].view(k, block.numel()).copy_(block)
+        out[k * block.numel():].copy_(block[:n - k * block.numel()])
+        sd[name] = out.mul_(std).view(shape)
+    return sd
+
+
+def cpu_baseline(threads: int, layout: bool, step_flops: float):
+    """The reference's CPU path (its fp32 PyTorch graph, restated in oracle/ctsd_oracle.py) timed in THIS run on the host cores:
+    ONE full-depth CFG forward of the step's model on 6 views x 1 frame - 1/16 of the images of the timed step (6 views x 16
+    frames; every layer, the full width, the full text length, the layout adapter when the step has it).  A step's work is
+    linear in the number of images except for the temporal attention (0.7 % of its FLOPs), so `value` = 1 / (16 x the measured
+    seconds).  The one full-size step that was timed once on a GPU box's host (1526 s on 248 threads, round 2) rides along as
+    `cited_full_step`."""
     from oracle import ctsd_oracle as O
     from opendwm_amd.dit import model_flops
     torch.set_num_threads(threads)
-    cfg = O.make_config(num_layers=3, dual_attention_layers=[0, 1, 2], crossview_block_layers=[1],
-                        temporal_block_layers=[2], pos_embed_max_size=64, sample_size=128)
-    gen = torch.Generator().manual_seed(0)
-    sd = {n: O.synth_param(n, s, cfg, gen) for n, s in O.param_shapes(cfg).items()}
-    T = 2
-    inp = O.make_inputs(cfg, 2, T, 6, 32, 56, seed=0)
+    kwargs = variant_kwargs(layout)
+    cfg = O.make_config(**kwargs)
+    t0 = time.perf_counter()
+    sd = _tiled_state_dict(cfg)
+    t_weights = time.perf_counter() - t0
+    w = WORKLOAD
+    inp = O.make_inputs(cfg, 2, 1, w["V"], w["H"], w["W"], seed=0, text_len=w["text_len"], n_time_ids=13 if layout else 11)
+    if layout:
+        inp["condition_image_tensor"] = torch.rand(2, 1, w["V"], 6, 8 * w["H"], 8 * w["W"], generator=torch.Generator().manual_seed(77))
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.dit_forward(sd, cfg, **inp)
+        out = O.dit_forward(sd, cfg, **inp)
         dt = time.perf_counter() - t0
-    sample_flops = model_flops(cfg, 2, T, 6, 32, 56)["total"]
-    if full_flops is None:
-        full_flops = model_flops(MODEL_KWARGS, 2, WORKLOAD["T"], WORKLOAD["V"], WORKLOAD["H"], WORKLOAD["W"])["total"]
-    live = dict(value=(sample_flops / dt) / full_flops, unit="denoise-steps/s", cores=threads,
-                sample=f"fp32 PyTorch-CPU oracle, CFG forward of 6 views x {T} frames x 32x56 latents, first 3 layers "
-                       f"(dual joint blocks + 1 cross-view + 1 temporal VT block) at full width d=1536: "
-                       f"{sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {sample_flops / dt / 1e12:.3f} TFLOP/s, scaled by "
-                       f"the {full_flops / 1e12:.1f} TFLOP of one full step (FLOP extrapolation: optimistic, the full-size step "
-                       f"runs at a lower rate)")
-    # `value` is the MEASURED one: ONE full-size denoise step of the same oracle was timed on a GPU box's host cores outside this
-    # script (scripts/cpu_full_step.py, ~25 minutes) and is cited from the committed record; the bounded sample timed just now
-    # (FLOP-extrapolated) rides along as `live_sample`
+    fl = model_flops(kwargs, 2, 1, w["V"], w["H"], w["W"], w["text_len"])
+    sample_flops = fl["total"] + (fl["adapter"] if layout else 0)
+    res = dict(value=1.0 / (w["T"] * dt), unit="denoise-steps/s", cores=threads, kind="port",
+               sample=f"measured in this run: ONE full-depth CFG forward of the fp32 PyTorch-CPU oracle "
+                      f"({'text+layout' if layout else 'text-only'} model, {kwargs['num_layers']} layers, d = 1536, {w['text_len']} text tokens) "
+                      f"on {w['V']} views x 1 frame x {w['H']}x{w['W']} latents = 1/{w['T']} of the step's images: {sample_flops / 1e12:.1f} TFLOP in "
+                      f"{dt:.1f} s on {threads} threads of {os.cpu_count()} host CPUs = {sample_flops / dt / 1e12:.3f} TFLOP/s; "
+                      f"value = 1 / ({w['T']} x {dt:.1f} s); weights tiled from a seeded block in {t_weights:.0f} s (untimed)",
+               seconds_measured=dt, sample_flop=sample_flops, step_flop=step_flops, finite=bool(torch.isfinite(out).all()))
     try:
         m = json.load(open(os.path.join(ROOT, "profiles", "r2_cpu_full_step.json")))
-        return dict(value=m["denoise_steps_per_s"], unit="denoise-steps/s", cores=m["threads"], kind="port",
-                    sample=f"one full-size denoise step ({m['variant']}) of the fp32 PyTorch-CPU oracle: {m['seconds_per_step']:.0f} s on "
-                           f"{m['threads']} threads of {m['host_cores']} host cores (profiles/r2_cpu_full_step.json, "
-                           f"scripts/cpu_full_step.py); this run's bounded sample: live_sample",
-                    live_sample=live)
+        res["cited_full_step"] = dict(value=m["denoise_steps_per_s"], seconds_per_step=m["seconds_per_step"], threads=m["threads"],
+                                      host_cores=m["host_cores"], variant=m["variant"], source="profiles/r2_cpu_full_step.json "
+                                      "(scripts/cpu_full_step.py: one FULL-SIZE step of the same oracle, timed once in round 2)")
     except Exception:
-        return dict(kind="port", **live)
+        pass
+    return res
 
 
 UNET_KWARGS = dict(   # examples/ctsd_21_6views_video_generation.json (reference repo)
@@ -370,8 +401,9 @@ def main_train(args):
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init("nccl", dev)
+    D.init("nccl", dev, force=args.preflight)     # --preflight on one GPU: a one-rank RCCL group, DDP and its probes included
     pre = D.preflight(dev) if (world > 1 or args.preflight) else None
+    use_ddp = world > 1 or args.preflight
     from opendwm_amd import _lib
     from opendwm_amd.dit import DiTCrossviewTemporalConditionModel, model_flops
     from opendwm_amd.pipeline import CTSDTrainer
@@ -392,7 +424,7 @@ def main_train(args):
         model.time_text_embed.requires_grad_(False)
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     n_all = sum(p.numel() for p in model.parameters())
-    trainer = CTSDTrainer(model, lr=1e-5, weight_decay=0.01, ddp=world > 1)
+    trainer = CTSDTrainer(model, lr=1e-5, weight_decay=0.01, ddp=use_ddp)
     w = WORKLOAD
     cond = {k: (v[:w["B"]] if torch.is_tensor(v) else v) for k, v in make_conditions(dev, seed=rank).items()}
     g = torch.Generator(device="cuda").manual_seed(rank)
@@ -407,21 +439,28 @@ def main_train(args):
     finite = bool(torch.isfinite(torch.stack(losses)).all().item())
     # gradient exchange (ctsd.py:1051-1054: DDP all-reduce), outside the timed region: the same step without synchronisation
     # (DDP no_sync) and one all-reduce of the gradient bytes on its own -> how much of the exchange hides behind the backward
+    # The probes run forward + backward only and drop the gradients (no optimizer step: the replicas stay identical), the same
+    # number of times with and without synchronisation.
     ddp_extra = None
-    if world > 1:
+    if use_ddp:
         import contextlib
-        nosync = trainer.wrapper.no_sync if trainer.ddp else contextlib.nullcontext
 
-        def step_nosync(i):
-            with nosync():
-                trainer.train_step(latents, cond, generator=gen)
-        dt_ns = D.timed_steps(step_nosync, 2, 1, dev)
+        def fwd_bwd(sync: bool):
+            def run(i):
+                with (contextlib.nullcontext() if sync else trainer.wrapper.no_sync()):
+                    trainer.loss(latents, cond, generator=gen).backward()
+                trainer.optimizer.zero_grad()
+            return run
+        n_probe = 2
+        dt_sync = D.timed_steps(fwd_bwd(True), n_probe, 1, dev)
+        dt_ns = D.timed_steps(fwd_bwd(False), n_probe, 1, dev)
         wire = torch.bfloat16 if getattr(trainer, "ddp_comm_dtype", None) == torch.bfloat16 else torch.float32
         nbytes = n_train * (2 if wire == torch.bfloat16 else 4)
         ar_ms = D.measure_allreduce(nbytes, dev, wire)
-        exposed = max(0.0, 1e3 * dt / args.steps - 1e3 * dt_ns / 2)
+        exposed = max(0.0, 1e3 * (dt_sync - dt_ns) / n_probe)
         ddp_extra = dict(allreduce_ms=ar_ms, allreduce_bytes=nbytes, wire_dtype=str(wire).replace("torch.", ""),
-                         step_ms_without_gradient_sync=1e3 * dt_ns / 2, exposed_allreduce_ms=exposed,
+                         forward_backward_ms_with_gradient_sync=1e3 * dt_sync / n_probe,
+                         forward_backward_ms_without_gradient_sync=1e3 * dt_ns / n_probe, exposed_allreduce_ms=exposed,
                          backward_overlap_frac=(1.0 - min(1.0, exposed / ar_ms)) if ar_ms > 0 else None)
     if rank == 0:
         fwd = model_flops(kwargs, w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])["total"]
@@ -629,7 +668,7 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init("nccl", dev)          # "nccl" == RCCL on ROCm; no-op for a single process
+    D.init("nccl", dev, force=args.preflight)     # "nccl" == RCCL on ROCm; a single process needs no group unless --preflight asks for one
     pre = D.preflight(dev) if (world > 1 or args.preflight) else None     # fails loudly (rc != 0) before anything is timed
 
     from opendwm_amd import _lib
@@ -777,7 +816,7 @@ def main():
                 "gemm_tflops": ks2.get("gemm", {}).get("tflops"), "attention_tflops": ks2.get("attn", {}).get("tflops"),
                 "whole_step_mfma_frac": fl2["total"] / (ms2 * 1e-3) / (PEAK_BF16_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))), step_flop)
+            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))), args.layout, step_flop)
         print(json.dumps(line))
     D.shutdown()
 

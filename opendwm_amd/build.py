@@ -58,7 +58,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
              "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"] + os.environ.get("DWM_EXTRA_FLAGS", "").split()
     jobs = []
-    old_hash = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    # the stamp holds the source hash and the extra flags of the objects on disk: other flags (e.g. -DDWM_DEV_HOOKS) change
+    # neither the hash nor a modification time, so they force a full rebuild here
+    extra = " ".join(os.environ.get("DWM_EXTRA_FLAGS", "").split())
+    old_stamp = (open(stamp).read().strip() if os.path.exists(stamp) else "").split("|", 1)
+    old_hash, old_extra = old_stamp[0], (old_stamp[1] if len(old_stamp) > 1 else "")
+    force = force or old_extra != extra
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -89,7 +94,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(stamp, "w") as f:
-        f.write(shash)
+        f.write(shash + "|" + extra)
     return LIB
 
 

@@ -21,9 +21,11 @@ def env_ranks() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str, device: torch.device = None) -> Tuple[int, int, int]:
+def init(backend: str, device: torch.device = None, force: bool = False) -> Tuple[int, int, int]:
+    """process group of a torch.distributed.run launch; a single process needs none - unless `force` (bench.py --preflight on
+    one GPU: a one-rank RCCL communicator, so that the collectives' code path runs on the hardware at hand)"""
     rank, local_rank, world = env_ranks()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -102,16 +104,29 @@ def preflight(device: torch.device = None, mbytes: int = 64) -> dict:
     lo, hi = buf.min().item(), buf.max().item()
     if lo != want or hi != want:
         raise RuntimeError(f"preflight: all_reduce over {world} ranks gave [{lo}, {hi}], expected {want} on rank {rank}")
-    # every rank on its own device: the (device index, host pid) pairs must be distinct
-    # (a tensor all-gather, not all_gather_object: no pickling through the backend's device path)
-    mine = torch.tensor([local_rank if on_gpu else -1 - rank, os.getpid()], dtype=torch.int64, device=dev)
+    # every rank on its own device: the (host, device index) pairs must be distinct - per HOST, so that a 2 x 8 launch (the same 8
+    # device indices on two nodes) passes and two ranks of one node on one GPU do not; the device index is the one the rank
+    # actually selected (`device.index`), not LOCAL_RANK: a rank whose set_device went to the wrong GPU is what this catches.
+    # (A tensor all-gather, not all_gather_object: no pickling through the backend's device path.)
+    import hashlib
+    import socket
+    host = int.from_bytes(hashlib.sha256(socket.gethostname().encode()).digest()[:7], "little")
+    mine = torch.tensor([host, device.index if on_gpu and device.index is not None else (torch.cuda.current_device() if on_gpu else -1 - rank),
+                         os.getpid()], dtype=torch.int64, device=dev)
     got = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)
     ids = [tuple(int(v) for v in t.tolist()) for t in got]
-    if on_gpu and len({i for i, _ in ids}) != world:
-        raise RuntimeError(f"preflight: ranks share a GPU: {ids}")
-    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True, distinct_devices=on_gpu)
+    if on_gpu:
+        check_distinct_devices(ids)
+    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True, distinct_devices=on_gpu,
+                hosts=len({h for h, _, _ in ids}))
     return info
+
+
+def check_distinct_devices(ids) -> None:
+    """ids: one (host hash, device index, pid) per rank.  Raises if two ranks of one host selected the same device."""
+    if len({(h, i) for h, i, _ in ids}) != len(ids):
+        raise RuntimeError(f"preflight: ranks share a GPU: (host hash, device index, pid) = {list(ids)}")
 
 
 def measure_allreduce(nbytes: int, device: torch.device = None, dtype: torch.dtype = torch.float32, repeat: int = 3) -> float:

@@ -74,8 +74,10 @@ def check_mixer_gradients(mixers: dict, calls: list, flat_tol: float):
     """mixers: name -> dict(rel = error of mix_factor.grad against fp32 autograd, cond = sum|terms| / |sum| of its d(alpha)).
     (1) every captured kernel call equals the fp64 sum of its own inputs to fp32 accumulation accuracy, measured against the
     sum of the absolute terms (so the statement holds at any conditioning); (2) where the sum is reasonably conditioned
-    (cond < 400) the gradient meets the flat tolerance.  For the badly conditioned sums (a -9.7 out of +-1e4 terms) what is
-    left beyond (1) is the bf16 rounding of the activations and incoming gradients, which have their own tolerances."""
+    (cond < 400) the gradient meets the flat tolerance; (3) the badly conditioned ones (a -9.7 out of +-1e4 terms) still meet a
+    bound that grows with the conditioning, 4e-4 x cond - the bf16 rounding of the activations and incoming gradients the sum
+    is handed, amplified by the cancellation - so a wrong operand, sign or scale reaching such a mixer (an O(1) relative error
+    at any conditioning below 2500) cannot pass on the strength of (1) alone."""
     worst_kernel = max((abs(c["kernel"] - c["exact"]) / max(c["abs"], 1e-300) for c in calls), default=0.0)
     assert len(calls) >= len(mixers) and worst_kernel < 2e-6, (len(calls), len(mixers), worst_kernel)
     for c in calls:
@@ -84,4 +86,6 @@ def check_mixer_gradients(mixers: dict, calls: list, flat_tol: float):
     for n, v in mixers.items():
         if v["cond"] < 400:
             assert v["rel"] < flat_tol, (n, v)
+        else:
+            assert v["rel"] < 4e-4 * v["cond"], (n, v)
     return worst_kernel

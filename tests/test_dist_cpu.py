@@ -356,3 +356,12 @@ def test_trainer_accumulation_no_sync_bf16_buckets_lr_schedule_two_ranks(comm):
         assert abs(lr - ref_lr) < 1e-12 and abs(lr - 1e-2 / 5) < 1e-12   # scheduler stepped on all four calls
         assert state_keys == [0, 3, 4] and t == 2                    # frozen parameters 1, 2 (own parameters come first): listed, no state
     assert res[0][-1] == res[1][-1]                  # replicas stay identical
+
+
+def test_preflight_device_check_is_per_host():
+    """16 ranks on 2 nodes x 8 GPUs use every device index twice (once per host): fine; two ranks of one host on one GPU: not"""
+    from opendwm_amd import dist as D
+    D.check_distinct_devices([(h, i, 1000 + 8 * h + i) for h in (11, 22) for i in range(8)])
+    D.check_distinct_devices([(11, 0, 1)])
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        D.check_distinct_devices([(11, 0, 1), (11, 1, 2), (11, 1, 3), (22, 1, 4)])
