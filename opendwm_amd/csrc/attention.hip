@@ -906,6 +906,13 @@ attn_group_lds_kernel(const AttnParams P) {
 // touches of the next head (loads return in order: the touches stall the next wait behind an HBM round trip), a refill point
 // inside the last round (its barrier costs the waves' skew), loader waves that copy behind the others' progress words (the
 // copy is hidden but the computing waves slow down by more), 8 computing + 4 loading waves, start skew between workgroups.
+// Round 4, measured and dropped as well (scripts/experiments/attn_refill_points.patch, profiles/r4a_microbench_refill_stream32.log):
+// two barrier-free refill points - the waves without a tile in the last round sleep on two LDS counters that the computing
+// waves bump (one atomic each) once they are past n / 2 and 3 n / 4 of their last unit, and copy the next head's rows into
+// the dead front of the images: bit-identical results, 3-5 % SLOWER at L = 602 (652-670 vs 693-701 TFLOP/s, same call) and
+// 10 % slower at L = 448 (520 vs 575), 627-636 vs 657-665 inside the bench; and a register prefetch of the next head by the
+// idle waves (5 x 31 KiB fit a head) - the register allocator puts the buffer in scratch at any size (the kernel sits at its
+// 168-register budget with 25 spills already).
 //
 // Softmax without a running maximum (the fast path): softmax is shift invariant, so P' = 2^s (s = the log2-domain score,
 // scale * log2(e) folded into Q) and O = (sum_k P'_k V_k) / (sum_k P'_k) need no maximum at all as long as nothing leaves
@@ -1074,16 +1081,9 @@ struct ResCtx {             // launch / workgroup invariants of attn_res_kernel'
 // the fallback), normalisation, and the stores.  qraw: this lane's raw Q fragments; op[t]: this lane's output row pointer
 // (rows past the last query are clamped to it: they then hold the same Q, compute the same output and store the same
 // bytes to the same address - unconditional stores keep the loop free of exec-masked blocks).
-// progress signals of a unit of the LAST round of a head (attn_res_kernel's refill points): after the step pair (k, k + 1)
-// with k == k1 (k2) every read of K sub-tiles <= k + 2 and V sub-tiles <= k of this wave has returned; the wave then adds one to
-// counter 0 (1).  sig == nullptr: no signals.
-struct ResSignal {
-    uint32_t* cnt;
-    int k1, k2;
-};
 template <int NT, class Fetch>
 DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe,
-                         const ResGlobal& gm, Fetch&& after_loop, const ResSignal& sig, long long* tr = nullptr) {
+                         const ResGlobal& gm, Fetch&& after_loop, long long* tr = nullptr) {
     bf16x8 qf[NT][4];
     f32x16 ot[NT][2];
     f32x2 lsum[NT][2];
@@ -1119,23 +1119,10 @@ DWM_DEVINL void res_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* c
 #ifdef DWM_ATTN_TRACE
         if (tr != nullptr) tr[4] = (long long)__builtin_readcyclecounter();
 #endif
-        // the step pairs, in three stretches with the progress signals between them: any control flow INSIDE the pair loop makes
-        // the compiler sink the row-sum adds to the loop's end and reload spilled addresses at its top - the signalling code has
-        // to stay out of the loop the steps are scheduled in
-#define DWM_RES_PAIRS(kend_)                                                                                              \
-        for (; k < (kend_); k += 2) {                                                                                     \
-            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 1) * 4096, c.vimg + (k - 1) * 4096, sa, sb, pb, pa);      \
-            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 2) * 4096, c.vimg + k * 4096, sb, sa, pa, pb);            \
+        for (; k + 2 < n; k += 2) {
+            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 1) * 4096, c.vimg + (k - 1) * 4096, sa, sb, pb, pa);
+            DWM_RES_STEP(true, true, true, false, c.kimg + (k + 2) * 4096, c.vimg + k * 4096, sb, sa, pa, pb);
         }
-        if (sig.cnt != nullptr) {                                          // (wave-uniform)
-            const int e1 = sig.k1 + 1 < n - 2 ? sig.k1 + 1 : n - 2, e2 = sig.k2 + 1 < n - 2 ? sig.k2 + 1 : n - 2;
-            DWM_RES_PAIRS(e1)
-            if (c.l31 + c.half == 0) __hip_atomic_fetch_add(sig.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            DWM_RES_PAIRS(e2)
-            if (c.l31 + c.half == 0) __hip_atomic_fetch_add(sig.cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        DWM_RES_PAIRS(n - 2)
-#undef DWM_RES_PAIRS
         if (k + 1 < n) {                                                   // step k, then the last sub-tile k + 1
             DWM_RES_STEP(true, true, true, false, c.kimg + (k + 1) * 4096, c.vimg + (k - 1) * 4096, sa, sb, pb, pa);
             if (ragged) DWM_RES_STEP(false, true, true, true, c.kimg, c.vimg + k * 4096, sa, sa, pa, pb);
@@ -1217,7 +1204,6 @@ attn_res_kernel(const AttnParams P) {
     // tables: input row offsets (see attn_fwd_kernel) of this item and of the next one, output row offsets of this item
     int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
     int32_t* const otab = tabs + 2 * Lt;
-    uint32_t* const progress = (uint32_t*)(otab + Lt);       // two counters of the refill points (below)
 
     ResCtx c;
     c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
@@ -1275,24 +1261,6 @@ attn_res_kernel(const AttnParams P) {
     const int nqt = (P.qend + 31) >> 5;                      // 32-query tiles of a head
     const int nwc = P.nwc;                                   // compute waves (<= NW): tile = round * nwc + wave
     const int rounds = (nqt + nwc - 1) / nwc;
-    // Refill points.  The images are full (L = 602: 152 of the 160 KiB) and in use until a head's closing barrier, so the copy
-    // of the next head used to stand between two heads: ~6 k of the 54.7 k cycles of a head in which no wave computes
-    // (profiles/r3_attn_timeline.txt).  But in the LAST round of a head some waves have no tile (19 tiles on 12 waves: waves 7-11;
-    // 14 tiles: waves 2-11), and the waves that do walk the keys front to back: once ALL of them are past sub-tile k, the image
-    // rows before it are dead.  The computing waves say so without waiting for anybody - one LDS atomic add at two points of the
-    // unit (k1 ~ n / 2, k2 ~ 3 n / 4; ResSignal) - and the free waves, which sleep on those counters, copy the next head's rows
-    // into the dead part while the others finish: K sub-tiles [0, k + 3), V sub-tiles [0, k + 1) (the software pipeline reads K
-    // two sub-tiles ahead of V).  Only the last quarter is left for after the barrier.  Counters only grow (target = heads so
-    // far x signalling waves), the two points have one counter each, so a fast wave's second signal never counts for a slow
-    // wave's first.  A unit that falls back to the online softmax re-reads K / V from global memory (res_tile_safe), never
-    // from the images.  (dwm_attn_args.variant bit 6: no refill points - everything after the barrier, as in round 3.)
-    const int n_last = nqt - (rounds - 1) * nwc;             // waves [0, n_last) own a tile in the last round
-    const int n_free = NW - n_last;
-    const int sig_k1 = ((c.nsub >> 1) - 1) | 1, sig_k2 = (((3 * c.nsub) >> 2) - 1) | 1;
-    const bool use_sig = !P.no_refill && n_free > 0 && c.nsub >= 8 && sig_k1 < sig_k2 && sig_k2 + 2 < c.nsub;
-    const int kq1 = use_sig ? sig_k1 + 3 : 0, vq1 = use_sig ? sig_k1 + 1 : 0;      // sub-tiles [0, q1) dead after the first point
-    const int kq2 = use_sig ? sig_k2 + 3 : 0, vq2 = use_sig ? sig_k2 + 1 : 0;      // ... [q1, q2) after the second
-    if (tid < 2) progress[tid] = 0u;
     const bool force_safe = P.safe_softmax != 0;             // dwm_attn_args.variant bit 4: online softmax for every unit
     const int n = c.nsub;
 
@@ -1374,37 +1342,22 @@ attn_res_kernel(const AttnParams P) {
                 }
                 ResGlobal gm;
                 gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
-                ResSignal sig;
-                sig.cnt = (use_sig && r == rounds - 1) ? progress : nullptr;
-                sig.k1 = sig_k1; sig.k2 = sig_k2;
 #ifdef DWM_ATTN_TRACE
-                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q, sig,
+                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q,
                             (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64 && r == 0) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
 #else
-                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q, sig);
+                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
 #endif
                 if (r == 0) DWM_TR(3);
             }
-        }
-        if (use_sig && has_next && wave >= n_last) {         // a free wave: refill behind the computing waves
-            const uint32_t target = (uint32_t)(g + 1) * (uint32_t)n_last;
-            const int fi = wave - n_last;
-            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)target)
-                __builtin_amdgcn_s_sleep(8);
-            copy_rows(ntab, nhoff, 0, kq1, false, fi, n_free);
-            copy_rows(ntab, nhoff, 0, vq1, true, fi, n_free);
-            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(progress + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)target)
-                __builtin_amdgcn_s_sleep(8);
-            copy_rows(ntab, nhoff, kq1, kq2, false, fi, n_free);
-            copy_rows(ntab, nhoff, vq1, vq2, true, fi, n_free);
         }
         DWM_TR(6);
         __syncthreads();                                     // everybody is done with this head's images
         DWM_TR(7);
         if (new_item_next) build_tab(nullptr, otab, nprob);  // the output row table of the next item (this item's is no longer read)
-        if (has_next) {                                      // what the refill points have not covered
-            copy_rows(ntab, nhoff, kq2, n, false, wave, NW);
-            copy_rows(ntab, nhoff, vq2, n, true, wave, NW);
+        if (has_next) {
+            copy_rows(ntab, nhoff, 0, n, false, wave, NW);
+            copy_rows(ntab, nhoff, 0, n, true, wave, NW);
         }
     }
 }
@@ -1451,7 +1404,6 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     // heads per workgroup: amortises the per-workgroup fixed cost (variant bits 8..11 override: 1..15).
     // Measured on the step's shapes (L = 168 .. 602): 2 ~ 3 > 1; single-tile problems (L <= 64) take more.
     P.safe_softmax = (a->variant >> 4) & 1;
-    P.no_refill = (a->variant >> 6) & 1;
     int hpb = (a->variant >> 8) & 15;
     if (hpb == 0) {
         if (L - P.kbeg <= KT) { for (hpb = 6; P.heads % hpb != 0; --hpb) {} }
@@ -1550,7 +1502,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         const unsigned nblk = (unsigned)(nitems < ncu ? nitems : ncu);           // persistent: one workgroup per CU
-        const size_t lds = (size_t)2 * ((L + 31) & ~31) * 128 + (size_t)3 * ((L + 3) & ~3) * sizeof(int32_t) + 16;    // images, row tables, progress counters
+        const size_t lds = (size_t)2 * ((L + 31) & ~31) * 128 + (size_t)3 * ((L + 3) & ~3) * sizeof(int32_t);
         // compute waves (variant bits 0-3 override; 12 = all)
         {
             int nwc = a->variant & 15;

@@ -41,7 +41,6 @@ struct AttnParams {
     int n_problems, heads, nqb;
     int nwc;                 // attn_res_kernel: compute waves
     int safe_softmax;        // attn_res_kernel: online softmax (running max) for every unit instead of the max-free fast path
-    int no_refill;           // attn_res_kernel: the next head's rows only after the head's closing barrier (no refill points)
     int hpb;                 // heads per workgroup (forward); fd_heads then divides by heads / hpb
     FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;
     float scale_log2;

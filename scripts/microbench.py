@@ -312,8 +312,8 @@ if __name__ == "__main__":
         bench_attn([0])
     if "attnx" in what:                  # resident kernel geometries (12 waves x 1 tile / 8 x 2; 6 / 3 / 2 heads per workgroup; online softmax) vs tiled
         bench_attn([0, 32 | 1])
-    if "attnr" in what:                  # resident kernel with / without its refill points (variant bit 6)
-        bench_attn([0, 64], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
+    if "attnr" in what:                  # the resident kernel's launches only
+        bench_attn([0], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
     if "s32" in what:
         bench_stream32()
     if "gemm" in what:

@@ -389,34 +389,38 @@ def test_attention_resident_forms(dev, scale, I, N, Lc, heads):
     assert all(e < (TOL_KERNEL if scale == 1.0 else 3e-2) for e in errs.values()), errs
 
 
-@pytest.mark.parametrize("I,N,Lc,heads,hs", [(150, 256, 40, 4, 2), (3, 448, 154, 24, 6), (40, 448, 0, 12, 1), (2, 576, 26, 6, 3), (70, 230, 0, 8, 2)])
-def test_attention_resident_refill_points(dev, I, N, Lc, heads, hs):
-    """the refill points of attn_res_kernel (round 4: the next head's K / V rows copied into the dead front part of the images by
-    the waves without a tile in the last round, behind two progress counters of the computing waves) against the plain form
-    (variant bit 6: the whole copy after the head's closing barrier): same arithmetic on the same data, so the outputs must be
-    bit-identical - across head seams inside an item, item seams of a persistent workgroup (more items than CUs), both image
-    sizes of the model (L = 602: 5 free waves, L = 448: 10) and L = 256 (12 free waves: no wave computes in a second round)"""
+@pytest.mark.parametrize("I,N,Lc,heads,hs", [(150, 256, 40, 4, 2), (3, 448, 154, 24, 6), (40, 448, 0, 12, 1), (70, 230, 0, 8, 2)])
+def test_attention_resident_persistent_workgroups_across_item_seams(dev, I, N, Lc, heads, hs):
+    """attn_res_kernel as a persistent kernel: more items than CUs (150 x 2 = 300 items, 40 x 12 = 480), so a workgroup walks
+    several (problem, head group) items - table rebuilds, the copy pipeline across item seams, both wave geometries - against
+    the reference on the first and the LAST problems (the ones a workgroup reaches after its first item), and repeated
+    launches bit-identical"""
     from opendwm_amd import ops
     D = heads * 64
     qkv = _rand((I * N, 3 * D), dev, 21)
     cqkv = _rand((I * Lc, 3 * D), dev, 22) if Lc else None
     rm = ops.rowmap_identity(I, N)
     outs = {}
-    for variant in ((hs << 8), (hs << 8) | 64, (hs << 8) | 8, (hs << 8) | 8 | 64):
-        out = torch.full((I * N, D), float("nan"), dtype=bf16, device=dev)
-        cout = torch.full((I * Lc, D), float("nan"), dtype=bf16, device=dev) if Lc else None
-        kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout) if Lc else {}
-        for _ in range(3):                      # (a race would not show up the same way three times)
+    for variant in ((hs << 8), (hs << 8) | 8):
+        runs = []
+        for _ in range(2):
+            out = torch.full((I * N, D), float("nan"), dtype=bf16, device=dev)
+            cout = torch.full((I * Lc, D), float("nan"), dtype=bf16, device=dev) if Lc else None
+            kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout) if Lc else {}
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant, **kw)
-        outs[variant] = (out, cout)
-    f, cf = qkv[:2 * N].float(), (cqkv[:2 * Lc].float() if Lc else None)
-    r0, r1 = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], ops.rowmap_identity(2, N).rows().to(dev), heads,
-                       q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
-    e = max(rel_err(outs[hs << 8][0][:2 * N], r0), rel_err(outs[hs << 8][1][:2 * Lc], r1) if Lc else 0.0)
-    _log("attention_resident_refill_points", I=I, N=N, Lc=Lc, heads=heads, hs=hs, rel=e)
-    assert e < TOL_KERNEL
-    for a, b in (((hs << 8), (hs << 8) | 64), ((hs << 8) | 8, (hs << 8) | 8 | 64)):
-        assert torch.equal(outs[a][0], outs[b][0]) and (not Lc or torch.equal(outs[a][1], outs[b][1])), (a, b)
+            runs.append((out, cout))
+        assert torch.equal(runs[0][0], runs[1][0]) and (not Lc or torch.equal(runs[0][1], runs[1][1]))
+        outs[variant] = runs[0]
+    errs = []
+    for p0 in (0, I - 2):                       # two problems at the front, two at the back
+        f = qkv[p0 * N:(p0 + 2) * N].float()
+        cf = cqkv[p0 * Lc:(p0 + 2) * Lc].float() if Lc else None
+        r0, r1 = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], ops.rowmap_identity(2, N).rows().to(dev), heads,
+                           q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
+        for variant, (out, cout) in outs.items():
+            errs.append(max(rel_err(out[p0 * N:(p0 + 2) * N], r0), rel_err(cout[p0 * Lc:(p0 + 2) * Lc], r1) if Lc else 0.0))
+    _log("attention_resident_item_seams", I=I, N=N, Lc=Lc, heads=heads, hs=hs, rel=max(errs))
+    assert max(errs) < TOL_KERNEL
 
 
 def test_attention_resident_temporal_rowmap_multihead(dev):
