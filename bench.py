@@ -562,6 +562,133 @@ def main_train_unet(args):
     D.shutdown()
 
 
+# BASELINE configs[4]: examples/ctsd_35_tvae_6views_video_generation_with_layout.json (reference repo) - inference_config :55-69
+TVAE_AR = dict(frames=40, sequence_length_per_iteration=17, vae_pre=1, vae_stride=4, reference_frame_count=1, guidance_scale=4.0,
+               inference_steps=40, memory_efficient_batch=2, n_time_ids=11)
+
+
+def main_tvae_ar(args):
+    """BASELINE configs[4] on one GPU: the SD 3.5 CTSD text+layout model over the CogVideoX temporal VAE, 6 views x 40 frames
+    generated autoregressively as the reference does (ctsd.py:1656-1833 with the inference_config of the example JSON): windows
+    of 17 frames = 5 latent frames (vae_pre 1, vae_stride 4), stride 16, the last latent frame of a window is the clean
+    reference frame of the next one; every window = 40 guided FlowMatch-Euler steps of the FULL-SIZE model on latents
+    [1,5,6,16,32,56] + one temporal-VAE decode of 6 clips x 17 frames x 256x448 (memory_efficient_batch 2).  40 frames -> 2
+    windows -> 33 generated frames (the reference's `range(0, total - length + 1, stride)` drops the ragged tail).  The timed
+    region is the whole job: both windows' denoise loops and both decodes; conditions (text / layout tensors) are resident, as
+    for the headline.  --steps = inference steps per window (default: the example's 40), --warmup = untimed steps of a
+    warm-up window (and one untimed decode)."""
+    from opendwm_amd import dist as D
+    rank, local_rank, world = D.env_ranks()
+    assert world == args.gpus == 1, "--tvae-ar is a one-GPU line (the multi-GPU form of this job is --frame-shard / replicas)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from opendwm_amd import _lib
+    from opendwm_amd.build import ensure_built
+    from opendwm_amd.dit import model_flops
+    from opendwm_amd.drivers import AutoregressiveDriver, LatentDecoder, LatentEncoder, latent_sequence_length
+    from opendwm_amd.pipeline import CTSDDenoiser
+    from opendwm_amd.vae_cogvideox import AutoencoderKLCogVideoX
+    ensure_built()
+    _lib.load()
+    c, w = TVAE_AR, WORKLOAD
+    steps = args.steps if args.steps_given else c["inference_steps"]
+    kwargs = variant_kwargs(True)
+    kwargs.update(projection_class_embeddings_input_dim=256 * c["n_time_ids"])           # "fps_camera_transforms": 11 ids
+    timer = KernelTimer().install()
+    try:
+        model = build_model(kwargs, dev, seed=0)
+        if args.residual_bf16:
+            model.residual_dtype = torch.bfloat16
+        model.cache_adapter_residuals = bool(args.adapter_cache)
+        vae = AutoencoderKLCogVideoX().to(dev).to(torch.bfloat16).eval()                  # THUDM/CogVideoX-2b widths
+        synth_init_(vae, 1)
+        T_lat = latent_sequence_length(c["sequence_length_per_iteration"], c["vae_pre"], c["vae_stride"])
+        wl = dict(w, T=T_lat)
+        icfg = dict(inference_steps=steps, sequence_length_per_iteration=c["sequence_length_per_iteration"], vae_pre=c["vae_pre"],
+                    vae_stride=c["vae_stride"], reference_frame_count=c["reference_frame_count"],
+                    autoregression_data_exception_for_take_sequence=["crossview_mask"])
+        den = CTSDDenoiser(model, guidance_scale=c["guidance_scale"], inference_steps=steps)
+        if args.graph:
+            den.enable_graph()
+        dec_events = []
+
+        class TimedDecoder(LatentDecoder):
+            def __call__(self, latents, diffusion_forcing=False):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = super().__call__(latents, diffusion_forcing)
+                e.record()
+                dec_events.append((s, e))
+                return out
+        decode = TimedDecoder(vae, memory_efficient_batch=c["memory_efficient_batch"])
+        drv = AutoregressiveDriver(den, icfg, decode=decode, generator=torch.Generator().manual_seed(0))
+        plan = drv.plan(T_lat, c["frames"], False)
+        # the windows' conditions (what get_conditions hands the model: CFG-doubled text / pooled / time ids / layout images per
+        # LATENT frame), built before the timed region
+        conds = {wd.clip: make_conditions(dev, seed=wd.clip[0], w=wl, n_time_ids=c["n_time_ids"], layout=True) for wd in plan}
+        shape = (w["B"], T_lat, w["V"], w["C"], w["H"], w["W"])
+        # warm-up: a short window + one decode (kernels, allocator, clocks)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        lat0 = torch.randn(shape, device=dev, generator=g)
+        den.prepare(lat0, conds[plan[0].clip])
+        for i in range(max(1, args.warmup)):
+            den.step(i % steps)
+        decode(den.result())
+        dec_events.clear()
+        timer.enabled = not args.graph
+        D.sync(dev)
+        t0 = time.perf_counter()
+        out = drv.run(shape, lambda a, b: conds[(a, b)], c["frames"], dev)
+        D.sync(dev)
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        img = out["images"]
+        finite = bool(torch.isfinite(img).all().item())
+        decode_ms = sum(s.elapsed_time(e) for s, e in dec_events)
+        # outside the timed region: the reference-frame encode an autoregressive CONTINUATION starts from
+        # (generate_frames_for_reference = false, ctsd.py:1677-1703): 6 views x 1 frame -> 1 latent frame
+        px = torch.rand(w["B"], 1, w["V"], 3, 8 * w["H"], 8 * w["W"], device=dev) * 2 - 1
+        enc = LatentEncoder(vae, memory_efficient_batch=c["memory_efficient_batch"])
+        enc(px, sample=False)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        ref_lat = enc(px, sample=False)
+        torch.cuda.synchronize()
+        enc_ms = 1e3 * (time.perf_counter() - te)
+    finally:
+        timer.uninstall()
+    n_steps = steps * len(plan)
+    frames = img.shape[0] // (w["B"] * w["V"])
+    fl = model_flops(kwargs, 2 * w["B"], T_lat, w["V"], w["H"], w["W"], w["text_len"])
+    step_flop = fl["total"] + (fl["adapter"] if not args.adapter_cache else 0)
+    ks = timer.summary()
+    gm, at = ks.get("gemm", {}), ks.get("attn", {})
+    print(json.dumps({
+        "metric": "denoise-steps/sec (6-view x40f as 17-frame windows over the CogVideoX tVAE), SD-3.5 CTSD, whole job incl. decode",
+        "value": n_steps / dt, "unit": "denoise-steps/s", "n_gpus": 1, "steps": n_steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / n_steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (seeded random-init weights of the SD 3.5 CTSD model and of the CogVideoX-2b VAE architecture, random text / layout conditions)",
+        "frames_per_s": frames / dt, "view_frames_per_s": img.shape[0] / dt, "seconds_total": dt,
+        "seconds_denoise": dt - 1e-3 * decode_ms, "seconds_decode": 1e-3 * decode_ms, "reference_frame_encode_ms_untimed": enc_ms,
+        "config": {"workload": "BASELINE.json configs[4] on one GPU: CTSD SD-3.5 MMDiT text+layout (24 layers, point-wise temporal, ImageAdapter) + "
+                               "AutoencoderKLCogVideoX, 6 views x 40 frames 448x256 as autoregressive 17-frame windows (5 latent frames, stride 16, "
+                               "1 reference frame), 40 guided FlowMatch-Euler steps per window, split decode (memory_efficient_batch 2)",
+                   "windows": len(plan), "latent_window": list(shape), "frames_generated": frames, "images": list(img.shape),
+                   "inference_steps_per_window": steps, "flop_per_step": step_flop, "finite": finite, "hip_graph": bool(args.graph),
+                   "reference_latent": list(ref_lat.shape),
+                   "residual_stream": "bf16" if args.residual_bf16 else "fp32 (GEMM operands and activations bf16)",
+                   "baseline_config": "BASELINE.json configs[4] (examples/ctsd_35_tvae_6views_video_generation_with_layout.json)"},
+        "roofline": None if not gm else {
+            "bound": "mfma", "kernel": "gemm_bf16_kernel (all launches of the job: model GEMMs + the VAE's implicit-GEMM convolutions)",
+            "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
+            "traffic": None, "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
+            "share_of_job_time": gm.get("ms", 0.0) / (1e3 * dt)},
+        "roofline_attention": None if not at else {"bound": "mfma", "kernel": "attn_res_kernel (joint L=602, dual L=448)", "achieved": at.get("tflops"),
+                                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS},
+        "denoise_mfma_frac": step_flop * n_steps / max(dt - 1e-3 * decode_ms, 1e-9) / (PEAK_BF16_TFLOPS * 1e12),
+    }))
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): re-execute this command line
     under torch.distributed.run with one rank per GPU (one process per GPU as src/dwm/train.py:60-67 of the reference
@@ -647,11 +774,16 @@ def main():
     ap.add_argument("--unet", action="store_true",
                     help="BASELINE config 2 instead of the headline metric: SD-2.1 cross-view temporal UNet, 6 views x 6 frames "
                          "(examples/ctsd_21_6views_video_generation.json: DPM-Solver++ 50 steps, guidance 3)")
+    ap.add_argument("--tvae-ar", action="store_true",
+                    help="BASELINE config 5 on one GPU instead of the headline metric: 6 views x 40 frames as autoregressive 17-frame "
+                         "windows over the CogVideoX temporal VAE (examples/ctsd_35_tvae_6views_video_generation_with_layout.json); "
+                         "--steps = inference steps per window (default 40)")
     ap.add_argument("--freeze-base", action="store_true",
                     help="with --train: freezing_pattern ^(transformer_blocks|time_text_embed)$ of the reference's warm-up configs")
     ap.add_argument("--debug-cpu-launch", action="store_true",
                     help="debug: exercise the launch / timing path on CPU over gloo with a stand-in step (INVALID as a bench line)")
     args = ap.parse_args()
+    args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
     if args.debug_cpu_launch:
@@ -662,6 +794,8 @@ def main():
         return main_train(args)
     if args.unet:
         return main_unet(args)
+    if args.tvae_ar:
+        return main_tvae_ar(args)
 
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()

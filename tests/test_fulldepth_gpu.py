@@ -204,8 +204,9 @@ def _heavy_tailed_init_(model, seed: int):
                     p[hot] *= 16.0
 
 
+@pytest.mark.parametrize("stream", ["fp32", "bf16"], ids=["fp32_streams", "bf16_streams"])
 @pytest.mark.parametrize("layout", [False, True], ids=["text_only_rowwise", "text_layout_pointwise"])
-def test_forty_step_denoise_heavy_tailed_weights_with_outlier_channels(dev, layout):
+def test_forty_step_denoise_heavy_tailed_weights_with_outlier_channels(dev, layout, stream):
     """the 40-step loop in the stress regime of _heavy_tailed_init_, full width, 8 layers, 6 views x 4 frames: the tolerance must
     hold when the hidden state has channels 16 x larger than the rest (LayerNorm statistics dominated by them) and the weights
     have heavy tails"""
@@ -216,6 +217,7 @@ def test_forty_step_denoise_heavy_tailed_weights_with_outlier_channels(dev, layo
     kwargs.update(num_layers=n, dual_attention_layers=list(range(n)), crossview_block_layers=[1, 5], temporal_block_layers=[2, 3, 6, 7])
     model = bench.build_model(kwargs, dev, seed=0)
     _heavy_tailed_init_(model, 5)
+    model.residual_dtype = torch.float32 if stream == "fp32" else bf16       # (fp32 is the default; bf16 streams for comparison)
     wl = dict(bench.WORKLOAD, T=4)
     cond = bench.make_conditions(dev, seed=4, w=wl, layout=layout)
     lat = torch.randn(1, wl["T"], wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=torch.Generator(device="cuda").manual_seed(12))
@@ -235,9 +237,71 @@ def test_forty_step_denoise_heavy_tailed_weights_with_outlier_channels(dev, layo
         O.dit_forward = fwd0
     e40 = rel_err(out, ref)
     move = ((out.double() - ref.double()).norm() / (ref.double() - lat.double()).norm()).item()
-    _log("denoise_40_steps_heavy_tailed", variant="text+layout" if layout else "text_only", layers=n, latents=list(lat.shape),
+    _log("denoise_40_steps_heavy_tailed", variant="text+layout" if layout else "text_only", streams=stream, layers=n, latents=list(lat.shape),
          rel_step40=e40, rel_to_displacement=move, finite=bool(torch.isfinite(out).all()))
     assert e40 < TOL, e40
+
+
+def test_tvae_autoregressive_window_full_size_vs_oracle_on_device(dev):
+    """BASELINE.json configs[4], one autoregressive window at FULL size (what `bench.py --tvae-ar` runs twice): the 24-layer
+    text+layout model on latents [1,5,6,16,32,56] with the previous window's last latent frame injected clean
+    (reference_frame_count 1: ctsd.py:1514-1526, 1623-1627), 40 guided FlowMatch-Euler steps, then the CogVideoX temporal VAE
+    at its published widths decoding 6 clips x 17 frames x 256x448 in split calls (memory_efficient_batch 2, :1606-1647) -
+    CTSDDenoiser + drivers.LatentDecoder against O.denoise + the fp32 VAE oracle, both evaluated on the device.  Checked
+    separately: the window's latents, the decode of the SAME (oracle) latents, and the end-to-end frames."""
+    import bench
+    from oracle import cogvideox_vae_oracle as CV
+    from opendwm_amd.drivers import LatentDecoder
+    from opendwm_amd.pipeline import CTSDDenoiser
+    from opendwm_amd.vae_cogvideox import AutoencoderKLCogVideoX
+    c = bench.TVAE_AR
+    kwargs = bench.variant_kwargs(True)
+    kwargs.update(projection_class_embeddings_input_dim=256 * c["n_time_ids"])
+    model = bench.build_model(kwargs, dev, seed=0)
+    wl = dict(bench.WORKLOAD, T=5)
+    cond = bench.make_conditions(dev, seed=16, w=wl, n_time_ids=c["n_time_ids"], layout=True)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    noise = torch.randn(1, 5, wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=g)
+    ref_frame = torch.randn(1, 1, wl["V"], wl["C"], wl["H"], wl["W"], device=dev, generator=g)
+    with torch.no_grad():
+        lat = CTSDDenoiser(model, guidance_scale=c["guidance_scale"], inference_steps=c["inference_steps"]).run(
+            noise, cond, image_latents=ref_frame, reference_frame_count=1).clone()
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    del model
+    torch.cuda.empty_cache()
+    cfg = O.make_config(**kwargs)
+    fwd0 = O.dit_forward
+    O.dit_forward = _oracle_on_device(fwd0)
+    try:
+        condf = {k: (v.float() if v.is_floating_point() else v) for k, v in cond.items()}
+        with torch.no_grad():
+            lat_ref = O.denoise(sd, cfg, noise, condf, steps=c["inference_steps"], guidance_scale=c["guidance_scale"],
+                                image_latents=ref_frame, reference_frame_count=1)
+    finally:
+        O.dit_forward = fwd0
+    del sd
+    torch.cuda.empty_cache()
+    e_lat = rel_err(lat, lat_ref)
+    assert torch.equal(lat[:, :1], ref_frame)                               # the reference frame comes back untouched
+    # the temporal VAE at its published widths
+    vae = AutoencoderKLCogVideoX().to(dev).to(bf16).eval()
+    bench.synth_init_(vae, 1)
+    vsd = {k: v.detach().float() for k, v in vae.state_dict().items()}
+    vcfg = CV.make_cogvideox_config()
+    dec = LatentDecoder(vae, memory_efficient_batch=c["memory_efficient_batch"], postprocess=False)
+    with torch.no_grad():
+        img_same = dec(lat_ref).float()                                     # HIP decode of the oracle's latents
+        img_e2e = dec(lat).float()                                          # HIP decode of the HIP latents
+        ref_imgs = []
+        for v in range(wl["V"]):                                            # the oracle, one view (clip) at a time
+            z = (lat_ref[:, :, v].to(bf16).float() / vcfg["scaling_factor"]).to(bf16).float().permute(0, 2, 1, 3, 4)      # b c t h w
+            ref_imgs.append(CV.decode(vsd, vcfg, z))                        # [1, 3, 17, 256, 448]
+        ref_img = torch.stack(ref_imgs, 1).permute(0, 3, 1, 2, 4, 5).flatten(0, 2)       # b v c t h w -> (b t v) c h w
+    assert img_same.shape == ref_img.shape == (17 * wl["V"], 3, 8 * wl["H"], 8 * wl["W"])
+    e_dec, e_e2e = rel_err(img_same, ref_img), rel_err(img_e2e, ref_img)
+    _log("tvae_ar_window_full_size", latents=list(lat.shape), frames=list(ref_img.shape), rel_latents=e_lat, rel_decode_same_latents=e_dec,
+         rel_frames_end_to_end=e_e2e, finite=bool(torch.isfinite(img_e2e).all()))
+    assert e_lat < TOL and e_dec < TOL and e_e2e < 2 * TOL, (e_lat, e_dec, e_e2e)
 
 
 def test_unet_full_width_config1_six_frames_vs_oracle_on_device(dev):
