@@ -516,6 +516,20 @@ int dwm_cast_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int6
  * lo = bf16(w - hi) (opendwm_amd.ops.split_weight); bias / gate / res / blend / rms_w fp32.  workspace (16-byte aligned):
  * at least 4*M*K + 4*M*N bytes (+ 256).  No implicit convolution (ntaps / a_map / c_map) in this mode. */
 int dwm_gemm_f32(const dwm_gemm_args* args, void* stream);
+/* fp32-I/O forms of the token-major glue kernels of the SD 2.1 UNet / the 2-D VAE / the layout ImageAdapter (same argument meaning
+ * as the bf16 entry points above; gamma / beta fp32): GroupNorm(+SiLU) incl. the row-mapped form of TemporalResnetBlock
+ * (img_map may be NULL), nearest 2x upsample into a padded grid, padded-grid scatter, row softmax of the VAE's single-head
+ * mid-block attention, pixel-unshuffle, 2x2 average pooling.  The reference runs these in whatever dtype the pipeline selects
+ * (src/dwm/pipelines/ctsd.py:1189-1193); its CPU path - BASELINE.json configs[0] - is fp32. */
+int dwm_groupnorm_silu_f32(const float* x, float* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                           const float* gamma, const float* beta, int32_t silu, float* stats,
+                           const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream);
+int dwm_upsample2_padded_f32(const float* x, float* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream);
+int dwm_pad_tokens_f32(const float* x, float* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream);
+int dwm_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream);
+int dwm_unshuffle_tokens_f32(const float* x, int64_t I, int32_t C, int32_t H, int32_t W, int32_t r, float* out, int64_t ldo,
+                             void* stream);
+int dwm_avgpool2_tokens_f32(const float* x, int64_t I, int32_t h, int32_t w, int32_t C, float* out, void* stream);
 int dwm_layernorm_f32(const dwm_layernorm_args* args, void* stream);
 /* strides in fp32 elements; head_dim 64; every mask / row-map / segment mode of dwm_attention_fwd; optional lse */
 int dwm_attention_f32(const dwm_attn_args* args, void* stream);

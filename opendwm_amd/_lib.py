@@ -129,6 +129,12 @@ SIGNATURES = {
     "dwm_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_gemm_f32": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dwm_layernorm_f32": (_i32, [C.POINTER(LayerNormArgs), _vp]),
+    "dwm_groupnorm_silu_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),
+    "dwm_upsample2_padded_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dwm_pad_tokens_f32": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(RowMap2D), _vp]),
+    "dwm_softmax_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
+    "dwm_unshuffle_tokens_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "dwm_avgpool2_tokens_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dwm_attention_f32": (_i32, [C.POINTER(AttnArgs), _vp]),
     "dwm_silu_f32": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_timestep_sinusoid_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),

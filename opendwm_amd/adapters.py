@@ -159,40 +159,29 @@ class ImageAdapter(nn.Module):
 
     def _levels_f32(self, x: torch.Tensor):
         """the fp32 accuracy path of the body (model.compute_dtype = torch.float32): every activation and weight in fp32, the
-        convolutions by dwm_gemm_f32; PixelUnshuffle / AvgPool2d / the padded-grid scatter are plain data movement in torch"""
+        convolutions by dwm_gemm_f32, PixelUnshuffle / AvgPool2d / the padded-grid scatter by the fp32 forms of the kernels the
+        bf16 path uses (dwm_unshuffle_tokens_f32, dwm_avgpool2_tokens_f32, dwm_pad_tokens_f32)"""
         if self.zero_gates is not None:
             raise NotImplementedError("zero_gates (zero_gate_coef) is not used by any shipped CTSD config")
-        import torch.nn.functional as F
         f32 = torch.float32
-        x = x.flatten(0, -4).to(f32)
+        x = x.flatten(0, -4).to(f32).contiguous()
         I, _, H, W = x.shape
         r = self.downscale_factor
         h, w = H // r, W // r
-        cur = F.pixel_unshuffle(x, r)                        # [I, C r r, h, w]
+        cur = ops.unshuffle_tokens(x, r, dtype=f32)          # compact tokens [I*h*w, Cin padded to 64]
         cur_pad, grid = None, None
-
-        def to_pad(img, g):                                  # [I, C, h, w] -> padded token grid [g.rows, Cpad] (K granularity 64)
-            Cc = img.shape[1]
-            Cp = (Cc + 63) // 64 * 64
-            p = torch.zeros((g.I, g.h + 2, g.w + 2, Cp), dtype=f32, device=img.device)
-            p[:, 1:-1, 1:-1, :Cc] = img.permute(0, 2, 3, 1)
-            return p.view(g.rows, Cp)
-
-        def from_pad(p, g):                                  # -> [I, C, h, w]
-            return p.view(g.I, g.h + 2, g.w + 2, -1)[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
-
         for blk, zc in zip(self.body, self.zero_convs):
             if blk.downsample is not None:
-                if cur is None:
-                    cur = from_pad(cur_pad, grid)
+                if cur is None:                              # leave the padded grid of the previous level
+                    cur = cur_pad[grid.interior_index().to(cur_pad.device)].contiguous()
                 if h % 2 or w % 2:
                     raise NotImplementedError("AvgPool2d(ceil_mode) on odd sizes")
-                cur = F.avg_pool2d(cur, 2)
+                cur = ops.avgpool2_tokens(cur, I, h, w)
                 h, w = h // 2, w // 2
                 cur_pad = None
             if cur_pad is None:
                 grid = PaddedGrid(I, h, w)
-                cur_pad = to_pad(cur, grid)
+                cur_pad = ops.pad_tokens(cur, grid)
                 cur = None
             if blk.in_conv is not None:
                 wi = _bf(blk.in_conv.weight).reshape(blk.in_conv.weight.shape[0], -1)

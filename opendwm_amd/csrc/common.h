@@ -43,6 +43,27 @@ DWM_DEVINL uint2 pack4(const float* f) {
     uint2 v; v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]); return v;
 }
 
+// 8 consecutive elements of a bf16 or fp32 row <-> 8 fp32 registers (16 / 32 bytes, 16-byte aligned): the element-type
+// generic form of the token-major kernels that exist for both the bf16 path and the fp32 accuracy path
+template <typename T> DWM_DEVINL void load8(const T* p, float* f);
+template <> DWM_DEVINL void load8<bf16_t>(const bf16_t* p, float* f) { unpack8(*(const uint4*)p, f); }
+template <> DWM_DEVINL void load8<float>(const float* p, float* f) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <typename T> DWM_DEVINL void store8(T* p, const float* f);
+template <> DWM_DEVINL void store8<bf16_t>(bf16_t* p, const float* f) { *(uint4*)p = pack8(f); }
+template <> DWM_DEVINL void store8<float>(float* p, const float* f) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+    *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <typename T> DWM_DEVINL void copy8(T* dst, const T* src);
+template <> DWM_DEVINL void copy8<bf16_t>(bf16_t* dst, const bf16_t* src) { *(uint4*)dst = *(const uint4*)src; }
+template <> DWM_DEVINL void copy8<float>(float* dst, const float* src) {
+    *(float4*)dst = *(const float4*)src;
+    *(float4*)(dst + 4) = *(const float4*)(src + 4);
+}
+
 DWM_DEVINL float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -243,10 +243,10 @@ cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) 
 
 // PixelUnshuffle(r) of an NCHW image batch written token-major:
 //   out[(i*h + y)*w + x][c*r*r + dy*r + dx] = in[i][c][y*r + dy][x*r + dx],  h = H/r, w = W/r
-template <typename TIN>
+template <typename TIN, typename TOUT = bf16_t>
 __global__ void __launch_bounds__(256)
 unshuffle_tokens_kernel(const TIN* __restrict__ x, int64_t I, int C, int H, int W, int r,
-                        bf16_t* __restrict__ out, int64_t ldo) {
+                        TOUT* __restrict__ out, int64_t ldo) {
     const int h = H / r, w = W / r, cols = C * r * r;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= I * h * w * ldo) return;
@@ -259,13 +259,15 @@ unshuffle_tokens_kernel(const TIN* __restrict__ x, int64_t I, int C, int H, int 
         const int64_t img = tok / ((int64_t)w * h);
         v = ld_as_f32(x, ((img * C + c) * H + yy * r + dy) * W + xx * r + dx);
     }
-    out[idx] = f32_to_bf16(v);
+    if constexpr (sizeof(TOUT) == 4) out[idx] = v;
+    else out[idx] = f32_to_bf16(v);
 }
 
 // AvgPool2d(2, stride 2) on token-major [I, h, w, C] -> [I, h/2, w/2, C]; 8 channels per thread
+template <typename T>
 __global__ void __launch_bounds__(256)
-avgpool2_tokens_kernel(const bf16_t* __restrict__ x, int64_t I, int h, int w, int C8,
-                       bf16_t* __restrict__ out) {
+avgpool2_tokens_kernel(const T* __restrict__ x, int64_t I, int h, int w, int C8,
+                       T* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int ho = h / 2, wo = w / 2;
     if (idx >= I * ho * wo * C8) return;
@@ -279,13 +281,13 @@ avgpool2_tokens_kernel(const bf16_t* __restrict__ x, int64_t I, int h, int w, in
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int64_t src = ((img * h + 2 * yo + a) * w + 2 * xo + b) * (int64_t)C8 + c8;
-            unpack8(*(const uint4*)(x + src * 8), t);
+            load8<T>(x + src * 8, t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += t[j];
         }
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
-    *(uint4*)(out + idx * 8) = pack8(acc);
+    store8<T>(out + idx * 8, acc);
 }
 
 __global__ void __launch_bounds__(256)
@@ -471,13 +473,32 @@ extern "C" int dwm_unshuffle_tokens(const void* x, int32_t x_is_f32, int64_t I, 
     return finish();
 }
 
-extern "C" int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t w, int32_t C, void* out, void* stream) {
+static int avgpool2_impl(const void* x, int64_t I, int32_t h, int32_t w, int32_t C, void* out, void* stream, bool f32) {
     if (x == nullptr || out == nullptr || I <= 0 || h <= 0 || w <= 0 || C <= 0) return DWM_EINVAL;
     if (h % 2 != 0 || w % 2 != 0 || C % 8 != 0) return DWM_EUNSUPPORTED;
     if (!dwm_aligned16(x) || !dwm_aligned16(out)) return DWM_EALIGN;
     const int64_t total = I * (h / 2) * (w / 2) * (C / 8);
-    hipLaunchKernelGGL(avgpool2_tokens_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, I, h, w, C / 8, (bf16_t*)out);
+    if (f32) hipLaunchKernelGGL(avgpool2_tokens_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                (const float*)x, I, h, w, C / 8, (float*)out);
+    else hipLaunchKernelGGL(avgpool2_tokens_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                            (const bf16_t*)x, I, h, w, C / 8, (bf16_t*)out);
+    return finish();
+}
+extern "C" int dwm_avgpool2_tokens(const void* x, int64_t I, int32_t h, int32_t w, int32_t C, void* out, void* stream) {
+    return avgpool2_impl(x, I, h, w, C, out, stream, false);
+}
+extern "C" int dwm_avgpool2_tokens_f32(const float* x, int64_t I, int32_t h, int32_t w, int32_t C, float* out, void* stream) {
+    return avgpool2_impl(x, I, h, w, C, out, stream, true);
+}
+
+// the fp32 accuracy path's pixel-unshuffle: fp32 NCHW images -> fp32 token-major rows (same index map)
+extern "C" int dwm_unshuffle_tokens_f32(const float* x, int64_t I, int32_t C, int32_t H, int32_t W, int32_t r, float* out, int64_t ldo,
+                                        void* stream) {
+    if (x == nullptr || out == nullptr || I <= 0 || C <= 0 || H <= 0 || W <= 0 || r <= 0) return DWM_EINVAL;
+    if (H % r != 0 || W % r != 0 || ldo < (int64_t)C * r * r) return DWM_EINVAL;
+    const int64_t total = I * (H / r) * (W / r) * ldo;
+    hipLaunchKernelGGL((unshuffle_tokens_kernel<float, float>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       x, I, C, H, W, r, out, ldo);
     return finish();
 }
 

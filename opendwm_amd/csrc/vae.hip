@@ -23,8 +23,9 @@ DWM_DEVINL int64_t img_row(const ImgMap& m, int64_t i, int64_t p, int64_t P) {
 // ppb pixels for all groups of image i into part[i][chunk][2G]; gn_finalize_kernel adds the chunks.  Every sum runs
 // in a fixed order (per-thread partials -> LDS -> one thread per group -> one thread per statistic): the result does
 // not depend on scheduling, so the whole UNet / VAE is bit-reproducible from run to run.
+template <typename T>     // T: bf16_t, or float (the fp32 accuracy path of the UNet / VAE: dwm_groupnorm_silu_f32)
 __global__ void __launch_bounds__(256)
-gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ part, ImgMap im) {
+gn_stats_kernel(const T* __restrict__ x, int64_t P, int C, int G, int64_t ppb, float* __restrict__ part, ImgMap im) {
     extern __shared__ float red[];            // [pstep][C8][4]: (sum, sumsq) of the two groups a chunk can touch
     const int i = blockIdx.y;
     const int C8 = C >> 3, CG = C / G;
@@ -39,7 +40,7 @@ gn_stats_kernel(const bf16_t* __restrict__ x, int64_t P, int C, int G, int64_t p
             float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
             for (int64_t p = p0 + prow; p < p1; p += pstep) {
                 float v[8];
-                unpack8(*(const uint4*)(x + img_row(im, i, p, P) * C + c8 * 8), v);
+                load8<T>(x + img_row(im, i, p, P) * C + c8 * 8, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < bnd) { s0 += v[j]; q0 += v[j] * v[j]; }
@@ -86,9 +87,10 @@ DWM_DEVINL int64_t pad_row(const PadMap& m, int64_t r) {
     return (int64_t)i * m.ipitch + (int64_t)yy * m.rpitch + xx + m.origin;
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I, int64_t P, int C, int G,
-                const float* __restrict__ stats, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t I, int64_t P, int C, int G,
+                const float* __restrict__ stats, const T* __restrict__ gamma, const T* __restrict__ beta,
                 float eps, int silu, PadMap pm, ImgMap im) {
     const int C8 = C >> 3, CG = C / G;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -109,16 +111,17 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I,
         rstd[hf] = rsqrtf(var + eps);
     }
     float v[8], ga[8], be[8];
-    unpack8(*(const uint4*)(x + r * C + c8 * 8), v);
-    unpack8(*(const uint4*)(gamma + c8 * 8), ga);
-    unpack8(*(const uint4*)(beta + c8 * 8), be);
+    load8<T>(x + r * C + c8 * 8, v);
+    load8<T>(gamma + c8 * 8, ga);
+    load8<T>(beta + c8 * 8, be);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int hf = j < bnd ? 0 : 1;
         float t = (v[j] - mean[hf]) * rstd[hf] * ga[j] + be[j];
-        v[j] = silu ? silu_f(t) : t;
+        if (sizeof(T) == 4) v[j] = silu ? t / (1.f + expf(-t)) : t;       // fp32 path: libm-accurate SiLU
+        else v[j] = silu ? silu_f(t) : t;
     }
-    *(uint4*)(y + pad_row(pm, r) * C + c8 * 8) = pack8(v);
+    store8<T>(y + pad_row(pm, r) * C + c8 * 8, v);
 }
 
 // ---- CogVideoXSpatialNorm3D apply: GroupNorm statistics as above, then * conv_y(zq) + conv_b(zq) gathered from the
@@ -192,18 +195,20 @@ frame_mix_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t f
 }
 
 // ---- copy compact token rows into a (zero-bordered) padded grid
+template <typename T>
 __global__ void __launch_bounds__(256)
-pad_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int C8, PadMap pm) {
+pad_tokens_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int C8, PadMap pm) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * C8) return;
     const int c8 = (int)(idx % C8);
     const int64_t r = idx / C8;
-    *(uint4*)(y + (pad_row(pm, r) * C8 + c8) * 8) = *(const uint4*)(x + idx * 8);
+    copy8<T>(y + (pad_row(pm, r) * C8 + c8) * 8, x + idx * 8);
 }
 
 // ---- nearest 2x upsample of token-major [I, h, w, C] into the padded grid of the [I, 2h, 2w] image
+template <typename T>
 __global__ void __launch_bounds__(256)
-upsample2_pad_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I, int h, int w, int C8) {
+upsample2_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t I, int h, int w, int C8) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int H = 2 * h, W = 2 * w;
     if (idx >= I * H * W * C8) return;
@@ -211,15 +216,14 @@ upsample2_pad_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64
     const int64_t r = idx / C8;
     const int X = (int)(r % W), Y = (int)((r / W) % H);
     const int64_t i = r / ((int64_t)W * H);
-    const uint4 v = *(const uint4*)(x + (((i * h + (Y >> 1)) * w + (X >> 1)) * (int64_t)C8 + c8) * 8);
     const int64_t orow = i * (int64_t)(H + 2) * (W + 2) + (int64_t)(Y + 1) * (W + 2) + X + 1;
-    *(uint4*)(y + (orow * C8 + c8) * 8) = v;
+    copy8<T>(y + (orow * C8 + c8) * 8, x + (((i * h + (Y >> 1)) * w + (X >> 1)) * (int64_t)C8 + c8) * 8);
 }
 
 // ---- row softmax (fp32 math) of bf16 x[rows, L] * scale, one wave per row, L <= 4096, L % 8 == 0
-template <int NI>
+template <int NI, typename T>
 __global__ void __launch_bounds__(256)
-softmax_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int L, int64_t ld, float scale_log2) {
+softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int L, int64_t ld, float scale_log2) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -229,7 +233,7 @@ softmax_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_
     for (int i = 0; i < NI; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c < L) {
-            unpack8(*(const uint4*)(x + row * ld + c), v[i]);
+            load8<T>(x + row * ld + c, v[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[i][j] *= scale_log2; mx = fmaxf(mx, v[i][j]); }
         } else {
@@ -243,16 +247,16 @@ softmax_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[i][j] = __builtin_amdgcn_exp2f(v[i][j] - mx); s += v[i][j]; }
+        for (int j = 0; j < 8; ++j) { v[i][j] = sizeof(T) == 4 ? exp2f(v[i][j] - mx) : __builtin_amdgcn_exp2f(v[i][j] - mx); s += v[i][j]; }
     s = wave_sum(s);
-    const float inv = __builtin_amdgcn_rcpf(s);
+    const float inv = sizeof(T) == 4 ? 1.f / s : __builtin_amdgcn_rcpf(s);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c < L) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] *= inv;
-            *(uint4*)(y + row * ld + c) = pack8(v[i]);
+            store8<T>(y + row * ld + c, v[i]);
         }
     }
 }
@@ -407,7 +411,8 @@ extern "C" int64_t dwm_groupnorm_stats_floats(int64_t I, int64_t P, int32_t G) {
 
 static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
                           const void* gamma, const void* beta, int32_t silu, float* stats,
-                          const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap, void* stream) {
+                          const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap, void* stream,
+                          bool f32 = false) {
     if (x == nullptr || y == nullptr || gamma == nullptr || beta == nullptr || stats == nullptr) return DWM_EINVAL;
     if (I <= 0 || P <= 0 || C <= 0 || G <= 0 || C % G != 0) return DWM_EINVAL;
     const int CG = C / G;
@@ -431,7 +436,8 @@ static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t 
     if (lds > 64 * 1024) return DWM_EUNSUPPORTED;
     float* part = stats + 2 * (int64_t)G * I;             // [I][nchunks][2G] behind the final statistics
     const dim3 grid((unsigned)nchunks, (unsigned)I);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds, s, (const bf16_t*)x, P, C, G, ppb, part, im);
+    if (f32) hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds, s, (const float*)x, P, C, G, ppb, part, im);
+    else hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)x, P, C, G, ppb, part, im);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)I), dim3(64), 0, s, (const float*)part, stats, nchunks, 2 * G);
     PadMap pm;
     pm.enabled = out_map != nullptr && out_map->rw > 0;
@@ -444,6 +450,7 @@ static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t 
     }
     const int64_t total = I * P * (C / 8);
     if (zmap != nullptr) {
+        if (f32) return DWM_EUNSUPPORTED;
         if (zmap->mod == nullptr || zmap->frames <= 0 || zmap->frames > 32 || zmap->videos <= 0 || zmap->h <= 0 || zmap->w <= 0 ||
             zmap->shift < 0 || zmap->shift > 8 || zmap->ld_mod < 2 * C || zmap->ld_mod % 8 != 0 || !dwm_aligned16(zmap->mod))
             return DWM_EINVAL;
@@ -459,8 +466,12 @@ static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t 
                            (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im, zm);
         return finish();
     }
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
-                       (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im);
+    if (f32)
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)x,
+                           (float*)y, I, P, C, G, stats, (const float*)gamma, (const float*)beta, eps, silu, pm, im);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
+                           (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im);
     return finish();
 }
 
@@ -506,7 +517,7 @@ extern "C" int dwm_groupnorm_bwd(const void* x, const void* dz, void* dx, int64_
     float* bstats = stats + half;
     float* bpart = bstats + 2 * (int64_t)G * I;
     const dim3 grid((unsigned)nchunks, (unsigned)I);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), lds_f, s, (const bf16_t*)x, P, C, G, ppb, fpart, im);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), lds_f, s, (const bf16_t*)x, P, C, G, ppb, fpart, im);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)I), dim3(64), 0, s, (const float*)fpart, fstats, nchunks, 2 * G);
     hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), lds_b, s, (const bf16_t*)x, (const bf16_t*)dz, P, C, G, ppb,
                        (const float*)fstats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, bpart, dgamma, dbeta, pm, im);
@@ -522,6 +533,12 @@ extern "C" int dwm_groupnorm_silu_mapped(const void* x, void* y, int64_t I, int6
                                          const void* gamma, const void* beta, int32_t silu, float* stats,
                                          const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream) {
     return groupnorm_impl(x, y, I, P, C, G, eps, gamma, beta, silu, stats, out_map, img_map, nullptr, stream);
+}
+
+extern "C" int dwm_groupnorm_silu_f32(const float* x, float* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                                      const float* gamma, const float* beta, int32_t silu, float* stats,
+                                      const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, void* stream) {
+    return groupnorm_impl(x, y, I, P, C, G, eps, gamma, beta, silu, stats, out_map, img_map, nullptr, stream, true);
 }
 
 extern "C" int dwm_groupnorm_spatial(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
@@ -556,17 +573,25 @@ extern "C" int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, 
     return dwm_groupnorm_silu_mapped(x, y, I, P, C, G, eps, gamma, beta, silu, stats, out_map, nullptr, stream);
 }
 
-extern "C" int dwm_upsample2_padded(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream) {
+static int upsample2_impl(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream, bool f32) {
     if (x == nullptr || y == nullptr || I <= 0 || h <= 0 || w <= 0 || C <= 0) return DWM_EINVAL;
     if (C % 8 != 0) return DWM_EUNSUPPORTED;
     if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
     const int64_t total = I * 4 * h * w * (C / 8);
-    hipLaunchKernelGGL(upsample2_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (bf16_t*)y, I, h, w, C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (f32) hipLaunchKernelGGL(upsample2_pad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, I, h, w, C / 8);
+    else hipLaunchKernelGGL(upsample2_pad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, I, h, w, C / 8);
     return finish();
 }
+extern "C" int dwm_upsample2_padded(const void* x, void* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream) {
+    return upsample2_impl(x, y, I, h, w, C, stream, false);
+}
+extern "C" int dwm_upsample2_padded_f32(const float* x, float* y, int64_t I, int32_t h, int32_t w, int32_t C, void* stream) {
+    return upsample2_impl(x, y, I, h, w, C, stream, true);
+}
 
-extern "C" int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream) {
+template <typename T>
+static int softmax_rows_impl(const T* x, T* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream) {
     if (x == nullptr || y == nullptr || rows <= 0 || L <= 0) return DWM_EINVAL;
     if (L % 8 != 0 || L > 4096 || ld % 8 != 0 || ld < L) return DWM_EUNSUPPORTED;
     if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
@@ -574,13 +599,26 @@ extern "C" int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L,
     const float sl = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     const int ni = (L + 511) / 512;
-    if (ni <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
-    else if (ni <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
-    else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, rows, L, ld, sl);
+    if (ni <= 2) hipLaunchKernelGGL((softmax_rows_kernel<2, T>), grid, block, 0, s, x, y, rows, L, ld, sl);
+    else if (ni <= 4) hipLaunchKernelGGL((softmax_rows_kernel<4, T>), grid, block, 0, s, x, y, rows, L, ld, sl);
+    else hipLaunchKernelGGL((softmax_rows_kernel<8, T>), grid, block, 0, s, x, y, rows, L, ld, sl);
     return finish();
 }
+extern "C" int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream) {
+    return softmax_rows_impl<bf16_t>((const bf16_t*)x, (bf16_t*)y, rows, L, ld, scale, stream);
+}
+extern "C" int dwm_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t L, int64_t ld, float scale, void* stream) {
+    return softmax_rows_impl<float>(x, y, rows, L, ld, scale, stream);
+}
 
+static int pad_tokens_impl(const void* x, void* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream, bool f32);
 extern "C" int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream) {
+    return pad_tokens_impl(x, y, rows, C, map, stream, false);
+}
+extern "C" int dwm_pad_tokens_f32(const float* x, float* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream) {
+    return pad_tokens_impl(x, y, rows, C, map, stream, true);
+}
+static int pad_tokens_impl(const void* x, void* y, int64_t rows, int32_t C, const dwm_rowmap2d* map, void* stream, bool f32) {
     if (x == nullptr || y == nullptr || map == nullptr || rows <= 0 || C <= 0 || map->rw <= 0 || map->rh <= 0) return DWM_EINVAL;
     if (C % 8 != 0 || rows % (map->rw * map->rh) != 0) return DWM_EUNSUPPORTED;
     if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
@@ -589,7 +627,8 @@ extern "C" int dwm_pad_tokens(const void* x, void* y, int64_t rows, int32_t C, c
     pm.rw = make_fastdiv((uint32_t)map->rw); pm.rh = make_fastdiv((uint32_t)map->rh);
     pm.rpitch = map->rpitch; pm.ipitch = map->ipitch; pm.origin = map->origin;
     const int64_t total = rows * (C / 8);
-    hipLaunchKernelGGL(pad_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (bf16_t*)y, rows, C / 8, pm);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (f32) hipLaunchKernelGGL(pad_tokens_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, rows, C / 8, pm);
+    else hipLaunchKernelGGL(pad_tokens_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, rows, C / 8, pm);
     return finish();
 }

@@ -171,7 +171,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          rows_per_alpha: int = 1,
          rms_w: Optional[torch.Tensor] = None, rms_ncols: int = 0, rms_eps: float = 1e-6,
          a_grid=None, conv3x3: bool = False, stride2=False, conv_taps: Optional[list] = None,
-         c_grid=None, out32: Optional[torch.Tensor] = None, mirror: bool = True,
+         c_grid=None, out32: Optional[torch.Tensor] = None, mirror: bool = True, w_is_activation: bool = False,
          rows: Optional[int] = None, split_k: int = 0, tile: int = 0, _debug: int = 0) -> torch.Tensor:
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  See dwm_gemm_bf16.
     tile: 0 = the kernel's choice, 1 = 256 x 256 tiles, 2 = 256 x 128 tiles (two workgroups per CU).
@@ -181,13 +181,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     1 = never, n > 1 = exactly n ranges.  _debug: ablation knobs, honoured only by -DDWM_DEV_HOOKS builds of the library.
     out32 (RESID): fp32 residual stream - `res` and `blend` are then fp32 matrices shaped like the output, the result goes to
     out32 in fp32 (out32 may be `res` or `blend` itself) and, rounded, to the bf16 `out`; mirror=False: no bf16 copy at all
-    (`out` must be None; the call returns out32) - the hidden / context streams of the bf16 MMDiT forward."""
+    (`out` must be None; the call returns out32) - the hidden / context streams of the bf16 MMDiT forward.
+    w_is_activation: `w` is a per-call tensor, not a parameter (fp32 path: its operand planes are not cached)."""
     if a.dtype == torch.float32:            # the fp32 accuracy path (dwm_gemm_f32)
-        if conv_taps is not None or stride2:
-            raise NotImplementedError("gemm: of the implicit convolutions only the dense 3x3 / 1x1 forms on a padded grid are part of the fp32 path")
         return _gemm_f32(a, w, bias, out=out, epilogue=epilogue, act=act, gate=gate, rows_per_gate=rows_per_gate, res=res,
                          res_mod=res_mod, blend=blend, alpha=alpha, rows_per_alpha=rows_per_alpha, rms_w=rms_w,
-                         rms_ncols=rms_ncols, rms_eps=rms_eps, rows=rows, a_grid=a_grid, conv3x3=conv3x3, c_grid=c_grid)
+                         rms_ncols=rms_ncols, rms_eps=rms_eps, rows=rows, a_grid=a_grid, conv3x3=conv3x3, c_grid=c_grid,
+                         stride2=stride2, conv_taps=conv_taps, cache_w=not w_is_activation)
     _chk2d(a, "a")
     _chk2d(w, "w")
     if not w.is_contiguous():
@@ -284,13 +284,13 @@ _SPLIT_WEIGHTS: dict = {}
 SPLIT_WEIGHT_CACHE_MAX = 2048        # > the ~1300 weight matrices of the largest model on the path
 
 
-def split_weight(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
+def split_weight(w: torch.Tensor, taps: int = 1, cache: bool = True) -> torch.Tensor:
     """fp32 [N, K] -> the pre-split bf16 operand [N, 3K] of dwm_gemm_f32 (hi = bf16(w), lo = bf16(w - hi)): [hi | lo | hi], or -
     `taps` > 1, K = taps x C tap-major (implicit convolution) - [hi_t | lo_t | hi_t] per tap t.
     Cached on the tensor's storage / version (weights and packed weights are long-lived), at most SPLIT_WEIGHT_CACHE_MAX entries
     (least recently used first out: per-call temporaries must not pile up); `clear_split_weights()` drops everything."""
     key = (w.data_ptr(), w._version, tuple(w.shape), taps)
-    hit = _SPLIT_WEIGHTS.pop(key, None)
+    hit = _SPLIT_WEIGHTS.pop(key, None) if cache else None
     if hit is None:
         hi = w.to(bf16)
         lo = (w - hi.float()).to(bf16)
@@ -301,6 +301,8 @@ def split_weight(w: torch.Tensor, taps: int = 1) -> torch.Tensor:
         else:
             ws = torch.cat([hi, lo, hi], 1).contiguous()
         hit = (ws, w)                                               # keeps `w` alive: its address is the key
+    if not cache:
+        return hit[0]
     _SPLIT_WEIGHTS[key] = hit                                       # (re-)inserted last: dict order = recency
     while len(_SPLIT_WEIGHTS) > SPLIT_WEIGHT_CACHE_MAX:
         _SPLIT_WEIGHTS.pop(next(iter(_SPLIT_WEIGHTS)))
@@ -312,21 +314,25 @@ def clear_split_weights() -> None:
 
 
 def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_mod, blend, alpha, rows_per_alpha, rms_w, rms_ncols,
-              rms_eps, rows, a_grid=None, conv3x3=False, c_grid=None):
+              rms_eps, rows, a_grid=None, conv3x3=False, c_grid=None, stride2=False, conv_taps=None, cache_w=True):
     f32 = torch.float32
     _chk2d(a, "a", f32)
     _chk2d(w, "w", f32)
     if not w.is_contiguous():
         raise RuntimeError("w must be contiguous [N, K]")
     N, K = w.shape
-    taps = 9 if conv3x3 else 1
+    taps = 9 if conv3x3 else len(conv_taps) if conv_taps is not None else 1
+    if taps > 9:
+        raise NotImplementedError("gemm (fp32): at most 9 taps (each is walked as three plane products: 27 tap slots)")
     if a_grid is not None:
         if a.shape[0] != a_grid.rows or a.shape[1] * taps != K or not a.is_contiguous():
             raise RuntimeError(f"gemm: padded A {tuple(a.shape)} does not match grid / weight {tuple(w.shape)}")
-        M, a_rows = a_grid.pixels, a_grid.rows
+        if stride2 and (not conv3x3 or a_grid.h % 2 or a_grid.w % 2):
+            raise RuntimeError("gemm: stride2 needs conv3x3 on an even-sized grid")
+        M, a_rows = (a_grid.pixels // 4 if stride2 else a_grid.pixels), a_grid.rows
     else:
-        if conv3x3:
-            raise RuntimeError("gemm: conv3x3 needs a_grid")
+        if conv3x3 or conv_taps is not None or stride2:
+            raise RuntimeError("gemm: convolution taps need a_grid")
         M = a.shape[0] if rows is None else rows
         a_rows = M
         if a.shape[1] != K:
@@ -341,15 +347,22 @@ def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_m
     if out.shape != (orow, nout):
         raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != {(orow, nout)}")
     _chkvec(bias, "bias", f32)
-    ws = split_weight(w, taps)
+    ws = split_weight(w, taps, cache=cache_w)      # (an activation in the W position - attention scores of the VAE - is not kept)
     g = _lib.GemmArgs()
     g.A, g.lda, g.W, g.bias, g.C, g.ldc = a.data_ptr(), a.stride(0), ws.data_ptr(), _p(bias), out.data_ptr(), out.stride(0)
     g.M, g.N, g.K, g.epilogue, g.act = M, N, K, epilogue, act
     if a_grid is not None:
-        a_grid.fill(g.a_map)
+        if stride2:
+            (a_grid.fill_stride2_sym if stride2 == "sym" else a_grid.fill_stride2)(g.a_map)
+        else:
+            a_grid.fill(g.a_map)
         if conv3x3:
             g.ntaps, g.k_per_tap = 9, a.shape[1]
-            for t, sh in enumerate(a_grid.tap_shifts()):
+            for t, sh in enumerate(a_grid.tap_shifts_stride2() if stride2 else a_grid.tap_shifts()):
+                g.tap_shift[t] = sh
+        elif conv_taps is not None:
+            g.ntaps, g.k_per_tap = len(conv_taps), a.shape[1]
+            for t, sh in enumerate(conv_taps):
                 g.tap_shift[t] = sh
     if c_grid is not None:
         c_grid.fill(g.c_map)
@@ -578,7 +591,7 @@ def attention_bwd(q, k, v, out, dout, dq, dk, dv, rowmap: RowMap, heads: int, ls
 
 def _cross_args(a, q, k, v, out, n_problems, heads, scale):
     for name, t in (("q", q), ("k", k), ("v", v), ("out", out)):
-        _chk2d(t, name)
+        _chk2d(t, name, q.dtype if q.dtype == torch.float32 else bf16)
     if k.stride(0) != v.stride(0) or q.shape[0] % n_problems or k.shape[0] % n_problems:
         raise RuntimeError("cross_attention: k, v must share a row stride; rows must be n_problems * L")
     a.q0 = a.q1 = q.data_ptr()
@@ -611,6 +624,11 @@ def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
         if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != n_problems * heads * (a.L0 + a.L1):
             raise RuntimeError("lse: fp32 contiguous [n_problems, heads, Lq+Lk] expected")
         a.lse = lse.data_ptr()
+    if q.dtype == torch.float32:                 # the fp32 accuracy path (UNet text cross-attention)
+        if lse is not None:
+            raise NotImplementedError("cross_attention: no LSE output on the fp32 path (inference only)")
+        _lib.check(_lib.load().dwm_attention_f32(C.byref(a), _stream()), "dwm_attention_f32")
+        return
     _lib.check(_lib.load().dwm_attention_fwd(C.byref(a), _stream()), "dwm_attention_fwd")
 
 
@@ -890,13 +908,20 @@ def cfg_ddim_step(pred: torch.Tensor, latents: torch.Tensor, coef: torch.Tensor,
                "dwm_cfg_ddim_step")
 
 
-def unshuffle_tokens(x: torch.Tensor, r: int, ldo: Optional[int] = None) -> torch.Tensor:
-    """PixelUnshuffle(r): [I, C, H, W] (fp32 / bf16) -> token-major bf16 [I*(H/r)*(W/r), ldo]."""
+def unshuffle_tokens(x: torch.Tensor, r: int, ldo: Optional[int] = None, dtype: torch.dtype = bf16) -> torch.Tensor:
+    """PixelUnshuffle(r): [I, C, H, W] (fp32 / bf16) -> token-major [I*(H/r)*(W/r), ldo], bf16 or (dtype=torch.float32, fp32
+    input: the accuracy path) fp32; columns past C r r are zero."""
     if not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, bf16):
         raise RuntimeError("unshuffle_tokens: expected a contiguous fp32/bf16 [I,C,H,W] device tensor")
     I, Cc, H, W = x.shape
     cols = Cc * r * r
     ldo = ldo or (cols + 63) // 64 * 64
+    if dtype == torch.float32:
+        if x.dtype != torch.float32:
+            raise RuntimeError("unshuffle_tokens: the fp32 form takes fp32 images")
+        out = torch.empty((I * (H // r) * (W // r), ldo), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().dwm_unshuffle_tokens_f32(x.data_ptr(), I, Cc, H, W, r, out.data_ptr(), ldo, _stream()), "dwm_unshuffle_tokens_f32")
+        return out
     out = torch.empty((I * (H // r) * (W // r), ldo), dtype=bf16, device=x.device)
     _lib.check(_lib.load().dwm_unshuffle_tokens(x.data_ptr(), int(x.dtype == torch.float32), I, Cc, H, W, r,
                                                 out.data_ptr(), ldo, _stream()), "dwm_unshuffle_tokens")
@@ -905,12 +930,13 @@ def unshuffle_tokens(x: torch.Tensor, r: int, ldo: Optional[int] = None) -> torc
 
 def avgpool2_tokens(x: torch.Tensor, I: int, h: int, w: int) -> torch.Tensor:
     """AvgPool2d(2) on token-major [I*h*w, C] -> [I*(h/2)*(w/2), C]."""
-    _chk2d(x, "x")
+    dt = torch.float32 if x.dtype == torch.float32 else bf16
+    _chk2d(x, "x", dt)
     if not x.is_contiguous() or x.shape[0] != I * h * w:
         raise RuntimeError("avgpool2_tokens: x must be contiguous [I*h*w, C]")
-    out = torch.empty((I * (h // 2) * (w // 2), x.shape[1]), dtype=bf16, device=x.device)
-    _lib.check(_lib.load().dwm_avgpool2_tokens(x.data_ptr(), I, h, w, x.shape[1], out.data_ptr(), _stream()),
-               "dwm_avgpool2_tokens")
+    out = torch.empty((I * (h // 2) * (w // 2), x.shape[1]), dtype=dt, device=x.device)
+    fn = _lib.load().dwm_avgpool2_tokens_f32 if dt == torch.float32 else _lib.load().dwm_avgpool2_tokens
+    _lib.check(fn(x.data_ptr(), I, h, w, x.shape[1], out.data_ptr(), _stream()), "dwm_avgpool2_tokens")
     return out
 
 
@@ -939,16 +965,17 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
     interior of a padded grid `out` [out_grid.rows, C] whose border must already be zero.  img_map =
     (iv, pn, s_ihi, s_ilo, s_phi): image i / pixel p -> token row (see dwm_groupnorm_silu_mapped).
     zmap = dict(mod [z rows, 2C], frames, videos, h, w, shift, zt): CogVideoXSpatialNorm3D (dwm_groupnorm_spatial)."""
-    _chk2d(x, "x")
+    dt = torch.float32 if x.dtype == torch.float32 else bf16           # fp32: the accuracy path (dwm_groupnorm_silu_f32)
+    _chk2d(x, "x", dt)
     if not x.is_contiguous() or x.shape[0] != I * P:
         raise RuntimeError("groupnorm_silu: x must be contiguous [I*P, C]")
     Cc = x.shape[1]
-    _chkvec(gamma, "gamma")
-    _chkvec(beta, "beta")
+    _chkvec(gamma, "gamma", dt)
+    _chkvec(beta, "beta", dt)
     rows = out_grid.rows if out_grid is not None else I * P
     if out is None:
-        out = (torch.zeros if out_grid is not None else torch.empty)((rows, Cc), dtype=bf16, device=x.device)
-    if out.shape != (rows, Cc) or not out.is_contiguous() or out.dtype != bf16:
+        out = (torch.zeros if out_grid is not None else torch.empty)((rows, Cc), dtype=dt, device=x.device)
+    if out.shape != (rows, Cc) or not out.is_contiguous() or out.dtype != dt:
         raise RuntimeError("groupnorm_silu: bad out")
     stats = torch.empty(_lib.load().dwm_groupnorm_stats_floats(I, P, groups), dtype=torch.float32, device=x.device)
     m = _lib.RowMap2D()
@@ -957,6 +984,13 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
     im = _lib.GnImgMap()
     if img_map is not None:
         im.iv, im.pn, im.s_ihi, im.s_ilo, im.s_phi = img_map
+    if dt == torch.float32:
+        if zmap is not None:
+            raise NotImplementedError("groupnorm_silu: the spatial (CogVideoX) form has no fp32 path")
+        _lib.check(_lib.load().dwm_groupnorm_silu_f32(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
+                                                      beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
+                                                      _stream()), "dwm_groupnorm_silu_f32")
+        return out
     if zmap is not None:
         mod = zmap["mod"]
         _chk2d(mod, "zmap.mod")
@@ -1001,36 +1035,42 @@ def frame_mix(x: torch.Tensor, frame_elems: int, f0, f1, w0, w1, out: Optional[t
 
 def upsample2_padded(x: torch.Tensor, I: int, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nearest 2x upsample of token-major [I*h*w, C] into the padded grid of the [I, 2h, 2w] image."""
-    _chk2d(x, "x")
+    dt = torch.float32 if x.dtype == torch.float32 else bf16
+    _chk2d(x, "x", dt)
     if not x.is_contiguous() or x.shape[0] != I * h * w:
         raise RuntimeError("upsample2_padded: x must be contiguous [I*h*w, C]")
     g = PaddedGrid(I, 2 * h, 2 * w)
     if out is None:
-        out = torch.zeros((g.rows, x.shape[1]), dtype=bf16, device=x.device)
-    _lib.check(_lib.load().dwm_upsample2_padded(x.data_ptr(), out.data_ptr(), I, h, w, x.shape[1], _stream()),
-               "dwm_upsample2_padded")
+        out = torch.zeros((g.rows, x.shape[1]), dtype=dt, device=x.device)
+    _chk2d(out, "out", dt)
+    fn = _lib.load().dwm_upsample2_padded_f32 if dt == torch.float32 else _lib.load().dwm_upsample2_padded
+    _lib.check(fn(x.data_ptr(), out.data_ptr(), I, h, w, x.shape[1], _stream()), "dwm_upsample2_padded")
     return out
 
 
 def pad_tokens(x: torch.Tensor, grid: PaddedGrid, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """compact token rows [grid.pixels, C] -> interior of a zero-bordered padded grid [grid.rows, C]."""
-    _chk2d(x, "x")
+    dt = torch.float32 if x.dtype == torch.float32 else bf16
+    _chk2d(x, "x", dt)
     if not x.is_contiguous() or x.shape[0] != grid.pixels:
         raise RuntimeError("pad_tokens: x must be contiguous [grid.pixels, C]")
     if out is None:
-        out = torch.zeros((grid.rows, x.shape[1]), dtype=bf16, device=x.device)
+        out = torch.zeros((grid.rows, x.shape[1]), dtype=dt, device=x.device)
+    _chk2d(out, "out", dt)
     m = _lib.RowMap2D()
     grid.fill(m)
-    _lib.check(_lib.load().dwm_pad_tokens(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], C.byref(m), _stream()),
-               "dwm_pad_tokens")
+    fn = _lib.load().dwm_pad_tokens_f32 if dt == torch.float32 else _lib.load().dwm_pad_tokens
+    _lib.check(fn(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], C.byref(m), _stream()), "dwm_pad_tokens")
     return out
 
 
 def softmax_rows(x: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk2d(x, "x")
+    dt = torch.float32 if x.dtype == torch.float32 else bf16
+    _chk2d(x, "x", dt)
     out = torch.empty_like(x) if out is None else out
-    _lib.check(_lib.load().dwm_softmax_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
-                                            float(scale), _stream()), "dwm_softmax_rows")
+    _chk2d(out, "out", dt)
+    fn = _lib.load().dwm_softmax_rows_f32 if dt == torch.float32 else _lib.load().dwm_softmax_rows
+    _lib.check(fn(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), float(scale), _stream()), "dwm_softmax_rows")
     return out
 
 

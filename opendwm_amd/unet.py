@@ -38,10 +38,10 @@ except Exception:
 
 
 def _conv3_w(w: torch.Tensor, c_pad: Optional[int] = None, n_pad: Optional[int] = None) -> torch.Tensor:
-    """[N, C, 3, 3] -> tap-major [Np, 9*Cp] bf16 (zero padded)"""
+    """[N, C, 3, 3] -> tap-major [Np, 9*Cp] in the compute dtype (zero padded)"""
     w = _bf(w)
     n, c = w.shape[:2]
-    t = torch.zeros((n_pad or n, 3, 3, c_pad or c), dtype=bf16, device=w.device)
+    t = torch.zeros((n_pad or n, 3, 3, c_pad or c), dtype=w.dtype, device=w.device)
     t[:n, :, :, :c] = w.permute(0, 2, 3, 1)
     return t.reshape(t.shape[0], -1).contiguous()
 
@@ -60,10 +60,11 @@ class _Scratch:
         self.buf: Dict[tuple, torch.Tensor] = {}
 
     def get(self, tag: str, rows: int, channels: int, device) -> torch.Tensor:
-        k = (tag, rows, channels, str(device))
+        dt = STORE.precision                                  # bf16, or fp32 while the accuracy path runs
+        k = (tag, rows, channels, str(device), dt)
         t = self.buf.get(k)
         if t is None:
-            t = torch.zeros((rows, channels), dtype=bf16, device=device)
+            t = torch.zeros((rows, channels), dtype=dt, device=device)
             self.buf[k] = t
         return t
 
@@ -201,9 +202,9 @@ class _TextContext:
     def __init__(self, encoder_hidden_states: torch.Tensor):
         self.source = encoder_hidden_states                  # held: its storage cannot be recycled under the cache key
         self.key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
-                    encoder_hidden_states.dtype, STORE.step)
+                    encoder_hidden_states.dtype, STORE.step, STORE.precision)
         ehs = encoder_hidden_states.flatten(0, -3)
-        ehs = ehs if ehs.dtype == bf16 else ehs.to(bf16)
+        ehs = ehs if ehs.dtype == STORE.precision else ehs.to(STORE.precision)
         self.rows = ehs.reshape(ehs.shape[0] * ehs.shape[1], -1).contiguous()
         self._kv = {}
 
@@ -216,7 +217,7 @@ class _TextContext:
 
     def matches(self, encoder_hidden_states: torch.Tensor) -> bool:
         t = encoder_hidden_states
-        return t is self.source and self.key == (t.data_ptr(), t._version, tuple(t.shape), t.dtype, STORE.step)
+        return t is self.source and self.key == (t.data_ptr(), t._version, tuple(t.shape), t.dtype, STORE.step, STORE.precision)
 
     def kv(self, attn: "_CrossAttention") -> torch.Tensor:
         out = self._kv.get(id(attn))
@@ -305,15 +306,15 @@ class TransformerModel(nn.Module):
         hn = ops.groupnorm_silu(x, g.I, g.N, _bf(self.norm.weight), _bf(self.norm.bias), 32, 1e-6, silu=False)
         h = ops.gemm(hn, _bf(self.proj_in.weight), _bf(self.proj_in.bias))
         # view / frame index embeddings depend on (B, T, V) and the weights only: kept across denoise steps
-        key = (STORE.step, B, Tn, V, str(dev))
+        key = (STORE.step, B, Tn, V, str(dev), STORE.precision)
         if self._emb_cache[0] != key:
             view_emb = seq_emb = None
             if self.view_pos_embed is not None:
                 idx = torch.arange(V, device=dev).view(1, 1, V).expand(B, Tn, V)
-                view_emb = self.view_pos_embed.run(ops.timestep_sinusoid(idx, C))
+                view_emb = self.view_pos_embed.run(ops.timestep_sinusoid(idx, C, dtype=STORE.precision))
             if self.time_pos_embed is not None:
                 idx = torch.arange(Tn, device=dev).view(1, Tn, 1).expand(B, Tn, V)
-                seq_emb = self.time_pos_embed.run(ops.timestep_sinusoid(idx, C))
+                seq_emb = self.time_pos_embed.run(ops.timestep_sinusoid(idx, C, dtype=STORE.precision))
             self._emb_cache = (key, view_emb, seq_emb)
         _, view_emb, seq_emb = self._emb_cache
         if self.view_pos_embed is not None:
@@ -358,7 +359,11 @@ class _Block(nn.Module):
 
 def _concat_cols(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], channel) on token-major rows: two strided copies into one buffer"""
-    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=bf16, device=a.device)
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=a.dtype, device=a.device)
+    if a.dtype == torch.float32:                              # (fp32 accuracy path: plain strided copies)
+        out[:, :a.shape[1]].copy_(a)
+        out[:, a.shape[1]:].copy_(b)
+        return out
     T.rowcombine(a, out=out[:, :a.shape[1]])
     T.rowcombine(b, out=out[:, a.shape[1]:])
     return out
@@ -380,6 +385,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
         nn.Module.__init__(self)
         if depth_net_config is not None or enforce_align_projection is not None:
             raise NotImplementedError("UNet: depth_net / align projection are not built")
+        self.compute_dtype = bf16           # torch.float32 selects the fp32 accuracy path of the inference forward
         n = len(block_out_channels)
         as_list = lambda v: [v] * n if isinstance(v, int) else list(v)
         heads, lpb, tl = as_list(num_attention_heads), as_list(layers_per_block), as_list(transformer_layers_per_block)
@@ -526,15 +532,23 @@ class UNetCrossviewTemporalConditionModel(_Base):
                 return {"noise_pred": out}
             return (out,), None, None
         with torch.no_grad():
-            return self._forward_infer(sample, timesteps, frustum_bev_residuals, encoder_hidden_states, condition_image_tensor,
-                                       disable_crossview, disable_temporal, crossview_attention_mask, camera_intrinsics,
-                                       camera_transforms, added_time_ids, camera_intrinsics_norm, camera2referego, return_dict)
+            try:
+                return self._forward_infer(sample, timesteps, frustum_bev_residuals, encoder_hidden_states, condition_image_tensor,
+                                           disable_crossview, disable_temporal, crossview_attention_mask, camera_intrinsics,
+                                           camera_transforms, added_time_ids, camera_intrinsics_norm, camera2referego, return_dict)
+            finally:
+                STORE.set_precision(bf16)   # the fp32 accuracy path is scoped to this forward (compute_dtype = torch.float32)
 
     def _forward_infer(self, sample: torch.Tensor, timesteps, frustum_bev_residuals=None, encoder_hidden_states=None,
                        condition_image_tensor=None, disable_crossview=None, disable_temporal=None, crossview_attention_mask=None,
                        camera_intrinsics=None, camera_transforms=None, added_time_ids=None, camera_intrinsics_norm=None,
                        camera2referego=None, return_dict=False):
-        STORE.set_precision(bf16)            # the UNet runs in bf16 only (the fp32 accuracy path covers the MMDiT forward)
+        # compute dtype: bf16, or - `model.compute_dtype = torch.float32` - the fp32 accuracy path (north_star's 1e-3 tolerance;
+        # BASELINE.json configs[0] is the reference's fp32 CPU denoise of this model, ctsd.py:1189-1193): every activation and
+        # weight in fp32, contractions by dwm_gemm_f32 (incl. the stride-2 / 3-tap temporal implicit convolutions), fp32 GroupNorm /
+        # LayerNorm / attention kernels
+        cd = getattr(self, "compute_dtype", bf16)
+        STORE.set_precision(cd)              # reset to bf16 by `forward` on the way out
         if not sample.is_cuda:
             raise RuntimeError("opendwm_amd runs on an MI355X (HIP) device only; got a CPU tensor")
         if isinstance(encoder_hidden_states, dict):
@@ -557,9 +571,9 @@ class UNetCrossviewTemporalConditionModel(_Base):
         c0 = self.block_out_channels[0]
 
         # 1. time embeddings (crossview_temporal_unet.py:708-715)
-        emb = self.time_embedding.run(ops.timestep_sinusoid(timesteps.flatten(), c0))
+        emb = self.time_embedding.run(ops.timestep_sinusoid(timesteps.flatten(), c0, dtype=cd))
         if added_time_ids is not None and self.add_embedding is not None:
-            aug = ops.timestep_sinusoid(added_time_ids.flatten(), self.addition_time_embed_dim).view(I, -1)
+            aug = ops.timestep_sinusoid(added_time_ids.flatten(), self.addition_time_embed_dim, dtype=cd).view(I, -1)
             emb = self.add_embedding.run(aug, res=emb)
         silu_emb = _TimeProj(self._time_proj_layers(), ops.silu(emb))
         if self._text_ctx is None or not self._text_ctx.matches(encoder_hidden_states):
@@ -568,9 +582,11 @@ class UNetCrossviewTemporalConditionModel(_Base):
 
         # 2. conv_in: NCHW -> token-major rows with the channels zero-padded to 64, 3x3 implicit GEMM
         xin = sample.flatten(0, 2).contiguous()
-        if xin.dtype not in (torch.float32, bf16):
+        if cd == torch.float32:
+            xin = xin.float()
+        elif xin.dtype not in (torch.float32, bf16):
             xin = xin.to(bf16)
-        tok = ops.unshuffle_tokens(xin, 1, 64)
+        tok = ops.unshuffle_tokens(xin, 1, 64, dtype=cd)
         grid = PaddedGrid(I, H, W)
         pin = ops.pad_tokens(tok, grid, out=self._scratch.get("in", grid.rows, 64, dev))
         wci = STORE.derived(self.conv_in.weight, "c3", lambda: _conv3_w(self.conv_in.weight, c_pad=64))
@@ -640,7 +656,7 @@ class UNetCrossviewTemporalConditionModel(_Base):
         co = self.out_channels_
         cop = (co + 7) // 8 * 8
         wco = STORE.derived(self.conv_out.weight, "c3", lambda: _conv3_w(self.conv_out.weight, n_pad=cop))
-        bco = STORE.derived(self.conv_out.bias, "pad", lambda: torch.cat([_bf(self.conv_out.bias), torch.zeros(cop - co, dtype=bf16, device=dev)]))
+        bco = STORE.derived(self.conv_out.bias, "pad", lambda: torch.cat([_bf(self.conv_out.bias), torch.zeros(cop - co, dtype=cd, device=dev)]))
         y = ops.gemm(pn, wco, bco, a_grid=gr, conv3x3=True)
         out = ops.unpatchify(y, I, co, H, W, 1).view(B, Tn, V, co, H, W)
         if squeeze:

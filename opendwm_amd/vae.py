@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .blocks import _bf
+from .blocks import STORE, _bf
 from .ops import EPI_RESID, PaddedGrid
 
 bf16 = torch.bfloat16
@@ -28,7 +28,7 @@ def _conv3_w(conv: nn.Conv2d, k_pad: Optional[int] = None) -> torch.Tensor:
     w = _bf(conv.weight)
     n, c = w.shape[:2]
     cp = k_pad or c
-    t = torch.zeros((n, 3, 3, cp), dtype=bf16, device=w.device)
+    t = torch.zeros((n, 3, 3, cp), dtype=w.dtype, device=w.device)
     t[..., :c] = w.permute(0, 2, 3, 1)
     return t.reshape(n, 9 * cp).contiguous()
 
@@ -44,14 +44,15 @@ class ResnetBlock2D(nn.Module):
         self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
-        self._pk = None
+        self._pk = {}
 
     def packed(self):
-        if self._pk is None:
-            self._pk = {"w1": _conv3_w(self.conv1), "w2": _conv3_w(self.conv2)}
+        pk = self._pk.get(STORE.precision)                    # one set per compute precision (bf16 / the fp32 accuracy path)
+        if pk is None:
+            pk = self._pk[STORE.precision] = {"w1": _conv3_w(self.conv1), "w2": _conv3_w(self.conv2)}
             if self.conv_shortcut is not None:
-                self._pk["ws"] = _bf(self.conv_shortcut.weight).reshape(self.conv_shortcut.weight.shape[0], -1).contiguous()
-        return self._pk
+                pk["ws"] = _bf(self.conv_shortcut.weight).reshape(self.conv_shortcut.weight.shape[0], -1).contiguous()
+        return pk
 
     def run(self, x: torch.Tensor, grid: PaddedGrid, scratch) -> torch.Tensor:
         pk = self.packed()
@@ -90,11 +91,11 @@ class _VaeAttention(nn.Module):
         wv = _bf(self.to_v.weight)
         for i in range(I):
             sl = slice(i * P, (i + 1) * P)
-            s = ops.gemm(q[sl], k[sl])                                   # [P, P] scores
+            s = ops.gemm(q[sl], k[sl], w_is_activation=True)             # [P, P] scores
             ops.softmax_rows(s, Cc ** -0.5, out=s)
-            vt = ops.gemm(wv, xn[sl])                                    # V^T without bias: [C, P]
+            vt = ops.gemm(wv, xn[sl], w_is_activation=True)              # V^T without bias: [C, P]
             # rows of softmax sum to 1, so P @ (V + 1 b^T) = P @ V + b^T: the v bias is the column bias here
-            ops.gemm(s, vt, _bf(self.to_v.bias), out=o[sl])
+            ops.gemm(s, vt, _bf(self.to_v.bias), out=o[sl], w_is_activation=True)
         to = self.to_out[0]
         return ops.gemm(o, _bf(to.weight), _bf(to.bias), epilogue=EPI_RESID, res=x, out=xn)      # (never into the A operand)
 
@@ -209,6 +210,10 @@ class AutoencoderKL(nn.Module):
                                             in_channels=in_channels, out_channels=out_channels,
                                             layers_per_block=layers_per_block, norm_num_groups=norm_num_groups)
         self._scratch: Dict[Tuple[int, int], torch.Tensor] = {}
+        # torch.float32 selects the fp32 accuracy path of encode / decode (north_star's 1e-3 tolerance; the reference's CPU path,
+        # BASELINE.json configs[0], decodes in fp32: ctsd.py:1189-1193, 1634-1640): fp32 activations and weights, convolutions
+        # by dwm_gemm_f32, fp32 GroupNorm / softmax kernels
+        self.compute_dtype = bf16
 
     @property
     def dtype(self):
@@ -237,12 +242,12 @@ class AutoencoderKL(nn.Module):
 
     def _pad_scratch(self, grid: PaddedGrid, channels: int) -> torch.Tensor:
         """zero-bordered padded buffers, reused (every producer rewrites the whole interior)."""
-        key = (grid.I, grid.h, grid.w, channels)
+        key = (grid.I, grid.h, grid.w, channels, STORE.precision)
         dev = self.decoder.conv_in.weight.device
         buf = self._scratch.get(key)
         if buf is None or buf.device != dev:
             self._scratch = {k: v for k, v in self._scratch.items() if k[:3] == key[:3]}   # drop other resolutions
-            buf = torch.zeros((grid.rows, channels), dtype=bf16, device=dev)
+            buf = torch.zeros((grid.rows, channels), dtype=STORE.precision, device=dev)
             self._scratch[key] = buf
         return buf
 
@@ -250,11 +255,13 @@ class AutoencoderKL(nn.Module):
     def encode(self, x: torch.Tensor, return_dict: bool = True, chunk: int = 8):
         """x [I, 3, H, W] in [-1, 1] -> object with .latent_dist (sample() / mode()), as ctsd.py uses it
         (ctsd.py:1213-1218 `.latent_dist.sample()`, :1689-1694 `.mode()`)."""
-        from .blocks import STORE
-        STORE.set_precision(torch.bfloat16)
         if not x.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
-        moments = torch.cat([self._encode_chunk(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)], 0)
+        STORE.set_precision(self.compute_dtype)
+        try:
+            moments = torch.cat([self._encode_chunk(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)], 0)
+        finally:
+            STORE.set_precision(bf16)
         dist = DiagonalGaussianDistribution(moments.float())
         if return_dict:
             return types.SimpleNamespace(latent_dist=dist)
@@ -263,12 +270,15 @@ class AutoencoderKL(nn.Module):
     def _encode_chunk(self, x: torch.Tensor) -> torch.Tensor:
         e = self.encoder
         I, ic, H, W = x.shape
+        cd = STORE.precision
         x = x.contiguous()
-        if x.dtype not in (torch.float32, bf16):
+        if cd == torch.float32:
+            x = x.float()
+        elif x.dtype not in (torch.float32, bf16):
             x = x.to(bf16)
         scratch = self._pad_scratch
         grid = PaddedGrid(I, H, W)
-        tok = ops.unshuffle_tokens(x, 1, 64 * ((ic + 63) // 64))
+        tok = ops.unshuffle_tokens(x, 1, 64 * ((ic + 63) // 64), dtype=cd)
         xp = ops.pad_tokens(tok, grid, out=scratch(grid, tok.shape[1]))
         h = ops.gemm(xp, _conv3_w(e.conv_in, tok.shape[1]), _bf(e.conv_in.bias), a_grid=grid, conv3x3=True)
         for db in e.down_blocks:
@@ -292,9 +302,9 @@ class AutoencoderKL(nn.Module):
         else:
             nm = self.quant_conv.weight.shape[0]
             kp = 64 * ((nm + 63) // 64)
-            m64 = torch.zeros((I * grid.h * grid.w, kp), dtype=bf16, device=h.device)      # K of the 1x1 conv padded to 64
+            m64 = torch.zeros((I * grid.h * grid.w, kp), dtype=cd, device=h.device)        # K of the 1x1 conv padded to 64
             ops.gemm(hp, _conv3_w(e.conv_out), _bf(e.conv_out.bias), a_grid=grid, conv3x3=True, out=m64[:, :nm])
-            wq = torch.zeros((nm, kp), dtype=bf16, device=h.device)
+            wq = torch.zeros((nm, kp), dtype=cd, device=h.device)
             wq[:, :nm] = _bf(self.quant_conv.weight).reshape(nm, nm)
             m = ops.gemm(m64, wq, _bf(self.quant_conv.bias))
         return m.reshape(I, grid.h, grid.w, -1).permute(0, 3, 1, 2).contiguous()
@@ -303,11 +313,13 @@ class AutoencoderKL(nn.Module):
     def decode(self, z: torch.Tensor, return_dict: bool = False, chunk: int = 8):
         """z [I, latent_channels, h, w] -> images [I, 3, 8h, 8w] (bf16).  Returns a 1-tuple like
         diffusers' decode(..., return_dict=False)."""
-        from .blocks import STORE
-        STORE.set_precision(torch.bfloat16)
         if not z.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
-        outs = [self._decode_chunk(z[i:i + chunk]) for i in range(0, z.shape[0], chunk)]
+        STORE.set_precision(self.compute_dtype)
+        try:
+            outs = [self._decode_chunk(z[i:i + chunk]) for i in range(0, z.shape[0], chunk)]
+        finally:
+            STORE.set_precision(bf16)
         img = torch.cat(outs, 0)
         if return_dict:
             return types.SimpleNamespace(sample=img)
@@ -316,17 +328,20 @@ class AutoencoderKL(nn.Module):
     def _decode_chunk(self, z: torch.Tensor) -> torch.Tensor:
         d = self.decoder
         I, lc, h, w = z.shape
+        cd = STORE.precision
         z = z.contiguous()
-        if z.dtype not in (torch.float32, bf16):
+        if cd == torch.float32:
+            z = z.float()
+        elif z.dtype not in (torch.float32, bf16):
             z = z.to(bf16)
         grid = PaddedGrid(I, h, w)
         scratch = self._pad_scratch
-        tok = ops.unshuffle_tokens(z, 1, 64 * ((lc + 63) // 64))                  # [I*h*w, 64], zero padded channels
+        tok = ops.unshuffle_tokens(z, 1, 64 * ((lc + 63) // 64), dtype=cd)        # [I*h*w, 64], zero padded channels
         if self.post_quant_conv is not None:
             kp = tok.shape[1]
-            wq = torch.zeros((kp, kp), dtype=bf16, device=z.device)               # output keeps the 64-column padding
+            wq = torch.zeros((kp, kp), dtype=cd, device=z.device)                 # output keeps the 64-column padding
             wq[:lc, :lc] = _bf(self.post_quant_conv.weight).reshape(lc, lc)
-            bq = torch.zeros(kp, dtype=bf16, device=z.device)
+            bq = torch.zeros(kp, dtype=cd, device=z.device)
             bq[:lc] = _bf(self.post_quant_conv.bias)
             tok = ops.gemm(tok, wq, bq)
         zp = ops.pad_tokens(tok, grid, out=scratch(grid, tok.shape[1]))
@@ -349,9 +364,9 @@ class AutoencoderKL(nn.Module):
                                 out=scratch(grid, x.shape[1]), out_grid=grid)
         oc = d.out_channels
         w_out = _conv3_w(d.conv_out)
-        wp = torch.zeros((8, w_out.shape[1]), dtype=bf16, device=w_out.device)      # N padded 3 -> 8
+        wp = torch.zeros((8, w_out.shape[1]), dtype=cd, device=w_out.device)        # N padded 3 -> 8
         wp[:oc] = w_out
-        bp = torch.zeros(8, dtype=bf16, device=w_out.device)
+        bp = torch.zeros(8, dtype=cd, device=w_out.device)
         bp[:oc] = _bf(d.conv_out.bias)
         y = ops.gemm(xp, wp, bp, a_grid=grid, conv3x3=True)                          # [I*P, 8]
         return y[:, :oc].reshape(I, grid.h, grid.w, oc).permute(0, 3, 1, 2).contiguous()
