@@ -530,6 +530,10 @@ int dwm_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t L, int6
 int dwm_unshuffle_tokens_f32(const float* x, int64_t I, int32_t C, int32_t H, int32_t W, int32_t r, float* out, int64_t ldo,
                              void* stream);
 int dwm_avgpool2_tokens_f32(const float* x, int64_t I, int32_t h, int32_t w, int32_t C, float* out, void* stream);
+/* dwm_cfg_multistep with an fp32 prediction and an fp32 model input: the guided DPM-Solver++ update of the SD 2.1 denoise loop on
+ * the fp32 path (src/dwm/pipelines/ctsd.py:1536-1575 with diffusers DPMSolverMultistepScheduler.step) */
+int dwm_cfg_multistep_f32(const float* pred, float* latents, float* x0_prev, float* model_in, int64_t n, float guidance,
+                          float kx, float ko, float A, float B, float C, void* stream);
 int dwm_layernorm_f32(const dwm_layernorm_args* args, void* stream);
 /* strides in fp32 elements; head_dim 64; every mask / row-map / segment mode of dwm_attention_fwd; optional lse */
 int dwm_attention_f32(const dwm_attn_args* args, void* stream);

@@ -135,6 +135,7 @@ SIGNATURES = {
     "dwm_softmax_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
     "dwm_unshuffle_tokens_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "dwm_avgpool2_tokens_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "dwm_cfg_multistep_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "dwm_attention_f32": (_i32, [C.POINTER(AttnArgs), _vp]),
     "dwm_silu_f32": (_i32, [_vp, _vp, _i64, _vp]),
     "dwm_timestep_sinusoid_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),

@@ -91,14 +91,20 @@ cfg_euler_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat, bf16_
 
 // classifier-free guidance + one linear multistep scheduler update (DPM-Solver++ 1st / 2nd order, DDIM, ...):
 //   out = u + g (c - u);  x0 = kx * x + ko * out;  x' = A * x + B * x0 + C * x0_prev;  x0_prev' = x0
+template <typename T>      // T: bf16_t, or float (the fp32 accuracy path: dwm_cfg_multistep_f32)
 __global__ void __launch_bounds__(256)
-cfg_multistep_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat, float* __restrict__ x0_prev,
-                     bf16_t* __restrict__ model_in, int64_t n, float guidance, float kx, float ko, float A, float B, float Cc) {
+cfg_multistep_kernel(const T* __restrict__ pred, float* __restrict__ lat, float* __restrict__ x0_prev,
+                     T* __restrict__ model_in, int64_t n, float guidance, float kx, float ko, float A, float B, float Cc) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     float u[4], c[4];
-    unpack4(*(const uint2*)(pred + i), u);
-    unpack4(*(const uint2*)(pred + n + i), c);
+    if constexpr (sizeof(T) == 4) {
+        const float4 a = *(const float4*)(pred + i), b = *(const float4*)(pred + n + i);
+        u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w; c[0] = b.x; c[1] = b.y; c[2] = b.z; c[3] = b.w;
+    } else {
+        unpack4(*(const uint2*)(pred + i), u);
+        unpack4(*(const uint2*)(pred + n + i), c);
+    }
     const float4 l = *(const float4*)(lat + i);
     const float4 pv = *(const float4*)(x0_prev + i);
     const float x[4] = {l.x, l.y, l.z, l.w}, pr[4] = {pv.x, pv.y, pv.z, pv.w};
@@ -111,9 +117,14 @@ cfg_multistep_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat, f
     *(float4*)(lat + i) = make_float4(o[0], o[1], o[2], o[3]);
     *(float4*)(x0_prev + i) = make_float4(z[0], z[1], z[2], z[3]);
     if (model_in) {
-        const uint2 b = pack4(o);
-        *(uint2*)(model_in + i) = b;
-        *(uint2*)(model_in + n + i) = b;
+        if constexpr (sizeof(T) == 4) {
+            *(float4*)(model_in + i) = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4*)(model_in + n + i) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            const uint2 b = pack4(o);
+            *(uint2*)(model_in + i) = b;
+            *(uint2*)(model_in + n + i) = b;
+        }
     }
 }
 
@@ -407,8 +418,18 @@ extern "C" int dwm_cfg_multistep(const void* pred, float* latents, float* x0_pre
     if (n % 4 != 0 || (((uintptr_t)pred) & 7u) || !dwm_aligned16(latents) || !dwm_aligned16(x0_prev) ||
         (model_in && (((uintptr_t)model_in) & 7u)))
         return DWM_EALIGN;
-    hipLaunchKernelGGL(cfg_multistep_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred,
+    hipLaunchKernelGGL(cfg_multistep_kernel<bf16_t>, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred,
                        latents, x0_prev, (bf16_t*)model_in, n, guidance, kx, ko, A, B, C);
+    return finish();
+}
+
+extern "C" int dwm_cfg_multistep_f32(const float* pred, float* latents, float* x0_prev, float* model_in, int64_t n, float guidance,
+                                     float kx, float ko, float A, float B, float C, void* stream) {
+    if (pred == nullptr || latents == nullptr || x0_prev == nullptr || n <= 0) return DWM_EINVAL;
+    if (n % 4 != 0 || !dwm_aligned16(pred) || !dwm_aligned16(latents) || !dwm_aligned16(x0_prev) || (model_in && !dwm_aligned16(model_in)))
+        return DWM_EALIGN;
+    hipLaunchKernelGGL(cfg_multistep_kernel<float>, dim3(blocks_for(n / 4)), dim3(256), 0, (hipStream_t)stream, pred,
+                       latents, x0_prev, model_in, n, guidance, kx, ko, A, B, C);
     return finish();
 }
 

@@ -221,6 +221,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
         # reference's forward does (crossview_temporal_dit.py:459-462) - then each zero convolution adds straight into the
         # hidden state from its GEMM epilogue (adapters.ImageAdapter.residual_adders)
         self.cache_adapter_residuals = True
+        self.adapter_cache_dtype = torch.float32      # arithmetic of the CACHED residuals: fp32 path (default) or torch.bfloat16
         self.frame_shard = None             # set by CTSDDenoiser(frame_group=...): opendwm_amd.sharding.FrameShard
         self.compute_dtype = bf16           # torch.float32 selects the fp32 accuracy path of the inference forward
         # dtype of the hidden / context streams of the bf16 inference forward.  fp32 (default): the ~130 residual adds of a
@@ -470,7 +471,20 @@ class DiTCrossviewTemporalConditionModel(_Base):
             from .blocks import STORE
             key = (condition_image_tensor.data_ptr(), condition_image_tensor._version, tuple(condition_image_tensor.shape), STORE.step)
             if self._adapter_cache[0] != key:
-                self._adapter_cache = (key, self.condition_image_adapter.run(condition_image_tensor, precise=True), condition_image_tensor)
+                # Computed once per condition tensor, so it can afford the fp32 accuracy path (dwm_gemm_f32, 3 x the MFMA work of
+                # the bf16 adapter, ~1 % of a 40-step loop): the adapter's error is the SAME at every denoise step and differs
+                # between the conditional and the unconditional half (different layout images), so classifier-free guidance
+                # multiplies it (4 c - 3 u) and the steps add it up coherently - it is what holds the text+layout model at
+                # 1.3e-2 after 40 steps when the text-only model is at 6e-3 (profiles/r4b_gpu_parity.log).
+                if self.adapter_cache_dtype == torch.float32:
+                    STORE.set_precision(torch.float32)
+                    try:
+                        feats = self.condition_image_adapter.run(condition_image_tensor)
+                    finally:
+                        STORE.set_precision(cd)
+                else:
+                    feats = self.condition_image_adapter.run(condition_image_tensor, precise=True)
+                self._adapter_cache = (key, feats, condition_image_tensor)
             condition_residuals = list(self._adapter_cache[1])
             for f in condition_residuals:
                 if f.shape != h.shape:

@@ -850,11 +850,18 @@ def cfg_multistep(pred: torch.Tensor, latents: torch.Tensor, x0_prev: torch.Tens
                   A: float, B: float, Cc: float, model_in: Optional[torch.Tensor] = None) -> None:
     """CFG combine + linear multistep scheduler update (see dwm_cfg_multistep); latents / x0_prev fp32 in place."""
     n = latents.numel()
-    if pred.dtype != bf16 or pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda:
-        raise RuntimeError("cfg_multistep: pred must be contiguous bf16 with 2x the latent elements")
+    if pred.dtype not in (bf16, torch.float32) or pred.numel() != 2 * n or not pred.is_contiguous() or not pred.is_cuda:
+        raise RuntimeError("cfg_multistep: pred must be contiguous bf16 (fp32: the accuracy path) with 2x the latent elements")
     for t in (latents, x0_prev):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
             raise RuntimeError("cfg_multistep: latents / x0_prev must be contiguous fp32 of the same size")
+    if model_in is not None and (model_in.dtype != pred.dtype or model_in.numel() != 2 * n or not model_in.is_contiguous()):
+        raise RuntimeError("cfg_multistep: model_in must be contiguous, of pred's dtype and size")
+    if pred.dtype == torch.float32:
+        _lib.check(_lib.load().dwm_cfg_multistep_f32(pred.data_ptr(), latents.data_ptr(), x0_prev.data_ptr(), _p(model_in), n,
+                                                     float(guidance), float(kx), float(ko), float(A), float(B), float(Cc), _stream()),
+                   "dwm_cfg_multistep_f32")
+        return
     _lib.check(_lib.load().dwm_cfg_multistep(pred.data_ptr(), latents.data_ptr(), x0_prev.data_ptr(), _p(model_in), n,
                                              float(guidance), float(kx), float(ko), float(A), float(B), float(Cc), _stream()),
                "dwm_cfg_multistep")

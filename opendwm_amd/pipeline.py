@@ -612,11 +612,14 @@ class UNetDenoiser:
         self.latents = latents.to(torch.float32).contiguous().clone()        # init_noise_sigma = 1
         self.x0_prev = torch.zeros_like(self.latents)
         B = latents.shape[0]
-        self.model_in = torch.empty((2 * B, *latents.shape[1:]), dtype=bf16, device=dev)
-        lat16 = ops.cast_bf16(self.latents)
+        # model input / conditions / prediction in the model's compute dtype: bf16, or fp32 for the accuracy path
+        # (`model.compute_dtype = torch.float32`: BASELINE.json configs[0], the reference's fp32 denoise)
+        self.cd = cd = getattr(self.model, "compute_dtype", bf16)
+        self.model_in = torch.empty((2 * B, *latents.shape[1:]), dtype=cd, device=dev)
+        lat16 = self.latents if cd == torch.float32 else ops.cast_bf16(self.latents)
         self.model_in[:B].copy_(lat16)
         self.model_in[B:].copy_(lat16)
-        self.conditions = {k: (v.to(bf16) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
+        self.conditions = {k: (v.to(cd) if torch.is_tensor(v) and v.is_floating_point() and k != "added_time_ids" else v)
                            for k, v in conditions.items()}
         self._ts = self.timesteps.to(dev).float()
         # DDIM: the [steps, 6] coefficient rows of every step, on the device, once per prepare() (no host-to-device copy and
@@ -635,9 +638,13 @@ class UNetDenoiser:
             from .schedulers import PREDICTION_TYPES
             sc = self.scheduler
             coef = self._ddim_coef[i].expand(B * T * V, 6).contiguous()
+            f32_path = self.cd == torch.float32       # (the kernel writes a bf16 model input; the fp32 path copies the latents)
             ops.cfg_ddim_step(pred, self.latents, coef, self.latents[0, 0, 0].numel(), PREDICTION_TYPES[sc.config.prediction_type],
                               guidance=self.guidance_scale, clip_range=sc.config.clip_sample_range if sc.config.clip_sample else 0.0,
-                              model_in=self.model_in)
+                              model_in=None if f32_path else self.model_in)
+            if f32_path:
+                self.model_in[:B].copy_(self.latents)
+                self.model_in[B:].copy_(self.latents)
             return
         kx, ko, A, Bc, Cc = dpm_solver_coefficients(self.sigmas, i, self.prediction_type)
         ops.cfg_multistep(pred, self.latents, self.x0_prev, self.guidance_scale, kx, ko, A, Bc, Cc, model_in=self.model_in)

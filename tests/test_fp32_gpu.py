@@ -312,3 +312,204 @@ def test_full_width_stack_fp32_vs_oracle_on_device(dev):
     e = rel_err(out[0], ref)
     _log("full_width_6layers_fp32", rel=e, finite=bool(torch.isfinite(out[0]).all()))
     assert e < TOL_F32, e
+
+
+# ------------------------------------------------------------------------------------------ SD 2.1 UNet + 2-D VAE (round 4)
+def test_glue_kernels_f32(dev):
+    """fp32 forms of the token-major glue kernels the UNet / VAE / layout adapter use: GroupNorm(+SiLU) compact, into a padded
+    grid and with the (b v) x (t h w) row map of TemporalResnetBlock; nearest 2x upsample into a padded grid; padded-grid
+    scatter; row softmax; pixel-unshuffle; 2x2 average pooling - against plain fp64 torch"""
+    import torch.nn.functional as F
+    from opendwm_amd import ops
+    from opendwm_amd.ops import PaddedGrid
+    I, h, w, C, G = 3, 8, 12, 320, 32
+    x = _rand((I * h * w, C), dev, 1, 2.0) + 0.3
+    ga, be = _rand((C,), dev, 2, 0.2) + 1.0, _rand((C,), dev, 3, 0.5)
+    img = x.double().view(I, h, w, C).permute(0, 3, 1, 2)
+    ref = F.silu(F.group_norm(img, G, ga.double(), be.double(), 1e-5)).permute(0, 2, 3, 1).reshape(I * h * w, C)
+    e_gn = rel_err(ops.groupnorm_silu(x, I, h * w, ga, be, G, 1e-5), ref.float())
+    grid = PaddedGrid(I, h, w)
+    pad = ops.groupnorm_silu(x, I, h * w, ga, be, G, 1e-5, out_grid=grid)
+    assert pad.dtype == f32 and pad.shape[0] == grid.rows
+    e_gn_pad = rel_err(pad[grid.interior_index().to(dev)], ref.float())
+    assert float(pad.abs().sum()) > 0 and torch.count_nonzero(pad.view(I, h + 2, w + 2, C)[:, 0]) == 0      # the border stays zero
+    # row-mapped statistics: image = (b, v), pixels = (t, h, w) of rows ordered (b t v)(h w)
+    B, T, V, N = 1, 3, 2, 16
+    xt = _rand((B * T * V * N, 64), dev, 4)
+    g2, b2 = _rand((64,), dev, 5, 0.2) + 1.0, _rand((64,), dev, 6, 0.3)
+    vol = xt.double().view(B, T, V, N, 64).permute(0, 2, 4, 1, 3).reshape(B * V, 64, T * N)
+    rt = F.group_norm(vol, 8, g2.double(), b2.double(), 1e-5).view(B, V, 64, T, N).permute(0, 3, 1, 4, 2).reshape(-1, 64)
+    yt = ops.groupnorm_silu(xt, B * V, T * N, g2, b2, 8, 1e-5, silu=False, img_map=(V, N, T * V * N, N, V * N))
+    e_map = rel_err(yt, rt.float())
+    # upsample / pad / softmax / unshuffle / avgpool
+    up = ops.upsample2_padded(x, I, h, w)
+    g2x = PaddedGrid(I, 2 * h, 2 * w)
+    want = F.interpolate(img.float(), scale_factor=2, mode="nearest").permute(0, 2, 3, 1).reshape(-1, C)
+    assert torch.equal(up[g2x.interior_index().to(dev)], want)
+    assert torch.equal(ops.pad_tokens(x, grid)[grid.interior_index().to(dev)], x)
+    s = _rand((100, 1024), dev, 7, 3.0)
+    e_sm = rel_err(ops.softmax_rows(s, 0.25), torch.softmax(s.double() * 0.25, -1).float())
+    px = _rand((2, 6, 16, 24), dev, 8)
+    tok = ops.unshuffle_tokens(px, 8, dtype=f32)
+    wantu = F.pixel_unshuffle(px, 8).permute(0, 2, 3, 1).reshape(2 * 2 * 3, 6 * 64)
+    assert tok.dtype == f32 and torch.equal(tok[:, :384], wantu) and tok.shape[1] == 384
+    pooled = ops.avgpool2_tokens(x, I, h, w)
+    e_pool = rel_err(pooled, F.avg_pool2d(img, 2).permute(0, 2, 3, 1).reshape(-1, C).float())
+    _log("glue_kernels_f32", gn=e_gn, gn_pad=e_gn_pad, gn_mapped=e_map, softmax=e_sm, avgpool=e_pool)
+    assert max(e_gn, e_gn_pad, e_map, e_sm, e_pool) < 1e-5
+
+
+def test_gemm_f32_strided_and_temporal_taps(dev):
+    """dwm_gemm_f32 as the stride-2 3x3 convolutions (Downsample2D: symmetric padding 1 in the UNet, (0, 1) padding in the VAE
+    encoder) and as the 3-tap temporal convolution of TemporalResnetBlock (Conv3d (3,1,1) over a T-padded row layout)"""
+    import torch.nn.functional as F
+    from opendwm_amd import ops
+    from opendwm_amd.ops import PaddedGrid, TimeGrid
+    I, h, w, C, N = 2, 8, 12, 64, 128
+    x = _rand((I, C, h, w), dev, 1)
+    wt, b = _rand((N, C, 3, 3), dev, 2, (9 * C) ** -0.5), _rand((N,), dev, 3, 0.1)
+    grid = PaddedGrid(I, h, w)
+    xp = ops.pad_tokens(x.permute(0, 2, 3, 1).reshape(I * h * w, C).contiguous(), grid)
+    wm = wt.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    errs = {}
+    for name, s2, ref in (("sym", "sym", F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=1)),
+                          ("asym", True, F.conv2d(F.pad(x.double(), (0, 1, 0, 1)), wt.double(), b.double(), stride=2))):
+        y = ops.gemm(xp, wm, b, a_grid=grid, conv3x3=True, stride2=s2)
+        errs[name] = rel_err(y, ref.permute(0, 2, 3, 1).reshape(-1, N).float())
+    B, T, VN = 2, 4, 24
+    tg = TimeGrid(B, T, VN)
+    xs = _rand((B, T, VN, C), dev, 4)
+    w3, b3 = _rand((N, C, 3), dev, 5, (3 * C) ** -0.5), _rand((N,), dev, 6, 0.1)
+    pad = torch.zeros((tg.rows, C), dtype=f32, device=dev)
+    pad.view(B, T + 2, VN, C)[:, 1:T + 1] = xs
+    y3 = ops.gemm(pad, w3.permute(0, 2, 1).reshape(N, 3 * C).contiguous(), b3, a_grid=tg, conv_taps=tg.tap_shifts())
+    ref3 = F.conv1d(xs.double().permute(0, 2, 3, 1).reshape(B * VN, C, T), w3.double(), b3.double(), padding=1)
+    errs["temporal"] = rel_err(y3, ref3.view(B, VN, N, T).permute(0, 3, 1, 2).reshape(-1, N).float())
+    _log("gemm_f32_strided_and_temporal_taps", **errs)
+    assert max(errs.values()) < TOL_KERNEL_F32, errs
+
+
+@pytest.mark.parametrize("rowwise", [True, False])
+def test_unet_forward_fp32_vs_cpu_oracle(dev, rowwise):
+    """the SD 2.1 cross-view temporal UNet, whole graph at small width (the configuration of tests/test_unet_gpu.py), fp32
+    weights and inputs untouched: `model.compute_dtype = torch.float32` against the CPU oracle at north_star's fp32 tolerance;
+    then the same object back in bf16"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = U.make_unet_config(block_out_channels=(128, 256, 512, 512), num_attention_heads=(2, 4, 8, 8), cross_attention_dim=128,
+                             projection_class_embeddings_input_dim=11 * 256, enable_rowwise_crossview=rowwise, enable_rowwise_temporal=rowwise)
+    sd = U.make_unet_state_dict(cfg, 0)
+    inp = U.make_unet_inputs(cfg, 2, 3, 3, 16, 24, text_len=10)
+    inp["disable_temporal"] = torch.tensor([False, True])
+    if not rowwise:
+        inp["crossview_attention_mask"] = None
+    ref = U.unet_forward(sd, cfg, **inp)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    m.compute_dtype = f32
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    e = rel_err(out, ref)
+    assert out.dtype == f32 and out.shape == ref.shape
+    m.compute_dtype = torch.bfloat16
+    di = to_dev(inp, dev)
+    out16 = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    e16 = rel_err(out16, ref)
+    _log("unet_forward_fp32", rowwise=rowwise, rel_fp32=e, rel_bf16_same_model=e16)
+    assert e < TOL_F32, e
+    assert out16.dtype == torch.bfloat16 and 1e-4 < e16 < 2e-2
+
+
+def test_unet_full_width_config0_fp32_vs_oracle_on_device(dev):
+    """BASELINE.json configs[0] - the configuration the reference's CPU fp32 denoise is quoted on - at FULL width (SD 2.1: 320 /
+    640 / 1280 / 1280 channels, 1.92 B parameters), six views x one frame x 256x256 px (latents [1,1,6,4,32,32], CFG batch 2, 77
+    text tokens): the fp32 path against the fp32 oracle evaluated on the device (the CPU needs minutes for it)"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = U.make_unet_config()
+    sd = U.make_unet_state_dict(cfg, 0)
+    inp = U.make_unet_inputs(cfg, 2, 1, 6, 32, 32, text_len=77)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    m.compute_dtype = f32
+    di = to_dev(inp, dev)
+    out = m(di.pop("sample"), di.pop("timesteps"), **di)[0][0]
+    del m
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        ref = U.unet_forward({k: v.to(dev) for k, v in sd.items()}, cfg, **to_dev(inp, dev))
+    e = rel_err(out, ref)
+    _log("unet_full_width_config0_fp32", rel=e, finite=bool(torch.isfinite(out).all()))
+    assert out.shape == (2, 1, 6, 4, 32, 32) and out.dtype == f32 and e < TOL_F32, e
+
+
+@pytest.mark.parametrize("kind", ["sd35", "sd21"])
+def test_vae_fp32_vs_cpu_oracle(dev, kind):
+    """AutoencoderKL encode + decode with `vae.compute_dtype = torch.float32` at small width (SD 3.5 form; SD 2.1 form with
+    quant / post-quant 1x1 convolutions) against the CPU oracle"""
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=2, norm_num_groups=16, latent_channels=16 if kind == "sd35" else 4,
+                use_quant_conv=kind == "sd21", use_post_quant_conv=kind == "sd21")
+    sd = O.make_vae_state_dict(vcfg, 0)
+    vae = AutoencoderKL(**vcfg)
+    vae.load_state_dict(sd)
+    vae = vae.to(dev).eval()
+    vae.compute_dtype = f32
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, vcfg["latent_channels"], 8, 16, generator=g)
+    x = torch.randn(2, 3, 64, 128, generator=g)
+    out = vae.decode(z.to(dev), return_dict=False)[0]
+    e_dec = rel_err(out, O.vae_decode(sd, vcfg, z))
+    mom = vae.encode(x.to(dev)).latent_dist.parameters
+    e_enc = rel_err(mom, O.vae_encode_moments(sd, vcfg, x))
+    _log("vae_fp32", kind=kind, rel_decode=e_dec, rel_encode=e_enc)
+    assert out.dtype == f32 and e_dec < TOL_F32 and e_enc < TOL_F32, (e_dec, e_enc)
+    vae.compute_dtype = torch.bfloat16
+    e16 = rel_err(vae.to(torch.bfloat16).decode(z.to(dev), return_dict=False)[0], O.vae_decode(sd, vcfg, z))
+    assert 1e-4 < e16 < 2e-2
+
+
+def test_vae_decode_fp32_full_width_vs_oracle_on_device(dev):
+    """the SD 2.1 VAE decoder at its real widths (128 / 256 / 512 / 512, 4 latent channels, post-quant convolution) on the
+    latents of BASELINE.json configs[0] (six 32x32 latents -> 256x256 px), fp32 path against the fp32 oracle on the device"""
+    from opendwm_amd.vae import AutoencoderKL
+    vcfg = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32, latent_channels=4,
+                use_quant_conv=True, use_post_quant_conv=True)
+    sd = O.make_vae_state_dict(vcfg, 0)
+    vae = AutoencoderKL(**vcfg)
+    vae.load_state_dict(sd)
+    vae = vae.to(dev).eval()
+    vae.compute_dtype = f32
+    z = torch.randn(6, 4, 32, 32, generator=torch.Generator().manual_seed(0)).to(dev)
+    out = vae.decode(z, return_dict=False)[0]
+    ref = O.vae_decode({k: v.to(dev) for k, v in sd.items()}, vcfg, z)
+    e = rel_err(out, ref)
+    _log("vae_decode_fp32_full_width", rel=e, shape=list(out.shape))
+    assert out.shape == (6, 3, 256, 256) and out.dtype == f32 and e < TOL_F32, e
+
+
+def test_unet_denoise_loop_fp32_vs_cpu_oracle(dev):
+    """the SD 2.1 guided DPM-Solver++(2M) loop (BASELINE.json configs[0] is this loop on the reference's CPU fp32 path) with
+    `model.compute_dtype = torch.float32`: fp32 model input, fp32 prediction, fp32 scheduler update (dwm_cfg_multistep_f32)"""
+    from oracle import unet_oracle as U
+    from opendwm_amd.pipeline import UNetDenoiser
+    from opendwm_amd.unet import UNetCrossviewTemporalConditionModel
+    cfg = U.make_unet_config(block_out_channels=(128, 256, 512, 512), num_attention_heads=(2, 4, 8, 8), cross_attention_dim=128,
+                             projection_class_embeddings_input_dim=11 * 256)
+    sd = U.make_unet_state_dict(cfg, 0)
+    inp = U.make_unet_inputs(cfg, 2, 2, 3, 16, 24, text_len=10)
+    lat = inp.pop("sample")[:1]
+    inp.pop("timesteps")
+    steps = 4
+    ref = U.unet_denoise(sd, cfg, lat, inp, steps, 3.0)
+    m = UNetCrossviewTemporalConditionModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.compute_dtype = f32
+    den = UNetDenoiser(m, 3.0, steps)
+    out = den.run(lat.to(dev), to_dev(inp, dev))
+    e = rel_err(out, ref)
+    _log("unet_denoise_loop_fp32", steps=steps, rel=e)
+    assert den.model_in.dtype == f32 and e < TOL_F32, e

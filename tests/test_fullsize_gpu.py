@@ -153,13 +153,19 @@ def test_full_size_layout_adapter_and_pointwise_temporal(full_layout):
     B2, T, V = x.shape[:3]
     model._adapter_cache = (None, None)
     model.cache_adapter_residuals = True
+    model.adapter_cache_dtype = torch.float32                      # (default) cached residuals through the fp32 path
+    p32 = fwd(model, x, ts, cond)
+    model._adapter_cache = (None, None)
+    model.adapter_cache_dtype = torch.bfloat16                     # the same arithmetic as the per-step recompute
     a = fwd(model, x, ts, cond)
     assert model._adapter_cache[0] is not None
-    b = fwd(model, x, ts, cond)                                    # cached fp32 residuals, added by dwm_add_f32_inplace
+    b = fwd(model, x, ts, cond)                                    # cached fp32 residuals, added by dwm_add_f32_f32_inplace
     model.cache_adapter_residuals = False
     c = fwd(model, x, ts, cond)                                    # recomputed, zero convolutions adding from their GEMM epilogues
     model.cache_adapter_residuals = True
     assert torch.isfinite(a.float()).all() and torch.equal(a, b) and torch.equal(a, c)
+    d32 = ((p32.double() - a.double()).norm() / a.double().norm()).item()
+    assert 0.0 < d32 < 1e-2, d32                                   # the fp32-path residuals: close to, not equal to, the bf16 ones
     cond2 = dict(cond)
     img2 = cond["condition_image_tensor"].clone()
     img2[1] = 1.0 - img2[1]
