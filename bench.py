@@ -833,7 +833,7 @@ def main():
         sample_id, n_samples = 0, 1
     ninf = w["inference_steps"]
 
-    def run_variant(layout: bool, steps: int, warmup: int):
+    def run_variant(layout: bool, steps: int, warmup: int, adapter_cache: bool = bool(args.adapter_cache)):
         """build the model of one variant, W untimed + K timed denoise steps; -> (kwargs, seconds, KernelTimer, finite)"""
         kwargs = variant_kwargs(layout)
         if args.layers is not None:
@@ -854,7 +854,7 @@ def main():
             if args.graph:
                 den.enable_graph()
 
-            model.cache_adapter_residuals = bool(args.adapter_cache)     # default: the adapter runs inside every timed step
+            model.cache_adapter_residuals = adapter_cache     # default: the adapter runs inside every timed step
 
             def step(i):
                 timer.enabled = i >= warmup and not args.graph
@@ -879,6 +879,16 @@ def main():
             other = (k2, dt2, t2, fin2)
         except Exception as e:          # never lose the headline line to the secondary leg
             print(f"text-only leg failed: {e!r}", file=sys.stderr)
+
+    # and the headline model with the layout residuals computed ONCE per prepare() (through the fp32 path) instead of inside
+    # every step: the model class's own default (`cache_adapter_residuals`), what a deployment would run - reported beside the
+    # headline, outside its timed region, at N=1 only
+    cached = None
+    if world == 1 and args.layout and not args.adapter_cache and not args.no_text_only_leg and not args.graph and args.layers is None:
+        try:
+            cached = run_variant(True, args.steps, args.warmup, adapter_cache=True)
+        except Exception as e:
+            print(f"adapter-cache leg failed: {e!r}", file=sys.stderr)
 
     if rank == 0:
         fl = model_flops(kwargs, 2 * w["B"], w["T"], w["V"], w["H"], w["W"], w["text_len"])
@@ -949,6 +959,17 @@ def main():
                 "flop_per_step": fl2["total"], "finite": fin2,
                 "gemm_tflops": ks2.get("gemm", {}).get("tflops"), "attention_tflops": ks2.get("attn", {}).get("tflops"),
                 "whole_step_mfma_frac": fl2["total"] / (ms2 * 1e-3) / (PEAK_BF16_TFLOPS * 1e12)}
+        if cached is not None:
+            _, dt3, t3, fin3 = cached
+            ms3 = 1e3 * dt3 / args.steps
+            line["adapter_cached"] = {
+                "variant": "text+layout with the ImageAdapter residuals computed once per prepare() through the fp32 path and kept across "
+                           "the denoise steps (model.cache_adapter_residuals, the model class's default): the same function of the same "
+                           "step-invariant input, 40-step parity 1.5e-3 instead of 1.3e-2 (profiles/r4c_gpu_parity.log); timed after "
+                           "the headline with the same --steps / --warmup",
+                "value": n_samples * args.steps / dt3, "unit": "denoise-steps/s", "ms_per_step": ms3, "flop_per_step": fl["total"],
+                "finite": fin3, "gemm_tflops": t3.summary().get("gemm", {}).get("tflops"),
+                "whole_step_mfma_frac": fl["total"] / (ms3 * 1e-3) / (PEAK_BF16_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, int(os.environ.get("DWM_CPU_THREADS", "64"))), args.layout, step_flop)
         print(json.dumps(line))

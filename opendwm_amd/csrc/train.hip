@@ -207,7 +207,8 @@ rowcombine_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __res
 // One wave per row (row in registers), RB/4 rows per wave sequentially; per-lane fp32 partial
 // sums of the parameter / modulation gradients over the wave's rows, reduced over the 4 waves in
 // LDS and flushed with one atomic per column and workgroup.
-constexpr int LN_BWD_RB = 128;
+constexpr int LN_BWD_RB = 64;        // (round 4: 128 -> 64.  One training sample is 43 008 rows = 336 blocks of 128: 1.3 blocks per CU, 32
+                                     //  rows per wave one after the other, each a chain of three memory round trips - 219 us for 400 MB)
 template <int NI>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
@@ -276,6 +277,17 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
                 for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
             }
         }
+        // the incoming gradients are requested NOW, before the two wave reductions of the statistics (they do not depend on
+        // them): one memory round trip per row less on the critical path
+        const bf16_t* __restrict__ dy = (const bf16_t*)p.dy + row * p.lddy;
+        const bf16_t* __restrict__ dy2 = p.dy2 ? (const bf16_t*)p.dy2 + row * p.lddy2 : nullptr;
+        uint4 dyr[NI], dy2r[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = ok[i] ? (i * 64 + lane) * 8 : 0;
+            dyr[i] = *(const uint4*)(dy + c);
+            dy2r[i] = dy2 ? *(const uint4*)(dy2 + c) : dyr[i];
+        }
         const float mean = wave_sum(s) / (float)D;
         float q = 0.f;
 #pragma unroll
@@ -286,8 +298,6 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
             }
         const float rstd = rsqrtf(wave_sum(q) / (float)D + p.eps);
 
-        const bf16_t* __restrict__ dy = (const bf16_t*)p.dy + row * p.lddy;
-        const bf16_t* __restrict__ dy2 = p.dy2 ? (const bf16_t*)p.dy2 + row * p.lddy2 : nullptr;
         float dxh[NI][8];                    // d loss / d xhat
         float m1 = 0.f, m2 = 0.f;            // sum dxhat, sum dxhat * xhat
 #pragma unroll
@@ -297,7 +307,7 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
             for (int j = 0; j < 8; ++j) dxh[i][j] = 0.f;
             if (!ok[i]) continue;
             float d[8];
-            unpack8(*(const uint4*)(dy + c), d);
+            unpack8(dyr[i], d);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xh = (v[i][j] - mean) * rstd;
@@ -307,7 +317,7 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
                 dxh[i][j] = d[j] * gam[i][j];
             }
             if (dy2) {
-                unpack8(*(const uint4*)(dy2 + c), d);
+                unpack8(dy2r[i], d);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sg2[i][j] += d[j] * v[i][j];
