@@ -199,7 +199,7 @@ class KernelTimer:
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (scripts/pmc_traffic.sh -> profiles/r3_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
+    (scripts/pmc_traffic.sh -> profiles/r4_pmc_traffic.json; FETCH_SIZE*2 + WRITE_SIZE, separate passes).
     Counters cannot be collected inside the timed run, so the bench line cites the committed measurement."""
     for name in PMC_FILES:
         try:
@@ -209,7 +209,7 @@ def pmc_traffic(kernel: str):
     return None
 
 
-PMC_FILES = ("r3_pmc_traffic.json", "r2_pmc_traffic.json")
+PMC_FILES = ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json")
 
 
 def pmc_source() -> str:
