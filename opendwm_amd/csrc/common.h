@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef uint16_t bf16_t;                                         // raw bfloat16 storage
 typedef __attribute__((ext_vector_type(8))) short bf16x8;        // MFMA A/B operand (8 bf16, 4 VGPR)
@@ -68,6 +69,25 @@ DWM_DEVINL float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// The same sum by DPP row operations instead of six LDS-routed shuffles (ds_bpermute: an LDS round trip each): quad swaps,
+// half-row / row mirrors, then the two cross-row broadcasts of GFX9 (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and
+// 3); the total lands in lane 63 and is read back as a scalar.  For kernels whose row loop is latency bound on its reductions
+// (LayerNorm backward: four per row).
+DWM_DEVINL float wave_sum_dpp(float v) {
+    auto add_dpp = [](float x, auto ctrl, auto row_mask) {
+        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        return x + __int_as_float(y);
+    };
+    using std::integral_constant;
+    v = add_dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});       // quad_perm [1,0,3,2]
+    v = add_dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});       // quad_perm [2,3,0,1]
+    v = add_dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});      // row_half_mirror
+    v = add_dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});      // row_mirror: every lane holds its row's sum
+    v = add_dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});      // row_bcast15 -> rows 1, 3
+    v = add_dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});      // row_bcast31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3); one v_exp + one v_rcp

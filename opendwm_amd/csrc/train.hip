@@ -288,7 +288,7 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
             dyr[i] = *(const uint4*)(dy + c);
             dy2r[i] = dy2 ? *(const uint4*)(dy2 + c) : dyr[i];
         }
-        const float mean = wave_sum(s) / (float)D;
+        const float mean = wave_sum_dpp(s) / (float)D;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -296,7 +296,7 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
             }
-        const float rstd = rsqrtf(wave_sum(q) / (float)D + p.eps);
+        const float rstd = rsqrtf(wave_sum_dpp(q) / (float)D + p.eps);
 
         float dxh[NI][8];                    // d loss / d xhat
         float m1 = 0.f, m2 = 0.f;            // sum dxhat, sum dxhat * xhat
@@ -328,8 +328,8 @@ layernorm_bwd_kernel(const dwm_layernorm_bwd_args p, int chunks_per_group) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { m1 += dxh[i][j]; m2 += dxh[i][j] * v[i][j]; }
         }
-        m1 = wave_sum(m1) / (float)D;
-        m2 = wave_sum(m2) / (float)D;
+        m1 = wave_sum_dpp(m1) / (float)D;
+        m2 = wave_sum_dpp(m2) / (float)D;
         bf16_t* __restrict__ dx = (bf16_t*)p.dx + row * p.lddx;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
