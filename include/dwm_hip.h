@@ -374,6 +374,8 @@ int dwm_softmax_rows(const void* x, void* y, int64_t rows, int32_t L, int64_t ld
  * intrinsics (9, row-major), camera->reference-ego rotation (9), camera origin (3) };
  * out bf16 [I*h*w, ldo >= 72]: [ sin(o_d 2^k pi), d-major, k < 8 | cos | sin(ray_d 2^k pi), k < 4 | cos ], rest zero. */
 int dwm_ray_features(const float* cam, int64_t I, int32_t h, int32_t w, void* out, int64_t ldo, void* stream);
+/* the same features in fp32 (the fp32 accuracy path: RayEncoder.proj then runs through dwm_gemm_f32) */
+int dwm_ray_features_f32(const float* cam, int64_t I, int32_t h, int32_t w, float* out, int64_t ldo, void* stream);
 
 /* out = coef[g][0] * x + coef[g][1] * y, fp32, one coefficient pair per group of `group_elems` consecutive elements
  * (g = element / group_elems); `out` (fp32) and / or `out_bf16` receive the result.  DDPMScheduler.add_noise / get_velocity

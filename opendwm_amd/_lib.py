@@ -143,6 +143,7 @@ SIGNATURES = {
     "dwm_unpatchify_f32": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dwm_cfg_euler_step_f32": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
     "dwm_ray_features": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "dwm_ray_features_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "dwm_frame_affine": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "dwm_cfg_ddim_step": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _f32, _i32, _vp]),
     "dwm_cfg_multistep": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),

@@ -210,8 +210,10 @@ cfg_ddim_kernel(const PT* __restrict__ pred, int64_t cond_offset, float* __restr
 // rotation), o (3, camera origin) } fp32.  out[(i*h + y)*w + x][0:72] = [ sin(o_d 2^k pi) (d-major, 24) | cos (24) |
 // sin(r_d 2^k pi) (12) | cos (12) ], columns [72, ldo) zero.  fp32 math with full-range sinf / cosf (arguments reach
 // 128 pi |o|).
+template <typename T>
 __global__ void __launch_bounds__(256)
-ray_features_kernel(const float* __restrict__ cam, int64_t I, int h, int w, bf16_t* __restrict__ out, int64_t ldo) {
+ray_features_kernel(const float* __restrict__ cam, int64_t I, int h, int w, T* __restrict__ out, int64_t ldo) {
+    auto cv = [](float v) { if constexpr (std::is_same<T, float>::value) return v; else return f32_to_bf16(v); };
     const int64_t tok = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tok >= I * h * w) return;
     const int x = (int)(tok % w), y = (int)((tok / w) % h);
@@ -223,24 +225,24 @@ ray_features_kernel(const float* __restrict__ cam, int64_t I, int h, int w, bf16
 #pragma unroll
     for (int a = 0; a < 3; ++a) r[a] = c[9 + 3 * a] * d[0] + c[9 + 3 * a + 1] * d[1] + c[9 + 3 * a + 2] * d[2];
     const float inv = 1.f / sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    bf16_t* o = out + tok * ldo;
+    T* o = out + tok * ldo;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float pos = c[18 + a], ray = r[a] * inv;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float v = pos * (3.14159265358979323846f * (float)(1 << k));
-            o[a * 8 + k] = f32_to_bf16(sinf(v));
-            o[24 + a * 8 + k] = f32_to_bf16(cosf(v));
+            o[a * 8 + k] = cv(sinf(v));
+            o[24 + a * 8 + k] = cv(cosf(v));
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float v = ray * (3.14159265358979323846f * (float)(1 << k));
-            o[48 + a * 4 + k] = f32_to_bf16(sinf(v));
-            o[60 + a * 4 + k] = f32_to_bf16(cosf(v));
+            o[48 + a * 4 + k] = cv(sinf(v));
+            o[60 + a * 4 + k] = cv(cosf(v));
         }
     }
-    for (int64_t k = 72; k < ldo; ++k) o[k] = 0;
+    for (int64_t k = 72; k < ldo; ++k) o[k] = T(0);
 }
 
 __global__ void __launch_bounds__(256)
@@ -467,8 +469,14 @@ extern "C" int dwm_cfg_ddim_step(const void* pred, int32_t pred_is_f32, int32_t 
 
 extern "C" int dwm_ray_features(const float* cam, int64_t I, int32_t h, int32_t w, void* out, int64_t ldo, void* stream) {
     if (cam == nullptr || out == nullptr || I <= 0 || h <= 0 || w <= 0 || ldo < 72) return DWM_EINVAL;
-    hipLaunchKernelGGL(ray_features_kernel, dim3(blocks_for(I * h * w)), dim3(256), 0, (hipStream_t)stream, cam, I, h, w,
+    hipLaunchKernelGGL(ray_features_kernel<bf16_t>, dim3(blocks_for(I * h * w)), dim3(256), 0, (hipStream_t)stream, cam, I, h, w,
                        (bf16_t*)out, ldo);
+    return finish();
+}
+
+extern "C" int dwm_ray_features_f32(const float* cam, int64_t I, int32_t h, int32_t w, float* out, int64_t ldo, void* stream) {
+    if (cam == nullptr || out == nullptr || I <= 0 || h <= 0 || w <= 0 || ldo < 72) return DWM_EINVAL;
+    hipLaunchKernelGGL(ray_features_kernel<float>, dim3(blocks_for(I * h * w)), dim3(256), 0, (hipStream_t)stream, cam, I, h, w, out, ldo);
     return finish();
 }
 

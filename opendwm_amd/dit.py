@@ -115,8 +115,8 @@ class RayEncoder(nn.Module):
         from .blocks import STORE
         w = self.proj.weight
 
-        def make():
-            wp = torch.zeros((w.shape[0], 128), dtype=bf16, device=w.device)
+        def make():                                   # (per compute precision: STORE.derived keys on it)
+            wp = torch.zeros((w.shape[0], 128), dtype=STORE.precision, device=w.device)
             wp[:, :w.shape[1]] = _bf(w)
             return wp
         return STORE.derived(w, "k128", make)
@@ -134,7 +134,9 @@ class RayEncoder(nn.Module):
         return torch.cat([torch.inverse(K).reshape(-1, 9), M[:, :3, :3].reshape(-1, 9), M[:, :3, 3]], 1).contiguous()
 
     def features(self, camera_intrinsics_norm, camera2referego, height: int, width: int) -> torch.Tensor:
-        return ops.ray_features(self.camera_rows(camera_intrinsics_norm, camera2referego, height, width), height, width, 128)
+        from .blocks import STORE
+        return ops.ray_features(self.camera_rows(camera_intrinsics_norm, camera2referego, height, width), height, width, 128,
+                                dtype=STORE.precision)
 
 
 class DiTCrossviewTemporalConditionModel(_Base):
@@ -413,9 +415,6 @@ class DiTCrossviewTemporalConditionModel(_Base):
         from .blocks import STORE
         cd = self.compute_dtype
         STORE.set_precision(cd)           # reset to bf16 by `forward` on the way out
-        if cd == torch.float32 and (fs is not None or self.perspective_modeling_type == "explicit"):
-            raise NotImplementedError("the fp32 accuracy path covers the text / text+layout models with implicit perspective "
-                                      "modelling (no explicit perspective modelling, no frame sharding)")
 
         def as_bf16(t):
             if cd == torch.float32:

@@ -867,12 +867,16 @@ def cfg_multistep(pred: torch.Tensor, latents: torch.Tensor, x0_prev: torch.Tens
                "dwm_cfg_multistep")
 
 
-def ray_features(cam: torch.Tensor, h: int, w: int, ldo: int = 128) -> torch.Tensor:
-    """cam fp32 [I, 21] (see dwm_ray_features) -> bf16 [I*h*w, ldo]: RayEncoder's 72 positional-encoding inputs per token."""
+def ray_features(cam: torch.Tensor, h: int, w: int, ldo: int = 128, dtype: torch.dtype = bf16) -> torch.Tensor:
+    """cam fp32 [I, 21] (see dwm_ray_features) -> bf16 (or, the fp32 accuracy path, fp32) [I*h*w, ldo]: RayEncoder's 72
+    positional-encoding inputs per token."""
     if cam.dtype != torch.float32 or cam.dim() != 2 or cam.shape[1] != 21 or not cam.is_contiguous() or not cam.is_cuda:
         raise RuntimeError("ray_features: cam must be a contiguous fp32 device tensor [I, 21]")
-    out = torch.empty((cam.shape[0] * h * w, ldo), dtype=bf16, device=cam.device)
-    _lib.check(_lib.load().dwm_ray_features(cam.data_ptr(), cam.shape[0], h, w, out.data_ptr(), ldo, _stream()), "dwm_ray_features")
+    if dtype not in (bf16, torch.float32):
+        raise RuntimeError("ray_features: bf16 or fp32 output")
+    out = torch.empty((cam.shape[0] * h * w, ldo), dtype=dtype, device=cam.device)
+    fn = "dwm_ray_features_f32" if dtype == torch.float32 else "dwm_ray_features"
+    _lib.check(getattr(_lib.load(), fn)(cam.data_ptr(), cam.shape[0], h, w, out.data_ptr(), ldo, _stream()), fn)
     return out
 
 

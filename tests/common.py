@@ -75,9 +75,11 @@ def check_mixer_gradients(mixers: dict, calls: list, flat_tol: float):
     (1) every captured kernel call equals the fp64 sum of its own inputs to fp32 accumulation accuracy, measured against the
     sum of the absolute terms (so the statement holds at any conditioning); (2) where the sum is reasonably conditioned
     (cond < 400) the gradient meets the flat tolerance; (3) the badly conditioned ones (a -9.7 out of +-1e4 terms) still meet a
-    bound that grows with the conditioning, 4e-4 x cond - the bf16 rounding of the activations and incoming gradients the sum
-    is handed, amplified by the cancellation - so a wrong operand, sign or scale reaching such a mixer (an O(1) relative error
-    at any conditioning below 2500) cannot pass on the strength of (1) alone."""
+    bound that grows with the conditioning, 8e-4 x cond - the bf16 rounding of the activations and incoming gradients the sum
+    is handed (2^-9 per operand, i.e. up to 2.8e-3 x cond if every term rounded the same way), amplified by the cancellation;
+    the observed errors wander between 3.4e-4 and 4.1e-4 x cond from run to run (the order of the fp32 atomics that finish
+    the upstream bias gradients, the reduction tree of the LayerNorm backward) - so a wrong operand, sign or scale reaching such
+    a mixer (an O(1) relative error at any conditioning below 1250) cannot pass on the strength of (1) alone."""
     worst_kernel = max((abs(c["kernel"] - c["exact"]) / max(c["abs"], 1e-300) for c in calls), default=0.0)
     assert len(calls) >= len(mixers) and worst_kernel < 2e-6, (len(calls), len(mixers), worst_kernel)
     for c in calls:
@@ -87,5 +89,5 @@ def check_mixer_gradients(mixers: dict, calls: list, flat_tol: float):
         if v["cond"] < 400:
             assert v["rel"] < flat_tol, (n, v)
         else:
-            assert v["rel"] < 4e-4 * v["cond"], (n, v)
+            assert v["rel"] < 8e-4 * v["cond"], (n, v)
     return worst_kernel

@@ -513,3 +513,77 @@ def test_unet_denoise_loop_fp32_vs_cpu_oracle(dev):
     e = rel_err(out, ref)
     _log("unet_denoise_loop_fp32", steps=steps, rel=e)
     assert den.model_in.dtype == f32 and e < TOL_F32, e
+
+
+# ------------------------------------------------------------------------- the variants the fp32 mode refused until round 4
+def test_model_explicit_perspective_fp32_vs_cpu_oracle(dev):
+    """perspective_modeling_type="explicit" (crossview_temporal_dit.py:11-102, 440-458) in the fp32 mode: the ray features in fp32
+    (dwm_ray_features_f32) against the oracle's positional encodings of the executed reference rays, RayEncoder.proj through
+    dwm_gemm_f32 inside every VT block, the whole forward against the CPU oracle and the executed reference forward"""
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "reference_forward.pt"))["explicit"]
+    cfg = small_config(perspective_modeling_type="explicit")
+    sd = O.make_state_dict(cfg, 0)
+    inp = small_inputs(cfg, 0)
+    inp.pop("added_time_ids")
+    cams = {k: fx[k] for k in ("camera_intrinsics_norm", "camera2referego")}
+    m = _fp32_model(cfg, sd, dev)
+    hh, ww = inp["sample"].shape[-2] // 2, inp["sample"].shape[-1] // 2
+    from opendwm_amd.blocks import STORE
+    STORE.set_precision(f32)
+    try:
+        feat = m.rayencoder.features(cams["camera_intrinsics_norm"].to(dev), cams["camera2referego"].to(dev), hh, ww)
+    finally:
+        STORE.set_precision(torch.bfloat16)
+    I = fx["rays_o"].shape[0]
+    want = torch.cat([O.positional_encoding(fx["rays_o"].unsqueeze(1), 8).view(I, 1, 1, -1).repeat(1, hh, ww, 1),
+                      O.positional_encoding(fx["rays_d"].flatten(1, 2), 4).view(I, hh, ww, -1)], -1).view(I * hh * ww, 72)
+    e_feat = (feat[:, :72].cpu() - want).abs().max().item()
+    assert feat.dtype == f32 and feat.shape == (I * hh * ww, 128) and torch.count_nonzero(feat[:, 72:]) == 0
+    ref = O.dit_forward(sd, cfg, **inp, **cams)
+    di = to_dev({**inp, **cams}, dev)
+    out, _, _ = m(di.pop("sample"), di.pop("timestep"), **di)
+    e, efx = rel_err(out[0], ref), rel_err(out[0], fx["output"])
+    _log("explicit_perspective_fp32", feature_max_abs=e_feat, rel_vs_oracle=e, rel_vs_reference_forward=efx)
+    # features: sin / cos of arguments up to 128 pi |o| (camera origins of a few metres): fp32 argument reduction, ~1e-4 absolute
+    assert out[0].dtype == f32 and e_feat < 5e-4 and e < TOL_F32 and efx < TOL_F32, (e_feat, e, efx)
+
+
+def _frame_shard_fp32_worker(rank, world, port, cfg, sd, lat, cond, path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opendwm_amd.pipeline import CTSDDenoiser
+    d = torch.device("cuda:0")
+    m = _fp32_model(cfg, sd, d)
+    out = CTSDDenoiser(m, guidance_scale=4.0, inference_steps=4, frame_group=dist.group.WORLD).run(lat.to(d), to_dev(cond, d))
+    torch.save(out.cpu(), f"{path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("temporal", ["rowwise", "pointwise"])
+def test_frame_shard_two_ranks_fp32_vs_cpu_oracle(dev, temporal):
+    """intra-sample frame sharding (opendwm_amd.sharding) in the fp32 mode: the 4 frames of one sample on two ranks (gloo, both on
+    the one GPU), fp32 hidden state through the all-to-alls around every temporal block; every rank returns the whole sample,
+    within the mode's tolerance of the CPU oracle's unsharded guided loop"""
+    import tempfile
+    import torch.multiprocessing as mp
+    cfg = small_config(temporal_attention_type=temporal)
+    sd = O.make_state_dict(cfg, 0)
+    inp = small_inputs(cfg, 0, T=4)
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    lat = torch.randn(1, 4, 3, 16, 8, 12, generator=torch.Generator().manual_seed(13))
+    ref = O.denoise(sd, cfg, lat, cond, steps=4, guidance_scale=4.0)
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() + 23) % 2000
+    path = os.path.join(tempfile.mkdtemp(), "frame_shard_fp32")
+    procs = [ctx.Process(target=_frame_shard_fp32_worker, args=(r, 2, port, cfg, sd, lat, cond, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    a, b = torch.load(path + ".0"), torch.load(path + ".1")
+    e = rel_err(a, ref)
+    _log("frame_shard_fp32", temporal=temporal, ranks_equal=bool(torch.equal(a, b)), rel_vs_oracle=e)
+    assert a.shape == ref.shape and torch.equal(a, b) and e < TOL_F32, e
