@@ -351,12 +351,17 @@ typedef struct dwm_gn_zmap {
 int dwm_groupnorm_spatial(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
                           const void* gamma, const void* beta, int32_t silu, float* stats,
                           const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap, void* stream);
+/* the same in fp32 (x, y, gamma, beta, zmap->mod fp32; ld_mod % 4 == 0; libm SiLU): the fp32 accuracy path of the temporal VAE */
+int dwm_groupnorm_spatial_f32(const float* x, float* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                              const float* gamma, const float* beta, int32_t silu, float* stats,
+                              const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap, void* stream);
 
 /* out frame j = w0[j] * x[f0[j]] + w1[j] * x[f1[j]] on frames of `frame_elems` contiguous bf16 elements: the temporal
  * average pooling of CogVideoXDownsample3D (0.5 / 0.5, first frame of an odd clip kept) and the temporal nearest
  * upsampling of CogVideoXUpsample3D (1 / 0 with repeated sources).  n_out <= 64. */
 typedef struct dwm_frame_mix { int32_t n_out; int32_t f0[64], f1[64]; float w0[64], w1[64]; } dwm_frame_mix;
 int dwm_frame_mix_bf16(const void* x, void* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream);
+int dwm_frame_mix_f32(const float* x, float* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream);   /* fp32 elements */
 
 /* F.interpolate(scale_factor=2, mode="nearest") of token-major x [I, h, w, C], written into the
  * padded grid y [I, 2h+2, 2w+2, C] (diffusers Upsample2D before its 3x3 conv). */
@@ -515,8 +520,11 @@ int dwm_cast_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int6
  * transcendental functions, and for the GEMM three bf16 MFMA products of a two-plane split of both operands.
  * ---------------------------------------------------------------------- */
 /* C fp32 = epilogue(A fp32 [M, K] x W^T).  W: the PRE-SPLIT bf16 weight [N, 3K] = [ hi | lo | hi ] with hi = bf16(w),
- * lo = bf16(w - hi) (opendwm_amd.ops.split_weight); bias / gate / res / blend / rms_w fp32.  workspace (16-byte aligned):
- * at least 4*M*K + 4*M*N bytes (+ 256).  No implicit convolution (ntaps / a_map / c_map) in this mode. */
+ * lo = bf16(w - hi) (opendwm_amd.ops.split_weight); bias / gate / res / blend / rms_w fp32.
+ * Implicit convolution as in dwm_gemm_bf16 (a_map / c_map / tap_shift, up to 27 taps): W = [ hi_t | lo_t | hi_t ] per tap t, taps in
+ * groups of 9 (group g = [N, 9 * 3 * k_per_tap] contiguous, groups one after the other; <= 9 taps: one group = the plain [N, 3K]).
+ * workspace (16-byte aligned): the two bf16 planes of A (4 * A rows * k_per_tap bytes, + 256) followed by the fp32 partial sums,
+ * 4*M*N bytes per group of taps (more, if given, lets the call split K over ranges when the tile grid is small). */
 int dwm_gemm_f32(const dwm_gemm_args* args, void* stream);
 /* fp32-I/O forms of the token-major glue kernels of the SD 2.1 UNet / the 2-D VAE / the layout ImageAdapter (same argument meaning
  * as the bf16 entry points above; gamma / beta fp32): GroupNorm(+SiLU) incl. the row-mapped form of TemporalResnetBlock

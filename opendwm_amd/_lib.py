@@ -160,6 +160,9 @@ SIGNATURES = {
     "dwm_groupnorm_spatial": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D),
                                      C.POINTER(GnImgMap), C.POINTER(GnZMap), _vp]),
     "dwm_frame_mix_bf16": (_i32, [_vp, _vp, _i64, C.POINTER(FrameMix), _vp]),
+    "dwm_frame_mix_f32": (_i32, [_vp, _vp, _i64, C.POINTER(FrameMix), _vp]),
+    "dwm_groupnorm_spatial_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _vp, C.POINTER(RowMap2D),
+                                         C.POINTER(GnImgMap), C.POINTER(GnZMap), _vp]),
     "dwm_softmax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _f32, _vp]),
     # training
     "dwm_transpose_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),

@@ -931,9 +931,13 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 30) || a->N >= (1ll << 31)) return DWM_EINVAL;
     if (a->K % BK != 0 || a->N % 8 != 0) return DWM_EUNSUPPORTED;
     // implicit convolution (a_map / c_map / taps as in dwm_gemm_bf16): every tap is walked as three plane taps (A_hi x W_hi, A_hi x
-    // W_lo, A_lo x W_hi), so at most 9 taps (a 3x3 kernel) fit the 27 tap slots; W is [N, ntaps * 3 * k_per_tap] (ops.split_weight)
+    // W_lo, A_lo x W_hi), so 9 taps (a 3x3 kernel) fill the 27 tap slots of one main-loop launch; W is [N, ntaps * 3 * k_per_tap]
+    // (ops.split_weight).  More taps (the 27 of a causal 3x3x3 convolution: the temporal VAE) run as GROUPS of 9 - one main-loop
+    // launch per group, each into its own fp32 partial slices, all summed in order by the one finishing kernel; W then holds the
+    // groups one after the other, group g = [N, taps_g * 3 * k_per_tap] contiguous.
     const int ctaps = a->ntaps > 0 ? a->ntaps : 1;
-    if (ctaps > 9) return DWM_EUNSUPPORTED;
+    if (ctaps > 27) return DWM_EUNSUPPORTED;
+    const int ngroups = (ctaps + 8) / 9;
     const int64_t kpt = a->ntaps > 0 ? a->k_per_tap : a->K;
     if (kpt <= 0 || kpt % BK != 0 || kpt * ctaps != a->K) return DWM_EINVAL;
     // rows of the A buffer (both planes cover all of them: taps reach into the padded border)
@@ -941,7 +945,13 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     if (a->a_map.rw > 0) {
         const int64_t ppi = a->a_map.rw * a->a_map.rh;
         if (a->a_map.rh <= 0 || a->M % ppi != 0) return DWM_EINVAL;
-        a_rows = (a->M / ppi) * a->a_map.ipitch;
+        // one past the last row any tap of any output pixel reads (every grid of opendwm_amd.ops ends exactly there: PaddedGrid
+        // and its stride-2 maps, TimeGrid, and Grid3D, whose two context frames sit in FRONT of the mapped images)
+        int64_t reach = 0;
+        for (int t = 0; t < ctaps && a->ntaps > 0; ++t) reach = a->tap_shift[t] > reach ? a->tap_shift[t] : reach;
+        a_rows = a->a_map.origin + (a->M / ppi - 1) * a->a_map.ipitch + (a->a_map.rh - 1) * a->a_map.rpitch +
+                 (a->a_map.rw - 1) * (a->a_map.xstep > 0 ? a->a_map.xstep : 1) + reach + 1;
+        if (a_rows <= 0) return DWM_EINVAL;
     } else if (a->ntaps > 0) return DWM_EUNSUPPORTED;            // taps need the padded-grid map
     if (a->lda % 4 != 0 || a->ldc % 4 != 0 || !dwm_aligned16(a->A) || !dwm_aligned16(a->W) || !dwm_aligned16(a->C) ||
         !dwm_aligned16(a->workspace)) return DWM_EALIGN;
@@ -963,16 +973,18 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     // workspace: [A_hi ; A_lo] bf16 planes, then the fp32 partial sums
     const int64_t plane_bytes = ((2 * a_rows * kpt * 2 + 255) / 256) * 256;
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);
-    const int64_t tiles = (int64_t)ntm * ntn, nk = 3 * a->K / BK, slice_bytes = a->M * a->N * 4;
+    // (K ranges per launch: chosen for the shortest group, so that every range of every group has K steps)
+    const int last_taps = ctaps - 9 * (ngroups - 1);
+    const int64_t tiles = (int64_t)ntm * ntn, nk = 3 * kpt * last_taps / BK, slice_bytes = a->M * a->N * 4;
     int ksplit = 1;
-    if (tiles <= 128 && nk >= 16) {
-        ksplit = (int)(256 / tiles);
+    if (tiles * ngroups <= 128 && nk >= 16) {
+        ksplit = (int)(256 / (tiles * ngroups));
         if (ksplit > nk / 8) ksplit = (int)(nk / 8);
-        if (ksplit > 32) ksplit = 32;
+        if (ksplit > 32 / ngroups) ksplit = 32 / ngroups;
         if (ksplit < 1) ksplit = 1;
     }
-    while (ksplit > 1 && plane_bytes + ksplit * slice_bytes > a->workspace_bytes) --ksplit;
-    if (plane_bytes + slice_bytes > a->workspace_bytes) return DWM_EINVAL;
+    while (ksplit > 1 && plane_bytes + (int64_t)ngroups * ksplit * slice_bytes > a->workspace_bytes) --ksplit;
+    if (plane_bytes + (int64_t)ngroups * slice_bytes > a->workspace_bytes) return DWM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     bf16_t* planes = (bf16_t*)a->workspace;
     {
@@ -981,7 +993,7 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
                            kpt, planes);
     }
     dwm_gemm_args g = *a;
-    g.A = planes; g.lda = kpt; g.K = 3 * a->K;
+    g.A = planes; g.lda = kpt;
     ConvParams cp;
     auto mk = [](const dwm_rowmap2d& r, DevRowMap& d) -> bool {
         d.enabled = r.rw > 0;
@@ -998,13 +1010,8 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     cp.fd_rpg = make_fastdiv((uint32_t)(a->rows_per_gate > 0 ? a->rows_per_gate : 1));
     cp.fd_rmod = make_fastdiv((uint32_t)(a->res_mod > 0 ? a->res_mod : a->res_mod < 0 ? -a->res_mod : 1));
     cp.fd_rpa = make_fastdiv((uint32_t)(a->rows_per_alpha > 0 ? a->rows_per_alpha : 1));
-    for (int t = 0; t < 27; ++t) cp.tap_shift[t] = 0;
-    for (int t = 0; t < ctaps; ++t) {                 // per tap: A_hi (x W_hi), A_hi (x W_lo), A_lo (x W_hi)
-        const int64_t sh = a->ntaps > 0 ? a->tap_shift[t] : 0;
-        cp.tap_shift[3 * t] = sh; cp.tap_shift[3 * t + 1] = sh; cp.tap_shift[3 * t + 2] = sh + a_rows;
-    }
     cp.ksplit = ksplit;
-    cp.ws = (float*)((char*)a->workspace + plane_bytes);
+    float* const ws_base = (float*)((char*)a->workspace + plane_bytes);
     cp.ws_slice = a->M * a->N;
     hipError_t e;
     {
@@ -1016,8 +1023,21 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
         }
     }
     g.reserved = 0;
-    set_raster(cp, g, ntn);
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI_SPLITK>, dim3((unsigned)(ntm * ntn * ksplit)), dim3(512), LDS_BYTES, s, g, cp, ntm, ntn);
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int tg = gi + 1 < ngroups ? 9 : last_taps;
+        g.K = 3 * kpt * tg;
+        g.W = (const bf16_t*)a->W + (int64_t)a->N * (3 * kpt * 9) * gi;
+        for (int t = 0; t < 27; ++t) cp.tap_shift[t] = 0;
+        for (int t = 0; t < tg; ++t) {                // per tap: A_hi (x W_hi), A_hi (x W_lo), A_lo (x W_hi)
+            const int64_t sh = a->ntaps > 0 ? a->tap_shift[9 * gi + t] : 0;
+            cp.tap_shift[3 * t] = sh; cp.tap_shift[3 * t + 1] = sh; cp.tap_shift[3 * t + 2] = sh + a_rows;
+        }
+        cp.ws = ws_base + (int64_t)gi * ksplit * cp.ws_slice;
+        set_raster(cp, g, ntn);
+        hipLaunchKernelGGL(gemm_bf16_kernel<EPI_SPLITK>, dim3((unsigned)(ntm * ntn * ksplit)), dim3(512), LDS_BYTES, s, g, cp, ntm, ntn);
+    }
+    cp.ws = ws_base;
+    cp.ksplit = ngroups * ksplit;                     // the finishing kernel sums every range of every group, in order
     const int64_t nthr = a->M * (nout >> 3);
     const dim3 fg((unsigned)((nthr + 255) / 256));
     switch (a->epilogue) {

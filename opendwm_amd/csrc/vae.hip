@@ -127,14 +127,15 @@ gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t I, int64_t P
 // ---- CogVideoXSpatialNorm3D apply: GroupNorm statistics as above, then * conv_y(zq) + conv_b(zq) gathered from the
 //      latent-resolution modulation rows (nearest resize folded into the index), optional SiLU
 struct ZMap {
-    const bf16_t* mod; int64_t ld_mod;
+    const void* mod; int64_t ld_mod;
     FastDiv n, w, b;          // pixels per frame, width, videos
     int hz, wz, shift;
     int zt[32];
 };
+template <typename T>     // (float: dwm_groupnorm_spatial_f32, the fp32 accuracy path of the temporal VAE)
 __global__ void __launch_bounds__(256)
-gn_spatial_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t I, int64_t P, int C, int G,
-                        const float* __restrict__ stats, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+gn_spatial_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t I, int64_t P, int C, int G,
+                        const float* __restrict__ stats, const T* __restrict__ gamma, const T* __restrict__ beta,
                         float eps, int silu, PadMap pm, ImgMap im, ZMap zm) {
     const int C8 = C >> 3, CG = C / G;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,38 +161,41 @@ gn_spatial_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, in
     const uint32_t yy = fdiv(pix, zm.w), xx = pix - yy * zm.w.d;
     const int64_t zr = (((int64_t)zm.zt[t] * zm.b.d + b) * zm.hz + (yy >> zm.shift)) * zm.wz + (xx >> zm.shift);
     float v[8], ga[8], be[8], my[8], mb[8];
-    unpack8(*(const uint4*)(x + r * C + c8 * 8), v);
-    unpack8(*(const uint4*)(gamma + c8 * 8), ga);
-    unpack8(*(const uint4*)(beta + c8 * 8), be);
-    unpack8(*(const uint4*)(zm.mod + zr * zm.ld_mod + c8 * 8), my);
-    unpack8(*(const uint4*)(zm.mod + zr * zm.ld_mod + C + c8 * 8), mb);
+    const T* __restrict__ mod = (const T*)zm.mod;
+    load8<T>(x + r * C + c8 * 8, v);
+    load8<T>(gamma + c8 * 8, ga);
+    load8<T>(beta + c8 * 8, be);
+    load8<T>(mod + zr * zm.ld_mod + c8 * 8, my);
+    load8<T>(mod + zr * zm.ld_mod + C + c8 * 8, mb);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int hf = j < bnd ? 0 : 1;
         const float tv = ((v[j] - mean[hf]) * rstd[hf] * ga[j] + be[j]) * my[j] + mb[j];
-        v[j] = silu ? silu_f(tv) : tv;
+        if (sizeof(T) == 4) v[j] = silu ? tv / (1.f + expf(-tv)) : tv;       // fp32 path: libm-accurate SiLU
+        else v[j] = silu ? silu_f(tv) : tv;
     }
-    *(uint4*)(y + pad_row(pm, r) * C + c8 * 8) = pack8(v);
+    store8<T>(y + pad_row(pm, r) * C + c8 * 8, v);
 }
 
 // ---- out frame j = w0 * x[f0] + w1 * x[f1]
 struct FrameMix { int n_out; int f0[64], f1[64]; float w0[64], w1[64]; };
+template <typename T>
 __global__ void __launch_bounds__(256)
-frame_mix_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t fe8, FrameMix fm) {
+frame_mix_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t fe8, FrameMix fm) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= fe8) return;
     const int j = blockIdx.y;
     float a[8], b[8];
-    unpack8(*(const uint4*)(x + ((int64_t)fm.f0[j] * fe8 + idx) * 8), a);
+    load8<T>(x + ((int64_t)fm.f0[j] * fe8 + idx) * 8, a);
     if (fm.w1[j] != 0.f) {
-        unpack8(*(const uint4*)(x + ((int64_t)fm.f1[j] * fe8 + idx) * 8), b);
+        load8<T>(x + ((int64_t)fm.f1[j] * fe8 + idx) * 8, b);
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] = fm.w0[j] * a[k] + fm.w1[j] * b[k];
     } else if (fm.w0[j] != 1.f) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] *= fm.w0[j];
     }
-    *(uint4*)(y + ((int64_t)j * fe8 + idx) * 8) = pack8(a);
+    store8<T>(y + ((int64_t)j * fe8 + idx) * 8, a);
 }
 
 // ---- copy compact token rows into a (zero-bordered) padded grid
@@ -450,20 +454,23 @@ static int groupnorm_impl(const void* x, void* y, int64_t I, int64_t P, int32_t 
     }
     const int64_t total = I * P * (C / 8);
     if (zmap != nullptr) {
-        if (f32) return DWM_EUNSUPPORTED;
         if (zmap->mod == nullptr || zmap->frames <= 0 || zmap->frames > 32 || zmap->videos <= 0 || zmap->h <= 0 || zmap->w <= 0 ||
-            zmap->shift < 0 || zmap->shift > 8 || zmap->ld_mod < 2 * C || zmap->ld_mod % 8 != 0 || !dwm_aligned16(zmap->mod))
+            zmap->shift < 0 || zmap->shift > 8 || zmap->ld_mod < 2 * C || zmap->ld_mod % (f32 ? 4 : 8) != 0 || !dwm_aligned16(zmap->mod))
             return DWM_EINVAL;
         if ((int64_t)zmap->frames * zmap->videos * zmap->h * zmap->w != I * P) return DWM_EINVAL;
         if ((zmap->h >> zmap->shift) << zmap->shift != zmap->h || (zmap->w >> zmap->shift) << zmap->shift != zmap->w) return DWM_EINVAL;
         ZMap zm;
-        zm.mod = (const bf16_t*)zmap->mod; zm.ld_mod = zmap->ld_mod;
+        zm.mod = zmap->mod; zm.ld_mod = zmap->ld_mod;
         zm.n = make_fastdiv((uint32_t)(zmap->h * zmap->w)); zm.w = make_fastdiv((uint32_t)zmap->w);
         zm.b = make_fastdiv((uint32_t)zmap->videos);
         zm.hz = zmap->h >> zmap->shift; zm.wz = zmap->w >> zmap->shift; zm.shift = zmap->shift;
         for (int t = 0; t < 32; ++t) zm.zt[t] = t < zmap->frames ? zmap->zt[t] : 0;
-        hipLaunchKernelGGL(gn_spatial_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
-                           (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im, zm);
+        if (f32)
+            hipLaunchKernelGGL(gn_spatial_apply_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)x,
+                               (float*)y, I, P, C, G, stats, (const float*)gamma, (const float*)beta, eps, silu, pm, im, zm);
+        else
+            hipLaunchKernelGGL(gn_spatial_apply_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
+                               (bf16_t*)y, I, P, C, G, stats, (const bf16_t*)gamma, (const bf16_t*)beta, eps, silu, pm, im, zm);
         return finish();
     }
     if (f32)
@@ -549,7 +556,15 @@ extern "C" int dwm_groupnorm_spatial(const void* x, void* y, int64_t I, int64_t 
     return groupnorm_impl(x, y, I, P, C, G, eps, gamma, beta, silu, stats, out_map, img_map, zmap, stream);
 }
 
-extern "C" int dwm_frame_mix_bf16(const void* x, void* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream) {
+extern "C" int dwm_groupnorm_spatial_f32(const float* x, float* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,
+                                         const float* gamma, const float* beta, int32_t silu, float* stats,
+                                         const dwm_rowmap2d* out_map, const dwm_gn_imgmap* img_map, const dwm_gn_zmap* zmap,
+                                         void* stream) {
+    if (zmap == nullptr) return DWM_EINVAL;
+    return groupnorm_impl(x, y, I, P, C, G, eps, gamma, beta, silu, stats, out_map, img_map, zmap, stream, true);
+}
+
+static int frame_mix_impl(const void* x, void* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream, bool f32) {
     if (x == nullptr || y == nullptr || mix == nullptr || frame_elems <= 0 || mix->n_out <= 0 || mix->n_out > 64) return DWM_EINVAL;
     if (frame_elems % 8 != 0) return DWM_EUNSUPPORTED;
     if (!dwm_aligned16(x) || !dwm_aligned16(y)) return DWM_EALIGN;
@@ -562,9 +577,16 @@ extern "C" int dwm_frame_mix_bf16(const void* x, void* y, int64_t frame_elems, c
         fm.w0[j] = ok ? mix->w0[j] : 0.f; fm.w1[j] = ok ? mix->w1[j] : 0.f;
     }
     const int64_t fe8 = frame_elems / 8;
-    hipLaunchKernelGGL(frame_mix_kernel, dim3((unsigned)((fe8 + 255) / 256), (unsigned)mix->n_out), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (bf16_t*)y, fe8, fm);
+    const dim3 grid((unsigned)((fe8 + 255) / 256), (unsigned)mix->n_out);
+    if (f32) hipLaunchKernelGGL(frame_mix_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, fe8, fm);
+    else hipLaunchKernelGGL(frame_mix_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, fe8, fm);
     return finish();
+}
+extern "C" int dwm_frame_mix_bf16(const void* x, void* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream) {
+    return frame_mix_impl(x, y, frame_elems, mix, stream, false);
+}
+extern "C" int dwm_frame_mix_f32(const float* x, float* y, int64_t frame_elems, const dwm_frame_mix* mix, void* stream) {
+    return frame_mix_impl(x, y, frame_elems, mix, stream, true);
 }
 
 extern "C" int dwm_groupnorm_silu(const void* x, void* y, int64_t I, int64_t P, int32_t C, int32_t G, float eps,

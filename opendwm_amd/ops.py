@@ -286,7 +286,9 @@ SPLIT_WEIGHT_CACHE_MAX = 2048        # > the ~1300 weight matrices of the larges
 
 def split_weight(w: torch.Tensor, taps: int = 1, cache: bool = True) -> torch.Tensor:
     """fp32 [N, K] -> the pre-split bf16 operand [N, 3K] of dwm_gemm_f32 (hi = bf16(w), lo = bf16(w - hi)): [hi | lo | hi], or -
-    `taps` > 1, K = taps x C tap-major (implicit convolution) - [hi_t | lo_t | hi_t] per tap t.
+    `taps` > 1, K = taps x C tap-major (implicit convolution) - [hi_t | lo_t | hi_t] per tap t; more than 9 taps (the 27 of a causal
+    3x3x3 convolution) are laid out as groups of 9, group g = [N, 9 * 3C] contiguous, one after the other (dwm_gemm_f32 walks a
+    group per main-loop launch).
     Cached on the tensor's storage / version (weights and packed weights are long-lived), at most SPLIT_WEIGHT_CACHE_MAX entries
     (least recently used first out: per-call temporaries must not pile up); `clear_split_weights()` drops everything."""
     key = (w.data_ptr(), w._version, tuple(w.shape), taps)
@@ -297,7 +299,11 @@ def split_weight(w: torch.Tensor, taps: int = 1, cache: bool = True) -> torch.Te
         if taps > 1:
             N, K = w.shape
             h3, l3 = hi.view(N, taps, K // taps), lo.view(N, taps, K // taps)
-            ws = torch.stack([h3, l3, h3], 2).reshape(N, 3 * K).contiguous()
+            ws = torch.stack([h3, l3, h3], 2)                                  # [N, taps, 3, C]
+            if taps > 9:
+                ws = torch.cat([ws[:, t0:t0 + 9].reshape(-1) for t0 in range(0, taps, 9)]).view(N, 3 * K)
+            else:
+                ws = ws.reshape(N, 3 * K).contiguous()
         else:
             ws = torch.cat([hi, lo, hi], 1).contiguous()
         hit = (ws, w)                                               # keeps `w` alive: its address is the key
@@ -322,8 +328,8 @@ def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_m
         raise RuntimeError("w must be contiguous [N, K]")
     N, K = w.shape
     taps = 9 if conv3x3 else len(conv_taps) if conv_taps is not None else 1
-    if taps > 9:
-        raise NotImplementedError("gemm (fp32): at most 9 taps (each is walked as three plane products: 27 tap slots)")
+    if taps > 27:
+        raise NotImplementedError("gemm (fp32): at most 27 taps (three groups of 9, each tap walked as three plane products)")
     if a_grid is not None:
         if a.shape[0] != a_grid.rows or a.shape[1] * taps != K or not a.is_contiguous():
             raise RuntimeError(f"gemm: padded A {tuple(a.shape)} does not match grid / weight {tuple(w.shape)}")
@@ -382,9 +388,10 @@ def _gemm_f32(a, w, bias, *, out, epilogue, act, gate, rows_per_gate, res, res_m
     if rms_w is not None:
         _chkvec(rms_w, "rms_w", f32)
         g.rms_w, g.rms_ncols, g.rms_eps = rms_w.data_ptr(), rms_ncols, rms_eps
-    need = 4 * a_rows * (K // taps) + 256 + 4 * M * N
+    groups = (taps + 8) // 9                                  # one set of fp32 partial slices per group of 9 taps
+    need = 4 * a_rows * (K // taps) + 256 + 4 * M * N * groups
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    if tiles <= 128:
+    if tiles * groups <= 128:
         need += 4 * M * N * min(32, 256 // tiles)          # room for the kernel's own split-K rule
     wsb = _f32_workspace(a.device, need)
     g.workspace, g.workspace_bytes = wsb.data_ptr(), wsb.numel() * 4
@@ -995,16 +1002,14 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
     im = _lib.GnImgMap()
     if img_map is not None:
         im.iv, im.pn, im.s_ihi, im.s_ilo, im.s_phi = img_map
-    if dt == torch.float32:
-        if zmap is not None:
-            raise NotImplementedError("groupnorm_silu: the spatial (CogVideoX) form has no fp32 path")
+    if dt == torch.float32 and zmap is None:
         _lib.check(_lib.load().dwm_groupnorm_silu_f32(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
                                                       beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
                                                       _stream()), "dwm_groupnorm_silu_f32")
         return out
     if zmap is not None:
         mod = zmap["mod"]
-        _chk2d(mod, "zmap.mod")
+        _chk2d(mod, "zmap.mod", dt)
         zm = _lib.GnZMap()
         zm.mod, zm.ld_mod = mod.data_ptr(), mod.stride(0)
         zm.frames, zm.videos, zm.h, zm.w, zm.shift = zmap["frames"], zmap["videos"], zmap["h"], zmap["w"], zmap["shift"]
@@ -1013,9 +1018,9 @@ def groupnorm_silu(x: torch.Tensor, I: int, P: int, gamma: torch.Tensor, beta: t
         need = ((max(zmap["zt"]) + 1) * zmap["videos"]) * (zmap["h"] >> zmap["shift"]) * (zmap["w"] >> zmap["shift"])
         if mod.shape[0] < need or mod.shape[1] < 2 * Cc:
             raise RuntimeError("groupnorm_silu: zmap.mod is smaller than the latent grid it is indexed with")
-        _lib.check(_lib.load().dwm_groupnorm_spatial(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
-                                                     beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
-                                                     C.byref(zm), _stream()), "dwm_groupnorm_spatial")
+        fn = "dwm_groupnorm_spatial_f32" if dt == torch.float32 else "dwm_groupnorm_spatial"
+        _lib.check(getattr(_lib.load(), fn)(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(), beta.data_ptr(),
+                                            int(silu), stats.data_ptr(), C.byref(m), C.byref(im), C.byref(zm), _stream()), fn)
         return out
     _lib.check(_lib.load().dwm_groupnorm_silu_mapped(x.data_ptr(), out.data_ptr(), I, P, Cc, groups, eps, gamma.data_ptr(),
                                                      beta.data_ptr(), int(silu), stats.data_ptr(), C.byref(m), C.byref(im),
@@ -1027,20 +1032,22 @@ def frame_mix(x: torch.Tensor, frame_elems: int, f0, f1, w0, w1, out: Optional[t
     """out frame j = w0[j] * x[f0[j]] + w1[j] * x[f1[j]] over frames of `frame_elems` contiguous bf16 elements of the
     flat tensor x (temporal average pooling / temporal nearest upsampling of the CogVideoX VAE)."""
     n = len(f0)
-    if x.dtype != bf16 or not x.is_cuda or not x.is_contiguous() or x.numel() % frame_elems != 0:
-        raise RuntimeError("frame_mix: x must be a contiguous bf16 device tensor of whole frames")
+    dt = x.dtype
+    if dt not in (bf16, torch.float32) or not x.is_cuda or not x.is_contiguous() or x.numel() % frame_elems != 0:
+        raise RuntimeError("frame_mix: x must be a contiguous bf16 (or, the fp32 accuracy path, fp32) device tensor of whole frames")
     nin = x.numel() // frame_elems
     if not (len(f1) == len(w0) == len(w1) == n) or n == 0 or n > 64 or max(max(f0), max(f1)) >= nin:
         raise RuntimeError("frame_mix: bad frame tables")
     if out is None:
-        out = torch.empty(n * frame_elems, dtype=bf16, device=x.device)
-    if out.numel() != n * frame_elems or out.dtype != bf16 or not out.is_contiguous():
+        out = torch.empty(n * frame_elems, dtype=dt, device=x.device)
+    if out.numel() != n * frame_elems or out.dtype != dt or not out.is_contiguous():
         raise RuntimeError("frame_mix: bad out")
     fm = _lib.FrameMix()
     fm.n_out = n
     for j in range(n):
         fm.f0[j], fm.f1[j], fm.w0[j], fm.w1[j] = f0[j], f1[j], w0[j], w1[j]
-    _lib.check(_lib.load().dwm_frame_mix_bf16(x.data_ptr(), out.data_ptr(), frame_elems, C.byref(fm), _stream()), "dwm_frame_mix_bf16")
+    fn = "dwm_frame_mix_f32" if dt == torch.float32 else "dwm_frame_mix_bf16"
+    _lib.check(getattr(_lib.load(), fn)(x.data_ptr(), out.data_ptr(), frame_elems, C.byref(fm), _stream()), fn)
     return out
 
 

@@ -30,7 +30,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .blocks import _bf
+from .blocks import STORE, _bf
 from .ops import EPI_RESID, Grid3D, PaddedGrid
 from .vae import AutoencoderKL, DiagonalGaussianDistribution, _conv3_w
 
@@ -194,6 +194,10 @@ class AutoencoderKLCogVideoX(nn.Module):
             up_block_types=up_block_types or ("CogVideoXUpBlock3D",) * len(block_out_channels))
         self.num_latent_frames_batch_size = 2
         self.num_sample_frames_batch_size = 8
+        # bf16 (storage bf16, fp32 accumulation / statistics), or torch.float32: the fp32 accuracy path (north_star's 1e-3) - the
+        # causal 3x3x3 convolutions through dwm_gemm_f32 (27 taps as three groups of 9), GroupNorm / spatial norm / frame mixes /
+        # resampling in their fp32 forms; the reference runs this VAE in whatever dtype the caller loaded it in
+        self.compute_dtype = bf16
         self._scratch: Dict[tuple, torch.Tensor] = {}
         self._packed: Dict[int, torch.Tensor] = {}
 
@@ -215,18 +219,19 @@ class AutoencoderKLCogVideoX(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def packed(self, module: nn.Module, make) -> torch.Tensor:
-        t = self._packed.get(id(module))
+        key = (id(module), STORE.precision)                  # one set per compute precision
+        t = self._packed.get(key)
         if t is None:
-            t = self._packed[id(module)] = make()
+            t = self._packed[key] = make()
         return t
 
     def scratch(self, grid, channels: int) -> torch.Tensor:
         """zero-bordered padded buffers, reused: every producer rewrites the whole interior, the border stays zero"""
-        key = (type(grid).__name__,) + tuple(getattr(grid, f) for f in grid.__dataclass_fields__) + (channels,)
+        key = (type(grid).__name__,) + tuple(getattr(grid, f) for f in grid.__dataclass_fields__) + (channels, STORE.precision)
         dev = self.decoder.conv_in.conv.weight.device
         buf = self._scratch.get(key)
         if buf is None or buf.device != dev:
-            buf = self._scratch[key] = torch.zeros((grid.rows, channels), dtype=bf16, device=dev)
+            buf = self._scratch[key] = torch.zeros((grid.rows, channels), dtype=STORE.precision, device=dev)
         return buf
 
     @staticmethod
@@ -235,7 +240,7 @@ class AutoencoderKLCogVideoX(nn.Module):
         w = _bf(conv.weight)
         n, c = w.shape[:2]
         cp, npad = k_pad or c, n_pad or n
-        t = torch.zeros((npad, 3, 3, 3, cp), dtype=bf16, device=w.device)
+        t = torch.zeros((npad, 3, 3, 3, cp), dtype=w.dtype, device=w.device)
         t[:n, ..., :c] = w.permute(0, 2, 3, 4, 1)
         return t.reshape(npad, 27 * cp).contiguous()
 
@@ -253,7 +258,7 @@ class AutoencoderKLCogVideoX(nn.Module):
         w = self.packed(mod, lambda: self._conv27_w(mod.conv, buf.shape[1], n_pad))
         bias = _bf(mod.conv.bias)
         if n_pad is not None and n_pad != bias.shape[0]:
-            bias = self.packed(mod.conv, lambda: torch.cat([bias, torch.zeros(n_pad - bias.shape[0], dtype=bf16, device=bias.device)]))
+            bias = self.packed(mod.conv, lambda: torch.cat([bias, torch.zeros(n_pad - bias.shape[0], dtype=bias.dtype, device=bias.device)]))
         return ops.gemm(buf, w, bias, a_grid=grid, conv_taps=grid.tap_shifts(), **kw)
 
     def norm_to_grid(self, ctx: _Ctx, norm: nn.Module, x: torch.Tensor, grid: Grid3D, groups: int, eps: float) -> torch.Tensor:
@@ -266,7 +271,7 @@ class AutoencoderKLCogVideoX(nn.Module):
                                       img_map=imap)
         def make():
             zc = norm.conv_y.conv.weight.shape[1]
-            wyb = torch.zeros((2 * C_, ctx.zrows.shape[1]), dtype=bf16, device=x.device)
+            wyb = torch.zeros((2 * C_, ctx.zrows.shape[1]), dtype=STORE.precision, device=x.device)
             wyb[:C_, :zc] = _bf(norm.conv_y.conv.weight).reshape(C_, zc)
             wyb[C_:, :zc] = _bf(norm.conv_b.conv.weight).reshape(C_, zc)
             return wyb
@@ -318,14 +323,18 @@ class AutoencoderKLCogVideoX(nn.Module):
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         """x [B, 3, T, H, W] in [-1, 1] -> object with .latent_dist over the moments [B, 2*latent, T', H/8, W/8]
         (ctsd.py:1206-1218: `.latent_dist.sample()`; :1689-1694 `.mode()`)."""
-        from .blocks import STORE
-        STORE.set_precision(torch.bfloat16)
         if not x.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
         if x.dim() != 5:
             raise ValueError("AutoencoderKLCogVideoX.encode expects [B, C, T, H, W]")
-        ctx = _Ctx(self, x.shape[0], x.device)
-        parts = [self._encode_chunk(ctx, x[:, :, a:b]) for a, b in _chunks(x.shape[2], self.num_sample_frames_batch_size)]
+        if self.compute_dtype not in (bf16, torch.float32):
+            raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
+        STORE.set_precision(self.compute_dtype)
+        try:
+            ctx = _Ctx(self, x.shape[0], x.device)
+            parts = [self._encode_chunk(ctx, x[:, :, a:b]) for a, b in _chunks(x.shape[2], self.num_sample_frames_batch_size)]
+        finally:
+            STORE.set_precision(bf16)
         dist = DiagonalGaussianDistribution(torch.cat(parts, 2).float())
         if return_dict:
             return types.SimpleNamespace(latent_dist=dist)
@@ -334,10 +343,13 @@ class AutoencoderKLCogVideoX(nn.Module):
     def _encode_chunk(self, ctx: _Ctx, x: torch.Tensor) -> torch.Tensor:
         e = self.encoder
         B, ic, T, H, W = x.shape
+        cd = STORE.precision
         xt = x.permute(2, 0, 1, 3, 4).reshape(T * B, ic, H, W).contiguous()
-        if xt.dtype not in (torch.float32, bf16):
+        if cd == torch.float32:
+            xt = xt.float()
+        elif xt.dtype not in (torch.float32, bf16):
             xt = xt.to(bf16)
-        tok = ops.unshuffle_tokens(xt, 1, 64 * ((ic + 63) // 64))
+        tok = ops.unshuffle_tokens(xt, 1, 64 * ((ic + 63) // 64), dtype=cd)
         grid = Grid3D(T, B, H, W)
         buf = ops.pad_tokens(tok, grid, out=self.scratch(grid, tok.shape[1]))
         hcur = self.causal_conv(ctx, e.conv_in, buf, grid)
@@ -358,15 +370,19 @@ class AutoencoderKLCogVideoX(nn.Module):
     # ------------------------------------------------------------------ decode
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
-        """z [B, latent, T', h, w] -> frames [B, 3, T, 8h, 8w] (bf16); 1-tuple like diffusers' decode(return_dict=False)"""
-        from .blocks import STORE
-        STORE.set_precision(torch.bfloat16)
+        """z [B, latent, T', h, w] -> frames [B, 3, T, 8h, 8w] (in compute_dtype); 1-tuple like diffusers' decode(return_dict=False)"""
         if not z.is_cuda:
             raise RuntimeError("opendwm_amd VAE runs on an MI355X (HIP) device only")
         if z.dim() != 5:
             raise ValueError("AutoencoderKLCogVideoX.decode expects [B, C, T, h, w]")
-        ctx = _Ctx(self, z.shape[0], z.device)
-        parts = [self._decode_chunk(ctx, z[:, :, a:b]) for a, b in _chunks(z.shape[2], self.num_latent_frames_batch_size)]
+        if self.compute_dtype not in (bf16, torch.float32):
+            raise ValueError("compute_dtype must be torch.bfloat16 or torch.float32")
+        STORE.set_precision(self.compute_dtype)
+        try:
+            ctx = _Ctx(self, z.shape[0], z.device)
+            parts = [self._decode_chunk(ctx, z[:, :, a:b]) for a, b in _chunks(z.shape[2], self.num_latent_frames_batch_size)]
+        finally:
+            STORE.set_precision(bf16)
         out = torch.cat(parts, 2)
         if return_dict:
             return types.SimpleNamespace(sample=out)
@@ -375,10 +391,13 @@ class AutoencoderKLCogVideoX(nn.Module):
     def _decode_chunk(self, ctx: _Ctx, z: torch.Tensor) -> torch.Tensor:
         d = self.decoder
         B, lc, T, h, w = z.shape
+        cd = STORE.precision
         zt = z.permute(2, 0, 1, 3, 4).reshape(T * B, lc, h, w).contiguous()
-        if zt.dtype not in (torch.float32, bf16):
+        if cd == torch.float32:
+            zt = zt.float()
+        elif zt.dtype not in (torch.float32, bf16):
             zt = zt.to(bf16)
-        ctx.zrows = ops.unshuffle_tokens(zt, 1, 64 * ((lc + 63) // 64))     # [T*B*h*w, 64]: zq of every spatial norm
+        ctx.zrows = ops.unshuffle_tokens(zt, 1, 64 * ((lc + 63) // 64), dtype=cd)     # [T*B*h*w, 64]: zq of every spatial norm
         ctx.Tz, ctx.hz, ctx.wz = T, h, w
         grid = Grid3D(T, B, h, w)
         buf = ops.pad_tokens(ctx.zrows, grid, out=self.scratch(grid, ctx.zrows.shape[1]))

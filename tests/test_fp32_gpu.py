@@ -587,3 +587,127 @@ def test_frame_shard_two_ranks_fp32_vs_cpu_oracle(dev, temporal):
     e = rel_err(a, ref)
     _log("frame_shard_fp32", temporal=temporal, ranks_equal=bool(torch.equal(a, b)), rel_vs_oracle=e)
     assert a.shape == ref.shape and torch.equal(a, b) and e < TOL_F32, e
+
+
+# ------------------------------------------------------------------------- the temporal VAE (AutoencoderKLCogVideoX) in fp32
+def test_temporal_vae_kernels_f32(dev):
+    """the fp32 forms the temporal VAE adds: the 27-tap causal convolution through dwm_gemm_f32 (three groups of 9 taps, Grid3D with
+    its two leading context frames), frame mixes, CogVideoXSpatialNorm3D (dwm_groupnorm_spatial_f32)"""
+    import torch.nn.functional as F
+    from oracle import cogvideox_vae_oracle as CV
+    from opendwm_amd import ops
+    from opendwm_amd.vae_cogvideox import _Ctx
+    # causal 3x3x3 convolution, first call (frame 0 twice) and continuation (cache of the previous call)
+    T, B, h, w, Cc, N = 3, 2, 4, 6, 64, 72
+    x1, x2 = _rand((B, Cc, T, h, w), dev, 1), _rand((B, Cc, T, h, w), dev, 2)
+    wt, b = _rand((N, Cc, 3, 3, 3), dev, 3, (27 * Cc) ** -0.5), _rand((N,), dev, 4)
+    sd = {"c.conv.weight": wt.cpu(), "c.conv.bias": b.cpu()}
+    cache = CV.ConvCache()
+    refs = [CV.causal_conv3d(sd, "c", x.cpu(), cache) for x in (x1, x2)]
+    grid = ops.Grid3D(T, B, h, w)
+    fr = grid.frame_rows
+    wp = wt.permute(0, 2, 3, 4, 1).reshape(N, 27 * Cc).contiguous()
+    prev, errs = None, []
+    for x, ref in zip((x1, x2), refs):
+        buf = ops.pad_tokens(x.permute(2, 0, 3, 4, 1).reshape(-1, Cc).contiguous(), grid)
+        if prev is None:
+            buf[:fr].copy_(buf[2 * fr:3 * fr])
+            buf[fr:2 * fr].copy_(buf[2 * fr:3 * fr])
+        else:
+            buf[:2 * fr].copy_(prev)
+        prev = buf[T * fr:(T + 2) * fr].clone()
+        out = ops.gemm(buf, wp, b, a_grid=grid, conv_taps=grid.tap_shifts())
+        errs.append(rel_err(out.reshape(T, B, h, w, N).permute(1, 4, 0, 2, 3), ref))
+    assert out.dtype == f32
+    # frame mix
+    xm = _rand((5, 6, 40), dev, 5)
+    mix = ops.frame_mix(xm, 240, [0, 1, 3], [0, 2, 4], [1.0, 0.5, 0.5], [0.0, 0.5, 0.5]).view(3, 6, 40)
+    e_mix = rel_err(mix, torch.stack([xm[0], 0.5 * (xm[1] + xm[2]), 0.5 * (xm[3] + xm[4])]))
+    assert torch.equal(ops.frame_mix(xm, 240, [0, 1, 1, 2, 2], [0] * 5, [1.0] * 5, [0.0] * 5).view(5, 6, 40), xm[[0, 1, 1, 2, 2]])
+    # spatial norm, odd clip (separate first frame) at 4x the latent resolution
+    Tz, Ts, shift, hz, wz, C2, zc, G = 3, 9, 2, 3, 4, 64, 16, 8
+    hh, ww = hz << shift, wz << shift
+    fmap, zq = _rand((B, C2, Ts, hh, ww), dev, 6), _rand((B, zc, Tz, hz, wz), dev, 7)
+    g = torch.Generator().manual_seed(8)
+    nsd = {"n.norm_layer.weight": 1 + 0.1 * torch.randn(C2, generator=g), "n.norm_layer.bias": 0.1 * torch.randn(C2, generator=g),
+           "n.conv_y.conv.weight": torch.randn(C2, zc, 1, 1, 1, generator=g) * 0.2, "n.conv_y.conv.bias": 1 + 0.1 * torch.randn(C2, generator=g),
+           "n.conv_b.conv.weight": torch.randn(C2, zc, 1, 1, 1, generator=g) * 0.2, "n.conv_b.conv.bias": 0.1 * torch.randn(C2, generator=g)}
+    ref = F.silu(CV.norm3d(nsd, "n", fmap.cpu(), zq.cpu(), G, 1e-6, CV.ConvCache()))
+    zrows = torch.zeros((Tz * B * hz * wz, 64), dtype=f32, device=dev)
+    zrows[:, :zc] = zq.permute(2, 0, 3, 4, 1).reshape(-1, zc)
+    wyb = torch.zeros((2 * C2, 64), dtype=f32, device=dev)
+    wyb[:C2, :zc] = nsd["n.conv_y.conv.weight"].reshape(C2, zc).to(dev)
+    wyb[C2:, :zc] = nsd["n.conv_b.conv.weight"].reshape(C2, zc).to(dev)
+    mod = ops.gemm(zrows, wyb, torch.cat([nsd["n.conv_y.conv.bias"], nsd["n.conv_b.conv.bias"]]).to(dev))
+    ctx = _Ctx(None, B, dev)
+    ctx.Tz = Tz
+    g3 = ops.Grid3D(Ts, B, hh, ww)
+    out = ops.groupnorm_silu(fmap.permute(2, 0, 3, 4, 1).reshape(-1, C2).contiguous(), B, Ts * hh * ww, nsd["n.norm_layer.weight"].to(dev),
+                             nsd["n.norm_layer.bias"].to(dev), G, 1e-6, out_grid=g3, img_map=(B, hh * ww, 0, hh * ww, B * hh * ww),
+                             zmap=dict(mod=mod, frames=Ts, videos=B, h=hh, w=ww, shift=shift, zt=ctx.zt(Ts)))
+    pad = out[2 * g3.frame_rows:].reshape(Ts * B, hh + 2, ww + 2, C2)
+    e_sn = rel_err(pad[:, 1:-1, 1:-1].reshape(Ts, B, hh, ww, C2).permute(1, 4, 0, 2, 3), ref)
+    _log("temporal_vae_kernels_f32", conv27_first=errs[0], conv27_cached=errs[1], frame_mix=e_mix, spatial_norm=e_sn)
+    assert out.dtype == f32 and torch.count_nonzero(pad[:, 0]) == 0 and torch.count_nonzero(pad[:, :, 0]) == 0
+    assert max(errs) < TOL_KERNEL_F32 and e_mix < 1e-6 and e_sn < TOL_KERNEL_F32, (errs, e_mix, e_sn)
+
+
+def _tvae_fp32(cfg, sd, dev):
+    from opendwm_amd.vae_cogvideox import AutoencoderKLCogVideoX
+    keep = ("in_channels", "out_channels", "block_out_channels", "latent_channels", "layers_per_block", "norm_eps",
+            "norm_num_groups", "temporal_compression_ratio", "scaling_factor", "shift_factor")
+    m = AutoencoderKLCogVideoX(**{k: cfg[k] for k in keep})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()                   # fp32 parameters
+    m.compute_dtype = f32
+    return m
+
+
+@pytest.mark.parametrize("frames", [17, 9])
+def test_temporal_vae_fp32_vs_cpu_oracle(dev, frames):
+    """AutoencoderKLCogVideoX with compute_dtype = float32, fp32 weights and inputs untouched: encode (chunks of 8 frames with the
+    remainder first, causal caches across chunks) and decode (chunks of 2 latent frames) against the CPU oracle, north_star's
+    1e-3; then the same object in bf16 mode still gives the bf16 result"""
+    from oracle import cogvideox_vae_oracle as CV
+    cfg = CV.make_cogvideox_config(block_out_channels=(64, 64, 128, 128), layers_per_block=1, norm_num_groups=8)
+    sd = CV.make_state_dict(cfg, 0)
+    m = _tvae_fp32(cfg, sd, dev)
+    x = torch.randn(2, 3, frames, 32, 48, generator=torch.Generator().manual_seed(3))
+    mref = CV.encode_moments(sd, cfg, x)
+    dist = m.encode(x.to(dev)).latent_dist
+    e_enc = rel_err(dist.parameters, mref)
+    z = mref[:, :cfg["latent_channels"]].contiguous()
+    ref = CV.decode(sd, cfg, z)
+    out = m.decode(z.to(dev), return_dict=False)[0]
+    e_dec = rel_err(out, ref)
+    m.compute_dtype = torch.bfloat16
+    out16 = m.to(torch.bfloat16).decode(z.to(dev), return_dict=False)[0]
+    e16 = rel_err(out16, ref)
+    _log("temporal_vae_fp32", frames=frames, latent_frames=mref.shape[2], rel_encode=e_enc, rel_decode=e_dec, rel_decode_bf16_same_model=e16)
+    assert dist.parameters.shape == mref.shape and out.shape == ref.shape and out.dtype == f32
+    assert e_enc < TOL_F32 and e_dec < TOL_F32, (e_enc, e_dec)
+    assert out16.dtype == torch.bfloat16 and 1e-4 < e16 < 2e-2
+
+
+def test_temporal_vae_fp32_full_width_vs_oracle_on_device(dev):
+    """THUDM/CogVideoX-2b widths (128 / 256 / 256 / 512 channels, 32 groups, 3 + 1 resnets per block): decode of one clip of 5 latent
+    frames x 8x14 latents (17 frames of 64x112 px) and the encode of the result in fp32, against the oracle on the device"""
+    from oracle import cogvideox_vae_oracle as CV
+    cfg = CV.make_cogvideox_config()
+    sd = CV.make_state_dict(cfg, 0)
+    m = _tvae_fp32(cfg, sd, dev)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    z = torch.randn(1, 16, 5, 8, 14, generator=torch.Generator().manual_seed(0)).to(dev)
+    prev = torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = torch.backends.cudnn.allow_tf32 = False
+    try:
+        ref = CV.decode(sdd, cfg, z)
+        out = m.decode(z, return_dict=False)[0]
+        x = ref.clamp(-1, 1)
+        mref = CV.encode_moments(sdd, cfg, x)
+        mout = m.encode(x).latent_dist.parameters
+    finally:
+        torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.allow_tf32 = prev
+    e_dec, e_enc = rel_err(out, ref), rel_err(mout, mref)
+    _log("temporal_vae_fp32_full_width", frames=ref.shape[2], rel_decode=e_dec, rel_encode=e_enc)
+    assert out.shape == (1, 3, 17, 64, 112) and e_dec < TOL_F32 and e_enc < TOL_F32, (e_dec, e_enc)
