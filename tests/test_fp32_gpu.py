@@ -252,11 +252,13 @@ def test_gemm_f32_implicit_conv3x3(dev):
     assert max(e0, e1, e2) < 1e-4 and torch.count_nonzero(res[border]) == 0
 
 
-def test_model_with_layout_adapter_fp32_vs_cpu_oracle(dev):
+@pytest.mark.parametrize("zero_convs", [True, False])
+def test_model_with_layout_adapter_fp32_vs_cpu_oracle(dev, zero_convs):
     """the text+layout model (ImageAdapter residuals + point-wise temporal attention, the headline variant of bench.py) in
-    the fp32 mode: fp32 convolutions of the adapter by dwm_gemm_f32, zero convolutions adding into the fp32 hidden state"""
+    the fp32 mode: fp32 convolutions of the adapter by dwm_gemm_f32, zero convolutions adding into the fp32 hidden state - or,
+    use_zero_convs=False (adapters.py:33-36), the level outputs added as they are (the plain fp32 add)"""
     ac = dict(in_channels=6, channels=[128, 128, 128], is_downblocks=[True, False, False], num_res_blocks=2, downscale_factor=8,
-              use_zero_convs=True)
+              use_zero_convs=zero_convs)
     cfg = small_config(temporal_attention_type="pointwise", condition_image_adapter_config=ac)
     sd = O.make_state_dict(cfg, 0)
     inp = small_inputs(cfg, 0)
@@ -276,7 +278,7 @@ def test_model_with_layout_adapter_fp32_vs_cpu_oracle(dev):
     finally:
         STORE.set_precision(torch.bfloat16)
     ea = max(rel_err(a, f.flatten(0, -4).permute(0, 2, 3, 1).reshape(-1, f.shape[-3])) for a, f in zip(mine, feats))
-    _log("model_forward_fp32_layout", rel_fp32=e, adapter_rel=ea)
+    _log("model_forward_fp32_layout", zero_convs=zero_convs, rel_fp32=e, adapter_rel=ea)
     assert out[0].dtype == f32 and e < TOL_F32 and ea < 1e-4, (e, ea)
 
 

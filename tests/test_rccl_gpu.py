@@ -104,8 +104,9 @@ def test_ddp_train_step_over_rccl_equals_plain_step(rccl):
     worst = max(((pp[n].double() - pd[n].double()).norm() / pp[n].double().norm().clamp_min(1e-30)).item() for n in pp)
     _log("ddp_over_rccl_one_rank", losses_plain=lp, losses_ddp=ld, params=len(pp), params_different=len(diff), worst_rel=worst)
     # bit-identical except where the backward itself is not: bias / modulation gradients are segmented column sums finished by fp32
-    # atomics (train.hip), whose order changes from run to run - those parameters (a handful) agree to accumulation accuracy
-    assert lp == ld and len(diff) <= len(pp) // 10 and worst < 1e-5, (diff[:5], worst)
+    # atomics (train.hip), whose order changes from run to run - those parameters (8 and 17 of the 240 in two runs of round 4)
+    # agree to accumulation accuracy (7.5e-9 observed); what the test holds is the losses, the accuracy, and that it is only those
+    assert lp == ld and len(diff) <= len(pp) // 4 and worst < 1e-6, (diff[:5], worst)
     assert all(n.endswith(("bias", "weight")) for n in diff)
 
 
