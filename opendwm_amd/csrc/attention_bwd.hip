@@ -22,10 +22,19 @@ namespace {
 
 constexpr int IMG = 8192;                    // one 64-row x 64-col bf16 image
 
-DWM_DEVINL void glds4(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+// The LDS-DMA requests of this file go through inline asm, as in gemm_bf16.hip: the compiler models the builtin
+// (global_load_lds) as a FLAT access that may touch the LDS, and with one of those pending it degrades every later LDS wait
+// to lgkmcnt(0) - each fragment read then drained the whole LDS queue (26 of the 33 LDS waits of attn_dq_kernel were full
+// drains).  Opaque requests keep its LDS bookkeeping exact (counted waits); the ordering the requests need is explicit here
+// anyway: every stage is followed by "s_waitcnt vmcnt(0)" + __syncthreads() before anything reads it.
+// lds_addr: wave-uniform LDS byte address (it goes to M0); per-lane destination = lds_addr + lane * bytes.
+DWM_DEVINL void dma16(const void* gsrc, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
 }
+DWM_DEVINL void dma4(const void* gsrc, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
+DWM_DEVINL uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 
 // row index (within its segment's buffers) of token l of problem prob
 DWM_DEVINL int64_t token_row(const AttnParams& P, int64_t base0, int prob, int l) {
@@ -164,6 +173,7 @@ attn_dq_kernel(const AttnParams P) {
     const int kc0 = ((lane & 7) ^ ((srow0 >> 1) & 7)) << 3, kc1 = ((lane & 7) ^ ((srow1 >> 1) & 7)) << 3;
     const int vc0 = ((lane & 7) ^ (((srow0 >> 1) & 1) << 2)) << 3, vc1 = ((lane & 7) ^ (((srow1 >> 1) & 1) << 2)) << 3;
     const int sdst = wave * 2048;
+    const uint32_t lds0 = lds_address(smem);
 #define DQ_DMA(kt_, stage_)                                                                  \
     do {                                                                                     \
         const int kb_ = P.kbeg + (kt_) * KT;                                                 \
@@ -171,10 +181,10 @@ attn_dq_kernel(const AttnParams P) {
         const int rb_ = kb_ + srow1 < L ? kb_ + srow1 : L - 1;                               \
         const int64_t oa_ = (ra_ < L0 ? (int64_t)rowidx[ra_] * P.ld0 : P.seg1_delta + (int64_t)rowidx[ra_] * P.ld1) + hoff; \
         const int64_t ob_ = (rb_ < L0 ? (int64_t)rowidx[rb_] * P.ld0 : P.seg1_delta + (int64_t)rowidx[rb_] * P.ld1) + hoff; \
-        char* l_ = smem + (stage_) * DQ_STAGE + sdst;                                        \
-        glds16(P.k0 + oa_ + kc0, l_);             glds16(P.k0 + ob_ + kc1, l_ + 1024);       \
-        glds16(P.k0 + oa_ + vc0, l_ + IMG);       glds16(P.k0 + ob_ + vc1, l_ + IMG + 1024); \
-        glds16(P.v0 + oa_ + kc0, l_ + 2 * IMG);   glds16(P.v0 + ob_ + kc1, l_ + 2 * IMG + 1024); \
+        const uint32_t l_ = lds0 + (stage_) * DQ_STAGE + sdst;                               \
+        dma16(P.k0 + oa_ + kc0, l_);             dma16(P.k0 + ob_ + kc1, l_ + 1024);         \
+        dma16(P.k0 + oa_ + vc0, l_ + IMG);       dma16(P.k0 + ob_ + vc1, l_ + IMG + 1024);   \
+        dma16(P.v0 + oa_ + kc0, l_ + 2 * IMG);   dma16(P.v0 + ob_ + kc1, l_ + 2 * IMG + 1024); \
     } while (0)
 
     DQ_DMA(0, 0);
@@ -186,14 +196,30 @@ attn_dq_kernel(const AttnParams P) {
         const char* ktimg = kimg + IMG;
         const char* vimg = kimg + 2 * IMG;
         if (wave_active) {
+            // S and dP: the four fragments of MFMA step ks + 1 are read while the four MFMAs of step ks run (two register sets,
+            // fenced so that the reads stay in front of the MFMAs they overlap with).  Written as read-then-use pairs the
+            // compiler reused ONE fragment register for all sixteen reads: every MFMA then waited for a full LDS round trip.
             f32x16 st[2], dp[2];
+            bf16x8 fk[2][2], fv[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) { fk[0][j] = read_frag(kimg, geo, j, 0, half); fv[0][j] = read_frag(vimg, geo, j, 0, half); }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(kimg, geo, j, ks, half), qf[ks], ks == 0 ? neglse : st[j], 0, 0, 0);
-                    dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(vimg, geo, j, ks, half), dof[ks], ks == 0 ? negdel : dp[j], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        fk[(ks + 1) & 1][j] = read_frag(kimg, geo, j, ks + 1, half);
+                        fv[(ks + 1) & 1][j] = read_frag(vimg, geo, j, ks + 1, half);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks & 1][j], qf[ks], ks == 0 ? neglse : st[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[ks & 1][j], dof[ks], ks == 0 ? negdel : dp[j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const int kbase = P.kbeg + kt * KT;
             if (kbase + KT > L) {
                 asm volatile("");
@@ -303,6 +329,7 @@ attn_dkv_kernel(const AttnParams P) {
     const int kc0 = ((lane & 7) ^ ((srow0 >> 1) & 7)) << 3, kc1 = ((lane & 7) ^ ((srow1 >> 1) & 7)) << 3;
     const int vc0 = ((lane & 7) ^ (((srow0 >> 1) & 1) << 2)) << 3, vc1 = ((lane & 7) ^ (((srow1 >> 1) & 1) << 2)) << 3;
     const int sdst = wave * 2048;
+    const uint32_t lds0 = lds_address(smem);
     const int64_t stat0 = ((int64_t)prob * P.heads + head) * L;
 #define DKV_DMA(qt_, stage_)                                                                 \
     do {                                                                                     \
@@ -314,19 +341,24 @@ attn_dkv_kernel(const AttnParams P) {
         const int64_t qb2_ = (rb_ < L0 ? ib_ * P.ld0 : P.seg1_delta + ib_ * P.ld1) + hoff;  \
         const int64_t da_ = (ra_ < L0 ? ia_ * P.ldo0 : P.doseg1_delta + ia_ * P.ldo1) + hoff; \
         const int64_t db_ = (rb_ < L0 ? ib_ * P.ldo0 : P.doseg1_delta + ib_ * P.ldo1) + hoff; \
-        char* l_ = smem + (stage_) * DKV_STAGE + sdst;                                       \
-        glds16(P.q0 + qa_ + kc0, l_);               glds16(P.q0 + qb2_ + kc1, l_ + 1024);    \
-        glds16(P.q0 + qa_ + vc0, l_ + IMG);         glds16(P.q0 + qb2_ + vc1, l_ + IMG + 1024); \
-        glds16(P.do0 + da_ + kc0, l_ + 2 * IMG);    glds16(P.do0 + db_ + kc1, l_ + 2 * IMG + 1024); \
-        glds16(P.do0 + da_ + vc0, l_ + 3 * IMG);    glds16(P.do0 + db_ + vc1, l_ + 3 * IMG + 1024); \
+        const uint32_t l_ = lds0 + (stage_) * DKV_STAGE + sdst;                              \
+        dma16(P.q0 + qa_ + kc0, l_);               dma16(P.q0 + qb2_ + kc1, l_ + 1024);      \
+        dma16(P.q0 + qa_ + vc0, l_ + IMG);         dma16(P.q0 + qb2_ + vc1, l_ + IMG + 1024); \
+        dma16(P.do0 + da_ + kc0, l_ + 2 * IMG);    dma16(P.do0 + db_ + kc1, l_ + 2 * IMG + 1024); \
+        dma16(P.do0 + da_ + vc0, l_ + 3 * IMG);    dma16(P.do0 + db_ + vc1, l_ + 3 * IMG + 1024); \
         if (wave < 2) {                                                                      \
             const int qi_ = qb_ + lane < QE ? qb_ + lane : QE - 1;                           \
-            glds4((wave == 0 ? P.lse : P.delta) + stat0 + qi_, smem + (stage_) * DKV_STAGE + 4 * IMG + wave * 256); \
+            dma4((wave == 0 ? P.lse : P.delta) + stat0 + qi_, lds0 + (stage_) * DKV_STAGE + 4 * IMG + wave * 256); \
         }                                                                                    \
     } while (0)
 
     DKV_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the key / value fragments count as used HERE: left to their first use inside the loop, the compiler's waits for these
+    // plain loads (which it counts; the LDS-DMA requests above it does not) land behind the requests of the next stage and
+    // drain them in the middle of every tile
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
     __syncthreads();
     for (int qt = 0; qt < nqt; ++qt) {
         if (qt + 1 < nqt) DKV_DMA(qt + 1, (qt + 1) & 1);
@@ -338,6 +370,12 @@ attn_dkv_kernel(const AttnParams P) {
         const float* ndel = nlse + 64;
         if (wave_active) {
             f32x16 st[2], dp[2];
+            constexpr bool kPipe = MASK != 2;       // (the dense-mask form is at 256 registers without the second fragment set)
+            bf16x8 fq[2][2], fo[2][2];
+            if constexpr (kPipe) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { fq[0][j] = read_frag(qimg, geo, j, 0, half); fo[0][j] = read_frag(doimg, geo, j, 0, half); }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // C-init: register r belongs to query j*32 + (r & 3) + 8 (r >> 2) + 4 half
@@ -348,11 +386,34 @@ attn_dkv_kernel(const AttnParams P) {
                     st[j][4 * g] = a.x; st[j][4 * g + 1] = a.y; st[j][4 * g + 2] = a.z; st[j][4 * g + 3] = a.w;
                     dp[j][4 * g] = b.x; dp[j][4 * g + 1] = b.y; dp[j][4 * g + 2] = b.z; dp[j][4 * g + 3] = b.w;
                 }
+            }
+            // S^T and dP^T: fragments of MFMA step ks + 1 read under the MFMAs of step ks (see attn_dq_kernel)
+            if constexpr (kPipe) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(qimg, geo, j, ks, half), kf[ks], st[j], 0, 0, 0);
-                    dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(doimg, geo, j, ks, half), vf[ks], dp[j], 0, 0, 0);
+                    if (ks < 3) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            fq[(ks + 1) & 1][j] = read_frag(qimg, geo, j, ks + 1, half);
+                            fo[(ks + 1) & 1][j] = read_frag(doimg, geo, j, ks + 1, half);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks & 1][j], kf[ks], st[j], 0, 0, 0);
+                        dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[ks & 1][j], vf[ks], dp[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(qimg, geo, j, ks, half), kf[ks], st[j], 0, 0, 0);
+                        dp[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_frag(doimg, geo, j, ks, half), vf[ks], dp[j], 0, 0, 0);
+                    }
             }
             const int qbase = qt * KT;
             if (qbase + KT > QE) {
