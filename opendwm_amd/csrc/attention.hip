@@ -751,12 +751,18 @@ attn_group_lds_kernel(const AttnParams P) {
     char* const myrow = sc + l31 * 128;
 
     // copy of head h_'s K / V rows of group `wave` into the images of stage (h_ & 1) (8 LDS-DMA instructions)
+    // (requests from inline asm: the compiler treats the builtin as a load that may alias any LDS access and put a vmcnt(0) in
+    // front of the output transpose right behind the requests of head h + 2 - the copy was waited for, not overlapped)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    auto dma16 = [](const void* src, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+    };
 #define DWM_GRP_COPY(h_)                                                                                          \
     do {                                                                                                          \
-        char* const st_ = smem + ((h_) & 1) * STAGE + wave * GRP_IMG;                                             \
+        const uint32_t st_ = lds0 + ((h_) & 1) * STAGE + wave * GRP_IMG;                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
-            glds16(P.k0 + srow[i] + (h_) * 64 + kcol[i], st_ + i * 1024);                                         \
-            glds16(P.v0 + srow[i] + (h_) * 64 + vcol[i], st_ + G * GRP_IMG + i * 1024);                           \
+            dma16(P.k0 + srow[i] + (h_) * 64 + kcol[i], st_ + i * 1024);                                          \
+            dma16(P.v0 + srow[i] + (h_) * 64 + vcol[i], st_ + G * GRP_IMG + i * 1024);                            \
         }                                                                                                         \
     } while (0)
     DWM_GRP_COPY(0);
@@ -793,20 +799,28 @@ attn_group_lds_kernel(const AttnParams P) {
                 gi[c] = rem ? __builtin_ctz(rem) : 0;
                 if (rem) { ++ng; rem &= rem - 1; }
             }
+            // all K fragments of the chunk are read first (12 reads in flight, absent groups re-read group gi[c] = 0's rows and
+            // are masked below), then the MFMAs follow behind counted waits: as read-then-use pairs the compiler kept ONE
+            // fragment register and every MFMA waited for a full LDS round trip
             f32x16 st[3];
+            bf16x8 kfr[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const char* kl = kimg + gi[c] * GRP_IMG;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kfr[c][ks] = *(const bf16x8*)(kl + l31 * 128 + (((2 * ks + half) ^ kswz) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[c][r] = 0.f;
-                if (c < ng) {
-                    const char* kl = kimg + gi[c] * GRP_IMG;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const bf16x8 kf = *(const bf16x8*)(kl + l31 * 128 + (((2 * ks + half) ^ kswz) << 4));
-                        st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[c], 0, 0, 0);
-                    }
-                }
             }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[c][ks], qf[ks], st[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             float mx = -INFINITY;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -861,6 +875,10 @@ attn_group_lds_kernel(const AttnParams P) {
         // ONE barrier per head: own fragment reads of this head done, own rows of the next head landed (everything this
         // wave has requested is at least a head old here: the wait is free) - after it stage hh & 1 may be refilled
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // the next head's Q rows count as used here (they have landed: see the wait above) - left to their first use below, the
+        // compiler's own wait for them would sit behind the copy requests of head hh + 2 and drain those
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qn[ks]));
         __syncthreads();
         if (hh + 2 < hpb) DWM_GRP_COPY(hh + 2);
         // normalise; transpose the 32 x 64 output tile through the wave's own LDS (same-wave LDS ops complete in order)
