@@ -137,15 +137,13 @@ DWM_DEVINL f32x2 gelu_erf2(f32x2 x) {
 }
 
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+// (the tiled and the resident forward attention kernels use this builtin form: with the requests as inline asm - the form of
+//  the GEMMs, the backward and the cross-view kernels, whose waits the compiler otherwise degrades - the resident kernel ran
+//  12 % SLOWER and the tiled one the same, profiles/r4i_microbench_attention_asm_dma_in_forward_kernels.log)
 DWM_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
-#ifdef DWM_GLDS_ASM          /* experiment: the request as inline asm (untracked by the compiler's wait insertion) */
-    const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory", "m0");
-#else
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)gsrc,
         (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-#endif
 }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b % 8): gives every
