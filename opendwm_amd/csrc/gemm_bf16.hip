@@ -103,10 +103,16 @@ DWM_DEVINL int64_t map_row(const DevRowMap& rm, int64_t m) {
 // storage rounding would otherwise accumulate block after block: the layout ImageAdapter (12 resnets, step-invariant input,
 // hence a step-invariant error) and - round 4 - the hidden state of the MMDiT itself (~130 residual adds per forward, each a
 // bf16 rounding of the whole stream: 1.1e-3 rms x sqrt(130) = the 1.3e-2 the bf16 forward showed against the fp32 oracle).
-template <int EPI, bool FAST = false, bool RF32 = false, int TC = 0>
+// RS (RESID): 0 = which of gate / residual / blend / bf16 mirror are present is read from the arguments at run time; otherwise a
+// bit mask (1 gate, 2 residual, 4 blend, 8 bf16 mirror, 16 the residual row is m / |res_mod|: one row per image, the time-embedding
+// term of the SD 2.1 UNet's resnets) known at compile time - the forms of the hidden-state stream of the
+// MMDiT (gate + residual: the joint blocks; residual: inside a VT block; residual + blend: a VT block's last GEMM): the
+// run-time form spends a third of its ~2000 epilogue instructions per wave on the selects and branches between the cases.
+template <int EPI, bool FAST = false, bool RF32 = false, int TC = 0, int RS = 0>
 __global__ void __launch_bounds__(TileCfg<TC>::nwaves * 64, 2)
 gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, const int ntn) {
     using T = TileCfg<TC>;
+    static_assert(RS == 0 || (EPI == DWM_EPI_RESID && FAST), "compile-time RESID operands: the FAST RESID kernels only");
     constexpr int BM = T::bm, BN = T::bn, BK = T::bk;        // (shadow the file-level constants of configuration 0)
     constexpr int NWN = T::nwn;                  // wave columns of the 2 x NWN wave grid
     constexpr int WCOLS = BN / NWN;              // output columns per wave: 64
@@ -526,16 +532,24 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
         // so the compiler's counted waits stay exact and never degrade to "everything outstanding, stores included"
         // (RF32: C may be absent - the dummy is then C32 with its own pitch, read as if it were bf16: in bounds a fortiori;
         //  the blend rows are fp32 and travel as two 16-byte pieces, gbA / gbB; the gate stays bf16)
-        const bf16_t* const dummy = (RF32 && p.C == nullptr) ? (const bf16_t*)p.C32 : (const bf16_t*)p.C;
-        const int64_t dummy_ld = (RF32 && p.C == nullptr) ? p.ldc32 : p.ldc;
-        const bool blend32 = RF32 && p.blend != nullptr;
-        const bf16_t* const gb_ptr = p.gate ? (const bf16_t*)p.gate : (p.blend && !RF32) ? (const bf16_t*)p.blend : dummy;
-        const int64_t gb_ld = p.gate ? p.ld_gate : (p.blend && !RF32) ? p.ld_blend : dummy_ld;
+        constexpr bool kSpec = RS != 0;                 // operands known at compile time (see RS above)
+        const bool f_gate = kSpec ? (RS & 1) != 0 : p.gate != nullptr;
+        const bool f_res = kSpec ? (RS & 2) != 0 : p.res != nullptr;
+        const bool f_blend = kSpec ? (RS & 4) != 0 : p.blend != nullptr;
+        const bool f_mirror = kSpec ? (RS & 8) != 0 : p.C != nullptr;
+        // run-time form: every load below is always issued (see "branch-free" above); compile-time form: only what is used
+        const bool ld_gb = kSpec ? (f_gate || f_blend) : true, ld_gb2 = kSpec ? f_blend : true, ld_r = kSpec ? f_res : true,
+                   ld_al = kSpec ? f_blend : true;
+        const bf16_t* const dummy = (RF32 && !f_mirror) ? (const bf16_t*)p.C32 : (const bf16_t*)p.C;
+        const int64_t dummy_ld = (RF32 && !f_mirror) ? p.ldc32 : p.ldc;
+        const bool blend32 = RF32 && f_blend;
+        const bf16_t* const gb_ptr = f_gate ? (const bf16_t*)p.gate : (f_blend && !RF32) ? (const bf16_t*)p.blend : dummy;
+        const int64_t gb_ld = f_gate ? p.ld_gate : (f_blend && !RF32) ? p.ld_blend : dummy_ld;
         const float* const bl32_ptr = blend32 ? (const float*)p.blend : (const float*)p.C32;
         const int64_t bl32_ld = blend32 ? p.ld_blend : p.ldc32;
-        const bf16_t* const r_ptr = p.res ? (const bf16_t*)p.res : dummy;
-        const int64_t r_ld = p.res ? p.ld_res : dummy_ld;
-        const float* const al_ptr = p.blend ? p.alpha : (const float*)dummy;
+        const bf16_t* const r_ptr = f_res ? (const bf16_t*)p.res : dummy;
+        const int64_t r_ld = f_res ? p.ld_res : dummy_ld;
+        const float* const al_ptr = f_blend ? p.alpha : (const float*)dummy;
         float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // RESID: bias of this lane's 8 output columns
         if constexpr (EPI == DWM_EPI_RESID) {
             if (p.bias != nullptr && nok) unpack8(*(const uint4*)((const bf16_t*)p.bias + ncol), b8);
@@ -545,20 +559,22 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
             uint32_t m_ = (uint32_t)(m0 + wm * 128 + (MT_) * 32 + (ST_) * RPS + brow);                            \
             m_ = m_ < (uint32_t)M ? m_ : (uint32_t)(M - 1);                                                       \
             const uint32_t nc_ = nok ? (uint32_t)ncol : 0u;                                                       \
-            const uint32_t grow_ = p.gate ? fdiv(m_, cp.fd_rpg) : m_;                                             \
+            const uint32_t grow_ = f_gate ? fdiv(m_, cp.fd_rpg) : m_;                                             \
             if constexpr (RF32) {       /* (selects, no branches: the load count per step stays fixed) */           \
                 const char* g0_ = blend32 ? (const char*)(bl32_ptr + ((uint64_t)m_ * (uint32_t)bl32_ld + nc_))    \
                                           : (const char*)(gb_ptr + ((uint64_t)grow_ * (uint32_t)gb_ld + nc_));    \
-                gbA[ST_] = *(const uint4*)g0_;                                                                    \
-                gbB[ST_] = *(const uint4*)(g0_ + (blend32 ? 16 : 0));                                             \
-                const float* rp_ = (const float*)(p.res ? p.res : p.C32) + ((uint64_t)m_ * (uint32_t)(p.res ? r_ld : p.ldc32) + nc_); \
-                rA[ST_] = *(const uint4*)rp_;                                                                     \
-                rB[ST_] = *(const uint4*)(rp_ + 4);                                                               \
+                if (ld_gb) gbA[ST_] = *(const uint4*)g0_;                                                         \
+                if (ld_gb2) gbB[ST_] = *(const uint4*)(g0_ + (blend32 ? 16 : 0));                                 \
+                const float* rp_ = (const float*)(f_res ? p.res : p.C32) + ((uint64_t)m_ * (uint32_t)(f_res ? r_ld : p.ldc32) + nc_); \
+                if (ld_r) {                                                                                       \
+                    rA[ST_] = *(const uint4*)rp_;                                                                 \
+                    rB[ST_] = *(const uint4*)(rp_ + 4);                                                           \
+                }                                                                                                 \
             } else {                                                                                              \
-                gbA[ST_] = *(const uint4*)(gb_ptr + ((uint64_t)grow_ * (uint32_t)gb_ld + nc_));                   \
-                rA[ST_] = *(const uint4*)(r_ptr + ((uint64_t)m_ * (uint32_t)r_ld + nc_));                         \
+                if (ld_gb) gbA[ST_] = *(const uint4*)(gb_ptr + ((uint64_t)grow_ * (uint32_t)gb_ld + nc_));        \
+                if (ld_r) rA[ST_] = *(const uint4*)(r_ptr + ((uint64_t)((RS & 16) ? fdiv(m_, cp.fd_rmod) : m_) * (uint32_t)r_ld + nc_)); \
             }                                                                                                     \
-            alA[ST_] = al_ptr[p.blend ? fdiv(m_, cp.fd_rpa) : 0u];                                                \
+            if (ld_al) alA[ST_] = al_ptr[f_blend ? fdiv(m_, cp.fd_rpa) : 0u];                                     \
         } else {                                                                                                  \
             int64_t m_ = m0 + wm * 128 + (MT_) * 32 + (ST_) * RPS + brow;                                         \
             m_ = m_ < M ? m_ : M - 1;                                                                             \
@@ -694,7 +710,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                         }
                         v[j] = y[0]; v[j + 1] = y[1];
                     }
-                    if (p.gate) {
+                    if (f_gate) {
                         unpack8(gbA[st], t);
     #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
@@ -702,7 +718,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                             v[j] = y[0]; v[j + 1] = y[1];
                         }
                     }
-                    if (p.res) {
+                    if (f_res) {
                         if constexpr (RF32) {
                             const float4 ta = *reinterpret_cast<const float4*>(&rA[st]), tb = *reinterpret_cast<const float4*>(&rB[st]);
                             t[0] = ta.x; t[1] = ta.y; t[2] = ta.z; t[3] = ta.w; t[4] = tb.x; t[5] = tb.y; t[6] = tb.z; t[7] = tb.w;
@@ -715,7 +731,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                             v[j] = y[0]; v[j + 1] = y[1];
                         }
                     }
-                    if (p.blend) {
+                    if (f_blend) {
                         if constexpr (RF32) {            // (gate and blend together are rejected by the entry point)
                             const float4 ta = *reinterpret_cast<const float4*>(&gbA[st]), tb = *reinterpret_cast<const float4*>(&gbB[st]);
                             t[0] = ta.x; t[1] = ta.y; t[2] = ta.z; t[3] = ta.w; t[4] = tb.x; t[5] = tb.y; t[6] = tb.z; t[7] = tb.w;
@@ -739,7 +755,7 @@ gemm_bf16_kernel(const dwm_gemm_args p, const ConvParams cp, const int ntm, cons
                     }
                 } else {
                     if (m < M && nok && !((DWM_RESERVED(p.reserved) & 2) && m >= 0)) {
-                        if (!RF32 || Cp != nullptr) {          // (RF32: the bf16 mirror is optional)
+                        if (!RF32 || f_mirror) {               // (RF32: the bf16 mirror is optional)
                             if constexpr (FAST) *(uint4*)(Cp + ((uint64_t)(uint32_t)mrow * (uint32_t)p.ldc + (uint32_t)ncol)) = pack8(v);
                             else *(uint4*)(Cp + mrow * p.ldc + ncol) = pack8(v);
                         }
@@ -1183,9 +1199,10 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     // the transformer blocks' linear layers (see FAST above); reserved bit 2 keeps the general kernels (A/B measurements)
     const int64_t lim = 1ll << 31;
     bool fast = !cp.c.enabled && a->ldc < lim && !(DWM_RESERVED(a->reserved) & 4);
+    const int rs16 = (a->gate ? 1 : 0) | (a->res ? 2 : 0) | (a->blend ? 4 : 0) | ((a->res && a->res_mod < 0) ? 16 : 0);
     if (a->epilogue == DWM_EPI_RESID)
-        fast = fast && a->res_mod == 0 && a->act == DWM_ACT_NONE && (a->gate == nullptr || a->ld_gate < lim) &&
-               (a->res == nullptr || a->ld_res < lim) && (a->blend == nullptr || a->ld_blend < lim);
+        fast = fast && (a->res_mod == 0 || (rs16 == 18 && a->C32 == nullptr)) && a->act == DWM_ACT_NONE &&
+               (a->gate == nullptr || a->ld_gate < lim) && (a->res == nullptr || a->ld_res < lim) && (a->blend == nullptr || a->ld_blend < lim);
 #define DWM_LAUNCH2(EPI)                                                                             \
     do {                                                                                             \
         if (fast) DWM_LAUNCH(EPI, true); else DWM_LAUNCH(EPI, false);                                \
@@ -1199,20 +1216,63 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        // the transformer blocks' hidden-state stream takes the FAST form (32-bit row arithmetic, no row map, no activation)
-        if (fast && a->ldc32 < lim)
-            hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, true, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
-        else
+        // the transformer blocks' hidden-state stream takes the FAST form (32-bit row arithmetic, no row map, no activation), and
+        // its three operand sets - gate + residual, residual, residual + blend, no bf16 mirror - their compile-time forms (RS)
+        const int rs = (a->gate ? 1 : 0) | (a->res ? 2 : 0) | (a->blend ? 4 : 0) | (a->C ? 8 : 0);
+#define DWM_LAUNCH_RS(RS_)                                                                                        \
+        do {                                                                                                      \
+            static bool set_ = false;                                                                             \
+            if (!set_) {                                                                                          \
+                e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<DWM_EPI_RESID, true, true, 0, RS_>,         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                  \
+                if (e != hipSuccess) return (int)e;                                                               \
+                set_ = true;                                                                                      \
+            }                                                                                                     \
+            hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, true, true, 0, RS_>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn); \
+        } while (0)
+        if (fast && a->ldc32 < lim) {
+            if (rs == 3) DWM_LAUNCH_RS(3);
+            else if (rs == 2) DWM_LAUNCH_RS(2);
+            else if (rs == 6) DWM_LAUNCH_RS(6);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, true, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
+        } else {
             hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, false, true>), grid, block, LDS_BYTES, s, *a, cp, ntm, ntn);
+        }
+#undef DWM_LAUNCH_RS
         e = hipGetLastError();
         return e == hipSuccess ? DWM_OK : (int)e;
     }
+    // bf16 RESID, FAST form: the operand sets of the transformer blocks at compile time as well (RS: gate + residual, residual,
+    // residual + blend) - the SD 2.1 UNet's K = 320 ... 1280 GEMMs are mostly epilogue
+#define DWM_LAUNCH_RS16(TC_, RS_)                                                                                 \
+    do {                                                                                                          \
+        static bool set_ = false;                                                                                 \
+        if (!set_) {                                                                                              \
+            e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<DWM_EPI_RESID, true, false, TC_, RS_>,          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, tile_lds_bytes<TC_>() + (TC_ ? DWM_DEV_LDS_PAD : 0)); \
+            if (e != hipSuccess) return (int)e;                                                                   \
+            set_ = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_kernel<DWM_EPI_RESID, true, false, TC_, RS_>), grid, block,                 \
+                           tile_lds_bytes<TC_>() + ((TC_ && (DWM_RESERVED(a->reserved) & 0x400)) ? DWM_DEV_LDS_PAD : 0), s, *a, cp, ntm, ntn); \
+    } while (0)
+    const bool spec16 = a->epilogue == DWM_EPI_RESID && fast && (rs16 == 2 || rs16 == 3 || rs16 == 6 || rs16 == 18);
+    if (spec16) {
+        if (tc == 1) {
+            if (rs16 == 2) DWM_LAUNCH_RS16(1, 2); else if (rs16 == 3) DWM_LAUNCH_RS16(1, 3); else if (rs16 == 6) DWM_LAUNCH_RS16(1, 6);
+            else DWM_LAUNCH_RS16(1, 18);
+        } else {
+            if (rs16 == 2) DWM_LAUNCH_RS16(0, 2); else if (rs16 == 3) DWM_LAUNCH_RS16(0, 3); else if (rs16 == 6) DWM_LAUNCH_RS16(0, 6);
+            else DWM_LAUNCH_RS16(0, 18);
+        }
+    } else
     switch (a->epilogue) {
         case DWM_EPI_PLAIN: DWM_LAUNCH2(DWM_EPI_PLAIN); break;
         case DWM_EPI_GEGLU: DWM_LAUNCH2(DWM_EPI_GEGLU); break;
         case DWM_EPI_RESID: DWM_LAUNCH2(DWM_EPI_RESID); break;
         default: DWM_LAUNCH2(DWM_EPI_RMSHEAD); break;
     }
+#undef DWM_LAUNCH_RS16
 #undef DWM_LAUNCH2
 #undef DWM_LAUNCH
 #undef DWM_LAUNCH_TC

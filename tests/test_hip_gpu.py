@@ -111,8 +111,18 @@ def test_gemm_resid(dev, M, N, K, rpg):
     pos = _rand((rpg, N), dev, 7)
     out3 = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=pos, res_mod=rpg)
     ref3 = y + pos.float()[torch.arange(M, device=dev) % rpg]
-    _log("gemm_resid", M=M, N=N, K=K, rel_gate=e1, rel_blend=e2, rel_mod=rel_err(out3, ref3))
-    assert e1 < TOL_KERNEL and e2 < TOL_KERNEL and rel_err(out3, ref3) < TOL_KERNEL
+    # plain residual add, and the one-row-per-group residual (res_mod < 0: the time-embedding term of the UNet's resnets) - with
+    # the gated and the blended form above the four operand sets that have compile-time forms of the kernel (RS)
+    out4 = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=res)
+    e4 = rel_err(out4, res.float() + y)
+    out5 = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=gate, res_mod=-rpg)
+    e5 = rel_err(out5, y + gate.float()[rows])
+    # ... and the same values from the run-time form (an activation keeps a call out of the FAST kernels)
+    out6 = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=gate, res_mod=-rpg, act=ops.ACT_RELU)
+    e6 = rel_err(out6, torch.relu(y) + gate.float()[rows])
+    _log("gemm_resid", M=M, N=N, K=K, rel_gate=e1, rel_blend=e2, rel_mod=rel_err(out3, ref3), rel_plain=e4, rel_row_per_group=e5,
+         rel_row_per_group_general=e6)
+    assert e1 < TOL_KERNEL and e2 < TOL_KERNEL and rel_err(out3, ref3) < TOL_KERNEL and max(e4, e5, e6) < TOL_KERNEL
     assert torch.equal(r2, out1) and torch.equal(bl, out2)
 
 
