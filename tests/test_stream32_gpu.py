@@ -69,7 +69,9 @@ def test_gemm_resid_fp32_stream(dev, M, N, K, rpg):
     e1 = rel_err(r1, ref1)
     o32 = torch.empty_like(res)
     o16 = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=rpg, res=res, out32=o32)
-    assert torch.equal(o32, r1) and torch.equal(o16, o32.to(bf16))
+    # (the call with the bf16 copy runs the run-time operand form of the kernel, the one without it a compile-time form: the same
+    #  arithmetic, but the compiler contracts multiply + add differently in the two - a last-bit difference of the fp32 values)
+    assert torch.allclose(o32, r1, rtol=1e-6, atol=4e-6) and torch.equal(o16, o32.to(bf16))
     # blend with an fp32 blend operand, written over it (the mixer of a VT block on the fp32 hidden stream)
     bl = blend.clone()
     ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=res, blend=bl, alpha=alpha, rows_per_alpha=rpg, out32=bl, mirror=False)
