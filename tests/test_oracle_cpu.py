@@ -525,3 +525,31 @@ def test_dpm_solver_tables_and_last_step():
         x = a_s * x0 + float(sig[i]) * a_s * eps
         xn = A * x + (B + Cc) * x0
         assert abs(xn - (a_t * x0 + float(sig[i + 1]) * a_t * eps)) < 1e-9
+
+
+def test_split_weight_planes_and_tap_groups():
+    """host side of dwm_gemm_f32's weight operand (opendwm_amd.ops.split_weight): hi + lo planes reproduce the fp32 weight to 2^-16,
+    the per-tap layout is [hi_t | lo_t | hi_t], and more than 9 taps (the 27 of a causal 3x3x3 convolution) are laid out as groups of
+    9 taps, each group a contiguous [N, 9 * 3C] matrix - what the kernel's one-main-loop-launch-per-group walk expects"""
+    from opendwm_amd import ops
+    g = torch.Generator().manual_seed(0)
+    N, Cc = 24, 64
+    w = torch.randn(N, 27 * Cc, generator=g)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    assert ((hi.float() + lo.float()) - w).abs().max() <= w.abs().max() * 2.0 ** -16
+    ws1 = ops.split_weight(w[:, :Cc].contiguous(), 1, cache=False)                     # plain: [hi | lo | hi]
+    assert ws1.shape == (N, 3 * Cc) and torch.equal(ws1[:, :Cc], hi[:, :Cc]) and torch.equal(ws1[:, Cc:2 * Cc], lo[:, :Cc]) \
+        and torch.equal(ws1[:, 2 * Cc:], hi[:, :Cc])
+    ws9 = ops.split_weight(w[:, :9 * Cc].contiguous(), 9, cache=False).view(N, 9, 3, Cc)
+    assert torch.equal(ws9[:, :, 0], hi.view(N, 27, Cc)[:, :9]) and torch.equal(ws9[:, :, 1], lo.view(N, 27, Cc)[:, :9]) \
+        and torch.equal(ws9[:, :, 2], ws9[:, :, 0])
+    ws27 = ops.split_weight(w, 27, cache=False)
+    assert ws27.shape == (N, 3 * 27 * Cc) and ws27.is_contiguous()
+    flat = ws27.reshape(-1)
+    per_group = N * 9 * 3 * Cc
+    for grp in range(3):
+        blk = flat[grp * per_group:(grp + 1) * per_group].view(N, 9, 3, Cc)
+        assert torch.equal(blk[:, :, 0], hi.view(N, 27, Cc)[:, 9 * grp:9 * grp + 9])
+        assert torch.equal(blk[:, :, 1], lo.view(N, 27, Cc)[:, 9 * grp:9 * grp + 9])
+        assert torch.equal(blk[:, :, 2], blk[:, :, 0])
