@@ -132,8 +132,11 @@ gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t
     const int nk = K / BK;
     bf16x8 af[2][8], wf[2][8];
     // prologue: tiles 0 and 1 requested back to back, accumulators zeroed under their round trip
+    // (whole groups of NJ requests per operand: the BUF form walks M0 through a group)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { stage_a(0, 0, j); stage_w(0, 0, j); }
+    for (int j = 0; j < NJ; ++j) stage_a(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) stage_w(0, 0, j);
     if (nk > 1) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) stage_a(1, 1, j);
