@@ -38,7 +38,9 @@ DEVINL uint32_t pack2(float a, float b) {
 // operand, the request's row block in an SGPR offset, the K walk on the descriptor's base, M0 bumped by 1024 behind every request:
 // 2 scalar-side instructions per request and no vector ones (the global_load_lds form: 64-bit vector add + s_add + s_mov m0 + s_nop)
 typedef __attribute__((ext_vector_type(4))) int i32x4;
-template <bool BUF>
+// TEPI: the output tile leaves through wave-private LDS (4 KiB per 16-row pass, 16-byte chunks XOR-swizzled by the row) so that every
+// store instruction writes whole 256-byte row pieces (16 bytes per lane); otherwise 8 bytes per lane straight from the accumulators
+template <bool BUF, bool TEPI>
 __global__ void __launch_bounds__(256, 1)
 gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int ntm, int ntn, int gm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,6 +220,31 @@ gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t
     if (nk > 1) k_step(std::integral_constant<int, 1>{});
     k_step(std::integral_constant<int, 2>{});
 
+    if constexpr (TEPI) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // every wave is done with the operand tiles
+        char* const scr = smem + wave * 4096;
+        const int rrow = lane >> 4, rch = lane & 15;      // read side: 4 rows x 16 chunks of 16 bytes per pass
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint2 o;
+                o.x = pack2(acc[i][j][0], acc[i][j][1]);
+                o.y = pack2(acc[i][j][2], acc[i][j][3]);
+                // row l15, logical 16-byte chunk 2 j + (lg >> 1), half (lg & 1); physical chunk = logical ^ row
+                *(uint2*)(scr + l15 * 256 + (((2 * j + (lg >> 1)) ^ l15) << 4) + (lg & 1) * 8) = o;
+            }
+            // same-wave LDS operations complete in order: the reads below see the writes above
+#pragma unroll
+            for (int pss = 0; pss < 4; ++pss) {
+                const int r = pss * 4 + rrow;
+                const uint4 v = *(const uint4*)(scr + r * 256 + ((rch ^ r) << 4));
+                const int64_t m = m0 + wm * 128 + i * 16 + r;
+                *(uint4*)(C + m * N + n0 + wn * 128 + rch * 8) = v;
+            }
+        }
+    } else {
     // PLAIN epilogue, straight from the accumulators: 8 bytes (4 consecutive columns) per lane and fragment
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -231,25 +258,32 @@ gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t
             *(uint2*)(C + m * N + n) = o;
         }
     }
+    }
 }
 
 }  // namespace
 
 extern "C" int gemm4w_plain(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t K, int buffer_form, void* stream) {
     if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0 || 256 * K * 2 >= (1ll << 31)) return 1;
+    // buffer_form: bit 0 = buffer_load...lds requests, bit 1 = output through LDS (whole-row stores)
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm4w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 2;
-        if (hipFuncSetAttribute((const void*)gemm4w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 2;
+        if (hipFuncSetAttribute((const void*)gemm4w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 2;
+        if (hipFuncSetAttribute((const void*)gemm4w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 2;
+        if (hipFuncSetAttribute((const void*)gemm4w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 2;
+        if (hipFuncSetAttribute((const void*)gemm4w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return 2;
         attr = true;
     }
     const int ntm = (int)(M / BM), ntn = (int)(N / BN);
     const int gm = K >= 4096 ? 4 : 8;
-    if (buffer_form)
-        hipLaunchKernelGGL(gemm4w_kernel<true>, dim3((unsigned)(ntm * ntn)), dim3(256), LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A,
-                           (const bf16_t*)W, (bf16_t*)C, (int)M, (int)N, (int)K, ntm, ntn, gm);
-    else
-        hipLaunchKernelGGL(gemm4w_kernel<false>, dim3((unsigned)(ntm * ntn)), dim3(256), LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A,
-                           (const bf16_t*)W, (bf16_t*)C, (int)M, (int)N, (int)K, ntm, ntn, gm);
+    const dim3 grid((unsigned)(ntm * ntn)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W; bf16_t* c = (bf16_t*)C;
+    switch (buffer_form & 3) {
+        case 0: hipLaunchKernelGGL((gemm4w_kernel<false, false>), grid, block, LDS_BYTES, st, a, w, c, (int)M, (int)N, (int)K, ntm, ntn, gm); break;
+        case 1: hipLaunchKernelGGL((gemm4w_kernel<true, false>), grid, block, LDS_BYTES, st, a, w, c, (int)M, (int)N, (int)K, ntm, ntn, gm); break;
+        case 2: hipLaunchKernelGGL((gemm4w_kernel<false, true>), grid, block, LDS_BYTES, st, a, w, c, (int)M, (int)N, (int)K, ntm, ntn, gm); break;
+        default: hipLaunchKernelGGL((gemm4w_kernel<true, true>), grid, block, LDS_BYTES, st, a, w, c, (int)M, (int)N, (int)K, ntm, ntn, gm); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -42,7 +42,7 @@ if __name__ == "__main__":
     for M, N, K in [(256, 256, 64), (512, 256, 128), (256, 512, 192), (1024, 768, 1536), (2048, 512, 6144)]:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
         ref = a.float() @ w.float().T
-        for buf in (0, 1):
+        for buf in (0, 1, 2, 3):
             out = g4(a, w, torch.full((M, N), float("nan"), device=a.device, dtype=a.dtype), buf)
             torch.cuda.synchronize()
             err = ((out.float() - ref).norm() / ref.norm()).item()
@@ -58,5 +58,7 @@ if __name__ == "__main__":
             res.setdefault("dwm_8wave", []).append(round(fl / timeit(lambda: ops.gemm(a, w, None, out=out)) / 1e9, 1))
             res.setdefault("exp_4wave", []).append(round(fl / timeit(lambda: g4(a, w, out, 0)) / 1e9, 1))
             res.setdefault("exp_4wave_buffer_loads", []).append(round(fl / timeit(lambda: g4(a, w, out, 1)) / 1e9, 1))
+            res.setdefault("exp_4wave_row_stores", []).append(round(fl / timeit(lambda: g4(a, w, out, 2)) / 1e9, 1))
+            res.setdefault("exp_4wave_buffer_loads_row_stores", []).append(round(fl / timeit(lambda: g4(a, w, out, 3)) / 1e9, 1))
             res.setdefault("library", []).append(round(fl / timeit(lambda: torch.matmul(a, w.t(), out=out)) / 1e9, 1))
         print(json.dumps(res), flush=True)
