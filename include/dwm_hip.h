@@ -124,6 +124,10 @@ typedef struct dwm_gemm_args {
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
+/* Opt-in (environment DWM_GEMM4W=1, read at the first dwm_gemm_bf16 call): launches without row maps / taps / split-K and with
+ * M % 256 == N % 256 == 0, K % 64 == 0, K >= 128 run the same epilogues on a 4-wave main loop (gemm_bf16_4w.hip; +12-14 % on the bench's
+ * shapes, profiles/README.md).  Not the default until the whole GPU suite has run on it.  This counts the launches it served. */
+int64_t dwm_gemm4w_launches(void);
 
 /* ------------------------------------------------------------------------
  * Weight-gradient GEMM, both operands row-major with the contraction index as their ROW (gemm_tn.hip):

@@ -15,9 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdwm_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_tn.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "vae.hip", "train.hip", "fp32path.hip"]
-# translation units built without -amdgpu-mfma-vgpr-form (accumulators allowed into AGPRs); none at present
-AGPR_SOURCES: set = set()
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_4w.hip", "gemm_tn.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "vae.hip",
+           "train.hip", "fp32path.hip"]
+# translation units built without -amdgpu-mfma-vgpr-form (accumulators allowed into AGPRs): the 4-wave GEMM keeps the 256 accumulator
+# registers of a wave there
+AGPR_SOURCES: set = {"gemm_bf16_4w.hip"}
 ARCH = "gfx950"
 
 

@@ -18,6 +18,7 @@
 // stages for the activation tile (requested two K steps ahead: it is the operand that streams from HBM
 // when K is long) and two for the weight tile (one step ahead, L2-resident); one barrier per K step with a
 // counted vmcnt that leaves the newest activation requests in flight.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -1066,6 +1067,9 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     return e == hipSuccess ? DWM_OK : (int)e;
 }
 
+// gemm_bf16_4w.hip: the 4-wave main loop under the same epilogues, opt-in (DWM_GEMM4W=1); -1 = not a launch it covers
+int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream);
+
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || (a->C == nullptr && a->C32 == nullptr)) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 31) || a->N >= (1ll << 31)) return DWM_EINVAL;
@@ -1094,6 +1098,13 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
         default: return DWM_EINVAL;
     }
     if (a->C32 != nullptr && a->epilogue != DWM_EPI_RESID) return DWM_EUNSUPPORTED;
+    {
+        static const bool use4w = [] { const char* v = getenv("DWM_GEMM4W"); return v != nullptr && v[0] != '\0' && v[0] != '0'; }();
+        if (use4w && !DWM_RESERVED(a->reserved) && a->lda % 64 == 0) {
+            const int rc4 = dwm_gemm4w_try(a, stream);
+            if (rc4 >= 0) return rc4;
+        }
+    }
     ConvParams cp;
     auto mk = [](const dwm_rowmap2d& r, DevRowMap& d) -> bool {
         d.enabled = r.rw > 0;
