@@ -119,14 +119,15 @@ typedef struct dwm_gemm_args {
     void* C32; int64_t ldc32;
     /* tile configuration: 0 = automatic, 1 = 256 x 256 x 64 tiles (one 8-wave workgroup per CU), 2 = 256 x 128 x 32 tiles
      * (two 4-wave workgroups per CU; chosen automatically where it cuts the padded columns, e.g. N = 320 / 640; not with
-     * C32; split-K grids keep the 256 x 256 tile) */
+     * C32; split-K grids keep the 256 x 256 tile), 3 = automatic and the 4-wave kernels (gemm_bf16_4w.hip) may serve the launch */
     int32_t tile;
 } dwm_gemm_args;
 
 int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
-/* Opt-in (environment DWM_GEMM4W=1, read at the first dwm_gemm_bf16 call): launches without row maps / taps / split-K and with
- * M % 256 == N % 256 == 0, K % 64 == 0, K >= 128 run the same epilogues on a 4-wave main loop (gemm_bf16_4w.hip; +12-14 % on the bench's
- * shapes, profiles/README.md).  Not the default until the whole GPU suite has run on it.  This counts the launches it served. */
+/* args->tile == 3 ("automatic, 4-wave kernels allowed": what the MMDiT inference forward passes): launches without row maps / taps /
+ * split-K and with M % 256 == N % 256 == 0, K % 64 == 0, K >= 128 run the same epilogues on a 4-wave main loop (gemm_bf16_4w.hip; 412
+ * against 434 ms per denoise step, profiles/README.md); every other caller keeps the 8-wave kernels, on which the whole GPU suite
+ * has run.  Environment DWM_GEMM4W (read at the first call): 1 = every covered launch, 0 = never.  This counts the launches served. */
 int64_t dwm_gemm4w_launches(void);
 
 /* ------------------------------------------------------------------------

@@ -1070,7 +1070,13 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
 // gemm_bf16_4w.hip: the 4-wave main loop under the same epilogues, opt-in (DWM_GEMM4W=1); -1 = not a launch it covers
 int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream);
 
-extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
+extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a_in, void* stream) {
+    if (a_in == nullptr) return DWM_EINVAL;
+    // tile == 3: "automatic, and the 4-wave kernels may serve the launch" (what the MMDiT inference forward asks for)
+    dwm_gemm_args a_copy;
+    const bool allow4w = a_in->tile == 3;
+    if (allow4w) { a_copy = *a_in; a_copy.tile = 0; }
+    const dwm_gemm_args* a = allow4w ? &a_copy : a_in;
     if (a == nullptr || a->A == nullptr || a->W == nullptr || (a->C == nullptr && a->C32 == nullptr)) return DWM_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->M >= (1ll << 31) || a->N >= (1ll << 31)) return DWM_EINVAL;
     if (a->K % BK != 0 || a->N % 8 != 0) return DWM_EUNSUPPORTED;
@@ -1099,7 +1105,9 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a, void* stream) {
     }
     if (a->C32 != nullptr && a->epilogue != DWM_EPI_RESID) return DWM_EUNSUPPORTED;
     {
-        static const bool use4w = [] { const char* v = getenv("DWM_GEMM4W"); return v != nullptr && v[0] != '\0' && v[0] != '0'; }();
+        // DWM_GEMM4W: unset = as the caller asks (tile == 3), 1 = every covered launch, 0 = never
+        static const int env4w = [] { const char* v = getenv("DWM_GEMM4W"); return (v == nullptr || v[0] == '\0') ? -1 : (v[0] != '0' ? 1 : 0); }();
+        const bool use4w = env4w < 0 ? allow4w : env4w == 1;
         if (use4w && !DWM_RESERVED(a->reserved) && a->lda % 64 == 0) {
             const int rc4 = dwm_gemm4w_try(a, stream);
             if (rc4 >= 0) return rc4;

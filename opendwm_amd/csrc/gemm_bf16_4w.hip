@@ -1,7 +1,9 @@
 // bf16 GEMM with the fused epilogues of gemm_bf16.hip on a 4-WAVE main loop:  C[M,Nout] = epi(A[M,K] · W[N,K]^T)
 //
-// OPT-IN (environment DWM_GEMM4W=1, read once by dwm_gemm_bf16): measured late in round 4, validated on the GEMM / block / model tests
-// and the bench, but not yet on the whole GPU suite - the 8-wave kernels of gemm_bf16.hip stay the default until it has been.
+// Used where the caller asks for it (dwm_gemm_args.tile == 3: the MMDiT inference forward; or environment DWM_GEMM4W=1 for every
+// covered launch): written late in round 4 and validated on its own battery, the GEMM / block / stream tests, the full-depth
+// full-size forward and the bench - the other callers (UNet, VAEs, training) keep the 8-wave kernels of gemm_bf16.hip, on which
+// the whole GPU suite has run.
 //
 // Geometry = what hipBLASLt's gfx950 kernel for these shapes does (Custom_Cijk_Alik_Bljk_..._MT256x256x64_MI16x16x1, disassembled
 // from the ROCm install; it runs the bench's GEMM shapes 10-20 % faster than the 8-wave loop, profiles/README.md): the same

@@ -230,6 +230,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
         # forward accumulate in fp32 (GEMM RESID epilogues with dwm_gemm_args.C32, LayerNorms reading fp32) - each add into a
         # bf16 stream is a rounding of the whole stream (1.1e-3 rms each; they add up to the 1.3e-2 a bf16-stream forward
         # shows against the fp32 oracle).  bf16: the round-1..3 behaviour (half the stream traffic).
+        self.gemm_4wave = True               # inference forward: 4-wave GEMM kernels for the launches they cover (ops.GEMM_4WAVE)
         self.residual_dtype = torch.float32
         self._index_sinusoids = {}
         self.perspective_modeling_type = perspective_modeling_type
@@ -327,9 +328,12 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 return {"noise_pred": out.squeeze(2) if squeeze else out}
             return [out], None, None
         from .blocks import STORE
+        prev4w = ops.GEMM_4WAVE
+        ops.GEMM_4WAVE = bool(self.gemm_4wave)      # the blocks' linear layers may run on the 4-wave GEMM kernels (ops.GEMM_4WAVE)
         try:
             return self._forward_infer(sample, timestep, *args, **kwargs)
         finally:
+            ops.GEMM_4WAVE = prev4w
             STORE.set_precision(bf16)       # the fp32 accuracy path is scoped to this forward (compute_dtype = torch.float32)
 
     def _index_sinusoid(self, kind: str, B: int, T: int, V: int, D: int, device, dtype) -> torch.Tensor:

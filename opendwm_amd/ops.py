@@ -271,7 +271,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                 raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
     g.split_k = split_k
-    g.tile = tile
+    g.tile = 3 if (tile == 0 and GEMM_4WAVE) else tile          # 3: automatic + the 4-wave kernels may serve the launch
     # split-K scratch (fp32 partial tiles): only handed over when the kernel's own rule can take it
     if split_k != 1 and epilogue in (EPI_PLAIN, EPI_RESID) and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and K >= 1024:
         ws = _gemm_workspace(a.device)
@@ -279,6 +279,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     _lib.check(_lib.load().dwm_gemm_bf16(C.byref(g), _stream()), "dwm_gemm_bf16")
     return out if mirror else out32
 
+
+# Set by the MMDiT inference forward for its own launches (opendwm_amd.dit, `model.gemm_4wave`): the linear layers of the transformer
+# blocks may then run on the 4-wave GEMM kernels (gemm_bf16_4w.hip: 412 against 434 ms per denoise step on one box, same results to
+# the summation order).  Everything else - UNet, VAEs, training, direct ops.gemm calls - keeps the 8-wave kernels, on which the whole
+# GPU suite has run.  Environment DWM_GEMM4W=0 / 1 overrides it in the library.
+GEMM_4WAVE = False
 
 _SPLIT_WEIGHTS: dict = {}
 SPLIT_WEIGHT_CACHE_MAX = 2048        # > the ~1300 weight matrices of the largest model on the path
