@@ -120,13 +120,15 @@ class KernelTimer:
         self.small_bytes = 0.0      # algorithmic bytes of the short-sequence (packed kernel) attention launches
         self.group_bytes = 0.0      # the same for the group-masked (cross-view) launches
         self.shapes = []            # per GEMM record: (M, N, K, epilogue, implicit conv)
+        self.four_wave = []         # per GEMM record: the launch was served by gemm4w_kernel (gemm_bf16_4w.hip), not gemm_bf16_kernel
         self.enabled = False
 
     def install(self):
-        from opendwm_amd import ops
+        from opendwm_amd import _lib, ops
         gemm0, attn0 = ops.gemm, ops.attention
         self._orig = (gemm0, attn0)
         timer = self
+        count4w = _lib.load().dwm_gemm4w_launches        # host-side launch counter of the 4-wave kernels
 
         def gemm(a, w, *args, **kw):
             if not timer.enabled:
@@ -134,8 +136,10 @@ class KernelTimer:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             st = torch.cuda.current_stream()
             s.record(st)
+            n4 = count4w()
             out = gemm0(a, w, *args, **kw)
             e.record(st)
+            timer.four_wave.append(count4w() > n4)
             grid = kw.get("a_grid")
             M = (grid.pixels // 4 if kw.get("stride2") else grid.pixels) if grid is not None else (kw.get("rows") or a.shape[0])
             timer.records.append(("gemm", 2.0 * M * w.shape[0] * w.shape[1], s, e))
@@ -194,6 +198,16 @@ class KernelTimer:
                 fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
                 out[kind] = dict(launches=len(rs), flops=fl, ms=ms, tflops=fl / ms / 1e9,
                                  avg_us=1e3 * ms / len(rs))
+        # the GEMM launches by the kernel that served them
+        if "gemm" in out and len(self.four_wave) == out["gemm"]["launches"]:
+            gemms = [(f, s.elapsed_time(e)) for k, f, s, e in self.records if k == "gemm"]
+            split = {}
+            for name, want in (("gemm4w_kernel", True), ("gemm_bf16_kernel", False)):
+                rs = [r for r, is4 in zip(gemms, self.four_wave) if is4 == want]
+                if rs:
+                    fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
+                    split[name] = dict(launches=len(rs), tflops=fl / ms / 1e9, avg_us=1e3 * ms / len(rs), ms=ms)
+            out["gemm"]["by_kernel"] = split
         return out
 
 
@@ -918,10 +932,13 @@ def main():
                        "variant": ("text+layout (ImageAdapter recomputed every step, pointwise temporal)" if not args.adapter_cache else
                                    "text+layout (ImageAdapter residuals cached across steps, pointwise temporal)")
                        if args.layout else "text only (rowwise temporal, no adapter)"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all epilogues)",
+            "roofline": {"bound": "mfma", "kernel": "every dwm_gemm_bf16 launch of the step: gemm4w_kernel (gemm_bf16_4w.hip) where it covers the "
+                                                    "launch, gemm_bf16_kernel otherwise (all epilogues; split in by_kernel)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_bf16_kernel"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, " + pmc_source() + ")",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC of the 8-wave kernel, same tile and raster, " + pmc_source() + ")",
+                         "by_kernel": {k: {kk: vv for kk, vv in v.items() if kk != "ms"} | {"share_of_step_time": (v["ms"] / args.steps) / step_ms}
+                                       for k, v in (gm.get("by_kernel") or {}).items()},
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},

@@ -1,10 +1,11 @@
-"""GPU leg: the opt-in 4-wave GEMM kernels (opendwm_amd/csrc/gemm_bf16_4w.hip, environment DWM_GEMM4W=1).
+"""GPU leg: the 4-wave GEMM kernels (opendwm_amd/csrc/gemm_bf16_4w.hip; what the MMDiT inference forward asks for with
+dwm_gemm_args.tile = 3, and what DWM_GEMM4W=1 turns on for every call).
 
 The switch is read once per process by dwm_gemm_bf16, so the battery runs in a subprocess with the variable set: every epilogue
 the 4-wave kernels cover (bias / activations, GEGLU, q-k RMSNorm heads, the gated / plain / blended residual on the bf16 and on the
-fp32 stream, in place) on shapes they accept, against fp64 matrix products of the same bf16 inputs, plus the fallback for a shape
-they do not accept; `dwm_gemm4w_launches` must count exactly the covered calls.  The default path (variable unset) is everything
-else in tests/."""
+fp32 stream, in place) on shapes they accept, against fp64 matrix products of the same bf16 inputs, plus the fallback for shapes
+they do not accept; `dwm_gemm4w_launches` must count exactly the covered calls.  Direct ops.gemm calls elsewhere in tests/ (variable
+unset, tile 0) run the 8-wave kernels; the full-size model tests run the mix the inference forward produces."""
 import json
 import os
 import subprocess
