@@ -129,6 +129,9 @@ int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
  * against 434 ms per denoise step, profiles/README.md); every other caller keeps the 8-wave kernels, on which the whole GPU suite
  * has run.  Environment DWM_GEMM4W (read at the first call): 1 = every covered launch, 0 = never.  This counts the launches served. */
 int64_t dwm_gemm4w_launches(void);
+/* ... and how many of them ran the general form of those kernels (ragged M / N, A row map, taps, per-image residual row): only
+ * with DWM_GEMM4W=2 - that form was written without a GPU at hand at the end of round 4 and is off until validated. */
+int64_t dwm_gemm4w_launches_general(void);
 
 /* ------------------------------------------------------------------------
  * Weight-gradient GEMM, both operands row-major with the contraction index as their ROW (gemm_tn.hip):

@@ -114,6 +114,7 @@ SIGNATURES = {
     "dwm_source_hash": (C.c_char_p, []),
     "dwm_gemm_bf16": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dwm_gemm4w_launches": (_i64, []),
+    "dwm_gemm4w_launches_general": (_i64, []),
     "dwm_gemm_tn": (_i32, [C.POINTER(GemmTnArgs), _vp]),
     "dwm_attention_fwd": (_i32, [C.POINTER(AttnArgs), _vp]),
     "dwm_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),
