@@ -5,6 +5,9 @@ import torch
 
 from oracle import ctsd_oracle as O
 
+# extended cases of the long GPU tests (tests/conftest.py: the driver's run has a 1200 s limit)
+HEAVY = bool(os.environ.get("DWM_HEAVY_TESTS"))
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
