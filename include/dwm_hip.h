@@ -198,8 +198,10 @@ typedef struct dwm_attn_args {
                                                 * for every unit of the resident kernel (default: its maximum-free fast path with
                                                 * a checked fallback), bit 5 keep the tiled kernel (default for L <= 32: the
                                                 * packed short-sequence kernel; for unmasked self-attention with 64 <= L <= 608:
-                                                * the resident kernel), bit 7 per-wave form of the group-masked kernel, bits 8-11
-                                                * heads per workgroup / item */
+                                                * the resident kernel), bit 6 paired form of the resident kernel (8 waves, two
+                                                * query tiles per wave share every K / V fragment read; also DWM_ATTN_RES2=1;
+                                                * opt-in until validated on a GPU), bit 7 per-wave form of the group-masked
+                                                * kernel, bits 8-11 heads per workgroup / item */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */

@@ -1380,6 +1380,197 @@ attn_res_kernel(const AttnParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Paired resident form (written at the end of round 4 WITHOUT a GPU at hand; opt-in: dwm_attn_args.variant bit 6 or
+// environment DWM_ATTN_RES2=1; attn_res_kernel above stays the default until this one has been validated and measured).
+// Why: the tile loop of attn_res_kernel is bound by LDS READ BANDWIDTH, not by the matrix pipes.  Every 32x32x16 MFMA of the
+// loop takes one 1 KiB fragment from the images (K rows for S, transposed V for PV; Q and P' are in registers), a CU has 4
+// SIMDs and 128 B / clock of LDS read bandwidth: 4 KiB per MFMA slot = 32 clocks - exactly the slot's own length, i.e. the
+// LDS pipe must be busy 100 % of the time to keep the matrix pipes fed, and the measured 52-60 clocks per slot
+// (profiles/r3_attn_timeline.txt; 40 in the isolated loop probe, 32 with the fragment reads removed) are what bank
+// conflicts, the transposing 8-byte reads and 12 waves' arbitration leave of that.  The remedy is to use every fragment
+// TWICE: a unit of TWO adjacent query tiles per wave (res_unit<2>: both tiles' MFMAs take the same K / V fragment
+// registers, 512 B of LDS reads per MFMA).  That needs ~256 registers per wave (two sets of accumulators, scores and P'), so
+// the workgroup has 8 waves (2 per SIMD) instead of 12.
+// Schedule of a head's nqt query tiles over the 8 waves: full rounds of 16 tiles (wave w: tiles 16 r + 2 w, + 1) while 16
+// remain; the remaining rem < 16 tiles are spread as evenly as whole tiles allow - wave w takes rem / 8 + (w < rem % 8)
+// adjacent tiles (a pair, a single tile through res_unit<1>, or nothing).  L = 602: 19 tiles = 16 + 3 singles on waves 0-2
+// (SIMD loads 5 / 5 / 5 / 4 tiles, as with 12 waves); L = 448: 14 tiles = pairs on waves 0-5, singles on 6, 7 (4 / 4 / 3 / 3).
+// Everything else - images, swizzles, row tables, persistent workgroups, Q prefetch after a unit's loop, the two barriers per
+// head, the max-free fast path with its acceptance test and fallback, the register-exchange stores - is attn_res_kernel's.
+DWM_DEVINL void res2_unit_of(int r, int wave, int nfull, int rem, int& t0, int& cnt) {
+    if (r < nfull) { t0 = r * 16 + 2 * wave; cnt = 2; return; }
+    const int q = rem >> 3, x = rem & 7;
+    cnt = q + (wave < x ? 1 : 0);
+    t0 = nfull * 16 + wave * q + (wave < x ? wave : x);
+}
+
+__global__ void __launch_bounds__(512, 1)
+attn_res2_kernel(const AttnParams P) {
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int L = P.L, L0 = P.L0;
+    const int Lp = (L + 31) & ~31;
+    const int Lt = (L + 3) & ~3;
+    char* const kimg = smem;
+    char* const vimg = smem + Lp * 128;
+    int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
+    int32_t* const otab = tabs + 2 * Lt;
+
+    ResCtx c;
+    c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
+    c.L = L; c.L0 = L0; c.nsub = Lp >> 5;
+    c.l31 = l31; c.half = half; c.kswz = (lane >> 1) & 7;
+    {
+        const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+            const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+            c.vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+            c.vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        }
+    }
+
+    const int hpb = P.hpb;
+    const int n_items = P.n_problems * (int)P.fd_heads.d;
+    const int n_my = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int G = n_my * hpb;
+    auto item_of = [&](int g, uint32_t& prob, int64_t& hoff) {
+        const int it = g / hpb, hh = g - it * hpb;
+        const uint32_t item = blockIdx.x + (uint32_t)it * gridDim.x;
+        prob = fdiv(item, P.fd_heads);
+        hoff = ((int64_t)(item - prob * P.fd_heads.d) * hpb + hh) * 64;
+    };
+    auto build_tab = [&](int32_t* tab, int32_t* ot, uint32_t prob) {
+        const int64_t base0 = seg0_base(P.rm, (int)prob);
+        for (int l = tid; l < L; l += NW * 64) {
+            const int64_t r0 = l < L0 ? seg0_row(P.rm, base0, l) : 0;
+            if (tab != nullptr) tab[l] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
+            if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
+        }
+    };
+    auto copy_rows = [&](const int32_t* tab, int64_t ho, int s0, int s1, bool is_v, int me, int np) {
+        int i = s0 * 4;
+        i += (me - i % np + np) % np;
+        for (; i < s1 * 4; i += np) {
+            const int r = i * 8 + (lane >> 3);
+            const int rc = r < L ? r : L - 1;
+            const int64_t off = ((int64_t)tab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
+            if (!is_v) glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
+            else glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
+        }
+    };
+
+    const int nqt = (P.qend + 31) >> 5;
+    const int nfull = nqt >> 4;
+    const int rem = nqt - (nfull << 4);
+    const int rounds = nfull + (rem > 0 ? 1 : 0);
+    const bool force_safe = P.safe_softmax != 0;
+    const int n = c.nsub;
+    if (G == 0) return;
+
+    // raw Q fragments of query tile t of the head at column offset ho (rows past the last query: a copy of the last one)
+    auto load_q = [&](bf16x8 (&dst)[4], const int32_t* tab, int64_t ho, int t) {
+        int lq = t * 32 + l31;
+        lq = lq < P.qend ? lq : P.qend - 1;
+        const bf16_t* qp = P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(qp + ks * 16);
+    };
+    auto zero_q = [&](bf16x8 (&dst)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dst[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    auto out_ptr = [&](int64_t ho, int t) -> bf16_t* {
+        int lq = t * 32 + l31;
+        lq = lq < P.qend ? lq : P.qend - 1;
+        return P.o0 + ((int64_t)otab[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + ho;
+    };
+
+    uint32_t prob; int64_t hoff;
+    item_of(0, prob, hoff);
+    build_tab(tabs, otab, prob);
+    __syncthreads();
+    copy_rows(tabs, hoff, 0, n, false, wave, NW);
+    copy_rows(tabs, hoff, 0, n, true, wave, NW);
+    int t_first, c_first;                                    // this wave's first unit of every head
+    res2_unit_of(0, wave, nfull, rem, t_first, c_first);
+    bf16x8 qn[2][4];                                         // raw Q fragments of this wave's next unit
+    if (c_first > 0) load_q(qn[0], tabs, hoff, t_first); else zero_q(qn[0]);
+    if (c_first > 1) load_q(qn[1], tabs, hoff, t_first + 1); else zero_q(qn[1]);
+
+    for (int g = 0; g < G; ++g) {
+        const int it = g / hpb;
+        const int32_t* const tab = tabs + (it & 1) * Lt;
+        item_of(g, prob, hoff);
+        const bool has_next = g + 1 < G;
+        uint32_t nprob = prob; int64_t nhoff = hoff;
+        const int32_t* ntab = tab;
+        const bool new_item_next = has_next && (g + 1) / hpb != it;
+        if (has_next) {
+            item_of(g + 1, nprob, nhoff);
+            if (new_item_next) {
+                ntab = tabs + ((it + 1) & 1) * Lt;
+                build_tab((int32_t*)ntab, nullptr, nprob);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
+        __syncthreads();                                     // ... and everybody else's
+        c.rowtab = tab;
+
+        for (int r = 0; r < rounds; ++r) {
+            int t0, cnt;
+            res2_unit_of(r, wave, nfull, rem, t0, cnt);
+            if (cnt == 0) continue;
+            // this wave's NEXT unit: the next round of this head, or its first unit of the next head; its Q rows are requested
+            // when this unit's tile loop is over and travel under the normalisation, the stores and the barriers
+            int tn = 0, cn = 0;
+            if (r + 1 < rounds) res2_unit_of(r + 1, wave, nfull, rem, tn, cn);
+            const bool same = cn > 0;
+            if (!same && has_next) { tn = t_first; cn = c_first; }
+            auto fetch_next_q = [&]() {
+                const int32_t* const t2 = same ? tab : ntab;
+                const int64_t ho2 = same ? hoff : nhoff;
+                if (cn > 0) load_q(qn[0], t2, ho2, tn); else zero_q(qn[0]);
+                if (cn > 1) load_q(qn[1], t2, ho2, tn + 1); else zero_q(qn[1]);
+            };
+            ResGlobal gm;
+            gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
+            if (cnt == 2) {
+                bf16x8 q[2][4];
+                bf16_t* op[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) q[t][ks] = qn[t][ks];
+                    op[t] = out_ptr(hoff, t0 + t);
+                }
+                res_unit<2>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+            } else {
+                bf16x8 q[1][4];
+                bf16_t* op[1];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) q[0][ks] = qn[0][ks];
+                op[0] = out_ptr(hoff, t0);
+                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+            }
+        }
+        __syncthreads();                                     // everybody is done with this head's images
+        if (new_item_next) build_tab(nullptr, otab, nprob);
+        if (has_next) {
+            copy_rows(ntab, nhoff, 0, n, false, wave, NW);
+            copy_rows(ntab, nhoff, 0, n, true, wave, NW);
+        }
+    }
+}
+
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
 __global__ void __launch_bounds__(64)
@@ -1527,6 +1718,20 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             if (nwc == 0) nwc = 12;
             if (nwc < 1 || nwc > 12) return DWM_EINVAL;
             P.nwc = nwc;
+        }
+        // paired form (attn_res2_kernel: 8 waves, two query tiles per unit): variant bit 6, or DWM_ATTN_RES2=1 for every
+        // resident launch of the process (read at the first call).  Off by default: written without a GPU at hand.
+        static const bool env_res2 = [] { const char* v = getenv("DWM_ATTN_RES2"); return v != nullptr && v[0] != '\0' && v[0] != '0'; }();
+        if (((a->variant >> 6) & 1) || env_res2) {
+            if ((a->variant & 15) != 0) return DWM_EINVAL;          // (no compute-wave override in this form)
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                (void)hipFuncSetAttribute((const void*)attn_res2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2_set = true;
+            }
+            hipLaunchKernelGGL(attn_res2_kernel, dim3(nblk), dim3(512), lds, s, P);
+            const hipError_t e2 = hipGetLastError();
+            return e2 == hipSuccess ? DWM_OK : (int)e2;
         }
         static bool attr_set = false;
         if (!attr_set) {

@@ -314,6 +314,8 @@ if __name__ == "__main__":
         bench_attn([0, 32 | 1])
     if "attnr" in what:                  # the resident kernel's launches only
         bench_attn([0], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
+    if "attnr2" in what:                 # ... against the paired form (variant bit 6: attn_res2_kernel, 8 waves x two query tiles), alternating
+        bench_attn([0, 64, 0, 64], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
     if "s32" in what:
         bench_stream32()
     if "gemm" in what:
