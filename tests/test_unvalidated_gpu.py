@@ -6,8 +6,14 @@ next round).  A case moves into the regular files once it has passed on hardware
   * attn_res2_kernel (attention.hip; dwm_attn_args.variant bit 6 / DWM_ATTN_RES2=1): the resident attention kernel with two
     query tiles per wave - every shape class the resident kernel's own tests hold, against the fp32 reference AND against the
     default kernel's output (the same per-tile arithmetic in the same order: expected bit-equal, logged, not asserted).
+  * the GENERAL form of the 4-wave GEMM kernels (gemm_bf16_4w.hip, template parameter GEN; DWM_GEMM4W=2): ragged M / N, the A row
+    map and the taps of an implicit convolution (dense and stride 2), the per-image residual row - a battery in a subprocess with
+    the variable set (it is read once per process), against fp64 products / F.conv2d AND against the 8-wave kernels' output of
+    the same call in this process; `dwm_gemm4w_launches_general` must count exactly the covered calls.
 """
+import json
 import os
+import subprocess
 import sys
 
 import pytest
@@ -18,6 +24,129 @@ sys.path.insert(0, ROOT)
 
 from tests.common import rel_err                      # noqa: E402
 from tests.test_hip_gpu import TOL_KERNEL, _attn_ref, _log, _rand      # noqa: E402
+
+TOL, TOL32 = 6e-3, 2e-5
+
+
+def _gemm_general_battery():
+    """runs in a subprocess (DWM_GEMM4W=2, or unset for the 8-wave reference outputs); prints one JSON line + saves the outputs"""
+    import torch.nn.functional as F
+    from opendwm_amd import _lib, ops
+    from opendwm_amd.blocks import geglu_pack
+    f32 = torch.float32
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    out, keep = {}, {}
+
+    def rnd(shape, seed, scale=1.0, dtype=bf16):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(*shape, generator=g) * scale).to(dev).to(dtype)
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+    gen = lambda: int(lib.dwm_gemm4w_launches_general())
+    n0 = gen()
+    # PLAIN, ragged M and / or N (N % 8 == 0), several K lengths incl. two steps
+    for M, N, K in [(300, 256, 128), (256, 320, 128), (300, 328, 192), (1000, 512, 256), (29568 // 8, 1536, 1536), (257, 8, 128), (1, 264, 640)]:
+        a, w, b = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+        y = a.double() @ w.double().T + b.double()
+        got = ops.gemm(a, w, b, act=ops.ACT_SILU, split_k=1)
+        out[f"plain_{M}x{N}x{K}"] = rel(got, F.silu(y))
+        keep[f"plain_{M}x{N}x{K}"] = got
+    out["n_plain"] = gen() - n0
+    n0 = gen()
+    # GEGLU / RMSHEAD with ragged M and N % 64 == 0 but not % 256
+    for M, N, K in [(300, 384, 128), (462, 1536 + 128, 256)]:
+        a, w, b = rnd((M, K), 4), rnd((N, K), 5, K ** -0.5), rnd((N,), 6)
+        y = a.double() @ w.double().T + b.double()
+        got = ops.gemm(a, geglu_pack(w), geglu_pack(b), epilogue=ops.EPI_GEGLU)
+        out[f"geglu_{M}x{N}x{K}"] = rel(got, y[:, :N // 2] * F.gelu(y[:, N // 2:]))
+        keep[f"geglu_{M}x{N}x{K}"] = got
+    for M, heads, K in [(300, 2, 128), (154 * 3, 6, 384)]:
+        D = heads * 64
+        a, w, b = rnd((M, K), 7), rnd((3 * D, K), 8, K ** -0.5), rnd((3 * D,), 9)
+        rms = (1.0 + 0.1 * torch.randn(2 * D, generator=torch.Generator().manual_seed(10))).to(dev).to(bf16)
+        y = a.double() @ w.double().T + b.double()
+        qk = y[:, :2 * D].view(M, 2 * heads, 64)
+        qk = qk * torch.rsqrt(qk.pow(2).mean(-1, keepdim=True) + 1e-6) * rms.double().view(2 * heads, 64)
+        got = ops.gemm(a, w, b, epilogue=ops.EPI_RMSHEAD, rms_w=rms, rms_ncols=2 * D, rms_eps=1e-6)
+        out[f"rmshead_{M}x{heads}x{K}"] = rel(got, torch.cat([qk.reshape(M, 2 * D), y[:, 2 * D:]], 1))
+        keep[f"rmshead_{M}x{heads}x{K}"] = got
+    out["n_geglu_rmshead"] = gen() - n0
+    n0 = gen()
+    # RESID on the bf16 and on the fp32 stream with ragged M (the context stream: 154 tokens per image), in place
+    for M, N, K, rpg in [(154 * 3, 1536, 1536, 154), (300, 320, 128, 100)]:
+        a, w, b = rnd((M, K), 11), rnd((N, K), 12, K ** -0.5), rnd((N,), 13)
+        groups = (M + rpg - 1) // rpg
+        gate = rnd((groups, N), 14)
+        alpha = torch.rand(groups, generator=torch.Generator().manual_seed(15)).to(dev)
+        rows = torch.arange(M, device=dev) // rpg
+        y = a.double() @ w.double().T + b.double()
+        al = alpha.double()[rows][:, None]
+        for name, dt, tol in (("bf16", bf16, TOL), ("fp32", f32, TOL32)):
+            res, blend = rnd((M, N), 16, dtype=dt), rnd((M, N), 17, dtype=dt)
+            kw = (lambda t: dict(out32=t, mirror=False, split_k=1)) if dt == f32 else (lambda t: dict(out=t, split_k=1))
+            r1 = res.clone()
+            ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=rpg, res=r1, **kw(r1))
+            bl = blend.clone()
+            ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=res, blend=bl, alpha=alpha, rows_per_alpha=rpg, **kw(bl))
+            r3 = res.clone()
+            ops.gemm(a, w, None, epilogue=ops.EPI_RESID, res=r3, **kw(r3))
+            out[f"resid_{name}_{M}x{N}x{K}"] = {
+                "gate": rel(r1, res.double() + gate.double()[rows] * y),
+                "blend": rel(bl, al * blend.double() + (1 - al) * (res.double() + y)),
+                "plain": rel(r3, res.double() + a.double() @ w.double().T), "tol": tol}
+            keep[f"resid_{name}_{M}x{N}x{K}"] = torch.stack([r1.float(), bl.float(), r3.float()])
+    out["n_resid"] = gen() - n0
+    n0 = gen()
+    # the residual row per image (res_mod < 0), full tiles and ragged
+    for M, N, K, per in [(512, 256, 128, 64), (300, 320, 192, 50)]:
+        a, w, b = rnd((M, K), 18), rnd((N, K), 19, K ** -0.5), rnd((N,), 20)
+        rowres = rnd(((M + per - 1) // per, N), 21)
+        rows = torch.arange(M, device=dev) // per
+        got = ops.gemm(a, w, b, epilogue=ops.EPI_RESID, res=rowres, res_mod=-per, split_k=1)
+        out[f"rowres_{M}x{N}x{K}"] = rel(got, a.double() @ w.double().T + b.double() + rowres.double()[rows])
+        keep[f"rowres_{M}x{N}x{K}"] = got
+    out["n_rowres"] = gen() - n0
+    n0 = gen()
+    # implicit 3x3 convolution over the padded token grid (A row map + 9 taps), dense and stride 2, compact output
+    for I, h, w_, C, N in [(3, 16, 28, 128, 320), (2, 4, 6, 64, 192), (7, 9, 5, 320, 640), (2, 8, 12, 192, 256)]:
+        grid = ops.PaddedGrid(I, h, w_)
+        x = rnd((I, C, h, w_), 22)
+        wt, b = rnd((N, C, 3, 3), 23, (9 * C) ** -0.5), rnd((N,), 24)
+        idx = grid.interior_index().to(dev)
+        xp = torch.zeros((grid.rows, C), dtype=bf16, device=dev)
+        xp[idx] = x.permute(0, 2, 3, 1).reshape(-1, C)
+        wp = wt.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+        got = ops.gemm(xp, wp, b, act=ops.ACT_RELU, a_grid=grid, conv3x3=True, split_k=1)
+        ref = F.relu(F.conv2d(x.float(), wt.float(), b.float(), padding=1)).permute(0, 2, 3, 1).reshape(-1, N)
+        out[f"conv3x3_{I}x{h}x{w_}x{C}x{N}"] = rel(got, ref)
+        keep[f"conv3x3_{I}x{h}x{w_}x{C}x{N}"] = got
+        if h % 2 == 0 and w_ % 2 == 0:
+            got2 = ops.gemm(xp, wp, b, a_grid=grid, conv3x3=True, stride2="sym", split_k=1)
+            ref2 = F.conv2d(x.float(), wt.float(), b.float(), padding=1, stride=2).permute(0, 2, 3, 1).reshape(-1, N)
+            out[f"conv3x3s2_{I}x{h}x{w_}x{C}x{N}"] = rel(got2, ref2)
+            keep[f"conv3x3s2_{I}x{h}x{w_}x{C}x{N}"] = got2
+    out["n_conv"] = gen() - n0
+    out["n_total_4w"] = int(lib.dwm_gemm4w_launches())
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in keep.items()}, os.environ["DWM_BATTERY_OUT"])
+    print("GEMM4WGEN " + json.dumps(out))
+
+
+def _run_battery(mode, path):
+    env = dict(os.environ, DWM_BATTERY_OUT=path)
+    env.pop("DWM_GEMM4W", None)
+    if mode is not None:
+        env["DWM_GEMM4W"] = mode
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("GEMM4WGEN ")]
+    assert len(line) == 1, r.stdout[-2000:]
+    return json.loads(line[0][10:])
+
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("DWM_TEST_UNVALIDATED"),
@@ -125,3 +254,32 @@ def test_attention_paired_resident_rejects_wave_override(dev):
     out = torch.zeros((N, heads * 64), dtype=bf16, device=dev)
     with pytest.raises(RuntimeError):
         ops.attention(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], out, ops.rowmap_identity(1, N), heads, variant=RES2 | 8)
+
+
+def test_four_wave_gemm_general_form(dev, tmp_path):
+    gen = _run_battery("2", str(tmp_path / "gen.pt"))
+    base = _run_battery("0", str(tmp_path / "base.pt"))           # the same calls on the 8-wave kernels
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "gpu_parity.log"), "a") as f:
+        f.write(json.dumps({"test": "gemm4w_general_form", **gen}) + "\n")
+    # every call of the battery is one the general form covers; none ran it without the switch
+    assert gen["n_plain"] == 7 and gen["n_geglu_rmshead"] == 4 and gen["n_resid"] == 2 * 2 * 3 and gen["n_rowres"] == 2, gen
+    assert gen["n_conv"] == 4 + 3, gen
+    assert all(base[k] == 0 for k in base if k.startswith("n_")), base
+    for k, v in gen.items():
+        if k.startswith("n_"):
+            continue
+        if isinstance(v, dict):
+            tol = v.pop("tol", TOL)
+            assert all(e < tol for e in v.values()), (k, v)
+        else:
+            assert v < TOL, (k, v)
+    # against the 8-wave kernels on the same inputs: the same products in a different summation order
+    a, b = torch.load(str(tmp_path / "gen.pt")), torch.load(str(tmp_path / "base.pt"))
+    worst = {k: rel_err(a[k], b[k]) for k in a}
+    _log("gemm4w_general_vs_8wave", **{k: v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
+    assert all(v < TOL for v in worst.values()), worst
+
+
+if __name__ == "__main__":
+    _gemm_general_battery()
