@@ -1,0 +1,38 @@
+#!/bin/bash
+# gpurun call A of round 5 (prepared at the end of round 4, whose GPU budget was spent before these kernels were written):
+#   1. the gated tests of the kernels written without a GPU (tests/test_unvalidated_gpu.py): attn_res2_kernel, the general 4-wave GEMM
+#   2. attention microbench: resident kernel against its paired form, alternating in one process
+#   3. bench A/B on this box: default | DWM_ATTN_RES2=1 | DWM_GEMM4W=2 | both
+#   4. the default GPU suite with durations (the driver's limit for it is 1200 s; tests/conftest.py)
+# usage: gpurun --timeout 2700 -- 'bash scripts/calls/r5_a.sh'
+TAG=${1:-r5a}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+rm -f gpurun_out/gpu_parity.log
+echo "== gated tests (DWM_TEST_UNVALIDATED=1)"; date
+DWM_TEST_UNVALIDATED=1 timeout 900 python -m pytest tests/test_unvalidated_gpu.py -m gpu -q -rf --tb=short -p no:cacheprovider > $OUT/pytest_unvalidated.log 2>&1
+echo "exit $?" | tee -a $OUT/pytest_unvalidated.log; tail -30 $OUT/pytest_unvalidated.log | cut -c1-300
+cp gpurun_out/gpu_parity.log $OUT/gpu_parity_unvalidated.log 2>/dev/null
+echo "== attention microbench: variant 0 (attn_res_kernel<12>) against 64 (attn_res2_kernel)"; date
+timeout 300 python scripts/microbench.py attnr2 > $OUT/microbench_attn_res2.log 2>&1; cut -c1-200 $OUT/microbench_attn_res2.log
+echo "== bench A/B"; date
+for cfg in "default:" "res2:DWM_ATTN_RES2=1" "gemm4wgen:DWM_GEMM4W=2" "both:DWM_ATTN_RES2=1 DWM_GEMM4W=2" "default2:"; do
+  name=${cfg%%:*}; envs=${cfg#*:}
+  env $envs timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-text-only-leg > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  echo "$name exit $?"; python - "$OUT/bench_$name.json" <<'PY'
+import json, sys
+for ln in open(sys.argv[1]):
+    if ln.startswith("{"):
+        d = json.loads(ln)
+        print("  ms/step", round(d["ms_per_step"], 2), "gemm", round(d["roofline"]["achieved"] or 0, 1), "TFLOP/s", "attn_res frac", round(d["roofline_attention"]["frac"], 4),
+              "by_kernel", {k: round(v["tflops"], 1) for k, v in (d["roofline"].get("by_kernel") or {}).items()})
+PY
+done
+echo "== default GPU suite (as the driver runs it)"; date
+rm -f gpurun_out/gpu_parity.log
+timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider --durations=25 > $OUT/pytest.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest.log
+tail -45 $OUT/pytest.log | cut -c1-250
+cp gpurun_out/gpu_parity.log $OUT/gpu_parity.log 2>/dev/null
+date
