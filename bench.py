@@ -318,8 +318,7 @@ def main_unet(args):
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)          # (set_device included)
     D.init("nccl", dev)
     from opendwm_amd import _lib
     from opendwm_amd.pipeline import UNetDenoiser
@@ -413,8 +412,7 @@ def main_train(args):
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)          # (set_device included)
     D.init("nccl", dev, force=args.preflight)     # --preflight on one GPU: a one-rank RCCL group, DDP and its probes included
     pre = D.preflight(dev) if (world > 1 or args.preflight) else None
     use_ddp = world > 1 or args.preflight
@@ -524,8 +522,7 @@ def main_train_unet(args):
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)          # (set_device included)
     D.init("nccl", dev)
     from opendwm_amd import _lib
     from opendwm_amd.pipeline import CTSDTrainer
@@ -594,8 +591,7 @@ def main_tvae_ar(args):
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()
     assert world == args.gpus == 1, "--tvae-ar is a one-GPU line (the multi-GPU form of this job is --frame-shard / replicas)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)          # (set_device included)
     from opendwm_amd import _lib
     from opendwm_amd.build import ensure_built
     from opendwm_amd.dit import model_flops
@@ -814,8 +810,7 @@ def main():
     from opendwm_amd import dist as D
     rank, local_rank, world = D.env_ranks()
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = D.local_device(local_rank)          # (set_device included)
     D.init("nccl", dev, force=args.preflight)     # "nccl" == RCCL on ROCm; a single process needs no group unless --preflight asks for one
     pre = D.preflight(dev) if (world > 1 or args.preflight) else None     # fails loudly (rc != 0) before anything is timed
 

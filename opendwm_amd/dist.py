@@ -111,22 +111,46 @@ def preflight(device: torch.device = None, mbytes: int = 64) -> dict:
     import hashlib
     import socket
     host = int.from_bytes(hashlib.sha256(socket.gethostname().encode()).digest()[:7], "little")
-    mine = torch.tensor([host, device.index if on_gpu and device.index is not None else (torch.cuda.current_device() if on_gpu else -1 - rank),
-                         os.getpid()], dtype=torch.int64, device=dev)
+    index = device.index if on_gpu and device.index is not None else (torch.cuda.current_device() if on_gpu else -1 - rank)
+    mine = torch.tensor([host, device_identity(device) if on_gpu else -1 - rank, index, os.getpid()], dtype=torch.int64, device=dev)
     got = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)
     ids = [tuple(int(v) for v in t.tolist()) for t in got]
     if on_gpu:
         check_distinct_devices(ids)
     info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True, distinct_devices=on_gpu,
-                hosts=len({h for h, _, _ in ids}))
+                hosts=len({i[0] for i in ids}))
     return info
 
 
+def local_device(local_rank: int) -> torch.device:
+    """the GPU of this rank: index LOCAL_RANK when the launcher leaves all GPUs of the node visible to every rank (torchrun's
+    default), index LOCAL_RANK mod the visible count when it isolates them (one visible device per rank: index 0)"""
+    n = torch.cuda.device_count()
+    if n < 1:
+        raise RuntimeError("no visible GPU on this rank")
+    idx = local_rank if local_rank < n else local_rank % n
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
+def device_identity(device: torch.device) -> int:
+    """PCI address (domain, bus, device) of a visible GPU as one integer: the same physical GPU has the same value whatever
+    index a rank sees it under (-1 if this PyTorch build does not report it)"""
+    try:
+        p = torch.cuda.get_device_properties(device)
+        return (int(p.pci_domain_id) << 16) | (int(p.pci_bus_id) << 8) | int(p.pci_device_id)
+    except Exception:
+        return -1
+
+
 def check_distinct_devices(ids) -> None:
-    """ids: one (host hash, device index, pid) per rank.  Raises if two ranks of one host selected the same device."""
-    if len({(h, i) for h, i, _ in ids}) != len(ids):
-        raise RuntimeError(f"preflight: ranks share a GPU: (host hash, device index, pid) = {list(ids)}")
+    """ids: one (host hash, PCI identity, device index, pid) per rank - or (host hash, device index, pid).  Raises if two ranks
+    of one host selected the same device: the same PCI address AND the same index (ranks that each see only their own GPU all
+    report index 0 with different addresses; partitions of one GPU share the address and differ in the index)."""
+    key = [t[:-1] for t in ids]
+    if len(set(key)) != len(key):
+        raise RuntimeError(f"preflight: ranks share a GPU: (host hash, [PCI identity,] device index, pid) = {list(ids)}")
 
 
 def measure_allreduce(nbytes: int, device: torch.device = None, dtype: torch.dtype = torch.float32, repeat: int = 3) -> float:

@@ -365,3 +365,9 @@ def test_preflight_device_check_is_per_host():
     D.check_distinct_devices([(11, 0, 1)])
     with pytest.raises(RuntimeError, match="share a GPU"):
         D.check_distinct_devices([(11, 0, 1), (11, 1, 2), (11, 1, 3), (22, 1, 4)])
+    # with the PCI identity (host, pci, index, pid): ranks that each see only their own GPU (index 0 everywhere, different
+    # addresses) pass; so do partitions of one GPU (same address, different indices); the same address and index does not
+    D.check_distinct_devices([(11, 0x100 * b, 0, 50 + b) for b in range(8)])
+    D.check_distinct_devices([(11, 0x500, i, 60 + i) for i in range(4)])
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        D.check_distinct_devices([(11, 0x500, 0, 1), (11, 0x600, 0, 2), (11, 0x500, 0, 3)])
