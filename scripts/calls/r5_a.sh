@@ -30,6 +30,13 @@ for ln in open(sys.argv[1]):
               "by_kernel", {k: round(v["tflops"], 1) for k, v in (d["roofline"].get("by_kernel") or {}).items()})
 PY
 done
+echo "== other models on the 4-wave kernels (DWM_GEMM4W=1 / 2 force them for every covered launch): train step, UNet"; date
+for cfg in "train_8w:" "train_4w:DWM_GEMM4W=1" "unet_8w:" "unet_4wgen:DWM_GEMM4W=2"; do
+  name=${cfg%%:*}; envs=${cfg#*:}
+  flags="--train --steps 4 --warmup 2"; case $name in unet*) flags="--unet --steps 10 --warmup 3";; esac
+  env $envs timeout 600 python bench.py $flags > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  echo "$name exit $?"; grep '^{' $OUT/bench_$name.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  ', d['value'], d['unit'], round(d['ms_per_step'],2), 'ms')"
+done
 echo "== default GPU suite (as the driver runs it)"; date
 rm -f gpurun_out/gpu_parity.log
 timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider --durations=25 > $OUT/pytest.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest.log

@@ -155,3 +155,25 @@ def test_take_sequence_clip_and_latent_length():
     assert D.latent_sequence_length(8) == 8
     with pytest.raises(ValueError):
         D.latent_sequence_length(16, 1, 4)
+
+
+def test_bench_kernel_timer_summary_splits_gemm_launches_by_kernel():
+    """bench.KernelTimer.summary(): totals per kind and the 4-wave / 8-wave split of the GEMM records (stand-in events)"""
+    import bench
+
+    class Ev:
+        def __init__(self, t): self.t = t
+        def elapsed_time(self, other): return other.t - self.t
+
+    t = bench.KernelTimer()
+    t.records = [("gemm", 2e12, Ev(0.0), Ev(2.0)), ("attn", 1e12, Ev(2.0), Ev(3.0)), ("gemm", 1e12, Ev(3.0), Ev(5.0)),
+                 ("gemm", 3e12, Ev(5.0), Ev(6.0))]
+    t.four_wave = [True, False, True]
+    s = t.summary()
+    assert s["gemm"]["launches"] == 3 and abs(s["gemm"]["ms"] - 5.0) < 1e-9 and abs(s["gemm"]["tflops"] - 6e12 / 5.0 / 1e9) < 1e-6
+    by = s["gemm"]["by_kernel"]
+    assert by["gemm4w_kernel"]["launches"] == 2 and abs(by["gemm4w_kernel"]["ms"] - 3.0) < 1e-9
+    assert by["gemm_bf16_kernel"]["launches"] == 1 and abs(by["gemm_bf16_kernel"]["tflops"] - 1e12 / 2.0 / 1e9) < 1e-6
+    assert s["attn"]["launches"] == 1
+    t.four_wave = [True]                      # lengths out of step (a leg that recorded without the counter): no split, no error
+    assert "by_kernel" not in t.summary()["gemm"]
