@@ -1383,15 +1383,15 @@ attn_res_kernel(const AttnParams P) {
 // ---------------------------------------------------------------------------------------------------------------
 // Paired resident form (written at the end of round 4 WITHOUT a GPU at hand; opt-in: dwm_attn_args.variant bit 6 or
 // environment DWM_ATTN_RES2=1; attn_res_kernel above stays the default until this one has been validated and measured).
-// Why: the tile loop of attn_res_kernel is bound by LDS READ BANDWIDTH, not by the matrix pipes.  Every 32x32x16 MFMA of the
-// loop takes one 1 KiB fragment from the images (K rows for S, transposed V for PV; Q and P' are in registers), a CU has 4
-// SIMDs and 128 B / clock of LDS read bandwidth: 4 KiB per MFMA slot = 32 clocks - exactly the slot's own length, i.e. the
-// LDS pipe must be busy 100 % of the time to keep the matrix pipes fed, and the measured 52-60 clocks per slot
-// (profiles/r3_attn_timeline.txt; 40 in the isolated loop probe, 32 with the fragment reads removed) are what bank
-// conflicts, the transposing 8-byte reads and 12 waves' arbitration leave of that.  The remedy is to use every fragment
-// TWICE: a unit of TWO adjacent query tiles per wave (res_unit<2>: both tiles' MFMAs take the same K / V fragment
-// registers, 512 B of LDS reads per MFMA).  That needs ~256 registers per wave (two sets of accumulators, scores and P'), so
-// the workgroup has 8 waves (2 per SIMD) instead of 12.
+// Why: every 32x32x16 MFMA of attn_res_kernel's tile loop takes one 1 KiB fragment from the images (K rows for S, transposed V for
+// PV; Q and P' are in registers): 1.5 LDS instructions with their address adds and waits per MFMA.  The isolated loop probe runs
+// at 22.5 ns per MFMA slot with these reads and at 17.8 ns without them (17.2 for the bare MFMA; profiles/README.md), the kernel
+// at 52-60 clocks per 32-clock slot (profiles/r3_attn_timeline.txt).  The LDS array is not the limit by itself (256 B / clock for
+// ds_read_b128 / ds_read_b64_tr_b16: 16 of a slot's 32 clocks for 4 SIMDs), the instructions and their waits are what can go.
+// The remedy tried here is to use every fragment TWICE: a unit of TWO adjacent query tiles per wave (res_unit<2>: both tiles'
+// MFMAs take the same K / V fragment registers - half the LDS instructions and bytes per MFMA, two independent accumulation
+// chains).  That needs ~256 registers per wave (two sets of accumulators, scores and P'), so the workgroup has 8 waves (2 per
+// SIMD) instead of 12; whether the smaller number of resident waves costs more than the reads return is a measurement.
 // Schedule of a head's nqt query tiles over the 8 waves: full rounds of 16 tiles (wave w: tiles 16 r + 2 w, + 1) while 16
 // remain; the remaining rem < 16 tiles are spread as evenly as whole tiles allow - wave w takes rem / 8 + (w < rem % 8)
 // adjacent tiles (a pair, a single tile through res_unit<1>, or nothing).  L = 602: 19 tiles = 16 + 3 singles on waves 0-2
