@@ -17,6 +17,8 @@ echo "exit $?" | tee -a $OUT/pytest_unvalidated.log; tail -30 $OUT/pytest_unvali
 cp gpurun_out/gpu_parity.log $OUT/gpu_parity_unvalidated.log 2>/dev/null
 echo "== attention microbench: variant 0 (attn_res_kernel<12>) against 64 (attn_res2_kernel)"; date
 timeout 300 python scripts/microbench.py attnr2 > $OUT/microbench_attn_res2.log 2>&1; cut -c1-200 $OUT/microbench_attn_res2.log
+echo "== SQ counters of the joint attention: resident kernel (variant 0) against its paired form (64)"; date
+for v in 0 64; do timeout 240 bash scripts/pmc.sh ${TAG}_attn_joint_v$v attn_joint $v > $OUT/pmc_attn_joint_v$v.log 2>&1; cp gpurun_out/pmc_${TAG}_attn_joint_v$v/summary.txt $OUT/pmc_attn_joint_v$v.txt 2>/dev/null; cut -c1-400 $OUT/pmc_attn_joint_v$v.txt; done
 echo "== bench A/B"; date
 for cfg in "default:" "res2:DWM_ATTN_RES2=1" "gemm4wgen:DWM_GEMM4W=2" "both:DWM_ATTN_RES2=1 DWM_GEMM4W=2" "default2:"; do
   name=${cfg%%:*}; envs=${cfg#*:}
@@ -29,6 +31,12 @@ for ln in open(sys.argv[1]):
         print("  ms/step", round(d["ms_per_step"], 2), "gemm", round(d["roofline"]["achieved"] or 0, 1), "TFLOP/s", "attn_res frac", round(d["roofline_attention"]["frac"], 4),
               "by_kernel", {k: round(v["tflops"], 1) for k, v in (d["roofline"].get("by_kernel") or {}).items()})
 PY
+done
+echo "== per-shape GEMM table inside the bench: 8-wave only against the default mix (which epilogues keep the 4-wave gain)"; date
+for cfg in "8w:DWM_GEMM4W=0" "mix:"; do
+  name=${cfg%%:*}; envs=${cfg#*:}
+  env $envs timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-text-only-leg --gemm-shapes > $OUT/bench_shapes_$name.log 2> $OUT/gemm_shapes_$name.err
+  grep '^{"M"' $OUT/gemm_shapes_$name.err > $OUT/gemm_shapes_$name.jsonl; echo "$name: $(wc -l < $OUT/gemm_shapes_$name.jsonl) shapes"; head -8 $OUT/gemm_shapes_$name.jsonl | cut -c1-160
 done
 echo "== other models on the 4-wave kernels (DWM_GEMM4W=1 / 2 force them for every covered launch): train step, UNet"; date
 for cfg in "train_8w:" "train_4w:DWM_GEMM4W=1" "unet_8w:" "unet_4wgen:DWM_GEMM4W=2"; do
