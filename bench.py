@@ -750,6 +750,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stack-modulation", action="store_true",
+                    help="A/B: the AdaLN modulation rows of all joint blocks from one stacked GEMM per step (model.stack_modulation; opt-in)")
     ap.add_argument("--preflight", action="store_true",
                     help="run the launch preflight (device / RCCL facts, checked all-reduce) also with one rank; always on for N > 1")
     ap.add_argument("--gemm-shapes", action="store_true", help="diagnostics: per-shape GEMM totals on stderr")
@@ -855,6 +857,8 @@ def main():
             model = build_model(kwargs, dev, seed=0)
             if args.residual_bf16:
                 model.residual_dtype = torch.bfloat16
+            if args.stack_modulation:
+                model.stack_modulation = True
             cond = make_conditions(dev, seed=sample_id, layout=layout)
             g = torch.Generator(device="cuda").manual_seed(sample_id)
             latents = torch.randn(w["B"], w["T"], w["V"], w["C"], w["H"], w["W"], device=dev, generator=g)

@@ -283,14 +283,17 @@ class JointTransformerBlock(nn.Module):
         if not context_pre_only:
             self.ff_context = FeedForward(dim, dim, activation_fn="gelu-approximate")
 
-    def run(self, h: torch.Tensor, c: torch.Tensor, silu_temb: torch.Tensor, n_img: int):
+    def run(self, h: torch.Tensor, c: torch.Tensor, silu_temb: torch.Tensor, n_img: int, mod=None, cmod=None):
         """h [I*N, D], c [I*Lc, D] (updated in place): bf16, or the fp32 residual streams of a bf16 forward (`stream32`);
-        silu_temb [I, D].  Returns (c, h)."""
+        silu_temb [I, D].  mod / cmod: this block's AdaLN modulation rows [I, 6 D | 9 D] / [I, 6 D | 2 D] when the caller has
+        computed them already (column slices of one stacked launch, dit.stack_modulation).  Returns (c, h)."""
         D = self.dim
         N, Lc = h.shape[0] // n_img, c.shape[0] // n_img
         x32 = stream32(h)
-        mod = ops.gemm(silu_temb, _bf(self.norm1.linear.weight), _bf(self.norm1.linear.bias))
-        cmod = ops.gemm(silu_temb, _bf(self.norm1_context.linear.weight), _bf(self.norm1_context.linear.bias))
+        if mod is None:
+            mod = ops.gemm(silu_temb, _bf(self.norm1.linear.weight), _bf(self.norm1.linear.bias))
+        if cmod is None:
+            cmod = ops.gemm(silu_temb, _bf(self.norm1_context.linear.weight), _bf(self.norm1_context.linear.bias))
         sl = lambda m, i: m[:, i * D:(i + 1) * D]
         # AdaLayerNormZero(X) chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
         nh2 = _act_like(h) if self.use_dual_attention else None

@@ -231,6 +231,10 @@ class DiTCrossviewTemporalConditionModel(_Base):
         # bf16 stream is a rounding of the whole stream (1.1e-3 rms each; they add up to the 1.3e-2 a bf16-stream forward
         # shows against the fp32 oracle).  bf16: the round-1..3 behaviour (half the stream traffic).
         self.gemm_4wave = True               # inference forward: 4-wave GEMM kernels for the launches they cover (ops.GEMM_4WAVE)
+        # True: the AdaLN modulation rows of ALL joint blocks and of norm_out (they depend on the timestep embedding only) come
+        # from ONE stacked GEMM per forward instead of two M = I launches per block (35-223 TFLOP/s each).  Off: written at the
+        # end of round 4 without a GPU at hand (tests/test_unvalidated_gpu.py).
+        self.stack_modulation = False
         self.residual_dtype = torch.float32
         self._index_sinusoids = {}
         self.perspective_modeling_type = perspective_modeling_type
@@ -335,6 +339,24 @@ class DiTCrossviewTemporalConditionModel(_Base):
         finally:
             ops.GEMM_4WAVE = prev4w
             STORE.set_precision(bf16)       # the fp32 accuracy path is scoped to this forward (compute_dtype = torch.float32)
+
+    def _stacked_modulation(self, silu_temb: torch.Tensor):
+        """[norm1, norm1_context] modulation rows of every joint block + norm_out's, as column slices of ONE GEMM over the
+        stacked `linear` weights (the packed copy lives with the other packed weights: rebuilt after an optimizer step /
+        state-dict load)"""
+        from .blocks import STORE
+        lins = [lin for blk in self.transformer_blocks for lin in (blk.norm1.linear, blk.norm1_context.linear)] + [self.norm_out.linear]
+
+        def make():
+            return {"w": torch.cat([_bf(l.weight) for l in lins]).contiguous(), "b": torch.cat([_bf(l.bias) for l in lins]).contiguous()}
+        pk = STORE.cached(self, make)
+        allmod = ops.gemm(silu_temb, pk["w"], pk["b"])
+        out, off = [], 0
+        for l in lins:
+            n = l.weight.shape[0]
+            out.append(allmod[:, off:off + n])
+            off += n
+        return out
 
     def _index_sinusoid(self, kind: str, B: int, T: int, V: int, D: int, device, dtype) -> torch.Tensor:
         """sinusoid features [B*T*V, D] of the frame ("t") or view ("v") index of every image (crossview_temporal_dit.py:
@@ -503,6 +525,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
             view_sin = self._index_sinusoid("v", B, T, V, D, h.device, cd)
             v_alpha = self._mixer_alphas(self.view_mixers, disable_crossview, B)
 
+        mods = self._stacked_modulation(silu_temb) if (self.stack_modulation and cd == bf16) else None
         for i, block in enumerate(self.transformer_blocks):
             if condition_residuals:
                 ops.add_(h, condition_residuals.pop(0))                                 # :491-494 (fp32 residual, one rounding)
@@ -512,7 +535,10 @@ class DiTCrossviewTemporalConditionModel(_Base):
                     residual_adders = None
                 else:
                     add(h)                                                              # :491-494, fused into the zero-conv GEMM
-            c, h = block.run(h, c, silu_temb, I)
+            if mods is None:
+                c, h = block.run(h, c, silu_temb, I)
+            else:
+                c, h = block.run(h, c, silu_temb, I, mod=mods[2 * i], cmod=mods[2 * i + 1])
 
             if self.enable_temporal and i in self.temporal_block_layers:
                 k = self.temporal_block_layers.index(i)
@@ -567,7 +593,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
                     blend_alpha=alpha, rows_per_alpha=T * V * N, blend_into=h)
 
         # norm_out (AdaLayerNormContinuous: scale first) + proj_out + unpatchify
-        mod = ops.gemm(silu_temb, _bf(self.norm_out.linear.weight), _bf(self.norm_out.linear.bias))
+        mod = mods[-1] if mods is not None else ops.gemm(silu_temb, _bf(self.norm_out.linear.weight), _bf(self.norm_out.linear.bias))
         nh = ops.layernorm(h, eps=1e-6, scale=mod[:, :D], shift=mod[:, D:], rows_per_mod=N, x32=stream32(h))
         y = ops.gemm(nh, _bf(self.proj_out.weight), _bf(self.proj_out.bias))
         out = ops.unpatchify(y, I, self.out_channels, height, width, p)

@@ -32,6 +32,8 @@ for ln in open(sys.argv[1]):
               "by_kernel", {k: round(v["tflops"], 1) for k, v in (d["roofline"].get("by_kernel") or {}).items()})
 PY
 done
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-text-only-leg --stack-modulation > $OUT/bench_stackmod.json 2> $OUT/bench_stackmod.err
+echo "stack-modulation exit $?"; grep '^{' $OUT/bench_stackmod.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  ms/step', round(d['ms_per_step'],2), 'finite', d['config'].get('finite'))"
 echo "== per-shape GEMM table inside the bench: 8-wave only against the default mix (which epilogues keep the 4-wave gain)"; date
 for cfg in "8w:DWM_GEMM4W=0" "mix:"; do
   name=${cfg%%:*}; envs=${cfg#*:}

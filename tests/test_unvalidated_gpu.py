@@ -10,6 +10,9 @@ next round).  A case moves into the regular files once it has passed on hardware
     map and the taps of an implicit convolution (dense and stride 2), the per-image residual row - a battery in a subprocess with
     the variable set (it is read once per process), against fp64 products / F.conv2d AND against the 8-wave kernels' output of
     the same call in this process; `dwm_gemm4w_launches_general` must count exactly the covered calls.
+  * `DiTCrossviewTemporalConditionModel.stack_modulation` (dit.py): the AdaLN modulation rows of all joint blocks and norm_out from
+    ONE stacked GEMM per forward (host-side restructuring over validated kernels) - small model against the oracle and against
+    the default forward, three temporal types, and the stack rebuilt after a state-dict load.
 """
 import json
 import os
@@ -279,6 +282,36 @@ def test_four_wave_gemm_general_form(dev, tmp_path):
     worst = {k: rel_err(a[k], b[k]) for k in a}
     _log("gemm4w_general_vs_8wave", **{k: v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
     assert all(v < TOL for v in worst.values()), worst
+
+
+@pytest.mark.parametrize("tt", ["rowwise", "pointwise", "full"])
+def test_stacked_modulation_forward(dev, tt):
+    from oracle import ctsd_oracle as O
+    from tests.common import small_config, small_inputs, to_dev
+    from tests.test_hip_gpu import TOL_MODEL, _bf16_round_sd, _hip_model
+    cfg = small_config(temporal_attention_type=tt)
+    sd = _bf16_round_sd(O.make_state_dict(small_config(), 0))
+    m = _hip_model(cfg, sd, dev)
+    inp = small_inputs(cfg, 0)
+    inp16 = {k: (v.to(bf16).float() if v.is_floating_point() and k != "timestep" and k != "added_time_ids" else v) for k, v in inp.items()}
+    ref = O.dit_forward(sd, cfg, **inp16)
+
+    def run():
+        di = to_dev(inp16, dev)
+        return m(di.pop("sample"), di.pop("timestep"), **di)[0][0]
+    base = run()
+    m.stack_modulation = True
+    got = run()
+    assert torch.equal(got, run())                                   # deterministic
+    e, d = rel_err(got, ref), rel_err(got, base)
+    # another state dict: the stacked copy must follow (packed tensors are rebuilt after load_state_dict)
+    sd2 = _bf16_round_sd(O.make_state_dict(small_config(), 1))
+    m.load_state_dict(sd2)
+    m.to(dev).to(bf16)
+    e2 = rel_err(run(), O.dit_forward(sd2, cfg, **inp16))
+    _log("stacked_modulation_forward", temporal=tt, rel_vs_oracle=e, rel_vs_default=d, bit_equal_to_default=bool(torch.equal(got, base)),
+         rel_vs_oracle_after_reload=e2)
+    assert e < TOL_MODEL and e2 < TOL_MODEL and d < TOL_MODEL
 
 
 if __name__ == "__main__":
