@@ -223,7 +223,31 @@ def pmc_traffic(kernel: str):
     return None
 
 
-PMC_FILES = ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json")
+def pmc_traffic_file(kernel: str):
+    """the committed PMC file that holds `kernel`'s traffic (the newest one that has a row for it)"""
+    for name in PMC_FILES:
+        try:
+            json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]["hbm_bytes_per_launch"]
+            return "profiles/" + name
+        except Exception:
+            continue
+    return None
+
+
+def gemm_traffic(by_kernel: dict):
+    """launch-weighted HBM bytes per launch over the GEMM kernels of the step, each from ITS OWN PMC row; None if a kernel
+    that served launches has no committed PMC row (a figure of another kernel is not evidence for it)"""
+    tot, n = 0.0, 0
+    for k, v in (by_kernel or {}).items():
+        t = pmc_traffic(k)
+        if t is None:
+            return None
+        tot += t * v["launches"]
+        n += v["launches"]
+    return tot / n if n else None
+
+
+PMC_FILES = ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json")
 
 
 def pmc_source() -> str:
@@ -934,9 +958,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "every dwm_gemm_bf16 launch of the step: gemm4w_kernel (gemm_bf16_4w.hip) where it covers the "
                                                     "launch, gemm_bf16_kernel otherwise (all epilogues; split in by_kernel)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_bf16_kernel"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC of the 8-wave kernel, same tile and raster, " + pmc_source() + ")",
-                         "by_kernel": {k: {kk: vv for kk, vv in v.items() if kk != "ms"} | {"share_of_step_time": (v["ms"] / args.steps) / step_ms}
+                         "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": gemm_traffic(gm.get("by_kernel")),
+                         "traffic_unit": "HBM bytes per launch, launch-weighted over by_kernel (each kernel's own rocprofv3 PMC row: FETCH_SIZE x 2 "
+                                         "+ WRITE_SIZE in separate passes of this command, scripts/pmc_traffic.sh)",
+                         "by_kernel": {k: {kk: vv for kk, vv in v.items() if kk != "ms"} |
+                                       {"share_of_step_time": (v["ms"] / args.steps) / step_ms, "traffic": pmc_traffic(k),
+                                        "traffic_source": pmc_traffic_file(k)}
                                        for k, v in (gm.get("by_kernel") or {}).items()},
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),

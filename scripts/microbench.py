@@ -57,6 +57,23 @@ def bench_attn(variants, only=None):
             print(json.dumps({"kernel": "attn", "case": name, "variant": var, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
 
 
+def bench_attn_full():
+    """"full" temporal attention at the length the shipped UniMLVG example gives it (examples/ctsd_unimlvg_6views_video_generation.json:40,72:
+    19 frames x 448 tokens = 8512 per (CFG half, view); crossview_temporal_dit.py:336-344): lands on the tiled kernel (128 / 256-query
+    workgroups); never timed before round 5"""
+    H, D = 24, 1536
+    B, T, V, h, w = 2, 19, 6, 16, 28
+    R = B * T * V * h * w
+    qkv = rnd(R, 3 * D)
+    out = torch.empty(R, D, device=dev, dtype=bf16)
+    rm = ops.rowmap_temporal_full(B, T, V, h, w)
+    L = T * h * w
+    fl = 4.0 * rm.n_problems * H * L * L * 64
+    for var in (0, 2, 0, 2):
+        ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var), iters=3, warm=1)
+        print(json.dumps({"kernel": "attn", "case": f"temporal full L={L}", "variant": var, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
+
+
 def bench_pointwise():
     """point-wise temporal attention (L = 16): packed small-L kernel (heads per wave 8 / 4 / 12 / 2) vs the tiled kernel"""
     H, D = 24, 1536
@@ -316,6 +333,8 @@ if __name__ == "__main__":
         bench_attn([0], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
     if "attnr2" in what:                 # ... against the paired form (variant bit 6: attn_res2_kernel, 8 waves x two query tiles), alternating
         bench_attn([0, 64, 0, 64], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
+    if "attnfull" in what:
+        bench_attn_full()
     if "s32" in what:
         bench_stream32()
     if "gemm" in what:

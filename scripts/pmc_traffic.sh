@@ -18,7 +18,8 @@ for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            k = "gemm_bf16_kernel" if "gemm_bf16_kernel" in k else "attn_res_kernel" if "attn_res_kernel" in k else "attn_fwd_kernel" if "attn_fwd_kernel" in k else "attn_group_lds_kernel" if "attn_group_lds" in k else "attn_small_kernel" if "attn_small_kernel" in k else "layernorm_kernel" if "layernorm_kernel" in k else None
+            k = next((n for n in ("gemm4w_kernel", "gemm_bf16_kernel", "attn_res4_kernel", "attn_res2_kernel", "attn_res_kernel", "attn_fwd_kernel",
+                                  "attn_group_lds_kernel", "attn_small_kernel", "layernorm_kernel") if n in k), None)
             if k is None: continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == "FETCH_SIZE": calls[k] += 1
