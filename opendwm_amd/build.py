@@ -15,11 +15,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdwm_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_4w.hip", "gemm_tn.hip", "attention.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "vae.hip",
-           "train.hip", "fp32path.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_4w.hip", "gemm_tn.hip", "attention.hip", "attention_res4.hip", "attention_bwd.hip", "norm.hip",
+           "elementwise.hip", "vae.hip", "train.hip", "fp32path.hip"]
 # translation units built without -amdgpu-mfma-vgpr-form (accumulators allowed into AGPRs): the 4-wave GEMM keeps the 256 accumulator
 # registers of a wave there
 AGPR_SOURCES: set = {"gemm_bf16_4w.hip"}
+# per-file flags.  attention_res4.hip: the row-sum adds of its tile loop must stay scalar (left alone the SLP vectoriser packs the adds
+# of two slices into v_pk_add_f32 bunched behind the later one; packed fp32 VALU beside MFMAs costs more than the adds it replaces)
+FILE_FLAGS: dict = {"attention_res4.hip": ["-fno-slp-vectorize"]}
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the VALU epilogues / softmax read them
+# without v_accvgpr_read/write copies
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 ARCH = "gfx950"
 
 
@@ -55,16 +61,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     stamp = os.path.join(CSRC, "build", ".source_hash")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the
-    # VALU epilogues / softmax read them without v_accvgpr_read/write copies
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
-             "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"] + os.environ.get("DWM_EXTRA_FLAGS", "").split()
+    base = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"]
+    user = os.environ.get("DWM_EXTRA_FLAGS", "").split()
     jobs = []
     # the stamp holds the source hash and the extra flags of the objects on disk: other flags (e.g. -DDWM_DEV_HOOKS) change
     # neither the hash nor a modification time, so they force a full rebuild here
     extra = " ".join(os.environ.get("DWM_EXTRA_FLAGS", "").split())
-    old_stamp = (open(stamp).read().strip() if os.path.exists(stamp) else "").split("|", 1)
-    old_hash, old_extra = old_stamp[0], (old_stamp[1] if len(old_stamp) > 1 else "")
+    old_hash, old_extra = "", ""
+    if os.path.exists(stamp):
+        lines = open(stamp).read().split("\n")          # two lines: the hash, the flags (any character but a newline)
+        old_hash, old_extra = lines[0].strip(), (lines[1].strip() if len(lines) > 1 else "")
     force = force or old_extra != extra
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -75,8 +81,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(job):
         s, o = job
-        fl = [f for f in flags if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")] if os.path.basename(s) in AGPR_SOURCES else flags
-        if os.path.basename(s) == "elementwise.hip":
+        name = os.path.basename(s)
+        fl = base + ([] if name in AGPR_SOURCES else VGPR_FORM) + FILE_FLAGS.get(name, []) + user
+        if name == "elementwise.hip":
             fl = fl + [f'-DDWM_SOURCE_HASH="{shash}"']
         cmd = [hipcc] + fl + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -96,7 +103,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(stamp, "w") as f:
-        f.write(shash + "|" + extra)
+        f.write(shash + "\n" + extra)
     return LIB
 
 

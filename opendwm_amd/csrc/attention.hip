@@ -1025,76 +1025,6 @@ DWM_DEVINL void res_step(const char* __restrict__ kl, const char* __restrict__ v
     }
 }
 
-// One 32-key step by the textbook online softmax (running max m and sum l per lane, rescale every step): the fallback of a
-// unit whose fast-path sums left the safe range.  It reads K and V from GLOBAL memory, not from the images: by the time a unit
-// knows that it needs the fallback, the first sub-tiles of the images may already hold the NEXT head's rows (the refill point
-// of attn_res_kernel).  K fragments are the lanes' own rows (16 B per lane); V fragments are gathered element by element in the
-// MFMA A-operand layout with the key order of the P' registers.  Written for few registers and for correctness, not for speed.
-struct ResGlobal {
-    const bf16_t *k, *v;       // k0 / v0 + this head's column offset
-    const int32_t* tab;        // row table (LDS)
-    int64_t seg1_delta;
-};
-DWM_DEVINL void res_tile_safe(const ResGlobal& gm, int key0, int L, int L0, const bf16x8 (&qf)[4], f32x16 (&ot)[2], float& m_run, float& l_run,
-                              int l31, int half) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto row_off = [&](int key) -> int64_t {
-        key = key < L ? key : L - 1;
-        return ((int64_t)gm.tab[key] << 3) + (key < L0 ? 0 : gm.seg1_delta);
-    };
-    f32x16 st;
-    {
-        const bf16_t* kp = gm.k + row_off(key0 + l31) + half * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + ks * 16), qf[ks], ks == 0 ? zero : st, 0, 0, 0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[r] = -INFINITY;
-        mx = fmaxf(mx, st[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);                  // finite: the first step of a sequence holds key 0
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 at the first step (m_run = -inf)
-    m_run = m_new;
-    float pv[16], sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
-        sum += pv[r];
-    }
-    l_run = l_run * alpha + sum;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 pk = pack8(pv + 8 * s2);
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
-        // B-operand k-slot (half, e) of pf holds P' of key (e & 3) + 8 ((8 s2 + e) >> 2) + 4 half: the A operand takes the same keys
-        int64_t voff[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) voff[e] = row_off(key0 + (e & 3) + 8 * ((8 * s2 + e) >> 2) + 4 * half);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            bf16x8 vf;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) vf[e] = (short)gm.v[voff[e] + dt * 32 + l31];
-            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
-        }
-    }
-}
-
-struct ResCtx {             // launch / workgroup invariants of attn_res_kernel's helpers
-    const char *kimg, *vimg;
-    const int32_t* rowtab;
-    int L, L0, nsub, l31, half, kswz;     // nsub: 32-key sub-tiles of the sequence (the last one may be ragged)
-    int vra[2], vrb[2];
-};
-
 // one unit = NT query tiles of one head against the resident K / V images: tile loop, acceptance test of the fast path (or
 // the fallback), normalisation, and the stores.  qraw: this lane's raw Q fragments; op[t]: this lane's output row pointer
 // (rows past the last query are clamped to it: they then hold the same Q, compute the same output and store the same
@@ -1380,197 +1310,6 @@ attn_res_kernel(const AttnParams P) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Paired resident form (written at the end of round 4 WITHOUT a GPU at hand; opt-in: dwm_attn_args.variant bit 6 or
-// environment DWM_ATTN_RES2=1; attn_res_kernel above stays the default until this one has been validated and measured).
-// Why: every 32x32x16 MFMA of attn_res_kernel's tile loop takes one 1 KiB fragment from the images (K rows for S, transposed V for
-// PV; Q and P' are in registers): 1.5 LDS instructions with their address adds and waits per MFMA.  The isolated loop probe runs
-// at 22.5 ns per MFMA slot with these reads and at 17.8 ns without them (17.2 for the bare MFMA; profiles/README.md), the kernel
-// at 52-60 clocks per 32-clock slot (profiles/r3_attn_timeline.txt).  The LDS array is not the limit by itself (256 B / clock for
-// ds_read_b128 / ds_read_b64_tr_b16: 16 of a slot's 32 clocks for 4 SIMDs), the instructions and their waits are what can go.
-// The remedy tried here is to use every fragment TWICE: a unit of TWO adjacent query tiles per wave (res_unit<2>: both tiles'
-// MFMAs take the same K / V fragment registers - half the LDS instructions and bytes per MFMA, two independent accumulation
-// chains).  That needs ~256 registers per wave (two sets of accumulators, scores and P'), so the workgroup has 8 waves (2 per
-// SIMD) instead of 12; whether the smaller number of resident waves costs more than the reads return is a measurement.
-// Schedule of a head's nqt query tiles over the 8 waves: full rounds of 16 tiles (wave w: tiles 16 r + 2 w, + 1) while 16
-// remain; the remaining rem < 16 tiles are spread as evenly as whole tiles allow - wave w takes rem / 8 + (w < rem % 8)
-// adjacent tiles (a pair, a single tile through res_unit<1>, or nothing).  L = 602: 19 tiles = 16 + 3 singles on waves 0-2
-// (SIMD loads 5 / 5 / 5 / 4 tiles, as with 12 waves); L = 448: 14 tiles = pairs on waves 0-5, singles on 6, 7 (4 / 4 / 3 / 3).
-// Everything else - images, swizzles, row tables, persistent workgroups, Q prefetch after a unit's loop, the two barriers per
-// head, the max-free fast path with its acceptance test and fallback, the register-exchange stores - is attn_res_kernel's.
-DWM_DEVINL void res2_unit_of(int r, int wave, int nfull, int rem, int& t0, int& cnt) {
-    if (r < nfull) { t0 = r * 16 + 2 * wave; cnt = 2; return; }
-    const int q = rem >> 3, x = rem & 7;
-    cnt = q + (wave < x ? 1 : 0);
-    t0 = nfull * 16 + wave * q + (wave < x ? wave : x);
-}
-
-__global__ void __launch_bounds__(512, 1)
-attn_res2_kernel(const AttnParams P) {
-    constexpr int NW = 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5;
-    const int l31 = lane & 31;
-
-    const int L = P.L, L0 = P.L0;
-    const int Lp = (L + 31) & ~31;
-    const int Lt = (L + 3) & ~3;
-    char* const kimg = smem;
-    char* const vimg = smem + Lp * 128;
-    int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
-    int32_t* const otab = tabs + 2 * Lt;
-
-    ResCtx c;
-    c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
-    c.L = L; c.L0 = L0; c.nsub = Lp >> 5;
-    c.l31 = l31; c.half = half; c.kswz = (lane >> 1) & 7;
-    {
-        const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
-            const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
-            c.vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
-            c.vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
-        }
-    }
-
-    const int hpb = P.hpb;
-    const int n_items = P.n_problems * (int)P.fd_heads.d;
-    const int n_my = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int G = n_my * hpb;
-    auto item_of = [&](int g, uint32_t& prob, int64_t& hoff) {
-        const int it = g / hpb, hh = g - it * hpb;
-        const uint32_t item = blockIdx.x + (uint32_t)it * gridDim.x;
-        prob = fdiv(item, P.fd_heads);
-        hoff = ((int64_t)(item - prob * P.fd_heads.d) * hpb + hh) * 64;
-    };
-    auto build_tab = [&](int32_t* tab, int32_t* ot, uint32_t prob) {
-        const int64_t base0 = seg0_base(P.rm, (int)prob);
-        for (int l = tid; l < L; l += NW * 64) {
-            const int64_t r0 = l < L0 ? seg0_row(P.rm, base0, l) : 0;
-            if (tab != nullptr) tab[l] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
-            if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
-        }
-    };
-    auto copy_rows = [&](const int32_t* tab, int64_t ho, int s0, int s1, bool is_v, int me, int np) {
-        int i = s0 * 4;
-        i += (me - i % np + np) % np;
-        for (; i < s1 * 4; i += np) {
-            const int r = i * 8 + (lane >> 3);
-            const int rc = r < L ? r : L - 1;
-            const int64_t off = ((int64_t)tab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
-            if (!is_v) glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
-            else glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
-        }
-    };
-
-    const int nqt = (P.qend + 31) >> 5;
-    const int nfull = nqt >> 4;
-    const int rem = nqt - (nfull << 4);
-    const int rounds = nfull + (rem > 0 ? 1 : 0);
-    const bool force_safe = P.safe_softmax != 0;
-    const int n = c.nsub;
-    if (G == 0) return;
-
-    // raw Q fragments of query tile t of the head at column offset ho (rows past the last query: a copy of the last one)
-    auto load_q = [&](bf16x8 (&dst)[4], const int32_t* tab, int64_t ho, int t) {
-        int lq = t * 32 + l31;
-        lq = lq < P.qend ? lq : P.qend - 1;
-        const bf16_t* qp = P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(qp + ks * 16);
-    };
-    auto zero_q = [&](bf16x8 (&dst)[4]) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dst[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    };
-    auto out_ptr = [&](int64_t ho, int t) -> bf16_t* {
-        int lq = t * 32 + l31;
-        lq = lq < P.qend ? lq : P.qend - 1;
-        return P.o0 + ((int64_t)otab[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + ho;
-    };
-
-    uint32_t prob; int64_t hoff;
-    item_of(0, prob, hoff);
-    build_tab(tabs, otab, prob);
-    __syncthreads();
-    copy_rows(tabs, hoff, 0, n, false, wave, NW);
-    copy_rows(tabs, hoff, 0, n, true, wave, NW);
-    int t_first, c_first;                                    // this wave's first unit of every head
-    res2_unit_of(0, wave, nfull, rem, t_first, c_first);
-    bf16x8 qn[2][4];                                         // raw Q fragments of this wave's next unit
-    if (c_first > 0) load_q(qn[0], tabs, hoff, t_first); else zero_q(qn[0]);
-    if (c_first > 1) load_q(qn[1], tabs, hoff, t_first + 1); else zero_q(qn[1]);
-
-    for (int g = 0; g < G; ++g) {
-        const int it = g / hpb;
-        const int32_t* const tab = tabs + (it & 1) * Lt;
-        item_of(g, prob, hoff);
-        const bool has_next = g + 1 < G;
-        uint32_t nprob = prob; int64_t nhoff = hoff;
-        const int32_t* ntab = tab;
-        const bool new_item_next = has_next && (g + 1) / hpb != it;
-        if (has_next) {
-            item_of(g + 1, nprob, nhoff);
-            if (new_item_next) {
-                ntab = tabs + ((it + 1) & 1) * Lt;
-                build_tab((int32_t*)ntab, nullptr, nprob);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
-        __syncthreads();                                     // ... and everybody else's
-        c.rowtab = tab;
-
-        for (int r = 0; r < rounds; ++r) {
-            int t0, cnt;
-            res2_unit_of(r, wave, nfull, rem, t0, cnt);
-            if (cnt == 0) continue;
-            // this wave's NEXT unit: the next round of this head, or its first unit of the next head; its Q rows are requested
-            // when this unit's tile loop is over and travel under the normalisation, the stores and the barriers
-            int tn = 0, cn = 0;
-            if (r + 1 < rounds) res2_unit_of(r + 1, wave, nfull, rem, tn, cn);
-            const bool same = cn > 0;
-            if (!same && has_next) { tn = t_first; cn = c_first; }
-            auto fetch_next_q = [&]() {
-                const int32_t* const t2 = same ? tab : ntab;
-                const int64_t ho2 = same ? hoff : nhoff;
-                if (cn > 0) load_q(qn[0], t2, ho2, tn); else zero_q(qn[0]);
-                if (cn > 1) load_q(qn[1], t2, ho2, tn + 1); else zero_q(qn[1]);
-            };
-            ResGlobal gm;
-            gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
-            if (cnt == 2) {
-                bf16x8 q[2][4];
-                bf16_t* op[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) q[t][ks] = qn[t][ks];
-                    op[t] = out_ptr(hoff, t0 + t);
-                }
-                res_unit<2>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
-            } else {
-                bf16x8 q[1][4];
-                bf16_t* op[1];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) q[0][ks] = qn[0][ks];
-                op[0] = out_ptr(hoff, t0);
-                res_unit<1>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
-            }
-        }
-        __syncthreads();                                     // everybody is done with this head's images
-        if (new_item_next) build_tab(nullptr, otab, nprob);
-        if (has_next) {
-            copy_rows(ntab, nhoff, 0, n, false, wave, NW);
-            copy_rows(ntab, nhoff, 0, n, true, wave, NW);
-        }
-    }
-}
-
 // diagnostic: every lane issues one ds_read_b64_tr_b16 at byte offset offs[lane] of an LDS
 // image holding lds16[i] = i, and reports its 4 result elements (hardware-semantics probe).
 __global__ void __launch_bounds__(64)
@@ -1598,6 +1337,9 @@ void launch_attn(const AttnParams& P, hipStream_t s) {
 }
 
 }  // namespace
+
+// attention_res4.hip
+int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, bool pk, hipStream_t s);
 
 extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     AttnParams P;
@@ -1719,19 +1461,18 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             if (nwc < 1 || nwc > 12) return DWM_EINVAL;
             P.nwc = nwc;
         }
-        // paired form (attn_res2_kernel: 8 waves, two query tiles per unit): variant bit 6, or DWM_ATTN_RES2=1 for every
-        // resident launch of the process (read at the first call).  Off by default: written without a GPU at hand.
-        static const bool env_res2 = [] { const char* v = getenv("DWM_ATTN_RES2"); return v != nullptr && v[0] != '\0' && v[0] != '0'; }();
-        if (((a->variant >> 6) & 1) || env_res2) {
-            if ((a->variant & 15) != 0) return DWM_EINVAL;          // (no compute-wave override in this form)
-            static bool attr2_set = false;
-            if (!attr2_set) {
-                (void)hipFuncSetAttribute((const void*)attn_res2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr2_set = true;
+        // one-wave-per-SIMD form (attention_res4.hip: 4 waves, all query tiles of a wave in one pass over the keys): 8..20 query
+        // tiles (225 <= L <= 608).  variant bit 12 keeps attn_res_kernel (A/B measurements, tests), bit 13 selects the alternating
+        // S / PV MFMA order, bit 14 packed row-sum adds; DWM_ATTN_RES4 = 0 (never) / 1..4 (always: 1 plain, 2 = bit 13, 3 = bit 14, 4 = both)
+        {
+            const int nqt = (P.qend + 31) >> 5;
+            static const int env_res4 = [] { const char* v = getenv("DWM_ATTN_RES4"); return (v == nullptr || v[0] == '\0') ? -1 : (int)(v[0] - '0'); }();
+            const bool want4 = env_res4 >= 0 ? env_res4 != 0 : !((a->variant >> 12) & 1);
+            if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
+                const bool ilv = env_res4 > 0 ? (env_res4 == 2 || env_res4 == 4) : ((a->variant >> 13) & 1) != 0;
+                const bool pk = env_res4 > 0 ? (env_res4 == 3 || env_res4 == 4) : ((a->variant >> 14) & 1) != 0;
+                return dwm_attn_res4_launch(P, nblk, lds, ilv, pk, s);
             }
-            hipLaunchKernelGGL(attn_res2_kernel, dim3(nblk), dim3(512), lds, s, P);
-            const hipError_t e2 = hipGetLastError();
-            return e2 == hipSuccess ? DWM_OK : (int)e2;
         }
         static bool attr_set = false;
         if (!attr_set) {

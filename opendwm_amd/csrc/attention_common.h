@@ -96,6 +96,78 @@ DWM_DEVINL bf16x8 scale_frag(const bf16x8& v, float c) {
 }
 
 
+// ---- pieces shared by the resident forward kernels (attention.hip: attn_res_kernel; attention_res4.hip: attn_res4_kernel)
+// One 32-key step by the textbook online softmax (running max m and sum l per lane, rescale every step): the fallback of a
+// unit whose fast-path sums left the safe range.  It reads K and V from GLOBAL memory, not from the images: by the time a unit
+// knows that it needs the fallback, the first sub-tiles of the images may already hold the NEXT head's rows (the refill point
+// of attn_res_kernel).  K fragments are the lanes' own rows (16 B per lane); V fragments are gathered element by element in the
+// MFMA A-operand layout with the key order of the P' registers.  Written for few registers and for correctness, not for speed.
+struct ResGlobal {
+    const bf16_t *k, *v;       // k0 / v0 + this head's column offset
+    const int32_t* tab;        // row table (LDS)
+    int64_t seg1_delta;
+};
+DWM_DEVINL void res_tile_safe(const ResGlobal& gm, int key0, int L, int L0, const bf16x8 (&qf)[4], f32x16 (&ot)[2], float& m_run, float& l_run,
+                              int l31, int half) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto row_off = [&](int key) -> int64_t {
+        key = key < L ? key : L - 1;
+        return ((int64_t)gm.tab[key] << 3) + (key < L0 ? 0 : gm.seg1_delta);
+    };
+    f32x16 st;
+    {
+        const bf16_t* kp = gm.k + row_off(key0 + l31) + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + ks * 16), qf[ks], ks == 0 ? zero : st, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= L) st[r] = -INFINITY;
+        mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);                  // finite: the first step of a sequence holds key 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 at the first step (m_run = -inf)
+    m_run = m_new;
+    float pv[16], sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
+        sum += pv[r];
+    }
+    l_run = l_run * alpha + sum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 pk = pack8(pv + 8 * s2);
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pk);
+        // B-operand k-slot (half, e) of pf holds P' of key (e & 3) + 8 ((8 s2 + e) >> 2) + 4 half: the A operand takes the same keys
+        int64_t voff[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) voff[e] = row_off(key0 + (e & 3) + 8 * ((8 * s2 + e) >> 2) + 4 * half);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            bf16x8 vf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vf[e] = (short)gm.v[voff[e] + dt * 32 + l31];
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
+        }
+    }
+}
+
+struct ResCtx {             // launch / workgroup invariants of attn_res_kernel's helpers
+    const char *kimg, *vimg;
+    const int32_t* rowtab;
+    int L, L0, nsub, l31, half, kswz;     // nsub: 32-key sub-tiles of the sequence (the last one may be ragged)
+    int vra[2], vrb[2];
+};
+
+
 // ---- host side: validate a dwm_attn_args and fill the launch-invariant parameter block
 inline int fill_params(const dwm_attn_args* a, AttnParams& P) {
     if (a == nullptr || a->q0 == nullptr || a->k0 == nullptr || a->v0 == nullptr || a->o0 == nullptr) return DWM_EINVAL;

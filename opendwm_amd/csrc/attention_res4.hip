@@ -1,0 +1,391 @@
+// attn_res4_kernel: the resident attention forward (attention.hip: attn_res_kernel) with ONE wave per SIMD.  Its own translation
+// unit because of its flags: -fno-slp-vectorize (the row-sum adds must stay scalar, see res4_block) next to -amdgpu-mfma-vgpr-form.
+#include "attention_common.h"
+
+using namespace dwm_attn;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// One-wave-per-SIMD resident form (round 5): attn_res4_kernel.  Images, swizzles, row tables, persistent workgroups, the two
+// barriers per head, the maximum-free fast path with its acceptance test and fallback, and the register-exchange stores are
+// attn_res_kernel's.  What changes is who walks the images: FOUR waves - one per SIMD, 512 registers each - and every wave takes ALL
+// its query tiles of a head (NT = 2..5 adjacent tiles: 19 tiles -> 5 / 5 / 5 / 4, 14 -> 4 / 4 / 3 / 3) through ONE pass over the keys:
+//   * every K / V fragment read from the images feeds NT MFMAs (attn_res_kernel: one; the 12-wave kernel spends 1.5 LDS instructions
+//     with their address adds and waits per MFMA, 22.5 ns per MFMA slot against 17.8 without them, profiles/README.md);
+//   * no co-resident waves: on this chip a wave's own VALU work hides under its own MFMAs, another wave's does not
+//     (profiles/r3_mfma_valu_probe.txt; attn_res_kernel's three waves per SIMD run the same tile loop in 15.6 / 19.7 / 34.3 k cycles);
+//   * 19 tiles on 4 waves leave 5 % of the SIMD time idle (12 waves: 21 %).
+// Registers: the O accumulators of all tiles (NT x 32) live in AGPRs - the PV MFMAs are inline asm with "+a" operands, this file is
+// compiled with -amdgpu-mfma-vgpr-form, so the S accumulators (read by the VALU) stay in arch VGPRs -, Q fragments of all tiles
+// (NT x 16), two S buffers, two P' buffers and ONE set of K / V fragments in VGPRs.
+// Schedule: the units u = (key step k, tile t), k-major, form ONE software pipeline; slot u holds
+//     S(u+1) = K Q^T (4 MFMAs)  ||  E(u): P' = 2^S, row sums, bf16 pack  ||  PV(u-1): O^T += V^T P'^T (4 MFMAs)
+// as one instruction stream of 8 chunks (one MFMA + one slice of E each, order pinned by sched_barrier); a fragment register is
+// re-requested right behind its last reader (res4_block).  ILV: S and PV MFMAs alternate (consecutive MFMAs never share an
+// accumulator) instead of 4 + 4.
+// The inline-asm MFMAs are invisible to the compiler's hazard recogniser; what it would have checked holds by construction: their
+// P' operands are written by VALU converts at least a slot (>= 8 instructions) earlier, their V operands come from LDS reads (covered by
+// the compiler's lgkmcnt waits, which do follow asm operands), accumulation on the same AGPRs back to back needs no wait states, and the
+// one VALU read of the accumulators (v_accvgpr_read at the unit's end) sits behind explicit s_nops.
+template <int NT>
+struct Res4Regs {
+    bf16x8 qf[NT][4];
+    f32x16 ot[NT][2];
+    float ls[NT][2];
+    f32x2 ls2[NT][2];            // (PK)
+    f32x16 s[2];
+    bf16x8 p[2][2];
+    bf16x8 kf[4];
+    bf16x8 vf[2][2];             // [16-key half s2][d tile dt]
+};
+
+DWM_DEVINL void res4_mfma_pv(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+DWM_DEVINL bf16x8 res4_kread(const ResCtx& c, const char* kl, int m) {
+    return *(const bf16x8*)(kl + c.l31 * 128 + (((2 * m + c.half) ^ c.kswz) << 4));
+}
+DWM_DEVINL bf16x8 res4_vread(const ResCtx& c, const char* vl, int s2, int dt) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + c.vra[dt] + s2 * (16 * 128)));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + c.vrb[dt] + s2 * (16 * 128)));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// key step k of a unit: slots (k, 0) .. (k, NT - 1).  KP = k & 1 (the parity of unit (k, 0) follows from it), FIRST: k = 0 (no PV in
+// slot 0), LAST: k = n - 1 (no S in the last slot, no K request, and the trailing PV).
+// Fragment registers are single-buffered: a K fragment of step k + 1 is requested right behind the last MFMA that reads the same
+// fragment of step k (S(k, NT-1) in slot NT - 2; its next reader is S(k+1, 0) a slot later), a V fragment of step k right behind the last
+// PV MFMA of step k - 1 (PV(k-1, NT-1) in slot 0; next reader PV(k, 0) in slot 1): seven MFMAs of distance each.
+// Keys past the end of the sequence (the last key step of a ragged L) are masked in the S MFMAs themselves: the accumulators of step
+// n - 1 start from `mvec` (-inf for the absent keys, 0 elsewhere; 2^-inf = 0) instead of the inline constant 0 - MASKS = 1 for the
+// S MFMA chain this block issues for step k + 1 (k = n - 2), 2 for those of step k (k = n - 1) - and E needs no compare / select.
+template <int NT, int KP, bool FIRST, bool LAST, int MASKS, bool ILV, bool PK>
+DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16& mvec) {
+    constexpr int PB = (NT & 1) ? KP : 0;                 // parity of unit (k, 0): k * NT mod 2
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const char* const kln = c.kimg + (k + 1) * 4096;
+    const char* const vlc = c.vimg + k * 4096;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int par = (PB + t) & 1;                     // parity of this slot's unit: S buffer read, P' buffer written
+        const bool do_s = !(LAST && t == NT - 1);
+        const int ts = t + 1 == NT ? 0 : t + 1;           // S(u+1): tile
+        const bool do_pv = !(FIRST && t == 0);
+        const int tp = t == 0 ? NT - 1 : t - 1;           // PV(u-1): tile
+        uint32_t pk[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            // the MFMA of this chunk, and the request of its fragment's successor
+            const bool is_s = ILV ? (ch & 1) == 0 : ch < 4;
+            const int mi = ILV ? ch >> 1 : ch & 3;
+            if (is_s) {
+                const bool masked = t + 1 == NT ? MASKS == 1 : MASKS == 2;
+                if (do_s) r.s[par ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.kf[mi], r.qf[ts][mi], mi == 0 ? (masked ? mvec : zero) : r.s[par ^ 1], 0, 0, 0);
+                if (!LAST && t == NT - 2) r.kf[mi] = res4_kread(c, kln, mi);
+            } else {
+                if (do_pv) res4_mfma_pv(r.ot[tp][mi & 1], r.vf[mi >> 1][mi & 1], r.p[par ^ 1][mi >> 1]);
+                if (!FIRST && t == 0) r.vf[mi >> 1][mi & 1] = res4_vread(c, vlc, mi >> 1, mi & 1);
+            }
+            // slice ch of E(u): scores 2 ch, 2 ch + 1
+            {
+                const float a = r.s[par][2 * ch], b = r.s[par][2 * ch + 1];
+                const float pa = __builtin_amdgcn_exp2f(a), pb = __builtin_amdgcn_exp2f(b);
+                // (scalar adds - this file is built with -fno-slp-vectorize: left alone the compiler packs the adds of two slices into
+                //  v_pk_add_f32, bunched behind the later slice; packed fp32 VALU beside MFMAs costs more than the plain adds it
+                //  replaces, MI355X_MICROARCH.md "price of one filler")
+                if (PK) {                                   // A/B: one packed add per slice (attn_res_kernel's form)
+                    r.ls2[t][ch & 1] += (f32x2){pa, pb};
+                } else {
+                    float acc = r.ls[t][ch & 1];
+                    acc += pa;
+                    acc += pb;
+                    r.ls[t][ch & 1] = acc;
+                }
+                uint32_t w = pack_bf16x2(pa, pb);
+                asm volatile("" : "+v"(w));                 // pins the convert to its slice (res_step)
+                pk[ch] = w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const uint4 lo = {pk[0], pk[1], pk[2], pk[3]}, hi = {pk[4], pk[5], pk[6], pk[7]};
+        r.p[par][0] = *reinterpret_cast<const bf16x8*>(&lo);
+        r.p[par][1] = *reinterpret_cast<const bf16x8*>(&hi);
+    }
+    if (LAST) {                                             // PV of the last unit (k, NT - 1)
+        constexpr int par = (PB + NT - 1) & 1;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) res4_mfma_pv(r.ot[NT - 1][mi & 1], r.vf[mi >> 1][mi & 1], r.p[par][mi >> 1]);
+    }
+}
+
+// normalise and store one output tile (res_unit's store: lane (q, half) holds d = 32 dt + 8 g + 4 half + (0..3) in registers
+// 4 g .. 4 g + 3 of o[dt]; after the exchange of one 8-byte piece with lane ^ 32 per pair of g, the lower lane owns the whole
+// 16-byte chunk of the even g, the upper lane that of the odd g)
+DWM_DEVINL void res_store_tile(const f32x16 (&o)[2], float l_tot, bf16_t* op, int half) {
+    const float inv = __builtin_amdgcn_rcpf(l_tot);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            float a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = o[dt][gp * 8 + j] * inv;
+                b[j] = o[dt][gp * 8 + 4 + j] * inv;
+            }
+            const uint2 pa = pack4(a), pb = pack4(b);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+            const uint4 val = {s0[0], s1[0], s0[1], s1[1]};
+            *(uint4*)(op + dt * 32 + (2 * gp + half) * 8) = val;
+        }
+}
+
+// one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 2 key steps)
+template <int NT, bool ILV, bool PK, class Fetch>
+DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe,
+                          const ResGlobal& gm, Fetch&& after_loop) {
+    Res4Regs<NT> r;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) r.qf[t][ks] = scale_log2 == 1.f ? qraw[t][ks] : scale_frag(qraw[t][ks], scale_log2);
+        r.ls[t][0] = r.ls[t][1] = 0.f;
+        r.ls2[t][0] = r.ls2[t][1] = (f32x2){0.f, 0.f};
+        r.ot[t][0] = zero;
+        r.ot[t][1] = zero;
+    }
+    // prologue: fragments of key step 0, S(0, 0)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.kf[m] = res4_kread(c, c.kimg, m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.vf[i >> 1][i & 1] = res4_vread(c, c.vimg, i >> 1, i & 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r.s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.kf[m], r.qf[0][m], m == 0 ? zero : r.s[0], 0, 0, 0);
+    const int n = c.nsub;                                    // >= 3 (the host side launches this kernel for L >= 225)
+    res4_block<NT, 0, true, false, 0, ILV, PK>(r, c, 0, zero);
+    int k = 1;
+    for (; k + 1 < n - 2; k += 2) {
+        res4_block<NT, 1, false, false, 0, ILV, PK>(r, c, k, zero);
+        res4_block<NT, 0, false, false, 0, ILV, PK>(r, c, k + 1, zero);
+    }
+    if (k < n - 2) {
+        res4_block<NT, 1, false, false, 0, ILV, PK>(r, c, k, zero);
+        ++k;
+    }
+    // k = n - 2: the accumulators of the last key step start from the key mask
+    f32x16 mvec;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mvec[i] = ((n - 1) << 5) + (i & 3) + 8 * (i >> 2) + 4 * c.half >= c.L ? -INFINITY : 0.f;
+    if (k & 1) {
+        res4_block<NT, 1, false, false, 1, ILV, PK>(r, c, k, mvec);
+        res4_block<NT, 0, false, true, 2, ILV, PK>(r, c, k + 1, mvec);
+    } else {
+        res4_block<NT, 0, false, false, 1, ILV, PK>(r, c, k, mvec);
+        res4_block<NT, 1, false, true, 2, ILV, PK>(r, c, k + 1, mvec);
+    }
+    // the accumulators leave the matrix pipe: 2 x 16 wait states before anything reads them (the asm MFMAs are invisible to the
+    // hazard recogniser)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(r.ot[t][0]), "+a"(r.ot[t][1]));
+    after_loop();
+    bool ok = !force_safe;
+    float l_tot[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float l_half = PK ? (r.ls2[t][0][0] + r.ls2[t][0][1]) + (r.ls2[t][1][0] + r.ls2[t][1][1]) : r.ls[t][0] + r.ls[t][1];
+        const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
+        l_tot[t] = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
+        ok = ok && (l_tot[t] >= 5.421010862e-20f) && (l_tot[t] <= 1.8446744e19f);        // res_unit's acceptance test
+    }
+    if (__all(ok)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x16 o[2] = {r.ot[t][0], r.ot[t][1]};
+            res_store_tile(o, l_tot[t], op[t], c.half);
+        }
+    } else {                                                // wave-uniform: redo the unit by the online softmax (res_tile_safe)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float m_run = -INFINITY, l_run = 0.f;
+            f32x16 o[2] = {zero, zero};
+            for (int kk = 0; kk < c.nsub; ++kk) res_tile_safe(gm, kk << 5, c.L, c.L0, r.qf[t], o, m_run, l_run, c.l31, c.half);
+            res_store_tile(o, l_run + __shfl_xor(l_run, 32, 64), op[t], c.half);
+        }
+    }
+}
+
+// the persistent head loop of one wave with NT query tiles per head (tiles t0 .. t0 + NT - 1)
+template <int NT, bool ILV, bool PK>
+DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
+    constexpr int NW = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int L = P.L, L0 = P.L0;
+    const int Lp = (L + 31) & ~31;
+    const int Lt = (L + 3) & ~3;
+    char* const kimg = smem;
+    char* const vimg = smem + Lp * 128;
+    int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
+    int32_t* const otab = tabs + 2 * Lt;
+
+    ResCtx c;
+    c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
+    c.L = L; c.L0 = L0; c.nsub = Lp >> 5;
+    c.l31 = l31; c.half = half; c.kswz = (lane >> 1) & 7;
+    {
+        const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
+            const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+            c.vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+            c.vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+        }
+    }
+    const int hpb = P.hpb;
+    const int n_items = P.n_problems * (int)P.fd_heads.d;
+    const int n_my = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int G = n_my * hpb;
+    auto item_of = [&](int g, uint32_t& prob, int64_t& hoff) {
+        const int it = g / hpb, hh = g - it * hpb;
+        const uint32_t item = blockIdx.x + (uint32_t)it * gridDim.x;
+        prob = fdiv(item, P.fd_heads);
+        hoff = ((int64_t)(item - prob * P.fd_heads.d) * hpb + hh) * 64;
+    };
+    auto build_tab = [&](int32_t* tab, int32_t* ot, uint32_t prob) {
+        const int64_t base0 = seg0_base(P.rm, (int)prob);
+        for (int l = tid; l < L; l += NW * 64) {
+            const int64_t r0 = l < L0 ? seg0_row(P.rm, base0, l) : 0;
+            if (tab != nullptr) tab[l] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
+            if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
+        }
+    };
+    // copy of one head's K and V rows into the images (attn_res_kernel's copy_rows; instruction i belongs to wave i mod 4)
+    auto copy_head = [&](const int32_t* tab, int64_t ho) {
+        const int ni = (Lp >> 5) * 4;
+        for (int i = wave; i < ni; i += NW) {
+            const int r = i * 8 + (lane >> 3);
+            const int rc = r < L ? r : L - 1;
+            const int64_t off = ((int64_t)tab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
+            glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
+            glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
+        }
+    };
+    auto load_q = [&](bf16x8 (&dst)[NT][4], const int32_t* tab, int64_t ho) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int lq = (t0 + t) * 32 + l31;
+            lq = lq < P.qend ? lq : P.qend - 1;
+            const bf16_t* qp = P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dst[t][ks] = *(const bf16x8*)(qp + ks * 16);
+        }
+    };
+    const bool force_safe = P.safe_softmax != 0;
+    if (G == 0) return;
+    uint32_t prob; int64_t hoff;
+    item_of(0, prob, hoff);
+    build_tab(tabs, otab, prob);
+    __syncthreads();
+    copy_head(tabs, hoff);
+    bf16x8 qn[NT][4];                                        // raw Q fragments of this wave's tiles of the next head
+    load_q(qn, tabs, hoff);
+
+    for (int g = 0; g < G; ++g) {
+        const int it = g / hpb;
+        const int32_t* const tab = tabs + (it & 1) * Lt;
+        item_of(g, prob, hoff);
+        const bool has_next = g + 1 < G;
+        uint32_t nprob = prob; int64_t nhoff = hoff;
+        const int32_t* ntab = tab;
+        const bool new_item_next = has_next && (g + 1) / hpb != it;
+        if (has_next) {
+            item_of(g + 1, nprob, nhoff);
+            if (new_item_next) {
+                ntab = tabs + ((it + 1) & 1) * Lt;
+                build_tab((int32_t*)ntab, nullptr, nprob);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
+        __syncthreads();                                     // ... and everybody else's
+        c.rowtab = tab;
+        {
+            bf16x8 q[NT][4];
+            bf16_t* op[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) q[t][ks] = qn[t][ks];
+                int lq = (t0 + t) * 32 + l31;
+                lq = lq < P.qend ? lq : P.qend - 1;
+                op[t] = P.o0 + ((int64_t)otab[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + hoff;
+            }
+            // the next head's Q rows are requested when this head's tile loop is over (its registers are free then) and travel
+            // under the normalisation, the stores and the head seam
+            auto fetch_next_q = [&]() {
+                if (has_next) load_q(qn, ntab, nhoff);
+                else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) qn[t][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            };
+            ResGlobal gm;
+            gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
+            res4_unit<NT, ILV, PK>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+        }
+        __syncthreads();                                     // everybody is done with this head's images
+        if (new_item_next) build_tab(nullptr, otab, nprob);
+        if (has_next) copy_head(ntab, nhoff);
+    }
+}
+
+template <bool ILV, bool PK>
+__global__ void __launch_bounds__(256, 1)
+attn_res4_kernel(const AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // this wave's query tiles of every head: nqt / 4 (+ 1 for the first nqt % 4 waves) adjacent tiles; the host side launches
+    // this kernel for 8 <= nqt <= 20 only (2..5 tiles per wave)
+    const int nqt = (P.qend + 31) >> 5;
+    const int q4 = nqt >> 2, x4 = nqt & 3;
+    const int cnt = q4 + (wave < x4 ? 1 : 0);
+    const int t0 = wave * q4 + (wave < x4 ? wave : x4);
+    switch (cnt) {
+        case 2: res4_heads<2, ILV, PK>(P, smem, t0); break;
+        case 3: res4_heads<3, ILV, PK>(P, smem, t0); break;
+        case 4: res4_heads<4, ILV, PK>(P, smem, t0); break;
+        default: res4_heads<5, ILV, PK>(P, smem, t0); break;
+    }
+}
+
+}  // namespace
+
+// Called by dwm_attention_fwd (attention.hip) for the launches this kernel covers: unmasked self-attention whose K / V rows of a head
+// fit the LDS, 8 <= query tiles <= 20 (225 <= L <= 608: two to five tiles per wave).  P, nblk, lds: as for attn_res_kernel.
+int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, bool pk, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (ilv) {
+        if (pk) hipLaunchKernelGGL((attn_res4_kernel<true, true>), dim3(nblk), dim3(256), lds, s, P);
+        else hipLaunchKernelGGL((attn_res4_kernel<true, false>), dim3(nblk), dim3(256), lds, s, P);
+    } else {
+        if (pk) hipLaunchKernelGGL((attn_res4_kernel<false, true>), dim3(nblk), dim3(256), lds, s, P);
+        else hipLaunchKernelGGL((attn_res4_kernel<false, false>), dim3(nblk), dim3(256), lds, s, P);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}

@@ -1105,8 +1105,9 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a_in, void* stream) {
     }
     if (a->C32 != nullptr && a->epilogue != DWM_EPI_RESID) return DWM_EUNSUPPORTED;
     {
-        // DWM_GEMM4W: unset = as the caller asks (tile == 3), 1 = every covered launch, 2 = 1 + the general form (gemm_bf16_4w.hip), 0 = never
-        static const int env4w = [] { const char* v = getenv("DWM_GEMM4W"); return (v == nullptr || v[0] == '\0') ? -1 : (v[0] != '0' ? 1 : 0); }();
+        // DWM_GEMM4W: unset = as the caller asks (tile == 3), 1 = every covered launch, 0 = never, f = as the caller asks but only the
+        // fast form (gemm_bf16_4w.hip)
+        static const int env4w = [] { const char* v = getenv("DWM_GEMM4W"); return (v == nullptr || v[0] == '\0' || v[0] == 'f') ? -1 : (v[0] != '0' ? 1 : 0); }();
         const bool use4w = env4w < 0 ? allow4w : env4w == 1;
         if (use4w && !DWM_RESERVED(a->reserved) && a->lda % 64 == 0) {
             const int rc4 = dwm_gemm4w_try(a, stream);

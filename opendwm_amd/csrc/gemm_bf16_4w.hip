@@ -1,9 +1,8 @@
 // bf16 GEMM with the fused epilogues of gemm_bf16.hip on a 4-WAVE main loop:  C[M,Nout] = epi(A[M,K] · W[N,K]^T)
 //
-// Used where the caller asks for it (dwm_gemm_args.tile == 3: the MMDiT inference forward; or environment DWM_GEMM4W=1 for every
-// covered launch): written late in round 4 and validated on its own battery, the GEMM / block / stream tests, the full-depth
-// full-size forward and the bench - the other callers (UNet, VAEs, training) keep the 8-wave kernels of gemm_bf16.hip, on which
-// the whole GPU suite has run.
+// Used where the caller asks for it (dwm_gemm_args.tile == 3: the MMDiT inference forward and the MMDiT train step; or environment
+// DWM_GEMM4W=1 for every covered launch).  The other callers (UNet, VAEs) keep the 8-wave kernels of gemm_bf16.hip: measured slower
+// on this tile for the UNet's N = 320 / 640 shapes (profiles/r5a_*: 73.9 -> 75.6 ms per step).
 //
 // Geometry = what hipBLASLt's gfx950 kernel for these shapes does (Custom_Cijk_Alik_Bljk_..._MT256x256x64_MI16x16x1, disassembled
 // from the ROCm install; it runs the bench's GEMM shapes 10-20 % faster than the 8-wave loop, profiles/README.md): the same
@@ -24,8 +23,7 @@
 // gate / residual / blend rows and the stores.  RESID comes in the compile-time operand forms (RS) only: residual, gate + residual,
 // residual + blend, on the fp32 stream (RF32, no bf16 copy) or in bf16.
 // Covered launches (everything else stays on gemm_bf16.hip): no row maps, no taps, no split-K, M % 256 == N % 256 == K % 64 == 0.
-// General form (template parameter GEN; written at the end of round 4 WITHOUT a GPU at hand, so it only runs with DWM_GEMM4W=2 until
-// it has been validated): ragged M / N, the A row map, taps, the per-image residual row - see dwm_gemm4w_try.
+// General form (template parameter GEN): ragged M / N, the A row map, taps, the per-image residual row - see dwm_gemm4w_try.
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -64,7 +62,7 @@ DWM_DEVINL int64_t map_row4(const G4Map& rm, int64_t m) {
     return (int64_t)i * rm.ipitch + (int64_t)y * rm.rpitch + (int64_t)x * rm.xstep + rm.origin;
 }
 
-// GEN (general form; opt-in, see dwm_gemm4w_try): ragged M / N (operand rows clamped to the last one, stores guarded), A rows through
+// GEN (general form, see dwm_gemm4w_try): ragged M / N (operand rows clamped to the last one, stores guarded), A rows through
 // the row map `a_map`, K walked tap by tap (implicit convolution), RS bit 16 (the residual row is m / |res_mod|).  The per-lane
 // request offsets then differ from request to request (one VGPR each instead of two per operand) and the K walk of A is a scalar
 // that jumps at tap boundaries (the table sits in a VGPR, one lane per tap, read by v_readlane: gemm_bf16.hip's reason).
@@ -485,17 +483,19 @@ int launch4w(const dwm_gemm_args* a, const G4Params& gp, hipStream_t s) {
 // Called by dwm_gemm_bf16 (gemm_bf16.hip) after its argument validation when the caller (tile == 3) or DWM_GEMM4W asks for it.
 // Returns -1 if this launch is not one the 4-wave kernels cover (the caller then continues with the 8-wave kernels), otherwise the
 // launch status.
-//   fast form (validated on the GPU, the default coverage): no row maps, no taps, no split-K, M % 256 == N % 256 == K % 64 == 0.
-//   general form (GEN; only with DWM_GEMM4W=2 until it has run on the GPU): ragged M / N (N % 8 == 0; GEGLU / RMSHEAD: N % 64 == 0),
-//   an A row map, taps (implicit convolution), the per-image residual row (res_mod < 0) - no OUTPUT row map, no split-K.
+//   fast form: no row maps, no taps, no split-K, M % 256 == N % 256 == K % 64 == 0.
+//   general form (GEN; validated on the GPU in round 5, profiles/r5a_*: 22-call battery against fp64 / conv2d and the 8-wave kernels,
+//   393.8 -> 389.4 ms per denoise step on one box): ragged M / N (N % 8 == 0; GEGLU / RMSHEAD: N % 64 == 0), an A row map, taps
+//   (implicit convolution), the per-image residual row (res_mod < 0) - no OUTPUT row map, no split-K.
 int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream) {
-    static const bool ext = [] { const char* v = getenv("DWM_GEMM4W"); return v != nullptr && v[0] == '2'; }();
+    // DWM_GEMM4W=f: the fast form only (A/B measurements of the general form)
+    static const bool fast_only = [] { const char* v = getenv("DWM_GEMM4W"); return v != nullptr && v[0] == 'f'; }();
     const int64_t lim = 1ll << 31;
     if (a->c_map.rw > 0 || a->split_k > 1 || a->tile == 1 || a->tile == 2) return -1;        // (tile 1 / 2: an 8-wave configuration was asked for)
     if (a->K % BK != 0 || a->K < 2 * BK) return -1;        // (one K step: a known bad corner of the request form)
     const bool row_div = a->epilogue == DWM_EPI_RESID && a->res_mod < 0;
     const bool gen = a->a_map.rw > 0 || a->ntaps > 0 || a->M % BM != 0 || a->N % BN != 0 || row_div;
-    if (gen && !ext) return -1;
+    if (gen && fast_only) return -1;
     if (a->ldc >= lim || a->ldc32 >= lim || a->ld_res >= lim || a->ld_blend >= lim || a->ld_gate >= lim) return -1;
     // the automatic split-K rule of dwm_gemm_bf16 (small tile grids with a long K) keeps its kernels
     const int ntm = (int)((a->M + BM - 1) / BM), ntn = (int)((a->N + BN - 1) / BN);

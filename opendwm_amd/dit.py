@@ -230,11 +230,11 @@ class DiTCrossviewTemporalConditionModel(_Base):
         # forward accumulate in fp32 (GEMM RESID epilogues with dwm_gemm_args.C32, LayerNorms reading fp32) - each add into a
         # bf16 stream is a rounding of the whole stream (1.1e-3 rms each; they add up to the 1.3e-2 a bf16-stream forward
         # shows against the fp32 oracle).  bf16: the round-1..3 behaviour (half the stream traffic).
-        self.gemm_4wave = True               # inference forward: 4-wave GEMM kernels for the launches they cover (ops.GEMM_4WAVE)
-        # True: the AdaLN modulation rows of ALL joint blocks and of norm_out (they depend on the timestep embedding only) come
-        # from ONE stacked GEMM per forward instead of two M = I launches per block (35-223 TFLOP/s each).  Off: written at the
-        # end of round 4 without a GPU at hand (tests/test_unvalidated_gpu.py).
-        self.stack_modulation = False
+        self.gemm_4wave = True               # 4-wave GEMM kernels for the launches they cover (ops.gemm_4wave_scope): inference and training
+        # True (default): the AdaLN modulation rows of ALL joint blocks and of norm_out (they depend on the timestep embedding only) come
+        # from ONE stacked GEMM per forward instead of two M = I launches per block (35-223 TFLOP/s each): validated and measured in
+        # round 5 (393.8 -> 392.6 ms per step, profiles/r5a_*).  Costs a packed copy of those weights (1.7 GB at full size).
+        self.stack_modulation = True
         self.residual_dtype = torch.float32
         self._index_sinusoids = {}
         self.perspective_modeling_type = perspective_modeling_type
@@ -321,23 +321,22 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 for k in ("encoder_hidden_states", "pooled_projections", "disable_temporal"):
                     if kw.get(k) is not None:
                         kw[k] = kw[k].unsqueeze(2)
-            out = _train.forward_train(self, sample, timestep, kw.get("encoder_hidden_states"), kw.get("pooled_projections"),
-                                       disable_crossview=kw.get("disable_crossview"), disable_temporal=kw.get("disable_temporal"),
-                                       crossview_attention_mask=kw.get("crossview_attention_mask"),
-                                       added_time_ids=kw.get("added_time_ids"),
-                                       condition_image_tensor=kw.get("condition_image_tensor"),
-                                       camera_intrinsics_norm=kw.get("camera_intrinsics_norm"),
-                                       camera2referego=kw.get("camera2referego"))
+            with ops.gemm_4wave_scope(self.gemm_4wave):     # (the block Functions carry the scope into their backward)
+                out = _train.forward_train(self, sample, timestep, kw.get("encoder_hidden_states"), kw.get("pooled_projections"),
+                                           disable_crossview=kw.get("disable_crossview"), disable_temporal=kw.get("disable_temporal"),
+                                           crossview_attention_mask=kw.get("crossview_attention_mask"),
+                                           added_time_ids=kw.get("added_time_ids"),
+                                           condition_image_tensor=kw.get("condition_image_tensor"),
+                                           camera_intrinsics_norm=kw.get("camera_intrinsics_norm"),
+                                           camera2referego=kw.get("camera2referego"))
             if kw.get("return_dict"):                       # crossview_temporal_dit.py:620-630: only the dict form is squeezed
                 return {"noise_pred": out.squeeze(2) if squeeze else out}
             return [out], None, None
         from .blocks import STORE
-        prev4w = ops.GEMM_4WAVE
-        ops.GEMM_4WAVE = bool(self.gemm_4wave)      # the blocks' linear layers may run on the 4-wave GEMM kernels (ops.GEMM_4WAVE)
         try:
-            return self._forward_infer(sample, timestep, *args, **kwargs)
+            with ops.gemm_4wave_scope(self.gemm_4wave):      # this thread's launches may run on the 4-wave GEMM kernels
+                return self._forward_infer(sample, timestep, *args, **kwargs)
         finally:
-            ops.GEMM_4WAVE = prev4w
             STORE.set_precision(bf16)       # the fp32 accuracy path is scoped to this forward (compute_dtype = torch.float32)
 
     def _stacked_modulation(self, silu_temb: torch.Tensor):

@@ -3,7 +3,9 @@ memory and the current HIP stream; all arithmetic happens in libdwm_hip.so.  Eve
 function raises if its tensors are not bf16 CUDA(HIP) tensors — there is no fallback."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -271,7 +273,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                 raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
     g.split_k = split_k
-    g.tile = 3 if (tile == 0 and GEMM_4WAVE) else tile          # 3: automatic + the 4-wave kernels may serve the launch
+    g.tile = 3 if (tile == 0 and getattr(_G4W, "on", False)) else tile          # 3: automatic + the 4-wave kernels may serve the launch
     # split-K scratch (fp32 partial tiles): only handed over when the kernel's own rule can take it
     if split_k != 1 and epilogue in (EPI_PLAIN, EPI_RESID) and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and K >= 1024:
         ws = _gemm_workspace(a.device)
@@ -280,11 +282,45 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out if mirror else out32
 
 
-# Set by the MMDiT inference forward for its own launches (opendwm_amd.dit, `model.gemm_4wave`): the linear layers of the transformer
-# blocks may then run on the 4-wave GEMM kernels (gemm_bf16_4w.hip: 412 against 434 ms per denoise step on one box, same results to
-# the summation order).  Everything else - UNet, VAEs, training, direct ops.gemm calls - keeps the 8-wave kernels, on which the whole
-# GPU suite has run.  Environment DWM_GEMM4W=0 / 1 overrides it in the library.
-GEMM_4WAVE = False
+# 4-wave GEMM kernels (gemm_bf16_4w.hip) for the calling thread's launches: the MMDiT inference forward and the MMDiT train step open a
+# `gemm_4wave_scope` around their own launches (`model.gemm_4wave`); inside it `ops.gemm(..., tile=0)` asks for dwm_gemm_args.tile = 3
+# ("automatic, and the 4-wave kernels may serve the launch").  Everything else - UNet, VAEs, direct ops.gemm calls - keeps the 8-wave
+# kernels.  The switch is per thread (no module global to race on between models / streams driven from different threads); autograd
+# runs backward on its own thread, so the training Functions re-open the scope there (`scope_of` / `capture_scope`).
+# Environment DWM_GEMM4W=0 / 1 overrides it in the library.
+_G4W = threading.local()
+
+
+def gemm_4wave_enabled() -> bool:
+    return bool(getattr(_G4W, "on", False))
+
+
+@contextlib.contextmanager
+def gemm_4wave_scope(on: bool):
+    prev = gemm_4wave_enabled()
+    _G4W.on = bool(on)
+    try:
+        yield
+    finally:
+        _G4W.on = prev
+
+
+def carries_gemm_scope(cls):
+    """class decorator for torch.autograd.Function subclasses: the backward (autograd's own thread) runs inside the
+    gemm_4wave_scope its forward ran in"""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kwargs):
+        ctx._gemm_4wave = gemm_4wave_enabled()
+        return fwd(ctx, *args, **kwargs)
+
+    def backward(ctx, *grads):
+        with gemm_4wave_scope(getattr(ctx, "_gemm_4wave", False)):
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
 
 _SPLIT_WEIGHTS: dict = {}
 SPLIT_WEIGHT_CACHE_MAX = 2048        # > the ~1300 weight matrices of the largest model on the path

@@ -267,6 +267,7 @@ def joint_block_backward(blk: JointTransformerBlock, h: torch.Tensor, c: torch.T
     return dh1, dc1, dst
 
 
+@ops.carries_gemm_scope
 class JointBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, blk, n_img, h, c, st, *params):
@@ -367,6 +368,7 @@ def vt_block_backward(blk: VTSelfAttentionBlock, h: torch.Tensor, emb: torch.Ten
     return dh, demb, dalpha
 
 
+@ops.carries_gemm_scope
 class VTBlockFn(torch.autograd.Function):
     """h_out = AlphaBlender(h, VTSelfAttentionBlock(h + emb)); inputs that carry gradients: h, emb, alpha."""
 
@@ -408,6 +410,7 @@ def alpha_train(mixer: AlphaBlender, image_only_indicator: Optional[torch.Tensor
 
 
 # ------------------------------------------------------------------------------------------ small modules
+@ops.carries_gemm_scope
 class MlpFn(torch.autograd.Function):
     """TimestepEmbedding: linear_2(silu(linear_1(x))) [+ res]; x carries no gradient (sinusoids / pooled text)."""
 
@@ -435,6 +438,7 @@ def mlp_train(m: TimestepEmbedding, x: torch.Tensor, res: Optional[torch.Tensor]
     return MlpFn.apply(m, x, res, *_params(m))
 
 
+@ops.carries_gemm_scope
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lin, x, *params):
@@ -481,6 +485,7 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
+@ops.carries_gemm_scope
 class PatchEmbedFn(torch.autograd.Function):
     """SD3 PatchEmbed (strided conv as patchify + GEMM, + cropped pos embed); the latents carry no gradient."""
 
@@ -506,6 +511,7 @@ class PatchEmbedFn(torch.autograd.Function):
         return (None, None) + _grads_for(G, _params(pe), ctx.needs_input_grad[2:])
 
 
+@ops.carries_gemm_scope
 class OutFn(torch.autograd.Function):
     """norm_out (AdaLayerNormContinuous) + proj_out + unpatchify"""
 
@@ -551,6 +557,7 @@ def _conv3_flip(w: torch.Tensor) -> torch.Tensor:
     return STORE.derived(w, "c3flip", lambda: _bf(w).flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous())
 
 
+@ops.carries_gemm_scope
 class AdapterFn(torch.autograd.Function):
     """dwm.models.adapters.ImageAdapter (src/dwm/models/adapters.py:40-60) with a hand-written backward.  Forward =
     the inference path (opendwm_amd.adapters.ImageAdapter.run) keeping only the condition images (the reference wraps
@@ -692,6 +699,7 @@ class AdapterFn(torch.autograd.Function):
         return (None, None) + _grads_for(G, ps, ctx.needs_input_grad[2:])
 
 
+@ops.carries_gemm_scope
 class RayEmbFn(torch.autograd.Function):
     """Explicit perspective modelling (crossview_temporal_dit.py:440-458, 528-568): per-token embedding of a cross-view /
     temporal block = per-image index embedding [I, D] + RayEncoder.proj(ray features [I*N, 72]).  One K = 128 GEMM with the

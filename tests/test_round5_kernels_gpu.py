@@ -1,18 +1,18 @@
-"""GPU leg, OFF by default: kernels written at the end of round 4 WITHOUT a GPU at hand (the round's GPU budget was spent).  They
-are opt-in in the product (an environment variable or a variant bit each; the defaults are the kernels the whole suite has run
-on), and their tests are opt-in here: DWM_TEST_UNVALIDATED=1 runs them (scripts/calls/r5_a.sh does, as the first call of the
-next round).  A case moves into the regular files once it has passed on hardware.
+"""GPU leg: kernels and host restructurings that were written at the end of round 4 without a GPU at hand and validated + measured
+by the first call of round 5 (profiles/r5a_*), now defaults:
 
-  * attn_res2_kernel (attention.hip; dwm_attn_args.variant bit 6 / DWM_ATTN_RES2=1): the resident attention kernel with two
-    query tiles per wave - every shape class the resident kernel's own tests hold, against the fp32 reference AND against the
-    default kernel's output (the same per-tile arithmetic in the same order: expected bit-equal, logged, not asserted).
-  * the GENERAL form of the 4-wave GEMM kernels (gemm_bf16_4w.hip, template parameter GEN; DWM_GEMM4W=2): ragged M / N, the A row
-    map and the taps of an implicit convolution (dense and stride 2), the per-image residual row - a battery in a subprocess with
-    the variable set (it is read once per process), against fp64 products / F.conv2d AND against the 8-wave kernels' output of
-    the same call in this process; `dwm_gemm4w_launches_general` must count exactly the covered calls.
+  * the GENERAL form of the 4-wave GEMM kernels (gemm_bf16_4w.hip, template parameter GEN): ragged M / N, the A row map and the taps
+    of an implicit convolution (dense and stride 2), the per-image residual row - a battery in a subprocess with DWM_GEMM4W=1 (every
+    covered launch; the variable is read once per process), against fp64 products / F.conv2d AND against the 8-wave kernels' output of
+    the same calls (DWM_GEMM4W=0); `dwm_gemm4w_launches_general` must count exactly the covered calls.
   * `DiTCrossviewTemporalConditionModel.stack_modulation` (dit.py): the AdaLN modulation rows of all joint blocks and norm_out from
     ONE stacked GEMM per forward (host-side restructuring over validated kernels) - small model against the oracle and against
-    the default forward, three temporal types, and the stack rebuilt after a state-dict load.
+    the per-block forward, three temporal types, and the stack rebuilt after a state-dict load.
+  * attn_res4_kernel (attention.hip): the resident attention kernel with ONE wave per SIMD and up to five query tiles per wave -
+    every remainder class of its tile schedule, both softmax paths, item seams, a strided row map - against the fp32 reference and
+    against attn_res_kernel.
+(attn_res2_kernel, the 8-wave / two-tiles-per-wave form of round 4, measured 20 % SLOWER than attn_res_kernel - 611 against 769
+TFLOP/s at L = 602, profiles/r5a_microbench_attn_res2.log - and was deleted.)
 """
 import json
 import os
@@ -32,7 +32,7 @@ TOL, TOL32 = 6e-3, 2e-5
 
 
 def _gemm_general_battery():
-    """runs in a subprocess (DWM_GEMM4W=2, or unset for the 8-wave reference outputs); prints one JSON line + saves the outputs"""
+    """runs in a subprocess (DWM_GEMM4W=1, or 0 for the 8-wave reference outputs); prints one JSON line + saves the outputs"""
     import torch.nn.functional as F
     from opendwm_amd import _lib, ops
     from opendwm_amd.blocks import geglu_pack
@@ -151,11 +151,10 @@ def _run_battery(mode, path):
     return json.loads(line[0][10:])
 
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("DWM_TEST_UNVALIDATED"),
-                                 reason="kernels written without a GPU at hand: DWM_TEST_UNVALIDATED=1 runs their tests")]
+pytestmark = [pytest.mark.gpu]
 bf16 = torch.bfloat16
-RES2 = 64                                              # variant bit 6
+OLD = 1 << 12                                          # variant bit 12: keep attn_res_kernel (12 waves, one query tile per unit)
+ILV, PK = 1 << 13, 1 << 14                             # attn_res4_kernel: alternating S / PV MFMA order, packed row-sum adds
 
 
 @pytest.fixture(scope="module")
@@ -176,15 +175,14 @@ def _run(ops, qkv, cqkv, I, N, Lc, heads, rm, variant):
     return out, cout
 
 
-# sequence lengths: every remainder class of the tile schedule (nqt = tiles of 32 queries; full rounds of 16, then rem / 8 +
-# (wave < rem % 8) tiles per wave): nqt = 2, 3 (singles only), 4 (97 queries: ragged last tile), 8 (one single per wave), 9-15
-# (pairs and singles mixed), 14 (L = 448: the dual / temporal case), 16 (exactly one full round), 17, 18, 19 (L = 602 / 608: a
-# full round + singles: the joint case), and two segments
+# attn_res4_kernel serves unmasked self-attention with 8..19 query tiles of 32 (225 <= L <= 608); wave w of its 4 takes nqt / 4
+# (+ 1 for w < nqt % 4) adjacent tiles.  Sequence lengths: every tile count 8..19 (each split 2..5 tiles per wave, ragged and full last
+# tiles / key steps, one and two segments) + three lengths below the range (they stay on attn_res_kernel: same answers expected)
 @pytest.mark.parametrize("scale", [1.0, 8.0], ids=["unit_scores", "huge_scores_fallback"])
 @pytest.mark.parametrize("I,N,Lc,heads", [(2, 448, 154, 6), (2, 448, 0, 6), (2, 608, 0, 3), (2, 97, 0, 4), (1, 64, 0, 2), (2, 200, 33, 2),
-                                          (1, 575, 0, 2), (3, 33, 32, 3), (2, 256, 0, 2), (2, 290, 0, 2), (1, 480, 0, 2), (1, 512, 0, 2),
-                                          (1, 513, 30, 2), (2, 352, 0, 3), (1, 416, 1, 2)])
-def test_attention_paired_resident_forms(dev, scale, I, N, Lc, heads):
+                                          (1, 575, 0, 2), (2, 256, 0, 2), (1, 288, 0, 2), (2, 290, 0, 2), (2, 352, 0, 3), (1, 384, 0, 2),
+                                          (1, 400, 0, 2), (1, 416, 1, 2), (1, 480, 0, 2), (1, 512, 0, 2), (1, 513, 30, 2), (1, 225, 0, 2)])
+def test_attention_one_wave_per_simd_forms(dev, scale, I, N, Lc, heads):
     from opendwm_amd import ops
     D = heads * 64
     qkv = _rand((I * N, 3 * D), dev, 11, scale)
@@ -193,29 +191,29 @@ def test_attention_paired_resident_forms(dev, scale, I, N, Lc, heads):
     f, cf = qkv.float(), (cqkv.float() if Lc else None)
     r0, r1 = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads,
                        q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
-    base, cbase = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, 0)
-    errs, same = {}, {}
-    for variant in (RES2, RES2 | (heads << 8), RES2 | 16, RES2 | 16 | (heads << 8)):
+    base, cbase = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, OLD)
+    errs, same = {"old": max(rel_err(base, r0), rel_err(cbase, r1) if Lc else 0.0)}, {}
+    for variant in (0, heads << 8, 16, 16 | (heads << 8), ILV, PK, ILV | PK | 16):
         out, cout = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, variant)
         errs[variant] = max(rel_err(out, r0), rel_err(cout, r1) if Lc else 0.0)
         same[variant] = bool(torch.equal(out, base) and (not Lc or torch.equal(cout, cbase)))
-    _log("attention_paired_resident_forms", scale=scale, I=I, N=N, Lc=Lc, heads=heads, **{str(k): v for k, v in errs.items()},
-         bit_equal_to_default={str(k): v for k, v in same.items()})
+    _log("attention_one_wave_per_simd_forms", scale=scale, I=I, N=N, Lc=Lc, heads=heads, **{str(k): v for k, v in errs.items()},
+         bit_equal_to_12_wave_kernel={str(k): v for k, v in same.items()})
     assert all(e < (TOL_KERNEL if scale == 1.0 else 3e-2) for e in errs.values()), errs
 
 
-@pytest.mark.parametrize("I,N,Lc,heads,hs", [(150, 256, 40, 4, 2), (3, 448, 154, 24, 6), (40, 448, 0, 12, 1), (70, 230, 0, 8, 2)])
-def test_attention_paired_resident_across_item_seams(dev, I, N, Lc, heads, hs):
-    """persistent workgroups walking several (problem, head group) items: table rebuilds, the Q prefetch and the copy pipeline
+@pytest.mark.parametrize("I,N,Lc,heads,hs", [(150, 256, 40, 4, 2), (3, 448, 154, 24, 6), (40, 448, 0, 12, 1), (70, 230, 0, 8, 2), (300, 448, 154, 2, 1)])
+def test_attention_one_wave_per_simd_across_item_seams(dev, I, N, Lc, heads, hs):
+    """persistent workgroups walking several (problem, head group) items: table rebuilds, the Q prefetch and the image copies
     across head and item seams; repeated launches bit-identical"""
     from opendwm_amd import ops
     D = heads * 64
     qkv = _rand((I * N, 3 * D), dev, 21)
     cqkv = _rand((I * Lc, 3 * D), dev, 22) if Lc else None
     rm = ops.rowmap_identity(I, N)
-    a = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, RES2 | (hs << 8))
-    b = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, RES2 | (hs << 8))
-    d = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, hs << 8)
+    a = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, hs << 8)
+    b = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, hs << 8)
+    d = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, OLD | (hs << 8))
     assert torch.equal(a[0], b[0]) and (not Lc or torch.equal(a[1], b[1]))
     errs = []
     for p0 in (0, I - 2):
@@ -224,14 +222,14 @@ def test_attention_paired_resident_across_item_seams(dev, I, N, Lc, heads, hs):
         r0, r1 = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], ops.rowmap_identity(2, N).rows().to(dev), heads,
                            q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
         errs.append(max(rel_err(a[0][p0 * N:(p0 + 2) * N], r0), rel_err(a[1][p0 * Lc:(p0 + 2) * Lc], r1) if Lc else 0.0))
-    # against the default kernel over ALL problems (the reference above covers four of them)
+    # against the 12-wave kernel over ALL problems (the reference above covers four of them)
     whole = max(rel_err(a[0], d[0]), rel_err(a[1], d[1]) if Lc else 0.0)
-    _log("attention_paired_resident_item_seams", I=I, N=N, Lc=Lc, heads=heads, hs=hs, rel=max(errs), rel_to_default_all_problems=whole,
-         bit_equal_to_default=bool(torch.equal(a[0], d[0])))
+    _log("attention_one_wave_per_simd_item_seams", I=I, N=N, Lc=Lc, heads=heads, hs=hs, rel=max(errs), rel_to_12_wave_all_problems=whole,
+         bit_equal_to_12_wave_kernel=bool(torch.equal(a[0], d[0])))
     assert max(errs) < TOL_KERNEL and whole < TOL_KERNEL
 
 
-def test_attention_paired_resident_temporal_rowmap_multihead(dev):
+def test_attention_one_wave_per_simd_temporal_rowmap_multihead(dev):
     """through a strided row map (row-wise temporal attention: L = frames x row width), 24 heads in groups of 6"""
     from opendwm_amd import ops
     B, T, V, h, w, heads = 1, 16, 2, 3, 28, 24
@@ -242,25 +240,16 @@ def test_attention_paired_resident_temporal_rowmap_multihead(dev):
     f = qkv.float()
     ref, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads)
     errs = {}
-    for variant in (RES2 | (6 << 8), RES2 | (4 << 8), RES2):
+    for variant in (6 << 8, 4 << 8, 0, ILV, OLD):
         out = torch.full((R, D), float("nan"), dtype=bf16, device=dev)
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant)
         errs[variant] = rel_err(out, ref)
-    _log("attention_paired_resident_temporal_rowmap", L=rm.L0, **{str(k): v for k, v in errs.items()})
+    _log("attention_one_wave_per_simd_temporal_rowmap", L=rm.L0, **{str(k): v for k, v in errs.items()})
     assert all(e < TOL_KERNEL for e in errs.values()), errs
 
 
-def test_attention_paired_resident_rejects_wave_override(dev):
-    from opendwm_amd import ops
-    heads, N = 2, 128
-    qkv = _rand((N, 3 * heads * 64), dev, 3)
-    out = torch.zeros((N, heads * 64), dtype=bf16, device=dev)
-    with pytest.raises(RuntimeError):
-        ops.attention(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], out, ops.rowmap_identity(1, N), heads, variant=RES2 | 8)
-
-
 def test_four_wave_gemm_general_form(dev, tmp_path):
-    gen = _run_battery("2", str(tmp_path / "gen.pt"))
+    gen = _run_battery("1", str(tmp_path / "gen.pt"))
     base = _run_battery("0", str(tmp_path / "base.pt"))           # the same calls on the 8-wave kernels
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "gpu_parity.log"), "a") as f:
@@ -299,6 +288,7 @@ def test_stacked_modulation_forward(dev, tt):
     def run():
         di = to_dev(inp16, dev)
         return m(di.pop("sample"), di.pop("timestep"), **di)[0][0]
+    m.stack_modulation = False
     base = run()
     m.stack_modulation = True
     got = run()
