@@ -18,8 +18,8 @@ LIB = os.path.join(HERE, "libdwm_hip.so")
 SOURCES = ["gemm_bf16.hip", "gemm_bf16_4w.hip", "gemm_tn.hip", "attention.hip", "attention_res4.hip", "attention_bwd.hip", "norm.hip",
            "elementwise.hip", "vae.hip", "train.hip", "fp32path.hip"]
 # translation units built without -amdgpu-mfma-vgpr-form (accumulators allowed into AGPRs): the 4-wave GEMM keeps the 256 accumulator
-# registers of a wave there
-AGPR_SOURCES: set = {"gemm_bf16_4w.hip"}
+# registers of a wave there, the one-wave-per-SIMD attention the output accumulators of up to five query tiles
+AGPR_SOURCES: set = {"gemm_bf16_4w.hip", "attention_res4.hip"}
 # per-file flags.  attention_res4.hip: the row-sum adds of its tile loop must stay scalar (left alone the SLP vectoriser packs the adds
 # of two slices into v_pk_add_f32 bunched behind the later one; packed fp32 VALU beside MFMAs costs more than the adds it replaces)
 FILE_FLAGS: dict = {"attention_res4.hip": ["-fno-slp-vectorize"]}

@@ -1,5 +1,6 @@
 // attn_res4_kernel: the resident attention forward (attention.hip: attn_res_kernel) with ONE wave per SIMD.  Its own translation
-// unit because of its flags: -fno-slp-vectorize (the row-sum adds must stay scalar, see res4_block) next to -amdgpu-mfma-vgpr-form.
+// unit because of its flags: -fno-slp-vectorize (the row-sum adds must stay scalar, see res4_block) and no -amdgpu-mfma-vgpr-form
+// (build.py AGPR_SOURCES: the builtin MFMAs accumulate in AGPRs).
 #include "attention_common.h"
 
 using namespace dwm_attn;
@@ -16,32 +17,38 @@ namespace {
 //   * no co-resident waves: on this chip a wave's own VALU work hides under its own MFMAs, another wave's does not
 //     (profiles/r3_mfma_valu_probe.txt; attn_res_kernel's three waves per SIMD run the same tile loop in 15.6 / 19.7 / 34.3 k cycles);
 //   * 19 tiles on 4 waves leave 5 % of the SIMD time idle (12 waves: 21 %).
-// Registers: the O accumulators of all tiles (NT x 32) live in AGPRs - the PV MFMAs are inline asm with "+a" operands, this file is
-// compiled with -amdgpu-mfma-vgpr-form, so the S accumulators (read by the VALU) stay in arch VGPRs -, Q fragments of all tiles
-// (NT x 16), two S buffers, two P' buffers and ONE set of K / V fragments in VGPRs.
+// Registers: the O accumulators of all tiles (NT x 32) live in AGPRs (builtin MFMAs; this file is compiled WITHOUT
+// -amdgpu-mfma-vgpr-form), the S accumulators in arch VGPRs (inline-asm MFMAs, below), next to the Q fragments of all tiles (NT x 16),
+// two S buffers, two P' buffers and ONE set of K / V fragments.
 // Schedule: the units u = (key step k, tile t), k-major, form ONE software pipeline; slot u holds
 //     S(u+1) = K Q^T (4 MFMAs)  ||  E(u): P' = 2^S, row sums, bf16 pack  ||  PV(u-1): O^T += V^T P'^T (4 MFMAs)
 // as one instruction stream of 8 chunks (one MFMA + one slice of E each, order pinned by sched_barrier); a fragment register is
-// re-requested right behind its last reader (res4_block).  ILV: S and PV MFMAs alternate (consecutive MFMAs never share an
-// accumulator) instead of 4 + 4.
-// The inline-asm MFMAs are invisible to the compiler's hazard recogniser; what it would have checked holds by construction: their
-// P' operands are written by VALU converts at least a slot (>= 8 instructions) earlier, their V operands come from LDS reads (covered by
-// the compiler's lgkmcnt waits, which do follow asm operands), accumulation on the same AGPRs back to back needs no wait states, and the
-// one VALU read of the accumulators (v_accvgpr_read at the unit's end) sits behind explicit s_nops.
+// re-requested right behind its last reader (res4_block).
 template <int NT>
 struct Res4Regs {
     bf16x8 qf[NT][4];
     f32x16 ot[NT][2];
     float ls[NT][2];
-    f32x2 ls2[NT][2];            // (PK)
     f32x16 s[2];
     bf16x8 p[2][2];
     bf16x8 kf[4];
     bf16x8 vf[2][2];             // [16-key half s2][d tile dt]
 };
 
-DWM_DEVINL void res4_mfma_pv(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+// The S MFMAs are inline asm with arch-VGPR destinations: this file is compiled WITHOUT -amdgpu-mfma-vgpr-form, so every builtin MFMA
+// (the PV accumulation) keeps its accumulator in AGPRs, managed - with all hazards - by the compiler, while the scores, which the VALU
+// reads, must not pay a v_accvgpr_read each.  What the compiler cannot see about the asm MFMAs holds by construction and is checked
+// on the generated code by scripts/dev/check_res4_asm.py: a chain of four accumulates on one register tuple back to back (no wait
+// states needed), its destination is early-clobber (never overlaps the operands), and the first VALU read of a chain's result comes
+// a slot later (>= 4 MFMAs behind the chain's last one; an 8-pass MFMA needs 11 wait states before a VALU read).
+DWM_DEVINL void res4_mfma_s_first(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+DWM_DEVINL void res4_mfma_s_first(f32x16& acc, const bf16x8& a, const bf16x8& b, const f32x16& c0) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c0));
+}
+DWM_DEVINL void res4_mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 DWM_DEVINL bf16x8 res4_kread(const ResCtx& c, const char* kl, int m) {
     return *(const bf16x8*)(kl + c.l31 * 128 + (((2 * m + c.half) ^ c.kswz) << 4));
@@ -60,7 +67,7 @@ DWM_DEVINL bf16x8 res4_vread(const ResCtx& c, const char* vl, int s2, int dt) {
 // Keys past the end of the sequence (the last key step of a ragged L) are masked in the S MFMAs themselves: the accumulators of step
 // n - 1 start from `mvec` (-inf for the absent keys, 0 elsewhere; 2^-inf = 0) instead of the inline constant 0 - MASKS = 1 for the
 // S MFMA chain this block issues for step k + 1 (k = n - 2), 2 for those of step k (k = n - 1) - and E needs no compare / select.
-template <int NT, int KP, bool FIRST, bool LAST, int MASKS, bool ILV, bool PK>
+template <int NT, int KP, bool FIRST, bool LAST, int MASKS>
 DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16& mvec) {
     constexpr int PB = (NT & 1) ? KP : 0;                 // parity of unit (k, 0): k * NT mod 2
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -77,14 +84,21 @@ DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
             // the MFMA of this chunk, and the request of its fragment's successor
-            const bool is_s = ILV ? (ch & 1) == 0 : ch < 4;
-            const int mi = ILV ? ch >> 1 : ch & 3;
+            const bool is_s = ch < 4;                       // S(u+1) first: E(u+1) starts four PV MFMAs behind its last MFMA
+            const int mi = ch & 3;
             if (is_s) {
                 const bool masked = t + 1 == NT ? MASKS == 1 : MASKS == 2;
-                if (do_s) r.s[par ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.kf[mi], r.qf[ts][mi], mi == 0 ? (masked ? mvec : zero) : r.s[par ^ 1], 0, 0, 0);
+                if (do_s) {
+                    if (mi == 0) {
+                        if (masked) res4_mfma_s_first(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi], mvec);
+                        else res4_mfma_s_first(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi]);
+                    } else {
+                        res4_mfma_s(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi]);
+                    }
+                }
                 if (!LAST && t == NT - 2) r.kf[mi] = res4_kread(c, kln, mi);
             } else {
-                if (do_pv) res4_mfma_pv(r.ot[tp][mi & 1], r.vf[mi >> 1][mi & 1], r.p[par ^ 1][mi >> 1]);
+                if (do_pv) r.ot[tp][mi & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.vf[mi >> 1][mi & 1], r.p[par ^ 1][mi >> 1], r.ot[tp][mi & 1], 0, 0, 0);
                 if (!FIRST && t == 0) r.vf[mi >> 1][mi & 1] = res4_vread(c, vlc, mi >> 1, mi & 1);
             }
             // slice ch of E(u): scores 2 ch, 2 ch + 1
@@ -94,14 +108,10 @@ DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16
                 // (scalar adds - this file is built with -fno-slp-vectorize: left alone the compiler packs the adds of two slices into
                 //  v_pk_add_f32, bunched behind the later slice; packed fp32 VALU beside MFMAs costs more than the plain adds it
                 //  replaces, MI355X_MICROARCH.md "price of one filler")
-                if (PK) {                                   // A/B: one packed add per slice (attn_res_kernel's form)
-                    r.ls2[t][ch & 1] += (f32x2){pa, pb};
-                } else {
-                    float acc = r.ls[t][ch & 1];
-                    acc += pa;
-                    acc += pb;
-                    r.ls[t][ch & 1] = acc;
-                }
+                float acc = r.ls[t][ch & 1];
+                acc += pa;
+                acc += pb;
+                r.ls[t][ch & 1] = acc;
                 uint32_t w = pack_bf16x2(pa, pb);
                 asm volatile("" : "+v"(w));                 // pins the convert to its slice (res_step)
                 pk[ch] = w;
@@ -115,7 +125,7 @@ DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16
     if (LAST) {                                             // PV of the last unit (k, NT - 1)
         constexpr int par = (PB + NT - 1) & 1;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) res4_mfma_pv(r.ot[NT - 1][mi & 1], r.vf[mi >> 1][mi & 1], r.p[par][mi >> 1]);
+        for (int mi = 0; mi < 4; ++mi) r.ot[NT - 1][mi & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.vf[mi >> 1][mi & 1], r.p[par][mi >> 1], r.ot[NT - 1][mi & 1], 0, 0, 0);
     }
 }
 
@@ -143,9 +153,9 @@ DWM_DEVINL void res_store_tile(const f32x16 (&o)[2], float l_tot, bf16_t* op, in
 }
 
 // one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 2 key steps)
-template <int NT, bool ILV, bool PK, class Fetch>
+template <int NT, class Fetch>
 DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe,
-                          const ResGlobal& gm, Fetch&& after_loop) {
+                          const ResGlobal& gm, Fetch&& after_loop, long long* tr = nullptr) {
     Res4Regs<NT> r;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -153,7 +163,6 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) r.qf[t][ks] = scale_log2 == 1.f ? qraw[t][ks] : scale_frag(qraw[t][ks], scale_log2);
         r.ls[t][0] = r.ls[t][1] = 0.f;
-        r.ls2[t][0] = r.ls2[t][1] = (f32x2){0.f, 0.f};
         r.ot[t][0] = zero;
         r.ot[t][1] = zero;
     }
@@ -163,16 +172,23 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* 
 #pragma unroll
     for (int i = 0; i < 4; ++i) r.vf[i >> 1][i & 1] = res4_vread(c, c.vimg, i >> 1, i & 1);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) r.s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.kf[m], r.qf[0][m], m == 0 ? zero : r.s[0], 0, 0, 0);
+    for (int m = 0; m < 4; ++m) {
+        if (m == 0) res4_mfma_s_first(r.s[0], r.kf[m], r.qf[0][m]);
+        else res4_mfma_s(r.s[0], r.kf[m], r.qf[0][m]);
+    }
+    asm volatile("s_nop 15" : "+v"(r.s[0]));                 // E(0, 0) follows at once: the wait states the compiler cannot know about
     const int n = c.nsub;                                    // >= 3 (the host side launches this kernel for L >= 225)
-    res4_block<NT, 0, true, false, 0, ILV, PK>(r, c, 0, zero);
+#ifdef DWM_ATTN_TRACE
+    if (tr != nullptr) tr[4] = (long long)__builtin_readcyclecounter();
+#endif
+    res4_block<NT, 0, true, false, 0>(r, c, 0, zero);
     int k = 1;
     for (; k + 1 < n - 2; k += 2) {
-        res4_block<NT, 1, false, false, 0, ILV, PK>(r, c, k, zero);
-        res4_block<NT, 0, false, false, 0, ILV, PK>(r, c, k + 1, zero);
+        res4_block<NT, 1, false, false, 0>(r, c, k, zero);
+        res4_block<NT, 0, false, false, 0>(r, c, k + 1, zero);
     }
     if (k < n - 2) {
-        res4_block<NT, 1, false, false, 0, ILV, PK>(r, c, k, zero);
+        res4_block<NT, 1, false, false, 0>(r, c, k, zero);
         ++k;
     }
     // k = n - 2: the accumulators of the last key step start from the key mask
@@ -180,22 +196,21 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* 
 #pragma unroll
     for (int i = 0; i < 16; ++i) mvec[i] = ((n - 1) << 5) + (i & 3) + 8 * (i >> 2) + 4 * c.half >= c.L ? -INFINITY : 0.f;
     if (k & 1) {
-        res4_block<NT, 1, false, false, 1, ILV, PK>(r, c, k, mvec);
-        res4_block<NT, 0, false, true, 2, ILV, PK>(r, c, k + 1, mvec);
+        res4_block<NT, 1, false, false, 1>(r, c, k, mvec);
+        res4_block<NT, 0, false, true, 2>(r, c, k + 1, mvec);
     } else {
-        res4_block<NT, 0, false, false, 1, ILV, PK>(r, c, k, mvec);
-        res4_block<NT, 1, false, true, 2, ILV, PK>(r, c, k + 1, mvec);
+        res4_block<NT, 0, false, false, 1>(r, c, k, mvec);
+        res4_block<NT, 1, false, true, 2>(r, c, k + 1, mvec);
     }
-    // the accumulators leave the matrix pipe: 2 x 16 wait states before anything reads them (the asm MFMAs are invisible to the
-    // hazard recogniser)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(r.ot[t][0]), "+a"(r.ot[t][1]));
+#ifdef DWM_ATTN_TRACE
+    if (tr != nullptr) tr[5] = (long long)__builtin_readcyclecounter();
+#endif
     after_loop();
     bool ok = !force_safe;
     float l_tot[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float l_half = PK ? (r.ls2[t][0][0] + r.ls2[t][0][1]) + (r.ls2[t][1][0] + r.ls2[t][1][1]) : r.ls[t][0] + r.ls[t][1];
+        const float l_half = r.ls[t][0] + r.ls[t][1];
         const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
         l_tot[t] = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
         ok = ok && (l_tot[t] >= 5.421010862e-20f) && (l_tot[t] <= 1.8446744e19f);        // res_unit's acceptance test
@@ -218,7 +233,7 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* 
 }
 
 // the persistent head loop of one wave with NT query tiles per head (tiles t0 .. t0 + NT - 1)
-template <int NT, bool ILV, bool PK>
+template <int NT>
 DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     constexpr int NW = 4;
     const int tid = threadIdx.x;
@@ -289,6 +304,14 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     };
     const bool force_safe = P.safe_softmax != 0;
     if (G == 0) return;
+    // development aid (-DDWM_ATTN_TRACE): shader-clock stamps of the 4 waves of workgroups 0-7 at 8 points of every head, written to the
+    // (otherwise unused) lse buffer as int64 [8 workgroups][4 waves][64 heads][8] (scripts/experiments/attn_trace.py)
+#ifdef DWM_ATTN_TRACE
+#define DWM_TR4(slot_) do { if (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) \
+        ((long long*)P.lse)[(((int)blockIdx.x * NW + wave) * 64 + g) * 8 + (slot_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DWM_TR4(slot_) do {} while (0)
+#endif
     uint32_t prob; int64_t hoff;
     item_of(0, prob, hoff);
     build_tab(tabs, otab, prob);
@@ -312,8 +335,11 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
                 build_tab((int32_t*)ntab, nullptr, nprob);
             }
         }
+        DWM_TR4(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
+        DWM_TR4(1);
         __syncthreads();                                     // ... and everybody else's
+        DWM_TR4(2);
         c.rowtab = tab;
         {
             bf16x8 q[NT][4];
@@ -339,15 +365,22 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             };
             ResGlobal gm;
             gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
-            res4_unit<NT, ILV, PK>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+#ifdef DWM_ATTN_TRACE
+            res4_unit<NT>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q,
+                          (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
+#else
+            res4_unit<NT>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+#endif
         }
+        DWM_TR4(3);
         __syncthreads();                                     // everybody is done with this head's images
+        DWM_TR4(6);
         if (new_item_next) build_tab(nullptr, otab, nprob);
         if (has_next) copy_head(ntab, nhoff);
+        DWM_TR4(7);
     }
 }
 
-template <bool ILV, bool PK>
 __global__ void __launch_bounds__(256, 1)
 attn_res4_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -359,10 +392,10 @@ attn_res4_kernel(const AttnParams P) {
     const int cnt = q4 + (wave < x4 ? 1 : 0);
     const int t0 = wave * q4 + (wave < x4 ? wave : x4);
     switch (cnt) {
-        case 2: res4_heads<2, ILV, PK>(P, smem, t0); break;
-        case 3: res4_heads<3, ILV, PK>(P, smem, t0); break;
-        case 4: res4_heads<4, ILV, PK>(P, smem, t0); break;
-        default: res4_heads<5, ILV, PK>(P, smem, t0); break;
+        case 2: res4_heads<2>(P, smem, t0); break;
+        case 3: res4_heads<3>(P, smem, t0); break;
+        case 4: res4_heads<4>(P, smem, t0); break;
+        default: res4_heads<5>(P, smem, t0); break;
     }
 }
 
@@ -370,22 +403,13 @@ attn_res4_kernel(const AttnParams P) {
 
 // Called by dwm_attention_fwd (attention.hip) for the launches this kernel covers: unmasked self-attention whose K / V rows of a head
 // fit the LDS, 8 <= query tiles <= 20 (225 <= L <= 608: two to five tiles per wave).  P, nblk, lds: as for attn_res_kernel.
-int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, bool pk, hipStream_t s) {
+int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (ilv) {
-        if (pk) hipLaunchKernelGGL((attn_res4_kernel<true, true>), dim3(nblk), dim3(256), lds, s, P);
-        else hipLaunchKernelGGL((attn_res4_kernel<true, false>), dim3(nblk), dim3(256), lds, s, P);
-    } else {
-        if (pk) hipLaunchKernelGGL((attn_res4_kernel<false, true>), dim3(nblk), dim3(256), lds, s, P);
-        else hipLaunchKernelGGL((attn_res4_kernel<false, false>), dim3(nblk), dim3(256), lds, s, P);
-    }
+    hipLaunchKernelGGL(attn_res4_kernel, dim3(nblk), dim3(256), lds, s, P);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }

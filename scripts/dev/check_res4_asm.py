@@ -1,0 +1,81 @@
+"""Desk check of attention_res4.hip's generated code (hipcc -save-temps .s): the inline-asm S MFMAs are invisible to the compiler's
+hazard recogniser, so this script verifies on the instruction stream what the recogniser would have enforced:
+  * no instruction other than the next MFMA of the same accumulation chain touches an asm MFMA's destination registers within WAIT
+    wait states behind it (an 8-pass MFMA needs 11 before a VALU / memory read of its result; every instruction counts as one wait
+    state - which under-counts MFMAs and so errs on the safe side -, s_nop N as N + 1);
+  * an asm MFMA's destination never overlaps its A / B operands.
+Scans in layout order and follows fall-through only; a branch inside the window is reported (the window then has to be argued by hand).
+usage: python scripts/dev/check_res4_asm.py file.s [kernel_substring]"""
+import re
+import sys
+
+WAIT = 12
+path = sys.argv[1]
+key = sys.argv[2] if len(sys.argv) > 2 else "attn_res4_kernel"
+text = open(path).read().split("\n")
+
+
+def regs(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+problems, n_asm, kernels = [], 0, 0
+i = 0
+while i < len(text):
+    if re.match(r"^_Z\w*%s\w*:" % key, text[i]):
+        kernels += 1
+        name = text[i][:-1]
+        j = i + 1
+        ins = []                      # (line no, text, in_asm)
+        in_asm = False
+        while j < len(text) and not text[j].strip().startswith(".end_amdhsa_kernel") and not text[j].startswith("\t.section"):
+            t = text[j].strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif t and not t.startswith((";", ".", "//")) and not re.match(r"^\.?\w+:", t):
+                ins.append((j + 1, t, in_asm))
+            j += 1
+        for a, (ln, t, asm) in enumerate(ins):
+            if not (asm and t.startswith("v_mfma")):
+                continue
+            n_asm += 1
+            ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+            dst, srca, srcb, srcc = regs(ops[0]), regs(ops[1]), regs(ops[2]), regs(ops[3]) if len(ops) > 3 else set()
+            if dst & (srca | srcb):
+                problems.append((name[-40:], ln, "dst overlaps A/B", t))
+            if srcc and srcc != dst and (srcc & dst):
+                problems.append((name[-40:], ln, "dst partially overlaps C", t))
+            waited = 0
+            for b in range(a + 1, len(ins)):
+                ln2, t2, asm2 = ins[b]
+                if waited >= WAIT:
+                    break
+                if t2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                    problems.append((name[-40:], ln, f"branch {b - a} instructions behind an asm MFMA", t2))
+                    break
+                ops2 = [o.strip() for o in t2.split(None, 1)[1].split(",")] if " " in t2 else []
+                touched = set().union(*[regs(o) for o in ops2]) if ops2 else set()
+                if not (touched & dst):
+                    m = re.match(r"s_nop (\d+)", t2)
+                    waited += int(m.group(1)) + 1 if m else 1          # s_nop N = N + 1 wait states
+                    continue
+                # the next MFMA of the same chain: asm, same dst, srcC == dst
+                if asm2 and t2.startswith("v_mfma") and regs(ops2[0]) == dst and len(ops2) > 3 and regs(ops2[3]) == dst and not (dst & (regs(ops2[1]) | regs(ops2[2]))):
+                    break             # the chain continues: the window restarts at that MFMA
+                problems.append((name[-40:], ln, f"result touched {b - a} instructions later (line {ln2})", t2))
+                break
+        i = j
+    else:
+        i += 1
+print(f"{kernels} kernels, {n_asm} asm MFMAs checked, {len(problems)} problems")
+for p in problems[:40]:
+    print(p)
+sys.exit(1 if problems else 0)
