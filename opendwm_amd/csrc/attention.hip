@@ -1339,7 +1339,8 @@ void launch_attn(const AttnParams& P, hipStream_t s) {
 }  // namespace
 
 // attention_res4.hip
-int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, hipStream_t s);
+int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, hipStream_t s);
+constexpr bool DWM_RES4_ILV_DEFAULT = false;
 
 extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     AttnParams P;
@@ -1462,12 +1463,16 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             P.nwc = nwc;
         }
         // one-wave-per-SIMD form (attention_res4.hip: 4 waves, all query tiles of a wave in one pass over the keys): 8..20 query
-        // tiles (225 <= L <= 608).  variant bit 12 keeps attn_res_kernel (A/B measurements, tests); DWM_ATTN_RES4 = 0 / 1: never / always
+        // tiles (225 <= L <= 608).  variant bit 12 keeps attn_res_kernel (A/B measurements, tests), bit 13 flips the MFMA order of its
+        // tile loop (default: see DWM_RES4_ILV_DEFAULT); DWM_ATTN_RES4 = 0 never / 1 always, 4 + 4 order / 2 always, alternating order
         {
             const int nqt = (P.qend + 31) >> 5;
             static const int env_res4 = [] { const char* v = getenv("DWM_ATTN_RES4"); return (v == nullptr || v[0] == '\0') ? -1 : (int)(v[0] - '0'); }();
             const bool want4 = env_res4 >= 0 ? env_res4 != 0 : !((a->variant >> 12) & 1);
-            if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) return dwm_attn_res4_launch(P, nblk, lds, s);
+            if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
+                const bool ilv = env_res4 > 0 ? env_res4 == 2 : (((a->variant >> 13) & 1) != 0) != DWM_RES4_ILV_DEFAULT;
+                return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
+            }
         }
         static bool attr_set = false;
         if (!attr_set) {

@@ -8,10 +8,10 @@ using namespace dwm_attn;
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// One-wave-per-SIMD resident form (round 5): attn_res4_kernel.  Images, swizzles, row tables, persistent workgroups, the two
-// barriers per head, the maximum-free fast path with its acceptance test and fallback, and the register-exchange stores are
-// attn_res_kernel's.  What changes is who walks the images: FOUR waves - one per SIMD, 512 registers each - and every wave takes ALL
-// its query tiles of a head (NT = 2..5 adjacent tiles: 19 tiles -> 5 / 5 / 5 / 4, 14 -> 4 / 4 / 3 / 3) through ONE pass over the keys:
+// One-wave-per-SIMD resident form (round 5).  Images, swizzles, row tables, persistent workgroups, the two barriers per head, the
+// maximum-free fast path with its acceptance test and fallback, and the register-exchange stores are attn_res_kernel's.  What changes
+// is who walks the images: FOUR waves - one per SIMD, 512 registers each - and every wave takes ALL its query tiles of a head
+// (NT = 2..5 adjacent tiles: 19 tiles -> 5 / 5 / 5 / 4, 14 -> 4 / 4 / 3 / 3) through ONE pass over the keys:
 //   * every K / V fragment read from the images feeds NT MFMAs (attn_res_kernel: one; the 12-wave kernel spends 1.5 LDS instructions
 //     with their address adds and waits per MFMA, 22.5 ns per MFMA slot against 17.8 without them, profiles/README.md);
 //   * no co-resident waves: on this chip a wave's own VALU work hides under its own MFMAs, another wave's does not
@@ -19,11 +19,20 @@ namespace {
 //   * 19 tiles on 4 waves leave 5 % of the SIMD time idle (12 waves: 21 %).
 // Registers: the O accumulators of all tiles (NT x 32) live in AGPRs (builtin MFMAs; this file is compiled WITHOUT
 // -amdgpu-mfma-vgpr-form), the S accumulators in arch VGPRs (inline-asm MFMAs, below), next to the Q fragments of all tiles (NT x 16),
-// two S buffers, two P' buffers and ONE set of K / V fragments.
+// two S buffers, two P' buffers and ONE set of K / V fragments: 256 + 160 registers at NT = 5 - nothing else may be live across the
+// tile loop (the next head's Q rows are requested in the head seam, behind the image copy, not across the loop; the fallback re-reads
+// its Q rows), or the spills' scratch round trips - which queue behind the LDS-DMA and Q loads of the seam - cost more than the
+// loop (measured, profiles/r5d_trace4_L602.txt: 20 k cycles of "stores", 27 k of "copy issue" per head).
 // Schedule: the units u = (key step k, tile t), k-major, form ONE software pipeline; slot u holds
 //     S(u+1) = K Q^T (4 MFMAs)  ||  E(u): P' = 2^S, row sums, bf16 pack  ||  PV(u-1): O^T += V^T P'^T (4 MFMAs)
 // as one instruction stream of 8 chunks (one MFMA + one slice of E each, order pinned by sched_barrier); a fragment register is
-// re-requested right behind its last reader (res4_block).
+// re-requested right behind its last reader (res4_block).  ILV: S and PV MFMAs alternate, so that consecutive MFMAs never share an
+// accumulator (a filler instruction between two MFMAs on the SAME accumulator costs ~40 cycles, MI355X_MICROARCH.md; measured here:
+// 45-54 cycles per MFMA with the 4 + 4 order).
+// Keys past the end of a ragged sequence need no masking: the pad rows of both images are ZERO (written once at kernel start; the
+// copies skip them by EXEC), so a pad key scores exactly 0, contributes P' = 2^0 = 1 to the row sum and nothing to O, and the row
+// sum is corrected by the constant number of pad keys.  (A row sum below 2^-6 would lose precision in that subtraction: such a
+// unit takes the fallback like one that leaves the fast path's range.)
 template <int NT>
 struct Res4Regs {
     bf16x8 qf[NT][4];
@@ -35,17 +44,14 @@ struct Res4Regs {
     bf16x8 vf[2][2];             // [16-key half s2][d tile dt]
 };
 
-// The S MFMAs are inline asm with arch-VGPR destinations: this file is compiled WITHOUT -amdgpu-mfma-vgpr-form, so every builtin MFMA
-// (the PV accumulation) keeps its accumulator in AGPRs, managed - with all hazards - by the compiler, while the scores, which the VALU
-// reads, must not pay a v_accvgpr_read each.  What the compiler cannot see about the asm MFMAs holds by construction and is checked
-// on the generated code by scripts/dev/check_res4_asm.py: a chain of four accumulates on one register tuple back to back (no wait
-// states needed), its destination is early-clobber (never overlaps the operands), and the first VALU read of a chain's result comes
-// a slot later (>= 4 MFMAs behind the chain's last one; an 8-pass MFMA needs 11 wait states before a VALU read).
+// The S MFMAs are inline asm with arch-VGPR destinations: every builtin MFMA of this file (the PV accumulation) keeps its accumulator
+// in AGPRs, managed - with all hazards - by the compiler, while the scores, which the VALU reads, must not pay a v_accvgpr_read each.
+// What the compiler cannot see about the asm MFMAs holds by construction and is checked on the generated code by
+// scripts/dev/check_res4_asm.py: a chain of four accumulates on one register tuple (no wait states needed), its destination is
+// early-clobber (never overlaps the operands), and the first VALU read of a chain's result comes >= 11 wait states behind the
+// chain's last MFMA (an 8-pass MFMA -> VALU read; another MFMA in between is worth 8: it cannot issue before the pipe is free).
 DWM_DEVINL void res4_mfma_s_first(f32x16& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
-}
-DWM_DEVINL void res4_mfma_s_first(f32x16& acc, const bf16x8& a, const bf16x8& b, const f32x16& c0) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c0));
 }
 DWM_DEVINL void res4_mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
@@ -64,13 +70,9 @@ DWM_DEVINL bf16x8 res4_vread(const ResCtx& c, const char* vl, int s2, int dt) {
 // Fragment registers are single-buffered: a K fragment of step k + 1 is requested right behind the last MFMA that reads the same
 // fragment of step k (S(k, NT-1) in slot NT - 2; its next reader is S(k+1, 0) a slot later), a V fragment of step k right behind the last
 // PV MFMA of step k - 1 (PV(k-1, NT-1) in slot 0; next reader PV(k, 0) in slot 1): seven MFMAs of distance each.
-// Keys past the end of the sequence (the last key step of a ragged L) are masked in the S MFMAs themselves: the accumulators of step
-// n - 1 start from `mvec` (-inf for the absent keys, 0 elsewhere; 2^-inf = 0) instead of the inline constant 0 - MASKS = 1 for the
-// S MFMA chain this block issues for step k + 1 (k = n - 2), 2 for those of step k (k = n - 1) - and E needs no compare / select.
-template <int NT, int KP, bool FIRST, bool LAST, int MASKS>
-DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16& mvec) {
+template <int NT, int KP, bool FIRST, bool LAST, bool ILV>
+DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k) {
     constexpr int PB = (NT & 1) ? KP : 0;                 // parity of unit (k, 0): k * NT mod 2
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const char* const kln = c.kimg + (k + 1) * 4096;
     const char* const vlc = c.vimg + k * 4096;
 #pragma unroll
@@ -84,17 +86,12 @@ DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
             // the MFMA of this chunk, and the request of its fragment's successor
-            const bool is_s = ch < 4;                       // S(u+1) first: E(u+1) starts four PV MFMAs behind its last MFMA
-            const int mi = ch & 3;
+            const bool is_s = ILV ? (ch & 1) == 0 : ch < 4;
+            const int mi = ILV ? ch >> 1 : ch & 3;
             if (is_s) {
-                const bool masked = t + 1 == NT ? MASKS == 1 : MASKS == 2;
                 if (do_s) {
-                    if (mi == 0) {
-                        if (masked) res4_mfma_s_first(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi], mvec);
-                        else res4_mfma_s_first(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi]);
-                    } else {
-                        res4_mfma_s(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi]);
-                    }
+                    if (mi == 0) res4_mfma_s_first(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi]);
+                    else res4_mfma_s(r.s[par ^ 1], r.kf[mi], r.qf[ts][mi]);
                 }
                 if (!LAST && t == NT - 2) r.kf[mi] = res4_kread(c, kln, mi);
             } else {
@@ -118,6 +115,9 @@ DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (alternating order, first slot of a unit: no PV MFMAs between the S chain's last MFMA and the next slot's first read of its
+        //  result - the wait states the compiler cannot know about)
+        if (ILV && FIRST && t == 0) asm volatile("s_nop 7" : "+v"(r.s[par ^ 1]));
         const uint4 lo = {pk[0], pk[1], pk[2], pk[3]}, hi = {pk[4], pk[5], pk[6], pk[7]};
         r.p[par][0] = *reinterpret_cast<const bf16x8*>(&lo);
         r.p[par][1] = *reinterpret_cast<const bf16x8*>(&hi);
@@ -125,7 +125,8 @@ DWM_DEVINL void res4_block(Res4Regs<NT>& r, const ResCtx& c, int k, const f32x16
     if (LAST) {                                             // PV of the last unit (k, NT - 1)
         constexpr int par = (PB + NT - 1) & 1;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) r.ot[NT - 1][mi & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.vf[mi >> 1][mi & 1], r.p[par][mi >> 1], r.ot[NT - 1][mi & 1], 0, 0, 0);
+        for (int mi = 0; mi < 4; ++mi)
+            r.ot[NT - 1][mi & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.vf[mi >> 1][mi & 1], r.p[par][mi >> 1], r.ot[NT - 1][mi & 1], 0, 0, 0);
     }
 }
 
@@ -152,10 +153,12 @@ DWM_DEVINL void res_store_tile(const f32x16 (&o)[2], float l_tot, bf16_t* op, in
         }
 }
 
-// one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 2 key steps)
-template <int NT, class Fetch>
-DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* const (&op)[NT], float scale_log2, bool force_safe,
-                          const ResGlobal& gm, Fetch&& after_loop, long long* tr = nullptr) {
+// one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 3 key steps).
+// qraw: raw Q fragments (consumed: scaled into the unit's registers); out_ptr(t): this lane's output row of tile t; reload_q(t, dst):
+// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L)
+template <int NT, bool ILV, class OutPtr, class ReloadQ>
+DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float scale_log2, bool force_safe, const ResGlobal& gm, float n_pad,
+                          OutPtr&& out_ptr, ReloadQ&& reload_q, long long* tr = nullptr) {
     Res4Regs<NT> r;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -177,63 +180,61 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], bf16_t* 
         else res4_mfma_s(r.s[0], r.kf[m], r.qf[0][m]);
     }
     asm volatile("s_nop 15" : "+v"(r.s[0]));                 // E(0, 0) follows at once: the wait states the compiler cannot know about
-    const int n = c.nsub;                                    // >= 3 (the host side launches this kernel for L >= 225)
+    const int n = c.nsub;
 #ifdef DWM_ATTN_TRACE
     if (tr != nullptr) tr[4] = (long long)__builtin_readcyclecounter();
 #endif
-    res4_block<NT, 0, true, false, 0>(r, c, 0, zero);
+    res4_block<NT, 0, true, false, ILV>(r, c, 0);
     int k = 1;
-    for (; k + 1 < n - 2; k += 2) {
-        res4_block<NT, 1, false, false, 0>(r, c, k, zero);
-        res4_block<NT, 0, false, false, 0>(r, c, k + 1, zero);
+    for (; k + 2 < n; k += 2) {
+        res4_block<NT, 1, false, false, ILV>(r, c, k);
+        res4_block<NT, 0, false, false, ILV>(r, c, k + 1);
     }
-    if (k < n - 2) {
-        res4_block<NT, 1, false, false, 0>(r, c, k, zero);
-        ++k;
-    }
-    // k = n - 2: the accumulators of the last key step start from the key mask
-    f32x16 mvec;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mvec[i] = ((n - 1) << 5) + (i & 3) + 8 * (i >> 2) + 4 * c.half >= c.L ? -INFINITY : 0.f;
-    if (k & 1) {
-        res4_block<NT, 1, false, false, 1>(r, c, k, mvec);
-        res4_block<NT, 0, false, true, 2>(r, c, k + 1, mvec);
+    if (k + 1 < n) {                                        // two steps left: k (odd), k + 1 = n - 1
+        res4_block<NT, 1, false, false, ILV>(r, c, k);
+        res4_block<NT, 0, false, true, ILV>(r, c, k + 1);
     } else {
-        res4_block<NT, 0, false, false, 1>(r, c, k, mvec);
-        res4_block<NT, 1, false, true, 2>(r, c, k + 1, mvec);
+        res4_block<NT, 1, false, true, ILV>(r, c, k);
     }
 #ifdef DWM_ATTN_TRACE
     if (tr != nullptr) tr[5] = (long long)__builtin_readcyclecounter();
 #endif
-    after_loop();
+    // row sums: the two lanes of a query, minus the pad keys' contribution (exactly 1 each); acceptance test of the fast path
     bool ok = !force_safe;
+    const float lmin = n_pad > 0.f ? 0.015625f : 5.421010862e-20f;
     float l_tot[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float l_half = r.ls[t][0] + r.ls[t][1];
         const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
-        l_tot[t] = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
-        ok = ok && (l_tot[t] >= 5.421010862e-20f) && (l_tot[t] <= 1.8446744e19f);        // res_unit's acceptance test
+        l_tot[t] = (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1])) - n_pad;
+        ok = ok && (l_tot[t] >= lmin) && (l_tot[t] <= 1.8446744e19f);
     }
     if (__all(ok)) {
+        // tile by tile (the order is pinned: all accumulators at once would need 160 arch registers)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x16 o[2] = {r.ot[t][0], r.ot[t][1]};
-            res_store_tile(o, l_tot[t], op[t], c.half);
+            res_store_tile(o, l_tot[t], out_ptr(t), c.half);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {                                                // wave-uniform: redo the unit by the online softmax (res_tile_safe)
-#pragma unroll
+#pragma unroll 1
         for (int t = 0; t < NT; ++t) {
+            bf16x8 q[4];
+            reload_q(t, q);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) q[ks] = scale_log2 == 1.f ? q[ks] : scale_frag(q[ks], scale_log2);
             float m_run = -INFINITY, l_run = 0.f;
             f32x16 o[2] = {zero, zero};
-            for (int kk = 0; kk < c.nsub; ++kk) res_tile_safe(gm, kk << 5, c.L, c.L0, r.qf[t], o, m_run, l_run, c.l31, c.half);
-            res_store_tile(o, l_run + __shfl_xor(l_run, 32, 64), op[t], c.half);
+            for (int kk = 0; kk < c.nsub; ++kk) res_tile_safe(gm, kk << 5, c.L, c.L0, q, o, m_run, l_run, c.l31, c.half);
+            res_store_tile(o, l_run + __shfl_xor(l_run, 32, 64), out_ptr(t), c.half);
         }
     }
 }
 
 // the persistent head loop of one wave with NT query tiles per head (tiles t0 .. t0 + NT - 1)
-template <int NT>
+template <int NT, bool ILV>
 DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     constexpr int NW = 4;
     const int tid = threadIdx.x;
@@ -281,31 +282,39 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
         }
     };
-    // copy of one head's K and V rows into the images (attn_res_kernel's copy_rows; instruction i belongs to wave i mod 4)
+    // copy of one head's K and V rows into the images (attn_res_kernel's copy_rows; instruction i - 8 rows of both images - belongs to
+    // wave i mod 4).  Rows past the end of the sequence are NOT written (their lanes are switched off: LDS-DMA writes the active
+    // lanes' 16 bytes only): they keep the zeros of the kernel's start
     auto copy_head = [&](const int32_t* tab, int64_t ho) {
         const int ni = (Lp >> 5) * 4;
         for (int i = wave; i < ni; i += NW) {
             const int r = i * 8 + (lane >> 3);
             const int rc = r < L ? r : L - 1;
             const int64_t off = ((int64_t)tab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
-            glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
-            glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
+            if (r < L) {
+                glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
+                glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
+            }
         }
+    };
+    auto q_ptr = [&](const int32_t* tab, int64_t ho, int t) -> const bf16_t* {
+        int lq = (t0 + t) * 32 + l31;
+        lq = lq < P.qend ? lq : P.qend - 1;
+        return P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
     };
     auto load_q = [&](bf16x8 (&dst)[NT][4], const int32_t* tab, int64_t ho) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            int lq = (t0 + t) * 32 + l31;
-            lq = lq < P.qend ? lq : P.qend - 1;
-            const bf16_t* qp = P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
+            const bf16_t* qp = q_ptr(tab, ho, t);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dst[t][ks] = *(const bf16x8*)(qp + ks * 16);
         }
     };
     const bool force_safe = P.safe_softmax != 0;
+    const float n_pad = (float)(Lp - L);
     if (G == 0) return;
     // development aid (-DDWM_ATTN_TRACE): shader-clock stamps of the 4 waves of workgroups 0-7 at 8 points of every head, written to the
-    // (otherwise unused) lse buffer as int64 [8 workgroups][4 waves][64 heads][8] (scripts/experiments/attn_trace.py)
+    // (otherwise unused) lse buffer as int64 [8 workgroups][4 waves][64 heads][8] (scripts/experiments/attn_trace4.py)
 #ifdef DWM_ATTN_TRACE
 #define DWM_TR4(slot_) do { if (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) \
         ((long long*)P.lse)[(((int)blockIdx.x * NW + wave) * 64 + g) * 8 + (slot_)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -315,9 +324,15 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     uint32_t prob; int64_t hoff;
     item_of(0, prob, hoff);
     build_tab(tabs, otab, prob);
+    // the pad rows of both images: zero for the life of the kernel (16 bytes per lane: 8 lanes per row)
+    for (int i = tid; i < (Lp - L) * 8; i += NW * 64) {
+        const int off = (L + (i >> 3)) * 128 + (i & 7) * 16;
+        *(uint4*)(kimg + off) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(vimg + off) = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     copy_head(tabs, hoff);
-    bf16x8 qn[NT][4];                                        // raw Q fragments of this wave's tiles of the next head
+    bf16x8 qn[NT][4];                                        // raw Q fragments of this wave's tiles of the coming head
     load_q(qn, tabs, hoff);
 
     for (int g = 0; g < G; ++g) {
@@ -336,51 +351,44 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             }
         }
         DWM_TR4(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows has landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows (and its Q rows) have landed
         DWM_TR4(1);
         __syncthreads();                                     // ... and everybody else's
         DWM_TR4(2);
         c.rowtab = tab;
         {
-            bf16x8 q[NT][4];
-            bf16_t* op[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) q[t][ks] = qn[t][ks];
+            auto out_ptr = [&](int t) -> bf16_t* {
                 int lq = (t0 + t) * 32 + l31;
                 lq = lq < P.qend ? lq : P.qend - 1;
-                op[t] = P.o0 + ((int64_t)otab[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + hoff;
-            }
-            // the next head's Q rows are requested when this head's tile loop is over (its registers are free then) and travel
-            // under the normalisation, the stores and the head seam
-            auto fetch_next_q = [&]() {
-                if (has_next) load_q(qn, ntab, nhoff);
-                else {
+                return P.o0 + ((int64_t)otab[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + hoff;
+            };
+            auto reload_q = [&](int t, bf16x8 (&dst)[4]) {
+                const bf16_t* qp = q_ptr(tab, hoff, t);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) qn[t][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                }
+                for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(qp + ks * 16);
             };
             ResGlobal gm;
             gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
 #ifdef DWM_ATTN_TRACE
-            res4_unit<NT>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q,
-                          (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q,
+                               (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
 #else
-            res4_unit<NT>(c, q, op, P.scale_log2, force_safe, gm, fetch_next_q);
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q);
 #endif
         }
         DWM_TR4(3);
         __syncthreads();                                     // everybody is done with this head's images
         DWM_TR4(6);
         if (new_item_next) build_tab(nullptr, otab, nprob);
-        if (has_next) copy_head(ntab, nhoff);
+        if (has_next) {
+            copy_head(ntab, nhoff);
+            load_q(qn, ntab, nhoff);                         // behind the copy in the memory pipeline: both are waited for at the head top
+        }
         DWM_TR4(7);
     }
 }
 
+template <bool ILV>
 __global__ void __launch_bounds__(256, 1)
 attn_res4_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -392,10 +400,10 @@ attn_res4_kernel(const AttnParams P) {
     const int cnt = q4 + (wave < x4 ? 1 : 0);
     const int t0 = wave * q4 + (wave < x4 ? wave : x4);
     switch (cnt) {
-        case 2: res4_heads<2>(P, smem, t0); break;
-        case 3: res4_heads<3>(P, smem, t0); break;
-        case 4: res4_heads<4>(P, smem, t0); break;
-        default: res4_heads<5>(P, smem, t0); break;
+        case 2: res4_heads<2, ILV>(P, smem, t0); break;
+        case 3: res4_heads<3, ILV>(P, smem, t0); break;
+        case 4: res4_heads<4, ILV>(P, smem, t0); break;
+        default: res4_heads<5, ILV>(P, smem, t0); break;
     }
 }
 
@@ -403,13 +411,15 @@ attn_res4_kernel(const AttnParams P) {
 
 // Called by dwm_attention_fwd (attention.hip) for the launches this kernel covers: unmasked self-attention whose K / V rows of a head
 // fit the LDS, 8 <= query tiles <= 20 (225 <= L <= 608: two to five tiles per wave).  P, nblk, lds: as for attn_res_kernel.
-int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, hipStream_t s) {
+int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_res4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_res4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_res4_kernel, dim3(nblk), dim3(256), lds, s, P);
+    if (ilv) hipLaunchKernelGGL(attn_res4_kernel<true>, dim3(nblk), dim3(256), lds, s, P);
+    else hipLaunchKernelGGL(attn_res4_kernel<false>, dim3(nblk), dim3(256), lds, s, P);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }

@@ -14,12 +14,14 @@ import json
 for ln in open("gpurun_out/gpu_parity.log"):
     d = json.loads(ln)
     if d.get("test") == "attention_one_wave_per_simd_forms" and d["scale"] == 1.0:
-        print(d["N"], d["Lc"], {k: round(v, 4) for k, v in d.items() if k in ("old", "0", "16")}, d.get("bit_equal_to_12_wave_kernel"))
+        print(d["N"], d["Lc"], {k: round(v, 4) for k, v in d.items() if k in ("old", "0", "16", "8192")})
 PY
 timeout 200 python scripts/microbench.py attnr4 > $OUT/microbench.log 2>&1; cut -c1-200 $OUT/microbench.log
 echo "== trace build"; date
 cp opendwm_amd/libdwm_hip.so /tmp/libdwm_hip.so.keep
 DWM_EXTRA_FLAGS=-DDWM_ATTN_TRACE timeout 600 python -m opendwm_amd.build > $OUT/build_trace.log 2>&1; tail -2 $OUT/build_trace.log
-timeout 120 python scripts/experiments/attn_trace4.py 154 > $OUT/trace4_L602.txt 2>&1; cat $OUT/trace4_L602.txt | cut -c1-330
-timeout 120 python scripts/experiments/attn_trace4.py 0 > $OUT/trace4_L448.txt 2>&1; tail -6 $OUT/trace4_L448.txt | cut -c1-330
+for m in 1 2; do
+DWM_ATTN_RES4=$m timeout 120 python scripts/experiments/attn_trace4.py 154 > $OUT/trace4_L602_mode$m.txt 2>&1; tail -12 $OUT/trace4_L602_mode$m.txt | cut -c1-330
+DWM_ATTN_RES4=$m timeout 120 python scripts/experiments/attn_trace4.py 0 > $OUT/trace4_L448_mode$m.txt 2>&1; tail -5 $OUT/trace4_L448_mode$m.txt | cut -c1-330
+done
 date

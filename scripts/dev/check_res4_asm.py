@@ -2,7 +2,7 @@
 hazard recogniser, so this script verifies on the instruction stream what the recogniser would have enforced:
   * no instruction other than the next MFMA of the same accumulation chain touches an asm MFMA's destination registers within WAIT
     wait states behind it (an 8-pass MFMA needs 11 before a VALU / memory read of its result; every instruction counts as one wait
-    state - which under-counts MFMAs and so errs on the safe side -, s_nop N as N + 1);
+    state, s_nop N as N + 1, another 8-pass MFMA as 8);
   * an asm MFMA's destination never overlaps its A / B operands.
 Scans in layout order and follows fall-through only; a branch inside the window is reported (the window then has to be argued by hand).
 usage: python scripts/dev/check_res4_asm.py file.s [kernel_substring]"""
@@ -65,7 +65,9 @@ while i < len(text):
                 touched = set().union(*[regs(o) for o in ops2]) if ops2 else set()
                 if not (touched & dst):
                     m = re.match(r"s_nop (\d+)", t2)
-                    waited += int(m.group(1)) + 1 if m else 1          # s_nop N = N + 1 wait states
+                    # s_nop N = N + 1 wait states; another MFMA = 8 (it cannot issue before the matrix pipe has spent the 8 passes of the
+                    # one before it)
+                    waited += int(m.group(1)) + 1 if m else 8 if t2.startswith("v_mfma") else 1
                     continue
                 # the next MFMA of the same chain: asm, same dst, srcC == dst
                 if asm2 and t2.startswith("v_mfma") and regs(ops2[0]) == dst and len(ops2) > 3 and regs(ops2[3]) == dst and not (dst & (regs(ops2[1]) | regs(ops2[2]))):

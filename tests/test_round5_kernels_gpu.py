@@ -154,6 +154,7 @@ def _run_battery(mode, path):
 pytestmark = [pytest.mark.gpu]
 bf16 = torch.bfloat16
 OLD = 1 << 12                                          # variant bit 12: keep attn_res_kernel (12 waves, one query tile per unit)
+FLIP = 1 << 13                                         # attn_res4_kernel: the other MFMA order of its tile loop (4 + 4 / alternating)
 
 
 @pytest.fixture(scope="module")
@@ -192,7 +193,7 @@ def test_attention_one_wave_per_simd_forms(dev, scale, I, N, Lc, heads):
                        q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
     base, cbase = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, OLD)
     errs, same = {"old": max(rel_err(base, r0), rel_err(cbase, r1) if Lc else 0.0)}, {}
-    for variant in (0, heads << 8, 16, 16 | (heads << 8)):
+    for variant in (0, heads << 8, 16, 16 | (heads << 8), FLIP, FLIP | 16):
         out, cout = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, variant)
         errs[variant] = max(rel_err(out, r0), rel_err(cout, r1) if Lc else 0.0)
         same[variant] = bool(torch.equal(out, base) and (not Lc or torch.equal(cout, cbase)))
@@ -239,7 +240,7 @@ def test_attention_one_wave_per_simd_temporal_rowmap_multihead(dev):
     f = qkv.float()
     ref, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads)
     errs = {}
-    for variant in (6 << 8, 4 << 8, 0, OLD):
+    for variant in (6 << 8, 4 << 8, 0, FLIP, OLD):
         out = torch.full((R, D), float("nan"), dtype=bf16, device=dev)
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant)
         errs[variant] = rel_err(out, ref)
