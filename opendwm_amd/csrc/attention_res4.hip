@@ -282,33 +282,56 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
         }
     };
-    // copy of one head's K and V rows into the images (attn_res_kernel's copy_rows; instruction i - 8 rows of both images - belongs to
-    // wave i mod 4).  Rows past the end of the sequence are NOT written (their lanes are switched off: LDS-DMA writes the active
-    // lanes' 16 bytes only): they keep the zeros of the kernel's start
-    auto copy_head = [&](const int32_t* tab, int64_t ho) {
+    // Copy of one head's K and V rows into the images + the request of this wave's Q rows of that head (attn_res_kernel's copy_rows;
+    // DMA instruction i - 8 rows of both images - belongs to wave i mod 4).  The row-table entries are read by inline asm: the compiler
+    // orders an LDS read it knows about behind ALL LDS-DMA in flight (vmcnt(0): the DMA might write what the read reads), which costs a
+    // memory round trip per request (measured: 22-28 k cycles per head for 19 requests per wave, profiles/r5e_trace4_*); the tables are
+    // never a DMA destination.  The entry of request i + 4 is read while request i is issued.  Rows past the end of the sequence are
+    // NOT written (their lanes are switched off: LDS-DMA writes the active lanes' 16 bytes only): they keep the zeros of the kernel's start.
+    auto tab_read = [&](const int32_t* p) -> int32_t {
+        int32_t v;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int32_t*)p));
+        return v;
+    };
+    auto copy_head_and_q = [&](bf16x8 (&qdst)[NT][4], const int32_t* tab, int64_t ho) {
         const int ni = (Lp >> 5) * 4;
+        int32_t qrow[NT];
+        int lqs[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int lq = (t0 + t) * 32 + l31;
+            lqs[t] = lq < P.qend ? lq : P.qend - 1;
+            qrow[t] = tab_read(tab + lqs[t]);
+        }
+        int r = wave * 8 + (lane >> 3);
+        int32_t cur = tab_read(tab + (r < L ? r : L - 1));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(qrow[t]));
         for (int i = wave; i < ni; i += NW) {
-            const int r = i * 8 + (lane >> 3);
-            const int rc = r < L ? r : L - 1;
-            const int64_t off = ((int64_t)tab[rc] << 3) + (rc < L0 ? 0 : P.seg1_delta) + ho;
+            const int rn = r + NW * 8;
+            int32_t nxt = tab_read(tab + (rn < L ? rn : L - 1));
             if (r < L) {
+                const int64_t off = ((int64_t)cur << 3) + (r < L0 ? 0 : P.seg1_delta) + ho;
                 glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
                 glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt));
+            cur = nxt;
+            r = rn;
+        }
+        // the Q rows: behind the copy in the memory pipeline; both are waited for at the head top
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16_t* qp = P.q0 + ((int64_t)qrow[t] << 3) + (lqs[t] < L0 ? 0 : P.seg1_delta) + ho + half * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qdst[t][ks] = *(const bf16x8*)(qp + ks * 16);
         }
     };
     auto q_ptr = [&](const int32_t* tab, int64_t ho, int t) -> const bf16_t* {
         int lq = (t0 + t) * 32 + l31;
         lq = lq < P.qend ? lq : P.qend - 1;
         return P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
-    };
-    auto load_q = [&](bf16x8 (&dst)[NT][4], const int32_t* tab, int64_t ho) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const bf16_t* qp = q_ptr(tab, ho, t);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dst[t][ks] = *(const bf16x8*)(qp + ks * 16);
-        }
     };
     const bool force_safe = P.safe_softmax != 0;
     const float n_pad = (float)(Lp - L);
@@ -331,9 +354,8 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
         *(uint4*)(vimg + off) = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    copy_head(tabs, hoff);
     bf16x8 qn[NT][4];                                        // raw Q fragments of this wave's tiles of the coming head
-    load_q(qn, tabs, hoff);
+    copy_head_and_q(qn, tabs, hoff);
 
     for (int g = 0; g < G; ++g) {
         const int it = g / hpb;
@@ -380,10 +402,7 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
         __syncthreads();                                     // everybody is done with this head's images
         DWM_TR4(6);
         if (new_item_next) build_tab(nullptr, otab, nprob);
-        if (has_next) {
-            copy_head(ntab, nhoff);
-            load_q(qn, ntab, nhoff);                         // behind the copy in the memory pipeline: both are waited for at the head top
-        }
+        if (has_next) copy_head_and_q(qn, ntab, nhoff);
         DWM_TR4(7);
     }
 }
