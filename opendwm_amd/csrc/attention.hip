@@ -1341,6 +1341,7 @@ void launch_attn(const AttnParams& P, hipStream_t s) {
 // attention_res4.hip
 int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, hipStream_t s);
 constexpr bool DWM_RES4_ILV_DEFAULT = false;
+constexpr int DWM_RES4_STAGGER_DEFAULT = 1;          // x 8128 cycles per (workgroup mod 8)
 
 extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     AttnParams P;
@@ -1471,6 +1472,9 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             const bool want4 = env_res4 >= 0 ? env_res4 != 0 : !((a->variant >> 12) & 1);
             if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
                 const bool ilv = env_res4 > 0 ? env_res4 == 2 : (((a->variant >> 13) & 1) != 0) != DWM_RES4_ILV_DEFAULT;
+                // start stagger (attention_res4.hip): s_sleep(127) units per (workgroup mod 8); variant bit 14 switches it off, DWM_ATTN_STAGGER=n sets it
+                static const int env_stag = [] { const char* v = getenv("DWM_ATTN_STAGGER"); return v == nullptr || v[0] == '\0' ? -1 : atoi(v); }();
+                P.nwc = ((a->variant >> 14) & 1) ? 0 : env_stag >= 0 ? env_stag : DWM_RES4_STAGGER_DEFAULT;
                 return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
             }
         }

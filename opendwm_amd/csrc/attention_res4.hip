@@ -283,47 +283,33 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
         }
     };
     // Copy of one head's K and V rows into the images + the request of this wave's Q rows of that head (attn_res_kernel's copy_rows;
-    // DMA instruction i - 8 rows of both images - belongs to wave i mod 4).  The row-table entries are read by inline asm: the compiler
-    // orders an LDS read it knows about behind ALL LDS-DMA in flight (vmcnt(0): the DMA might write what the read reads), which costs a
-    // memory round trip per request (measured: 22-28 k cycles per head for 19 requests per wave, profiles/r5e_trace4_*); the tables are
-    // never a DMA destination.  The entry of request i + 4 is read while request i is issued.  Rows past the end of the sequence are
-    // NOT written (their lanes are switched off: LDS-DMA writes the active lanes' 16 bytes only): they keep the zeros of the kernel's start.
-    auto tab_read = [&](const int32_t* p) -> int32_t {
-        int32_t v;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int32_t*)p));
-        return v;
+    // DMA instruction i - 8 rows of both images - belongs to wave i mod 4).  The row offsets are COMPUTED here (the row map's fast
+    // divisions: ~25 vector instructions per row), not read from the row tables: an LDS read between two requests waits for every
+    // LDS-DMA in flight (the compiler puts vmcnt(0) in front of a read it knows about - the DMA might write what it reads -, and an
+    // lgkmcnt wait of a hidden one turned out to cover the DMAs' LDS writes as well), i.e. one memory round trip per request
+    // (measured: 22-28 k and 42 k cycles per head for 19 requests per wave, profiles/r5e_trace4_*, r5f_trace4_*).  Rows past the end
+    // of the sequence are NOT written (their lanes are switched off: LDS-DMA writes the active lanes' 16 bytes only): they keep the
+    // zeros of the kernel's start.
+    auto row_elems = [&](uint32_t prob_, int64_t base0_, int l) -> int64_t {      // element offset of token l's row in q / k / v
+        return l < L0 ? seg0_row(P.rm, base0_, l) * P.ld0 : ((int64_t)prob_ * P.L1 + (l - L0)) * P.ld1 + P.seg1_delta;
     };
-    auto copy_head_and_q = [&](bf16x8 (&qdst)[NT][4], const int32_t* tab, int64_t ho) {
+    auto copy_head_and_q = [&](bf16x8 (&qdst)[NT][4], uint32_t prob_, int64_t ho) {
         const int ni = (Lp >> 5) * 4;
-        int32_t qrow[NT];
-        int lqs[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int lq = (t0 + t) * 32 + l31;
-            lqs[t] = lq < P.qend ? lq : P.qend - 1;
-            qrow[t] = tab_read(tab + lqs[t]);
-        }
-        int r = wave * 8 + (lane >> 3);
-        int32_t cur = tab_read(tab + (r < L ? r : L - 1));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur));
-#pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(qrow[t]));
+        const int64_t base0_ = seg0_base(P.rm, (int)prob_);
         for (int i = wave; i < ni; i += NW) {
-            const int rn = r + NW * 8;
-            int32_t nxt = tab_read(tab + (rn < L ? rn : L - 1));
+            const int r = i * 8 + (lane >> 3);
             if (r < L) {
-                const int64_t off = ((int64_t)cur << 3) + (r < L0 ? 0 : P.seg1_delta) + ho;
+                const int64_t off = row_elems(prob_, base0_, r) + ho;
                 glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
                 glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt));
-            cur = nxt;
-            r = rn;
         }
         // the Q rows: behind the copy in the memory pipeline; both are waited for at the head top
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bf16_t* qp = P.q0 + ((int64_t)qrow[t] << 3) + (lqs[t] < L0 ? 0 : P.seg1_delta) + ho + half * 8;
+            int lq = (t0 + t) * 32 + l31;
+            lq = lq < P.qend ? lq : P.qend - 1;
+            const bf16_t* qp = P.q0 + row_elems(prob_, base0_, lq) + ho + half * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qdst[t][ks] = *(const bf16x8*)(qp + ks * 16);
         }
@@ -344,6 +330,13 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
 #else
 #define DWM_TR4(slot_) do {} while (0)
 #endif
+    // Start stagger: the workgroups are identical and start together, so left alone every CU copies its next head at the same time -
+    // 154 KiB x 256 CUs against the HBM at once, with every matrix pipe idle - and computes at the same time, with the memory idle.
+    // Workgroup b starts (b mod 8) / 8 of a head period late (s_sleep: no issue slots used), once.
+    if (P.nwc != 0) {
+        const int steps = (int)(blockIdx.x & 7u) * P.nwc;
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     uint32_t prob; int64_t hoff;
     item_of(0, prob, hoff);
     build_tab(tabs, otab, prob);
@@ -355,7 +348,7 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     }
     __syncthreads();
     bf16x8 qn[NT][4];                                        // raw Q fragments of this wave's tiles of the coming head
-    copy_head_and_q(qn, tabs, hoff);
+    copy_head_and_q(qn, prob, hoff);
 
     for (int g = 0; g < G; ++g) {
         const int it = g / hpb;
@@ -402,7 +395,7 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
         __syncthreads();                                     // everybody is done with this head's images
         DWM_TR4(6);
         if (new_item_next) build_tab(nullptr, otab, nprob);
-        if (has_next) copy_head_and_q(qn, ntab, nhoff);
+        if (has_next) copy_head_and_q(qn, nprob, nhoff);
         DWM_TR4(7);
     }
 }
