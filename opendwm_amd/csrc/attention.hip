@@ -1340,8 +1340,6 @@ void launch_attn(const AttnParams& P, hipStream_t s) {
 
 // attention_res4.hip
 int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, hipStream_t s);
-constexpr bool DWM_RES4_ILV_DEFAULT = false;
-constexpr int DWM_RES4_STAGGER_DEFAULT = 1;          // x 8128 cycles per (workgroup mod 8)
 
 extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     AttnParams P;
@@ -1464,17 +1462,19 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             P.nwc = nwc;
         }
         // one-wave-per-SIMD form (attention_res4.hip: 4 waves, all query tiles of a wave in one pass over the keys): 8..20 query
-        // tiles (225 <= L <= 608).  variant bit 12 keeps attn_res_kernel (A/B measurements, tests), bit 13 flips the MFMA order of its
-        // tile loop (default: see DWM_RES4_ILV_DEFAULT); DWM_ATTN_RES4 = 0 never / 1 always, 4 + 4 order / 2 always, alternating order
+        // tiles (225 <= L <= 608).  OPT-IN (variant bit 12, or DWM_ATTN_RES4=1 / 2 for every covered launch): validated on the GPU
+        // (tests/test_round5_kernels_gpu.py) but measured SLOWER than attn_res_kernel - 604 against 728-740 TFLOP/s at L = 602
+        // (profiles/r5g_*): its tile loop is faster (34 k against ~45 k cycles per head) but a workgroup of 4 waves keeps only ~8 KiB of
+        // LDS-DMA in flight, so the copy of the next head between two heads takes 20 k cycles instead of 7 k (attention_res4.hip).
+        // bit 13: the alternating MFMA order of its tile loop; bit 14: no start stagger (DWM_ATTN_STAGGER=n sets the stagger unit).
         {
             const int nqt = (P.qend + 31) >> 5;
             static const int env_res4 = [] { const char* v = getenv("DWM_ATTN_RES4"); return (v == nullptr || v[0] == '\0') ? -1 : (int)(v[0] - '0'); }();
-            const bool want4 = env_res4 >= 0 ? env_res4 != 0 : !((a->variant >> 12) & 1);
+            const bool want4 = env_res4 >= 0 ? env_res4 != 0 : ((a->variant >> 12) & 1) != 0;
             if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
-                const bool ilv = env_res4 > 0 ? env_res4 == 2 : (((a->variant >> 13) & 1) != 0) != DWM_RES4_ILV_DEFAULT;
-                // start stagger (attention_res4.hip): s_sleep(127) units per (workgroup mod 8); variant bit 14 switches it off, DWM_ATTN_STAGGER=n sets it
+                const bool ilv = env_res4 > 0 ? env_res4 == 2 : ((a->variant >> 13) & 1) != 0;
                 static const int env_stag = [] { const char* v = getenv("DWM_ATTN_STAGGER"); return v == nullptr || v[0] == '\0' ? -1 : atoi(v); }();
-                P.nwc = ((a->variant >> 14) & 1) ? 0 : env_stag >= 0 ? env_stag : DWM_RES4_STAGGER_DEFAULT;
+                P.nwc = ((a->variant >> 14) & 1) ? 0 : env_stag >= 0 ? env_stag : 1;      // (field reused: stagger units of 8128 cycles per workgroup mod 8)
                 return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
             }
         }

@@ -1,4 +1,4 @@
-"""timeline of attn_res4_kernel's heads (library built with DWM_EXTRA_FLAGS=-DDWM_ATTN_TRACE): per head, for the 4 waves of workgroups
+"""timeline of attn_res4_kernel's heads (library built with DWM_EXTRA_FLAGS=-DDWM_ATTN_TRACE; run with DWM_ATTN_RES4=1 or 2): per head, for the 4 waves of workgroups
 0-7, shader-clock stamps at: 0 head top, 1 own copy landed, 2 after barrier A, 4 tile loop starts, 5 tile loop ends, 3 unit done (stores
 issued), 6 after the closing barrier, 7 next head's copy issued"""
 import os, sys, statistics as st, torch

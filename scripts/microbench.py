@@ -331,12 +331,12 @@ if __name__ == "__main__":
         bench_attn([0, 32 | 1])
     if "attnr" in what:                  # the resident kernel's launches only
         bench_attn([0], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
-    if "attnr4" in what:                 # 12-wave kernel (variant bit 12) against the one-wave-per-SIMD form (default; bit 14: no start stagger; bit 13: the other MFMA order)
-        bench_attn([1 << 12, 0, 1 << 14, 1 << 13], only=("joint L=602", "dual L=448"))
+    if "attnr4" in what:                 # 12-wave kernel (default) against the one-wave-per-SIMD form (bit 12; bit 14: no start stagger; bit 13: the other MFMA order)
+        bench_attn([0, 1 << 12, (1 << 12) | (1 << 14), (1 << 12) | (1 << 13)], only=("joint L=602", "dual L=448"))
     if "attnfull" in what:
         bench_attn_full()
     if "attnr4x" in what:                # diagnostics: forced online-softmax fallback (16) of both kernels
-        bench_attn([1 << 12, 0, 16, 16 | (1 << 12)], only=("joint L=602", "dual L=448"))
+        bench_attn([0, 1 << 12, 16, 16 | (1 << 12)], only=("joint L=602", "dual L=448"))
     if "s32" in what:
         bench_stream32()
     if "gemm" in what:
