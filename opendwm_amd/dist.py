@@ -149,6 +149,12 @@ def check_distinct_devices(ids) -> None:
     of one host selected the same device: the same PCI address AND the same index (ranks that each see only their own GPU all
     report index 0 with different addresses; partitions of one GPU share the address and differ in the index)."""
     key = [t[:-1] for t in ids]
+    if any(len(t) == 4 and t[1] < 0 for t in ids):
+        # this PyTorch build does not report PCI addresses: ranks that each see only their own GPU all report (host, -1, 0) and
+        # cannot be told apart - a correct launch must not be aborted on that; warn and skip the check
+        import warnings
+        warnings.warn("preflight: the device PCI identity is not available in this PyTorch build; the distinct-device check is skipped")
+        return
     if len(set(key)) != len(key):
         raise RuntimeError(f"preflight: ranks share a GPU: (host hash, [PCI identity,] device index, pid) = {list(ids)}")
 

@@ -368,8 +368,13 @@ class DiTCrossviewTemporalConditionModel(_Base):
             else:
                 idx = torch.arange(V, device=device).view(1, 1, V).expand(B, T, V)
             hit = ops.timestep_sinusoid(idx, D, dtype=dtype)
-            if len(self._index_sinusoids) > 8:
-                self._index_sinusoids.clear()
+            # Kept for the life of the model, never evicted: a HIP graph captured by CTSDDenoiser.enable_graph holds the POINTERS of
+            # these tensors, and freeing one a captured graph still replays would let it read recycled memory.  They are a few KiB per
+            # (batch, frames, views) shape; a model that has seen more than 64 shapes says so once instead of growing silently.
+            if len(self._index_sinusoids) == 64:
+                import warnings
+                warnings.warn("DiTCrossviewTemporalConditionModel: more than 64 distinct (batch, frames, views) shapes seen; the "
+                              "index-embedding cache keeps growing (entries are never freed: captured graphs may reference them)")
             self._index_sinusoids[key] = hit
         return hit
 

@@ -69,9 +69,23 @@ def bench_attn_full():
     rm = ops.rowmap_temporal_full(B, T, V, h, w)
     L = T * h * w
     fl = 4.0 * rm.n_problems * H * L * L * 64
-    for var in (0, 2, 0, 2):
+    for var in (1, 2, 0, 1, 2, 0):            # 1: 32 queries per wave, 2: 64, 0: automatic
         ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var), iters=3, warm=1)
         print(json.dumps({"kernel": "attn", "case": f"temporal full L={L}", "variant": var, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
+
+
+def bench_attn_unet():
+    """spatial self-attention of the SD 2.1 UNet's first level (configs[1]: 2 x 6 frames x 6 views images of 32 x 56 latent pixels, 5 heads
+    of 64): L = 1792 on the tiled kernel, 32 (variant 1) against 64 (variant 2) queries per wave"""
+    H, D = 5, 320
+    I, L = 72, 1792
+    qkv = rnd(I * L, 3 * D)
+    out = torch.empty(I * L, D, device=dev, dtype=bf16)
+    rm = ops.rowmap_identity(I, L)
+    fl = 4.0 * I * H * L * L * 64
+    for var in (1, 2, 1, 2):
+        ms = timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, H, variant=var), iters=10, warm=2)
+        print(json.dumps({"kernel": "attn", "case": f"unet spatial L={L}", "variant": var, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
 
 
 def bench_pointwise():
@@ -335,6 +349,8 @@ if __name__ == "__main__":
         bench_attn([0, 1 << 12, (1 << 12) | (1 << 14), (1 << 12) | (1 << 13)], only=("joint L=602", "dual L=448"))
     if "attnfull" in what:
         bench_attn_full()
+    if "attnunet" in what:
+        bench_attn_unet()
     if "attnr4x" in what:                # diagnostics: forced online-softmax fallback (16) of both kernels
         bench_attn([0, 1 << 12, 16, 16 | (1 << 12)], only=("joint L=602", "dual L=448"))
     if "s32" in what:

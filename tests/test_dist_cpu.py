@@ -250,6 +250,25 @@ def test_bench_self_launches_ranks_when_started_plainly():
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
 
 
+def test_bench_self_launch_eight_ranks():
+    """the driver's first `--gpus 8` run must not die on launch plumbing: the same self-launch with EIGHT ranks (gloo stand-in) -
+    rendezvous, preflight with a checked all-reduce over 8 ranks, MAX over ranks, one JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--debug-cpu-launch"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["preflight"]["world_size"] == 8 and line["preflight"]["allreduce_sum_ok"] is True
+    assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+
+
 # ---------------------------------------------------------------- train step: accumulation + no_sync + bf16 buckets + LR schedule
 def _adamw_cpu(p, g, m, v, p_bf16, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """what dwm_adamw computes (torch.optim.AdamW's update), for the CPU ranks of the test below"""

@@ -182,3 +182,9 @@ def test_bench_train_ddp_fields_over_rccl():
     assert ddp is not None and ddp["allreduce_bytes"] > 0 and ddp["allreduce_ms"] > 0.0
     assert ddp["forward_backward_ms_with_gradient_sync"] > 0.0 and ddp["forward_backward_ms_without_gradient_sync"] > 0.0
     assert line["config"]["preflight"]["backend"] == "nccl" and line["config"]["finite"]
+    # the bucket timeline behind the modelled 8-GPU exchange: every bucket stamped inside the backward, all gradient elements covered
+    tl = ddp["bucket_timeline"]
+    assert "error" not in tl, tl
+    assert tl["buckets"] >= 1 and tl["elements"] * 4 == ddp["allreduce_bytes"]
+    assert all(0.0 <= t <= tl["backward_ms"] * 1.05 for t in tl["ready_ms_after_backward_start"]), tl
+    assert tl["fp32_ring_2_links"]["exposed_ms"] >= tl["bf16_ring_2_links"]["exposed_ms"] >= 0.0
