@@ -155,10 +155,11 @@ DWM_DEVINL void res_store_tile(const f32x16 (&o)[2], float l_tot, bf16_t* op, in
 
 // one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 3 key steps).
 // qraw: raw Q fragments (consumed: scaled into the unit's registers); out_ptr(t): this lane's output row of tile t; reload_q(t, dst):
-// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L)
-template <int NT, bool ILV, class OutPtr, class ReloadQ>
+// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L); after_loop(): called once, when
+// the tile loop is over (its fragment / score registers are free from here on)
+template <int NT, bool ILV, class OutPtr, class ReloadQ, class AfterLoop>
 DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float scale_log2, bool force_safe, const ResGlobal& gm, float n_pad,
-                          OutPtr&& out_ptr, ReloadQ&& reload_q, long long* tr = nullptr) {
+                          OutPtr&& out_ptr, ReloadQ&& reload_q, AfterLoop&& after_loop, long long* tr = nullptr) {
     Res4Regs<NT> r;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -199,6 +200,7 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
 #ifdef DWM_ATTN_TRACE
     if (tr != nullptr) tr[5] = (long long)__builtin_readcyclecounter();
 #endif
+    after_loop();                                           // (the next head's K / V rows are requested here: res4_heads)
     // row sums: the two lanes of a query, minus the pad keys' contribution (exactly 1 each); acceptance test of the fast path
     bool ok = !force_safe;
     const float lmin = n_pad > 0.f ? 0.015625f : 5.421010862e-20f;
@@ -232,6 +234,58 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
         }
     }
 }
+
+// The head seam as a function of its own (NOT inlined: inside the head loop - one function with the unrolled tile loops of all tile
+// counts - the compiler kept the 152 staging registers in scratch memory and waited for every load before storing it there):
+// this wave's pieces of one head's K and V rows (piece i - 8 rows of both images, 16 bytes per lane - belongs to wave i mod 4) are
+// REQUESTED as plain global loads, all in flight at once, then - behind the barrier that says everybody is done with the current
+// head's images (`sync`) - WRITTEN to the images.  LDS-DMA is not used: a wave sustains only ~2 KiB of it in flight, 4 waves then
+// copy a head in 20 k cycles (measured: profiles/r5g_trace4_*; attn_res_kernel's 12 waves: 7 k).
+// Rows past the end of the sequence are NOT written (their lanes are switched off): they keep the zeros of the kernel's start.
+// (19 named pieces, not an array: the compiler kept `uint4 kb[19]` in scratch memory even in this small function)
+#define DWM_RES4_PIECES(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(8) X_(9) X_(10) X_(11) X_(12) X_(13) X_(14) X_(15) X_(16) X_(17) X_(18)
+__device__ __attribute__((noinline)) void res4_copy_head(const bf16_t* __restrict__ k0g, const bf16_t* __restrict__ v0g, const int32_t* tab, int64_t seg1_delta,
+                                                         int64_t ho, int L, int L0, int ni, char* kimg, char* vimg, int sync, int store) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int cl = lane & 7, rl = lane >> 3;
+    const __attribute__((address_space(1))) bf16_t* const k0 = (const __attribute__((address_space(1))) bf16_t*)k0g;     // global, not flat, loads
+    const __attribute__((address_space(1))) bf16_t* const v0 = (const __attribute__((address_space(1))) bf16_t*)v0g;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    typedef const __attribute__((address_space(1))) u32x4* gptr;
+    const __attribute__((address_space(3))) int32_t* const ltab = (const __attribute__((address_space(3))) int32_t*)tab;     // LDS, not flat, reads
+    // pieces past the last one re-load the last one: unconditional code
+#define DWM_RES4_LOAD(J_)                                                                                   \
+    u32x4 kb##J_, vb##J_;                                                                                   \
+    {                                                                                                       \
+        int i = wave + J_ * 4;                                                                              \
+        i = i < ni ? i : ni - 1;                                                                            \
+        const int r = i * 8 + rl;                                                                           \
+        const int rc = r < L ? r : L - 1;                                                                   \
+        const int64_t off = ((int64_t)ltab[rc] << 3) + (rc < L0 ? 0 : seg1_delta) + ho;                     \
+        kb##J_ = *(gptr)(k0 + off + ((cl ^ ((r >> 1) & 7)) << 3));                                          \
+        vb##J_ = *(gptr)(v0 + off + ((cl ^ (((r >> 1) & 1) << 2)) << 3));                                   \
+    }
+    DWM_RES4_PIECES(DWM_RES4_LOAD)
+#undef DWM_RES4_LOAD
+    if (sync) __syncthreads();                               // everybody is done with the current head's images
+    if (store) {
+#define DWM_RES4_STORE(J_)                                                                                  \
+        {                                                                                                   \
+            const int i = wave + J_ * 4;                                                                    \
+            if (i < ni) {                                                                                   \
+                const int r = i * 8 + rl;                                                                   \
+                if (r < L) {                                                                                \
+                    *(u32x4*)(kimg + i * 1024 + lane * 16) = kb##J_;                                        \
+                    *(u32x4*)(vimg + i * 1024 + lane * 16) = vb##J_;                                        \
+                }                                                                                           \
+            }                                                                                               \
+        }
+        DWM_RES4_PIECES(DWM_RES4_STORE)
+#undef DWM_RES4_STORE
+    }
+}
+#undef DWM_RES4_PIECES
 
 // the persistent head loop of one wave with NT query tiles per head (tiles t0 .. t0 + NT - 1)
 template <int NT, bool ILV>
@@ -282,34 +336,13 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
         }
     };
-    // Copy of one head's K and V rows into the images + the request of this wave's Q rows of that head (attn_res_kernel's copy_rows;
-    // DMA instruction i - 8 rows of both images - belongs to wave i mod 4).  The row offsets are COMPUTED here (the row map's fast
-    // divisions: ~25 vector instructions per row), not read from the row tables: an LDS read between two requests waits for every
-    // LDS-DMA in flight (the compiler puts vmcnt(0) in front of a read it knows about - the DMA might write what it reads -, and an
-    // lgkmcnt wait of a hidden one turned out to cover the DMAs' LDS writes as well), i.e. one memory round trip per request
-    // (measured: 22-28 k and 42 k cycles per head for 19 requests per wave, profiles/r5e_trace4_*, r5f_trace4_*).  Rows past the end
-    // of the sequence are NOT written (their lanes are switched off: LDS-DMA writes the active lanes' 16 bytes only): they keep the
-    // zeros of the kernel's start.
-    auto row_elems = [&](uint32_t prob_, int64_t base0_, int l) -> int64_t {      // element offset of token l's row in q / k / v
-        return l < L0 ? seg0_row(P.rm, base0_, l) * P.ld0 : ((int64_t)prob_ * P.L1 + (l - L0)) * P.ld1 + P.seg1_delta;
-    };
-    auto copy_head_and_q = [&](bf16x8 (&qdst)[NT][4], uint32_t prob_, int64_t ho) {
-        const int ni = (Lp >> 5) * 4;
-        const int64_t base0_ = seg0_base(P.rm, (int)prob_);
-        for (int i = wave; i < ni; i += NW) {
-            const int r = i * 8 + (lane >> 3);
-            if (r < L) {
-                const int64_t off = row_elems(prob_, base0_, r) + ho;
-                glds16(P.k0 + off + (((lane & 7) ^ ((r >> 1) & 7)) << 3), kimg + i * 1024);
-                glds16(P.v0 + off + (((lane & 7) ^ (((r >> 1) & 1) << 2)) << 3), vimg + i * 1024);
-            }
-        }
-        // the Q rows: behind the copy in the memory pipeline; both are waited for at the head top
+    const int ni = (Lp >> 5) * 4;
+    auto load_q = [&](bf16x8 (&qdst)[NT][4], const int32_t* tab, int64_t ho) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             int lq = (t0 + t) * 32 + l31;
             lq = lq < P.qend ? lq : P.qend - 1;
-            const bf16_t* qp = P.q0 + row_elems(prob_, base0_, lq) + ho + half * 8;
+            const bf16_t* qp = P.q0 + ((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qdst[t][ks] = *(const bf16x8*)(qp + ks * 16);
         }
@@ -348,7 +381,8 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     }
     __syncthreads();
     bf16x8 qn[NT][4];                                        // raw Q fragments of this wave's tiles of the coming head
-    copy_head_and_q(qn, prob, hoff);
+    res4_copy_head(P.k0, P.v0, tabs, P.seg1_delta, hoff, L, L0, ni, kimg, vimg, 0, 1);
+    load_q(qn, tabs, hoff);
 
     for (int g = 0; g < G; ++g) {
         const int it = g / hpb;
@@ -366,7 +400,7 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             }
         }
         DWM_TR4(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of the head's rows (and its Q rows) have landed
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's share of the head's rows is in the images
         DWM_TR4(1);
         __syncthreads();                                     // ... and everybody else's
         DWM_TR4(2);
@@ -384,18 +418,22 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             };
             ResGlobal gm;
             gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
+            auto nothing = [&]() {};
 #ifdef DWM_ATTN_TRACE
-            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q,
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, nothing,
                                (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
 #else
-            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q);
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, nothing);
 #endif
         }
+        // the next head's rows (res4_copy_head: requested when this wave's outputs are on their way, written behind the barrier that
+        // says everybody is done with the current head's images; after the last head: the same rows once more, not written)
         DWM_TR4(3);
-        __syncthreads();                                     // everybody is done with this head's images
+        res4_copy_head(P.k0, P.v0, ntab, P.seg1_delta, nhoff, L, L0, ni, kimg, vimg, 1, has_next ? 1 : 0);
         DWM_TR4(6);
+        // (unconditional: a `qn` that is only conditionally redefined stays live across the whole tile loop)
+        load_q(qn, ntab, nhoff);                             // waited for behind the barrier of the head top, under the unit's set-up
         if (new_item_next) build_tab(nullptr, otab, nprob);
-        if (has_next) copy_head_and_q(qn, nprob, nhoff);
         DWM_TR4(7);
     }
 }
