@@ -363,11 +363,13 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
 #else
 #define DWM_TR4(slot_) do {} while (0)
 #endif
-    // Start stagger: the workgroups are identical and start together, so left alone every CU copies its next head at the same time -
-    // 154 KiB x 256 CUs against the HBM at once, with every matrix pipe idle - and computes at the same time, with the memory idle.
-    // Workgroup b starts (b mod 8) / 8 of a head period late (s_sleep: no issue slots used), once.
+    // Start stagger: the workgroups are identical and start together, so left alone every CU fetches its next head's rows at the same time
+    // - 230 KiB (K, V, Q) x 256 CUs against the memory at once, with every matrix pipe idle: 11 B / cycle / CU, the chip's HBM rate
+    // (measured: 13 k + 10 k cycles per head, profiles/r5h_trace4_*) - and computes at the same time, with the memory idle.  The
+    // workgroups of ONE XCD (consecutive b / 8: they share that XCD's path to the memory) start (b / 8 mod 8) / 8 of a head period
+    // apart (s_sleep: no issue slots used), once.
     if (P.nwc != 0) {
-        const int steps = (int)(blockIdx.x & 7u) * P.nwc;
+        const int steps = (int)((blockIdx.x >> 3) & 7u) * P.nwc;
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
     }
     uint32_t prob; int64_t hoff;
