@@ -1476,8 +1476,9 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
                 const bool ilv = env_res4 > 0 ? env_res4 == 2 : ((a->variant >> 13) & 1) != 0;
                 static const int env_stag = [] { const char* v = getenv("DWM_ATTN_STAGGER"); return v == nullptr || v[0] == '\0' ? -1 : atoi(v); }();
-                P.nwc = ((a->variant >> 14) & 1) ? 0 : env_stag >= 0 ? env_stag : 1;      // (field reused: stagger units of 8128 cycles per workgroup mod 8)
-                return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
+                // (field reused: start stagger in units of 8128 cycles per (workgroup / 8 mod 8); -1: no stagger and no L2 touches)
+                P.nwc = ((a->variant >> 14) & 1) ? -1 : env_stag >= 0 ? env_stag : 0;
+                return dwm_attn_res4_launch(P, nblk, lds + 256, ilv, s);          // (+ 256 bytes: the trash slot of its L2 touches)
             }
         }
         static bool attr_set = false;

@@ -155,11 +155,11 @@ DWM_DEVINL void res_store_tile(const f32x16 (&o)[2], float l_tot, bf16_t* op, in
 
 // one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 3 key steps).
 // qraw: raw Q fragments (consumed: scaled into the unit's registers); out_ptr(t): this lane's output row of tile t; reload_q(t, dst):
-// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L); after_loop(): called once, when
-// the tile loop is over (its fragment / score registers are free from here on)
+// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L); near_end(): called once, one or two
+// key steps before the end of the tile loop (the L2 touches of the next head's rows: res4_heads)
 template <int NT, bool ILV, class OutPtr, class ReloadQ, class AfterLoop>
 DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float scale_log2, bool force_safe, const ResGlobal& gm, float n_pad,
-                          OutPtr&& out_ptr, ReloadQ&& reload_q, AfterLoop&& after_loop, long long* tr = nullptr) {
+                          OutPtr&& out_ptr, ReloadQ&& reload_q, AfterLoop&& near_end, long long* tr = nullptr) {
     Res4Regs<NT> r;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -191,6 +191,7 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
         res4_block<NT, 1, false, false, ILV>(r, c, k);
         res4_block<NT, 0, false, false, ILV>(r, c, k + 1);
     }
+    near_end();
     if (k + 1 < n) {                                        // two steps left: k (odd), k + 1 = n - 1
         res4_block<NT, 1, false, false, ILV>(r, c, k);
         res4_block<NT, 0, false, true, ILV>(r, c, k + 1);
@@ -200,7 +201,6 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
 #ifdef DWM_ATTN_TRACE
     if (tr != nullptr) tr[5] = (long long)__builtin_readcyclecounter();
 #endif
-    after_loop();                                           // (the next head's K / V rows are requested here: res4_heads)
     // row sums: the two lanes of a query, minus the pad keys' contribution (exactly 1 each); acceptance test of the fast path
     bool ok = !force_safe;
     const float lmin = n_pad > 0.f ? 0.015625f : 5.421010862e-20f;
@@ -303,6 +303,7 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     char* const vimg = smem + Lp * 128;
     int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
     int32_t* const otab = tabs + 2 * Lt;
+    const int trash_off = 2 * Lp * 128 + 3 * Lt * 4;        // 256 bytes behind the tables: destination of the L2 touches
 
     ResCtx c;
     c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
@@ -368,7 +369,7 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     // (measured: 13 k + 10 k cycles per head, profiles/r5h_trace4_*) - and computes at the same time, with the memory idle.  The
     // workgroups of ONE XCD (consecutive b / 8: they share that XCD's path to the memory) start (b / 8 mod 8) / 8 of a head period
     // apart (s_sleep: no issue slots used), once.
-    if (P.nwc != 0) {
+    if (P.nwc > 0) {
         const int steps = (int)((blockIdx.x >> 3) & 7u) * P.nwc;
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -420,12 +421,35 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             };
             ResGlobal gm;
             gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
-            auto nothing = [&]() {};
+            // L2 touches of the NEXT head's K, V and Q rows, a key step or two before this head's tile loop ends: a CU fetches a head's
+            // 230 KiB at ~12 B / cycle from HBM whatever else the chip does (13 k + 9 k cycles of seam per head, measured with and
+            // without start stagger: profiles/r5h_*, r5i_*), so the fetch is started here, where nothing waits for memory - one dword per
+            // 128-byte row piece by LDS-DMA into a trash slot of the LDS (no destination register; inline asm: the compiler would put a
+            // vmcnt(0) in front of every fragment read behind a DMA it knows about) - and the seam's loads find the rows in the L2 /
+            // Infinity Cache.  (attn_res_kernel dropped the same idea in round 3: its tile loop has vmcnt waits that the touches stall.)
+            auto touch_next = [&]() {
+                if (!has_next || P.nwc < 0) return;
+                const uint32_t trash = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem + trash_off);
+                auto touch = [&](const bf16_t* p) {
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(trash) : "memory", "m0");
+                };
+                for (int r0 = wave * 64; r0 < L; r0 += NW * 64) {                 // K and V rows: 64 per instruction
+                    const int r = r0 + lane < L ? r0 + lane : L - 1;
+                    const int64_t off = ((int64_t)ntab[r] << 3) + (r < L0 ? 0 : P.seg1_delta) + nhoff;
+                    touch(P.k0 + off);
+                    touch(P.v0 + off);
+                }
+                for (int q0 = 0; q0 < NT * 32; q0 += 64) {                        // this wave's Q rows of the next head
+                    int lq = t0 * 32 + q0 + lane;
+                    lq = lq < P.qend ? lq : P.qend - 1;
+                    touch(P.q0 + ((int64_t)ntab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + nhoff);
+                }
+            };
 #ifdef DWM_ATTN_TRACE
-            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, nothing,
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, touch_next,
                                (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
 #else
-            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, nothing);
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, touch_next);
 #endif
         }
         // the next head's rows (res4_copy_head: requested when this wave's outputs are on their way, written behind the barrier that

@@ -17,7 +17,6 @@ for ln in open("gpurun_out/gpu_parity.log"):
         print(d["N"], d["Lc"], {k: round(v, 4) for k, v in d.items() if k in ("old", "0", "16", "8192")})
 PY
 timeout 200 python scripts/microbench.py attnr4 > $OUT/microbench.log 2>&1; cut -c1-200 $OUT/microbench.log
-for st in 0 2 3; do echo "stagger $st"; DWM_ATTN_STAGGER=$st timeout 200 python scripts/microbench.py attnr4 2>&1 | grep '"variant": 4096' | cut -c1-200 | tee -a $OUT/microbench_stagger$st.log; done
 echo "== trace build"; date
 cp opendwm_amd/libdwm_hip.so /tmp/libdwm_hip.so.keep
 DWM_EXTRA_FLAGS=-DDWM_ATTN_TRACE timeout 600 python -m opendwm_amd.build > $OUT/build_trace.log 2>&1; tail -2 $OUT/build_trace.log
