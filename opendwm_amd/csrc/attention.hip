@@ -1465,10 +1465,10 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         }
         // one-wave-per-SIMD form (attention_res4.hip: 4 waves, all query tiles of a wave in one pass over the keys): 8..20 query
         // tiles (225 <= L <= 608).  OPT-IN (variant bit 12, or DWM_ATTN_RES4=1 / 2 for every covered launch): validated on the GPU
-        // (tests/test_round5_kernels_gpu.py) but measured SLOWER than attn_res_kernel - 604 against 728-740 TFLOP/s at L = 602
-        // (profiles/r5g_*): its tile loop is faster (34 k against ~45 k cycles per head) but a workgroup of 4 waves keeps only ~8 KiB of
-        // LDS-DMA in flight, so the copy of the next head between two heads takes 20 k cycles instead of 7 k (attention_res4.hip).
-        // bit 13: the alternating MFMA order of its tile loop; bit 14: no start stagger (DWM_ATTN_STAGGER=n sets the stagger unit).
+        // (tests/test_round5_kernels_gpu.py) but measured SLOWER than attn_res_kernel - 620 against 750-760 TFLOP/s at L = 602
+        // (profiles/r5i_*): its tile loop is faster (34-35 k against ~45 k cycles per head) but the fetch of the next head between two
+        // heads costs ~22 k cycles however it is issued (attention_res4.hip: res4_copy_head), against 7 k hidden in the skew of 12 waves.
+        // bit 13: the alternating MFMA order of its tile loop; bit 14: start stagger (DWM_ATTN_STAGGER=n sets the stagger unit).
         {
             const int nqt = (P.qend + 31) >> 5;
             static const int env_res4 = [] { const char* v = getenv("DWM_ATTN_RES4"); return (v == nullptr || v[0] == '\0') ? -1 : (int)(v[0] - '0'); }();
@@ -1476,9 +1476,8 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
                 const bool ilv = env_res4 > 0 ? env_res4 == 2 : ((a->variant >> 13) & 1) != 0;
                 static const int env_stag = [] { const char* v = getenv("DWM_ATTN_STAGGER"); return v == nullptr || v[0] == '\0' ? -1 : atoi(v); }();
-                // (field reused: start stagger in units of 8128 cycles per (workgroup / 8 mod 8); -1: no stagger and no L2 touches)
-                P.nwc = ((a->variant >> 14) & 1) ? -1 : env_stag >= 0 ? env_stag : 0;
-                return dwm_attn_res4_launch(P, nblk, lds + 256, ilv, s);          // (+ 256 bytes: the trash slot of its L2 touches)
+                P.nwc = env_stag >= 0 ? env_stag : ((a->variant >> 14) & 1);      // (field reused: start stagger in units of 8128 cycles, default off)
+                return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
             }
         }
         static bool attr_set = false;

@@ -155,11 +155,11 @@ DWM_DEVINL void res_store_tile(const f32x16 (&o)[2], float l_tot, bf16_t* op, in
 
 // one unit = the NT query tiles of this wave against the resident K / V images of one head (n = c.nsub >= 3 key steps).
 // qraw: raw Q fragments (consumed: scaled into the unit's registers); out_ptr(t): this lane's output row of tile t; reload_q(t, dst):
-// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L); near_end(): called once, one or two
-// key steps before the end of the tile loop (the L2 touches of the next head's rows: res4_heads)
+// the raw Q fragments of tile t again (fallback only); n_pad: zero pad keys of the images (Lp - L); after_loop(): called once, when
+// the tile loop is over (its fragment / score registers are free from here on)
 template <int NT, bool ILV, class OutPtr, class ReloadQ, class AfterLoop>
 DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float scale_log2, bool force_safe, const ResGlobal& gm, float n_pad,
-                          OutPtr&& out_ptr, ReloadQ&& reload_q, AfterLoop&& near_end, long long* tr = nullptr) {
+                          OutPtr&& out_ptr, ReloadQ&& reload_q, AfterLoop&& after_loop, long long* tr = nullptr) {
     Res4Regs<NT> r;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -191,7 +191,6 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
         res4_block<NT, 1, false, false, ILV>(r, c, k);
         res4_block<NT, 0, false, false, ILV>(r, c, k + 1);
     }
-    near_end();
     if (k + 1 < n) {                                        // two steps left: k (odd), k + 1 = n - 1
         res4_block<NT, 1, false, false, ILV>(r, c, k);
         res4_block<NT, 0, false, true, ILV>(r, c, k + 1);
@@ -201,6 +200,7 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
 #ifdef DWM_ATTN_TRACE
     if (tr != nullptr) tr[5] = (long long)__builtin_readcyclecounter();
 #endif
+    after_loop();                                           // (the next head's K / V rows are requested here: res4_heads)
     // row sums: the two lanes of a query, minus the pad keys' contribution (exactly 1 each); acceptance test of the fast path
     bool ok = !force_safe;
     const float lmin = n_pad > 0.f ? 0.015625f : 5.421010862e-20f;
@@ -239,8 +239,17 @@ DWM_DEVINL void res4_unit(const ResCtx& c, const bf16x8 (&qraw)[NT][4], float sc
 // counts - the compiler kept the 152 staging registers in scratch memory and waited for every load before storing it there):
 // this wave's pieces of one head's K and V rows (piece i - 8 rows of both images, 16 bytes per lane - belongs to wave i mod 4) are
 // REQUESTED as plain global loads, all in flight at once, then - behind the barrier that says everybody is done with the current
-// head's images (`sync`) - WRITTEN to the images.  LDS-DMA is not used: a wave sustains only ~2 KiB of it in flight, 4 waves then
-// copy a head in 20 k cycles (measured: profiles/r5g_trace4_*; attn_res_kernel's 12 waves: 7 k).
+// head's images (`sync`) - WRITTEN to the images.
+// What the seam costs, measured (profiles/r5d .. r5j_trace4_*, cycles per head at L = 602, tile loop 34-35 k):
+//   LDS-DMA from 4 waves, row table read between requests           22-28 k   (an LDS read behind a DMA waits for the DMA)
+//   LDS-DMA, computed row offsets, nothing between the requests     20-23 k   (a wave keeps ~2 KiB of LDS-DMA in flight; 12 waves: 7 k)
+//   register-staged (this function) + the Q rows                    12-13 k + 9 k  = 12-13 B / cycle / CU for 230 KiB
+//   the same with a start stagger inside every XCD                  unchanged (not a contention effect)
+//   the same with L2 touches of the next head in the last key steps unchanged seam, tile loop + 13 k (the touches stall the loop)
+// i.e. a CU streams line-granular data at ~12 B / cycle whether it comes from HBM or the L2 (its vector L1's miss queue at these
+// latencies), and a synchronous seam of 230 KiB per head cannot get under ~18 k cycles: the copy has to run UNDER the tile loop - into
+// image rows that all four waves have passed - to beat attn_res_kernel, whose 12 waves hide it in their skew.  Not built; this kernel
+// stays opt-in.
 // Rows past the end of the sequence are NOT written (their lanes are switched off): they keep the zeros of the kernel's start.
 // (19 named pieces, not an array: the compiler kept `uint4 kb[19]` in scratch memory even in this small function)
 #define DWM_RES4_PIECES(X_) X_(0) X_(1) X_(2) X_(3) X_(4) X_(5) X_(6) X_(7) X_(8) X_(9) X_(10) X_(11) X_(12) X_(13) X_(14) X_(15) X_(16) X_(17) X_(18)
@@ -303,7 +312,6 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
     char* const vimg = smem + Lp * 128;
     int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
     int32_t* const otab = tabs + 2 * Lt;
-    const int trash_off = 2 * Lp * 128 + 3 * Lt * 4;        // 256 bytes behind the tables: destination of the L2 touches
 
     ResCtx c;
     c.kimg = kimg; c.vimg = vimg; c.rowtab = tabs;
@@ -364,11 +372,8 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
 #else
 #define DWM_TR4(slot_) do {} while (0)
 #endif
-    // Start stagger: the workgroups are identical and start together, so left alone every CU fetches its next head's rows at the same time
-    // - 230 KiB (K, V, Q) x 256 CUs against the memory at once, with every matrix pipe idle: 11 B / cycle / CU, the chip's HBM rate
-    // (measured: 13 k + 10 k cycles per head, profiles/r5h_trace4_*) - and computes at the same time, with the memory idle.  The
-    // workgroups of ONE XCD (consecutive b / 8: they share that XCD's path to the memory) start (b / 8 mod 8) / 8 of a head period
-    // apart (s_sleep: no issue slots used), once.
+    // Start stagger (opt-in, P.nwc > 0: units of 8128 cycles per (workgroup / 8 mod 8), i.e. between the workgroups of one XCD): measured
+    // without effect on the head seam (profiles/r5i_*) - the seam is not a contention effect, see below.
     if (P.nwc > 0) {
         const int steps = (int)((blockIdx.x >> 3) & 7u) * P.nwc;
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
@@ -421,35 +426,12 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
             };
             ResGlobal gm;
             gm.k = P.k0 + hoff; gm.v = P.v0 + hoff; gm.tab = tab; gm.seg1_delta = P.seg1_delta;
-            // L2 touches of the NEXT head's K, V and Q rows, a key step or two before this head's tile loop ends: a CU fetches a head's
-            // 230 KiB at ~12 B / cycle from HBM whatever else the chip does (13 k + 9 k cycles of seam per head, measured with and
-            // without start stagger: profiles/r5h_*, r5i_*), so the fetch is started here, where nothing waits for memory - one dword per
-            // 128-byte row piece by LDS-DMA into a trash slot of the LDS (no destination register; inline asm: the compiler would put a
-            // vmcnt(0) in front of every fragment read behind a DMA it knows about) - and the seam's loads find the rows in the L2 /
-            // Infinity Cache.  (attn_res_kernel dropped the same idea in round 3: its tile loop has vmcnt waits that the touches stall.)
-            auto touch_next = [&]() {
-                if (!has_next || P.nwc < 0) return;
-                const uint32_t trash = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem + trash_off);
-                auto touch = [&](const bf16_t* p) {
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(trash) : "memory", "m0");
-                };
-                for (int r0 = wave * 64; r0 < L; r0 += NW * 64) {                 // K and V rows: 64 per instruction
-                    const int r = r0 + lane < L ? r0 + lane : L - 1;
-                    const int64_t off = ((int64_t)ntab[r] << 3) + (r < L0 ? 0 : P.seg1_delta) + nhoff;
-                    touch(P.k0 + off);
-                    touch(P.v0 + off);
-                }
-                for (int q0 = 0; q0 < NT * 32; q0 += 64) {                        // this wave's Q rows of the next head
-                    int lq = t0 * 32 + q0 + lane;
-                    lq = lq < P.qend ? lq : P.qend - 1;
-                    touch(P.q0 + ((int64_t)ntab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + nhoff);
-                }
-            };
+            auto nothing = [&]() {};
 #ifdef DWM_ATTN_TRACE
-            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, touch_next,
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, nothing,
                                (P.lse != nullptr && blockIdx.x < 8 && lane == 0 && g < 64) ? (long long*)P.lse + (((int)blockIdx.x * NW + wave) * 64 + g) * 8 : nullptr);
 #else
-            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, touch_next);
+            res4_unit<NT, ILV>(c, qn, P.scale_log2, force_safe, gm, n_pad, out_ptr, reload_q, nothing);
 #endif
         }
         // the next head's rows (res4_copy_head: requested when this wave's outputs are on their way, written behind the barrier that
