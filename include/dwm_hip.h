@@ -193,15 +193,15 @@ typedef struct dwm_attn_args {
     int64_t ldiv[2], lstride[3];
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
     int32_t variant;                           /* 0 = auto.  Kernel selection (attention.hip): bits 0-3 tiled kernel: 2 = 64
-                                                * queries per wave (else 32); resident kernel: number of compute waves (1-12, the
-                                                * other waves of its 12 only copy), bit 4 online softmax with a running maximum
-                                                * for every unit of the resident kernel (default: its maximum-free fast path with
-                                                * a checked fallback), bit 5 keep the tiled kernel (default for L <= 32: the
-                                                * packed short-sequence kernel; for unmasked self-attention with 64 <= L <= 608:
-                                                * the resident kernel), bit 6 paired form of the resident kernel (8 waves, two
-                                                * query tiles per wave share every K / V fragment read; also DWM_ATTN_RES2=1;
-                                                * opt-in until validated on a GPU), bit 7 per-wave form of the group-masked
-                                                * kernel, bits 8-11 heads per workgroup / item */
+                                                * queries per wave, 1 = 32 (auto: 64 from L = 4096 on); resident kernel: number of
+                                                * compute waves (1-12, the other waves of its 12 only copy), bit 4 online softmax with a
+                                                * running maximum for every unit of the resident kernels (default: their maximum-free
+                                                * fast path with a checked fallback), bit 5 keep the tiled kernel (default for L <= 32:
+                                                * the packed short-sequence kernel; for unmasked self-attention with 64 <= L <= 608:
+                                                * the resident kernel), bit 7 per-wave form of the group-masked kernel, bits 8-11 heads
+                                                * per workgroup / item, bit 12 the one-wave-per-SIMD resident kernel (attention_res4.hip;
+                                                * 225 <= L <= 608; validated, measured slower than the 12-wave one: opt-in), bit 13 its
+                                                * alternating MFMA order, bit 14 its start stagger */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */
