@@ -100,7 +100,8 @@ def _battery():
                 "plain": rel(r3, res.double() + a.double() @ w.double().T), "tol": tol}
     out["launches_resid"] = launches() - n0
     n0 = launches()
-    # not covered (ragged M, N % 256 != 0, one K step): the 8-wave kernels answer, the counter stays
+    # ragged M and N % 256 != 0: the general form of the 4-wave kernels (round 5; its own battery: test_round5_kernels_gpu.py); one K
+    # step: not covered, the 8-wave kernels answer and the counter stays
     for M, N, K in [(300, 256, 128), (256, 320, 128), (256, 256, 64)]:
         a, w = rnd((M, K), 18), rnd((N, K), 19, K ** -0.5)
         out[f"fallback_{M}x{N}x{K}"] = rel(ops.gemm(a, w, None, split_k=1), a.double() @ w.double().T)
@@ -123,7 +124,7 @@ def test_four_wave_gemm_kernels_opt_in():
         f.write(json.dumps({"test": "gemm4w_opt_in", **out}) + "\n")
     # every covered call went through the 4-wave kernels, no uncovered one did
     assert out["launches_plain"] == 4 * 5 and out["launches_geglu"] == 2 and out["launches_rmshead"] == 2
-    assert out["launches_resid"] == 3 * 2 * 3 and out["launches_fallback"] == 0, out
+    assert out["launches_resid"] == 3 * 2 * 3 and out["launches_fallback"] == 2, out
     for k, v in out.items():
         if k.startswith("launches"):
             continue
