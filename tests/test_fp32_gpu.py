@@ -423,6 +423,7 @@ def test_unet_forward_fp32_vs_cpu_oracle(dev, rowwise):
     assert out16.dtype == torch.bfloat16 and 1e-4 < e16 < 2e-2
 
 
+@pytest.mark.cost(19, optional=True)
 def test_unet_full_width_config0_fp32_vs_oracle_on_device(dev):
     """BASELINE.json configs[0] - the configuration the reference's CPU fp32 denoise is quoted on - at FULL width (SD 2.1: 320 /
     640 / 1280 / 1280 channels, 1.92 B parameters), six views x one frame x 256x256 px (latents [1,1,6,4,32,32], CFG batch 2, 77

@@ -119,7 +119,7 @@ def _small_unet_cfg(**over):
     return cfg
 
 
-@pytest.mark.parametrize("rowwise", [True, False])
+@pytest.mark.parametrize("rowwise", [True, pytest.param(False, marks=pytest.mark.cost(23, optional=True))])
 def test_unet_forward_vs_oracle(dev, rowwise):
     """whole SD 2.1 UNet graph (4 levels, cross-attn down / up blocks, mid block, temporal resnets, row-wise or point-wise
     cross-view / temporal transformer blocks, skip concatenations) at small width against the fp32 oracle"""
@@ -179,6 +179,7 @@ def test_unet_denoise_loop_vs_oracle(dev):
     assert e < 3e-2
 
 
+@pytest.mark.cost(28, optional=True)
 def test_unet_ddim_denoise_loop_vs_oracle(dev):
     """the reference's DEFAULT test scheduler of the UNet (ctsd.py:969-974: DDIMScheduler when inference_config names none):
     UNetDenoiser(scheduler=DDIMScheduler()) - CFG + tensor-timestep DDIM step in one kernel - against the oracle UNet driven

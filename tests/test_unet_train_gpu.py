@@ -151,7 +151,7 @@ def _oracle_unet_grads(sd, cfg, inp, wgt, dev, mixer_cond=None):
     return ref.detach(), {k: v.grad for k, v in sdo.items() if torch.is_tensor(v) and v.requires_grad}
 
 
-@pytest.mark.parametrize("rowwise", [True, False])
+@pytest.mark.parametrize("rowwise", [True, pytest.param(False, marks=pytest.mark.cost(24, optional=True))])
 def test_unet_gradients_vs_oracle_autograd(dev, rowwise):
     """d(loss)/d(every parameter) of the UNet training path (checkpointed block Functions, HIP backward kernels, bf16 compute
     on fp32 masters) against fp32 autograd through the oracle on the small full-graph configuration (4 levels, cross-attn
