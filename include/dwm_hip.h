@@ -193,7 +193,7 @@ typedef struct dwm_attn_args {
     int64_t ldiv[2], lstride[3];
     const uint8_t* mask; int64_t mask_G; int64_t group_size; int64_t p_per_mask;
     int32_t variant;                           /* 0 = auto.  Kernel selection (attention.hip): bits 0-3 tiled kernel: 2 = 64
-                                                * queries per wave, 1 = 32 (auto: 64 from L = 4096 on); resident kernel: number of
+                                                * queries per wave, 1 = 32 (auto: 64 from L = 1024 on); resident kernel: number of
                                                 * compute waves (1-12, the other waves of its 12 only copy), bit 4 online softmax with a
                                                 * running maximum for every unit of the resident kernels (default: their maximum-free
                                                 * fast path with a checked fallback), bit 5 keep the tiled kernel (default for L <= 32:

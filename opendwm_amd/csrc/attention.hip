@@ -1349,9 +1349,10 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
 
     // variant bits 0-3, tiled kernel: 2 = 64 queries per wave (256 per workgroup); anything else = 32 (3 workgroups per CU:
     // measured faster in the full step).  The resident kernel reads the same bits as its number of compute waves.
-    // (automatic: 64 queries per wave from L = 4096 on - "full" temporal attention, 19 frames x 448 tokens = 8512 in the shipped UniMLVG
-    //  example: 629 against 521 TFLOP/s, profiles/r5a_microbench_attn_full.log; variant bits 0-3 = 1 keeps 32)
-    const int qt = (a->variant & 15) == 2 || ((a->variant & 15) == 0 && L - P.kbeg >= 4096) ? 2 : 1;
+    // (automatic: 64 queries per wave from L = 1024 on - the UNet's spatial self-attention at L = 1792: 808-843 against 685-715 TFLOP/s;
+    //  "full" temporal attention, 19 frames x 448 tokens = 8512 in the shipped UniMLVG example: 628 against 522 TFLOP/s,
+    //  profiles/r5y_microbench_attention.log; variant bits 0-3 = 1 keeps 32)
+    const int qt = (a->variant & 15) == 2 || ((a->variant & 15) == 0 && L - P.kbeg >= 1024) ? 2 : 1;
     const int qblock = qt * 128;
     P.nqb = (int)((P.qend + qblock - 1) / qblock);
     // heads per workgroup: amortises the per-workgroup fixed cost (variant bits 8..11 override: 1..15).
