@@ -318,6 +318,27 @@ def bench_stream32():
         print(json.dumps({"kernel": "ln-mod-dual", "stream": nm, "ms": round(ms, 4), "GBps": round((x.numel() * x.element_size() + 2 * y.numel() * 2) / ms / 1e6, 1)}))
 
 
+def bench_stream32_tiles():
+    """the K = 1536 RESID launch on the fp32 stream (34 ms of the step at 852-877 TFLOP/s): 8-wave 256 x 256 (tile 1), two 4-wave
+    workgroups per CU on 256 x 128 x 32 (tile 2), the 4-wave 256 x 256 kernel (tile 3) - does a second workgroup per CU overlap the
+    epilogue's stream traffic with the other's main loop?"""
+    M, D = 86016, 1536
+    h32 = torch.randn(M, D, device=dev)
+    gate = rnd(192, D)
+    for name, K in (("out-proj K=1536", 1536), ("ff2 K=6144", 6144)):
+        a, w, b = rnd(M, K), rnd(D, K, scale=K ** -0.5), rnd(D)
+        fl = 2.0 * M * D * K
+        for tile in (3, 1, 2, 3, 1, 2):
+            def call():
+                with ops.gemm_4wave_scope(tile == 3):
+                    ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=h32, out32=h32, mirror=False, tile=0 if tile == 3 else tile)
+            try:
+                ms = timeit(call)
+                print(json.dumps({"kernel": "gemm-resid-fp32", "case": name, "tile": tile, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}), flush=True)
+            except RuntimeError as e:
+                print(json.dumps({"kernel": "gemm-resid-fp32", "case": name, "tile": tile, "error": str(e)[:80]}), flush=True)
+
+
 def bench_ln():
     x = rnd(86016, 1536)
     mod = rnd(192, 9 * 1536)
@@ -353,6 +374,8 @@ if __name__ == "__main__":
         bench_attn_unet()
     if "attnr4x" in what:                # diagnostics: forced online-softmax fallback (16) of both kernels
         bench_attn([0, 1 << 12, 16, 16 | (1 << 12)], only=("joint L=602", "dual L=448"))
+    if "s32t" in what:
+        bench_stream32_tiles()
     if "s32" in what:
         bench_stream32()
     if "gemm" in what:
