@@ -27,7 +27,7 @@ BUDGET_SKIPS = []
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
-    config.addinivalue_line("markers", "cost(seconds, optional=False): measured duration of a long GPU test (see SUITE_BUDGET_S)")
+    config.addinivalue_line("markers", "cost(seconds, optional=False, priority=5): measured duration of a long GPU test (see SUITE_BUDGET_S)")
 
 
 def pytest_runtest_setup(item):
@@ -67,7 +67,10 @@ def pytest_collection_modifyitems(config, items):
         except Exception as e:                          # the tests themselves then fail loudly in _lib.load()
             print(f"[conftest] libdwm_hip.so could not be built: {e}", file=sys.stderr)
     # long tests first, required ones before optional ones, the most expensive first (stable: the others keep their order)
+    # (optional cases in the order of `priority` - the class-default cached-adapter mode first -, then the most expensive first)
     def rank(it):
         m = it.get_closest_marker("cost")
-        return (2, 0.0) if m is None else (1 if m.kwargs.get("optional") else 0, -float(m.args[0]))
+        if m is None:
+            return (2, 0, 0.0)
+        return (1, int(m.kwargs.get("priority", 5)), -float(m.args[0])) if m.kwargs.get("optional") else (0, 0, -float(m.args[0]))
     items.sort(key=rank)

@@ -128,14 +128,14 @@ def test_forty_step_denoise_vs_oracle_loop_on_device(dev, layout):
 #   * the text-only model on 2 frames.
 # DWM_HEAVY_TESTS=1 adds the text-only model at 16 frames and seeds 1 and 2 of the per-step adapter mode; their results of
 # this round are recorded in profiles/r4a_gpu_parity.log, r4b_gpu_parity.log (5.8e-3; 1.31 / 1.36 / 1.32e-2 over three seeds).
-def _case(layout, seed, frames, cached, name, cost, optional=False):
-    return pytest.param(layout, seed, frames, cached, id=name, marks=pytest.mark.cost(cost, optional=optional))
+def _case(layout, seed, frames, cached, name, cost, optional=False, priority=5):
+    return pytest.param(layout, seed, frames, cached, id=name, marks=pytest.mark.cost(cost, optional=optional, priority=priority))
 
 
 FULL_DEPTH_CASES = [
     _case(True, 0, 16, False, "text_layout_pointwise", 185),
     _case(False, 0, 2, False, "text_only_rowwise_2f", 25),
-    _case(True, 1, 2, True, "text_layout_seed1_2f_cached_fp32_adapter", 28, optional=True),
+    _case(True, 1, 2, True, "text_layout_seed1_2f_cached_fp32_adapter", 28, optional=True, priority=0),
 ] + ([
     _case(False, 0, 4, False, "text_only_rowwise_4f", 50),
     _case(True, 1, 4, True, "text_layout_seed1_4f_cached_fp32_adapter", 50),
@@ -271,7 +271,7 @@ def test_forty_step_denoise_heavy_tailed_weights_with_outlier_channels(dev, layo
     assert e40 < TOL, e40
 
 
-@pytest.mark.cost(250, optional=True)
+@pytest.mark.cost(250, optional=True, priority=1)
 def test_tvae_autoregressive_window_full_size_vs_oracle_on_device(dev):
     """BASELINE.json configs[4], one autoregressive window at FULL size (what `bench.py --tvae-ar` runs twice): the 24-layer
     text+layout model on latents [1,5,6,16,32,56] with the previous window's last latent frame injected clean
