@@ -19,9 +19,9 @@ if ROOT not in sys.path:
 # results are under profiles/.
 SUITE_T0 = time.time()
 SUITE_BUDGET_S = float(os.environ.get("DWM_SUITE_BUDGET_S", "1050"))
-# what the ~430 tests without a cost mark take after the cost-marked ones (measured in round 5: 208 s + 434 s for two halves of the
-# suite, profiles/r5s1_pytest.log, r5rest_pytest.log, less the ~100 s of tests that have since become optional cost cases)
-REST_OF_SUITE_S = float(os.environ.get("DWM_SUITE_REST_S", "540"))
+# what the ~430 tests without a cost mark take after the cost-marked ones: 360 s in the full run of round 5 (647 s in all with the
+# tVAE window test skipped, profiles/r5z_pytest.log); 400 leaves that test room on such a box (~850 s in all) and drops it on a slower one
+REST_OF_SUITE_S = float(os.environ.get("DWM_SUITE_REST_S", "400"))
 BUDGET_SKIPS = []
 
 
