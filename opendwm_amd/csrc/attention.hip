@@ -1477,7 +1477,7 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
                 const bool ilv = env_res4 > 0 ? env_res4 == 2 : ((a->variant >> 13) & 1) != 0;
                 static const int env_stag = [] { const char* v = getenv("DWM_ATTN_STAGGER"); return v == nullptr || v[0] == '\0' ? -1 : atoi(v); }();
-                P.nwc = env_stag >= 0 ? env_stag : ((a->variant >> 14) & 1);      // (field reused: start stagger in units of 8128 cycles, default off)
+                P.stagger = env_stag >= 0 ? env_stag : ((a->variant >> 14) & 1);     // start stagger in units of 8128 cycles, default off
                 return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
             }
         }

@@ -40,6 +40,7 @@ struct AttnParams {
     float scale;
     int n_problems, heads, nqb;
     int nwc;                 // attn_res_kernel: compute waves
+    int stagger;             // attn_res4_kernel: start stagger in units of 8128 cycles per (workgroup / 8 mod 8); 0 = none
     int safe_softmax;        // attn_res_kernel: online softmax (running max) for every unit instead of the max-free fast path
     int hpb;                 // heads per workgroup (forward); fd_heads then divides by heads / hpb
     FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;

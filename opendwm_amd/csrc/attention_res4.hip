@@ -372,10 +372,10 @@ DWM_DEVINL void res4_heads(const AttnParams& P, char* smem, int t0) {
 #else
 #define DWM_TR4(slot_) do {} while (0)
 #endif
-    // Start stagger (opt-in, P.nwc > 0: units of 8128 cycles per (workgroup / 8 mod 8), i.e. between the workgroups of one XCD): measured
+    // Start stagger (opt-in, P.stagger > 0: units of 8128 cycles per (workgroup / 8 mod 8), i.e. between the workgroups of one XCD): measured
     // without effect on the head seam (profiles/r5i_*) - the seam is not a contention effect, see below.
-    if (P.nwc > 0) {
-        const int steps = (int)((blockIdx.x >> 3) & 7u) * P.nwc;
+    if (P.stagger > 0) {
+        const int steps = (int)((blockIdx.x >> 3) & 7u) * P.stagger;
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
     }
     uint32_t prob; int64_t hoff;
