@@ -28,6 +28,8 @@ BUDGET_SKIPS = []
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
     config.addinivalue_line("markers", "cost(seconds, optional=False, priority=5): measured duration of a long GPU test (see SUITE_BUDGET_S)")
+    config.addinivalue_line("markers", "quick: the kernel batteries + small-model forwards (`pytest -m 'gpu and quick'`: ~1 GPU-minute) - "
+                                       "what a builder runs between kernel changes; the driver runs everything")
 
 
 def pytest_runtest_setup(item):
@@ -66,6 +68,11 @@ def pytest_collection_modifyitems(config, items):
             ensure_built()
         except Exception as e:                          # the tests themselves then fail loudly in _lib.load()
             print(f"[conftest] libdwm_hip.so could not be built: {e}", file=sys.stderr)
+    # `quick`: every GPU test of the kernel-level files that carries no cost mark
+    quick_files = ("test_hip_gpu.py", "test_gemm4w_gpu.py", "test_round5_kernels_gpu.py", "test_stream32_gpu.py")
+    for it in items:
+        if "gpu" in it.keywords and it.get_closest_marker("cost") is None and os.path.basename(str(it.fspath)) in quick_files:
+            it.add_marker(pytest.mark.quick)
     # long tests first, required ones before optional ones, the most expensive first (stable: the others keep their order)
     # (optional cases in the order of `priority` - the class-default cached-adapter mode first -, then the most expensive first)
     def rank(it):
