@@ -1017,7 +1017,8 @@ def main():
                        "layers": kwargs["num_layers"], "flop_per_step": step_flop, "flop_model": fl["total"], "flop_adapter": fl["adapter"],
                        "baseline_config": "BASELINE.json configs[2]", "finite": finite,
                        "residual_stream": "bf16" if args.residual_bf16 else "fp32 (GEMM operands and activations bf16)",
-                       "gemm_kernels": "4-wave (gemm_bf16_4w.hip) where they cover the launch, 8-wave otherwise; DWM_GEMM4W=0 forces 8-wave",
+                       "gemm_kernels": "4-wave (gemm_bf16_4w.hip: fast + general form) where they cover the launch, 8-wave otherwise (split-K launches, "
+                                       "one K step, output row maps); DWM_GEMM4W=0 forces 8-wave",
                        "variant": ("text+layout (ImageAdapter recomputed every step, pointwise temporal)" if not args.adapter_cache else
                                    "text+layout (ImageAdapter residuals cached across steps, pointwise temporal)")
                        if args.layout else "text only (rowwise temporal, no adapter)"},
