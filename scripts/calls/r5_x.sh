@@ -1,6 +1,8 @@
 #!/bin/bash
 # timing experiments on attn_res4_kernel's tile loop (wrong results by construction): what is the loop bound by?
 #   DWM_R4X=1 no row-sum adds, 2 no exponentials, 3 neither, 4 no fragment re-reads
+# (the hooks are not in the product source: `patch -p1 < scripts/experiments/attn_res4_loop_hooks.patch` first; results of round 5:
+#  profiles/r5x_attn_res4_loop_experiments.txt)
 TAG=${1:-r5x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
