@@ -479,9 +479,16 @@ class DiTCrossviewTemporalConditionModel(_Base):
             # embedding, instead of holding a 264 MB raymap and adding it in a separate pass
             if camera_intrinsics_norm is None or camera2referego is None:
                 raise RuntimeError("perspective_modeling_type='explicit' needs camera_intrinsics_norm and camera2referego")
-            if fs is not None:
-                raise NotImplementedError("explicit perspective modelling with frame sharding")
             ray_feat = self.rayencoder.features(camera_intrinsics_norm, camera2referego, height, width)
+            if fs is not None and self.enable_temporal and self.enable_crossview and not self.disable_view_emb_on_temporal_module:
+                # the temporal blocks run on "all frames, my token rows" (sharding.py): the features of those rows for every
+                # frame of the sample, from the gathered per-image camera matrices (a few hundred bytes per image) - the
+                # features themselves never cross the links
+                hl = height // fs.size
+                rf_all = self.rayencoder.features(fs.gather_frames(camera_intrinsics_norm, 1), fs.gather_frames(camera2referego, 1),
+                                                  height, width)
+                ray_rows = rf_all.view(B, Tg, V, height, width, rf_all.shape[-1])[:, :, :, fs.rank * hl:(fs.rank + 1) * hl] \
+                    .contiguous().view(-1, rf_all.shape[-1])
 
         if self.enable_crossview and disable_crossview is None:
             disable_crossview = torch.zeros(B, dtype=torch.bool, device=sample.device)
@@ -554,7 +561,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 seq_emb = self.time_pos_embeds[k].run(seq, res=(view_cam_emb if fs is None else cam_all) if use_cam else None)
                 rpe = N
                 if ray_feat is not None and self.enable_crossview and not self.disable_view_emb_on_temporal_module:
-                    seq_emb = ops.gemm(ray_feat, self.rayencoder.packed(), None, epilogue=ops.EPI_RESID, res=seq_emb, res_mod=-N)
+                    seq_emb = ops.gemm(ray_feat if fs is None else ray_rows, self.rayencoder.packed(), None, epilogue=ops.EPI_RESID,
+                                       res=seq_emb, res_mod=-(N if fs is None else (height // fs.size) * width))
                     rpe = 1
                 tt = self.temporal_attention_type
                 mk = ops.rowmap_temporal_full if tt == "full" else \
@@ -569,7 +577,7 @@ class DiTCrossviewTemporalConditionModel(_Base):
                     hl = height // fs.size
                     hx = fs.frames_to_rows(h, B, T, V, height, width)
                     self.temporal_transformer_blocks[k].run(
-                        hx, mk(B, Tg, V, hl, width), emb=seq_emb, rows_per_emb=hl * width,
+                        hx, mk(B, Tg, V, hl, width), emb=seq_emb, rows_per_emb=1 if rpe == 1 else hl * width,
                         blend_alpha=alpha, rows_per_alpha=Tg * V * hl * width, blend_into=hx)
                     fs.rows_to_frames(hx, B, T, V, height, width, out=h)
 

@@ -349,7 +349,8 @@ class CTSDTrainer:
     training_config keys honoured as the reference does: "freezing_pattern" (regex over module names, ctsd.py:1014-1022),
     "gradient_accumulation_steps" (optimizer step every k-th call, :1401-1432; the micro-steps in between run under DDP's
     no_sync, so one all-reduce per optimizer step carries the accumulated gradient - the same sum the reference gets
-    with an all-reduce per micro-step), "max_norm_for_grad_clip".  `lr_scheduler` (a callable optimizer -> scheduler, or
+    with an all-reduce per micro-step), "max_norm_for_grad_clip", "enable_grad_scaler" (torch.amp.GradScaler around our fused
+    AdamW: :1040-1048, :1401-1432).  `lr_scheduler` (a callable optimizer -> scheduler, or
     a scheduler) is stepped once per train_step (:1434-1435)."""
 
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
@@ -386,6 +387,16 @@ class CTSDTrainer:
         self.sigmas = flow_match_train_sigmas(num_train_timesteps, shift)
         self.num_train_timesteps, self.loss_coef = num_train_timesteps, loss_coef
         self.max_grad_norm = self.training_config.get("max_norm_for_grad_clip", max_grad_norm)
+        # "enable_grad_scaler" (every shipped training config sets it: ctsd.py:1040-1048, :1401-1432): dynamic loss scaling with
+        # torch.amp.GradScaler's defaults and state.  The compute type here is bf16, whose exponent range is fp32's, so
+        # the scale changes no rounding (a power of two) - what the mode keeps is the reference's control flow: gradients are
+        # unscaled before the clip, and a step whose gradients hold an inf / nan is SKIPPED and halves the scale.
+        self.grad_scaler = None
+        if self.training_config.get("enable_grad_scaler", False):
+            if self.common_config.get("distribution_framework", "ddp") != "ddp":
+                raise NotImplementedError("enable_grad_scaler with distribution_framework != 'ddp' (ShardedGradScaler / FSDP) - SURVEY.md s2")
+            dev_type = next(model.parameters()).device.type
+            self.grad_scaler = torch.amp.GradScaler(dev_type)
         self.weighting_scheme = weighting_scheme
         self.reference_latent_count = reference_latent_count
         # SD 2.1 branch (ctsd.py:1240-1253): the model is the UNet -> DDPM noising, epsilon / v_prediction target
@@ -532,13 +543,20 @@ class CTSDTrainer:
         k = self.training_config.get("gradient_accumulation_steps")
         should_optimize = k is None or (gs + 1) % k == 0                                 # :1401-1404
         sync = contextlib.nullcontext() if (should_optimize or not self.ddp) else self.wrapper.no_sync()
+        scaler = getattr(self, "grad_scaler", None)
         with sync:
             loss = self.loss(latents, conditions, generator, timestep_indices, noise)
-            loss.backward()
+            (loss if scaler is None else scaler.scale(loss)).backward()                   # :1401-1404
         if should_optimize:
             if self.max_grad_norm is not None:
+                if scaler is not None:
+                    scaler.unscale_(self.optimizer)                                      # :1411-1413
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
-            self.optimizer.step()
+            if scaler is not None:
+                scaler.step(self.optimizer)                                              # :1426-1428 (skips on inf / nan)
+                scaler.update()
+            else:
+                self.optimizer.step()
             self.optimizer.zero_grad()
         if self.lr_scheduler is not None:                                                # :1434-1435, every call
             self.lr_scheduler.step()

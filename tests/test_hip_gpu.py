@@ -1061,6 +1061,57 @@ def test_frame_shard_two_ranks(dev, small_cfg, temporal, mode):
     assert a.shape == single.shape and torch.equal(a, b) and e < 5e-3
 
 
+def _random_cameras(B, T, V, seed):
+    """normalised pinhole intrinsics + camera -> reference-ego rigid transforms, [B, T, V, 3, 3] / [B, T, V, 4, 4]"""
+    g = torch.Generator().manual_seed(seed)
+    K = torch.zeros(B, T, V, 3, 3)
+    K[..., 0, 0] = 0.8 + 0.4 * torch.rand(B, T, V, generator=g)
+    K[..., 1, 1] = 1.2 + 0.4 * torch.rand(B, T, V, generator=g)
+    K[..., 0, 2] = 0.45 + 0.1 * torch.rand(B, T, V, generator=g)
+    K[..., 1, 2] = 0.45 + 0.1 * torch.rand(B, T, V, generator=g)
+    K[..., 2, 2] = 1.0
+    M = torch.zeros(B, T, V, 4, 4)
+    q, _ = torch.linalg.qr(torch.randn(B, T, V, 3, 3, generator=g))
+    M[..., :3, :3] = q
+    M[..., :3, 3] = 0.5 * torch.randn(B, T, V, 3, generator=g)
+    M[..., 3, 3] = 1.0
+    return K, M
+
+
+@pytest.mark.parametrize("temporal", ["rowwise", "pointwise"])
+def test_frame_shard_two_ranks_explicit_perspective(dev, temporal):
+    """Frame sharding with perspective_modeling_type="explicit" (examples/ctsd_unimlvg_6views_video_generation.json;
+    crossview_temporal_dit.py:440-458): the temporal blocks of a rank run on all frames of its token rows, so their per-token ray
+    embedding is built from the gathered camera matrices of every frame, restricted to those rows.  Equal to the single-process
+    run up to bf16 round-off, both ranks bit-identical."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from opendwm_amd.pipeline import CTSDDenoiser
+    cfg = small_config(perspective_modeling_type="explicit", temporal_attention_type=temporal)
+    sd = _bf16_round_sd(O.make_state_dict(cfg, 0))
+    inp = small_inputs(cfg, 0, T=4)
+    inp.pop("added_time_ids")
+    cond = {k: v for k, v in inp.items() if k not in ("sample", "timestep")}
+    K, M = _random_cameras(1, 4, 3, 21)
+    cond["camera_intrinsics_norm"] = torch.cat([K, K])                     # CFG-doubled, as every other condition
+    cond["camera2referego"] = torch.cat([M, M])
+    lat = torch.randn(1, 4, 3, 16, 8, 12, generator=torch.Generator().manual_seed(13))
+    single = CTSDDenoiser(_hip_model(cfg, sd, dev), guidance_scale=4.0, inference_steps=4).run(lat.to(dev), to_dev(cond, dev), stop=3).cpu()
+    ctx = mp.get_context("spawn")
+    port = 29500 + (os.getpid() + 17) % 2000
+    path = os.path.join(tempfile.mkdtemp(), "frame_shard_explicit")
+    procs = [ctx.Process(target=_frame_shard_worker, args=(r, 2, port, cfg, sd, lat, cond, {}, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    a, b = torch.load(path + ".0"), torch.load(path + ".1")
+    e = rel_err(a, single)
+    _log("frame_shard_explicit", temporal=temporal, ranks_equal=bool(torch.equal(a, b)), rel_vs_single=e)
+    assert a.shape == single.shape and torch.equal(a, b) and e < 5e-3
+
+
 @pytest.mark.parametrize("name", ["crossview_rowwise_0", "crossview_rowwise_1", "crossview_full_0", "temporal_full", "temporal_rowwise", "temporal_pointwise"])
 def test_attention_rowmaps_and_mixer_vs_reference_fixture(dev, name):
     """Golden vectors produced by the REFERENCE's own forward_crossview / forward_temporal_block_and_mix_result code

@@ -514,6 +514,48 @@ def test_train_step_loss_and_descent(dev):
     assert losses[-1] < losses[0]
 
 
+def test_train_step_grad_scaler_mode(dev):
+    """training_config["enable_grad_scaler"] (set by every shipped CTSD training config; ctsd.py:1040-1048, 1401-1432): the loss is
+    scaled before the backward, the gradients are unscaled before the clip, a step whose gradients hold inf / nan is skipped and
+    halves the scale.  The backward is linear in the upstream gradient and the scale is a power of two, so a scaled step must
+    land on the weights of the unscaled one (up to the few fp32 sums whose order autograd may change: 1e-5); a poisoned batch must
+    leave every weight bit-identical."""
+    from oracle import ctsd_oracle as O
+    from opendwm_amd.pipeline import CTSDTrainer
+    from tests.common import small_config, small_inputs, to_dev
+    cfg = small_config()
+    sd = {k: v.to(bf16).float() for k, v in O.make_state_dict(cfg, 0).items()}
+    inp = small_inputs(cfg, 0)
+    inp = {k: (v.to(bf16).float() if v.is_floating_point() and k not in ("timestep", "added_time_ids") else v) for k, v in inp.items()}
+    lat = inp.pop("sample")
+    inp.pop("timestep")
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(5))
+    idx = torch.tensor([250, 800])
+    di = to_dev(inp, dev)
+    tc = {"max_norm_for_grad_clip": 1.0}
+    plain = CTSDTrainer(_train_model(cfg, sd, dev), lr=2e-4, weight_decay=0.0, training_config=dict(tc))
+    scaled = CTSDTrainer(_train_model(cfg, sd, dev), lr=2e-4, weight_decay=0.0, training_config=dict(tc, enable_grad_scaler=True))
+    assert plain.grad_scaler is None and scaled.grad_scaler is not None and scaled.grad_scaler.get_scale() == 65536.0
+    l0 = plain.train_step(lat.to(dev), di, timestep_indices=idx, noise=noise).item()
+    l1 = scaled.train_step(lat.to(dev), di, timestep_indices=idx, noise=noise).item()
+    worst = max(((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12)).item()
+                for a, b in zip(scaled.model.parameters(), plain.model.parameters()))
+    moved = any(not torch.equal(p.detach().cpu(), sd[k].to(p.dtype)) for k, p in scaled.model.named_parameters() if k in sd)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0) and moved and worst < 1e-5 and scaled.grad_scaler.get_scale() == 65536.0
+    before = [p.detach().clone() for p in scaled.model.parameters()]
+    t_before = scaled.optimizer.t
+    bad = lat.clone()
+    bad[0, 0, 0, 0, 0, 0] = float("inf")
+    scaled.train_step(bad.to(dev), di, timestep_indices=idx, noise=noise)
+    same = all(torch.equal(a, b.detach()) for a, b in zip(before, scaled.model.parameters()))
+    _log("grad_scaler", loss_plain=l0, loss_scaled=l1, worst_param_rel=worst, skipped_step_kept_weights=same,
+         scale_after_skip=scaled.grad_scaler.get_scale())
+    assert same and scaled.optimizer.t == t_before and scaled.grad_scaler.get_scale() == 32768.0
+    assert all(p.grad is None or not p.grad.any() for p in scaled.model.parameters())        # zero_grad ran
+    l2 = scaled.train_step(lat.to(dev), di, timestep_indices=idx, noise=noise).item()        # and the next clean step trains on
+    assert l2 == l2 and scaled.optimizer.t == t_before + 1
+
+
 @pytest.mark.parametrize("style", ["diffusion_forcing", "ctsd"])
 def test_trainer_task_styles_vs_oracle(dev, style):
     """CTSDTrainer.loss in the two non-trivial training styles (ctsd.py:619-741, 1232-1237, 1363-1367): per-frame timesteps
