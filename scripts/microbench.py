@@ -328,7 +328,7 @@ def bench_stream32_tiles():
     for name, K in (("out-proj K=1536", 1536), ("ff2 K=6144", 6144)):
         a, w, b = rnd(M, K), rnd(D, K, scale=K ** -0.5), rnd(D)
         fl = 2.0 * M * D * K
-        for tile in (3, 1, 2, 3, 1, 2):
+        for tile in [int(t) for t in os.environ.get("S32T_TILES", "3,1,2,3,1,2").split(",")]:
             def call():
                 with ops.gemm_4wave_scope(tile == 3):
                     ops.gemm(a, w, b, epilogue=ops.EPI_RESID, gate=gate, rows_per_gate=448, res=h32, out32=h32, mirror=False, tile=0 if tile == 3 else tile)
