@@ -351,7 +351,22 @@ class AlphaBlender(nn.Module):
             self.register_parameter("mix_factor", nn.Parameter(torch.tensor([float(alpha)])))
 
     def get_alpha(self, image_only_indicator: Optional[torch.Tensor], batch: int) -> torch.Tensor:
-        """fp32 alpha[batch] (crossview_temporal.py:33-51)."""
+        """fp32 alpha[batch] (crossview_temporal.py:33-51).  Read-only for the caller: the tensor is kept and handed out again while
+        neither the mix factor (its storage, its version, the optimizer step: the HIP AdamW writes through the raw pointer) nor
+        the indicator (the same tensor object at the same version; held here, so its address cannot be reused) changed - the
+        UNet asks 54 times per denoise step, five tiny launches each."""
+        mfp, ind = self.mix_factor, image_only_indicator
+        if mfp.is_cuda and torch.cuda.is_current_stream_capturing():
+            return self._alpha(ind, batch)      # a captured graph derives alpha from the indicator on every replay, as before
+        key = (mfp.data_ptr(), mfp._version, STORE.step, batch, None if ind is None else ind._version)
+        c = getattr(self, "_alpha_cache", None)
+        if c is not None and c[0] == key and c[1] is ind:
+            return c[2]
+        a = self._alpha(ind, batch)
+        self._alpha_cache = (key, ind, a)
+        return a
+
+    def _alpha(self, image_only_indicator: Optional[torch.Tensor], batch: int) -> torch.Tensor:
         mf = self.mix_factor.detach().float()
         if self.merge_strategy == "fixed":
             return mf.expand(batch).contiguous()
