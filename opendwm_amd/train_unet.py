@@ -16,7 +16,7 @@ forward under autocast, `loss.backward()` :1401-1404).  Same design as opendwm_a
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 
@@ -24,8 +24,8 @@ from . import ops
 from . import train_ops as T
 from .blocks import STORE, _bf
 from .ops import EPI_RESID, PaddedGrid, TimeGrid
-from .train import (AdapterFn, AddFn, Grads, SiluFn, _conv3_flip, _grads_for, _params, alpha_train, lin_bwd, lin_fwd, linear_train, mlp_train,
-                    project_qkv_train, qkv_bwd, vt_block_train, w_t)
+from .train import (AdapterFn, AddFn, Grads, SiluFn, _conv3_flip, _grads_for, _params, alpha_train, lin_bwd, lin_fwd, mlp_train,
+                    project_qkv_train, qkv_bwd, vt_block_train)
 from . import unet as UM
 
 bf16 = torch.bfloat16
