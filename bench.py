@@ -111,6 +111,108 @@ def _make_conditions(dev, seed, w, n_time_ids, text_dim=4096, pooled_dim=2048):
     )
 
 
+class ClockPowerSampler:
+    """GPU clock and socket power DURING the timed region (the step runs at the board's power limit, so the sustained clock - not the
+    2.4 GHz the nominal MFMA peak assumes - is what bounds it): a thread reads the amdgpu sysfs files of the device (current sclk level
+    of pp_dpm_sclk, hwmon power1_average / power1_input) every `period` seconds; where they are not readable it falls back to one
+    `rocm-smi --showclocks --showpower --json` per second.  Host-side only: nothing is launched on the GPU."""
+
+    def __init__(self, device_index: int = 0, period: float = 0.1):
+        import threading
+        self.period, self.samples, self._stop, self.source, self.error = period, [], threading.Event(), None, None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._dir = self._find_sysfs(device_index)
+        self.index = device_index
+
+    @staticmethod
+    def _find_sysfs(index: int):
+        import glob
+        try:
+            p = torch.cuda.get_device_properties(index)
+            want = f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}"
+        except Exception:
+            want = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        for c in cards:
+            try:
+                if want is not None and os.path.basename(os.path.realpath(c)).startswith(want) and os.path.exists(c + "/pp_dpm_sclk"):
+                    return c
+            except Exception:
+                pass
+        amd = [c for c in cards if os.path.exists(c + "/pp_dpm_sclk")]
+        return amd[index] if index < len(amd) else (amd[0] if amd else None)
+
+    def _read_sysfs(self):
+        import glob
+        mhz = watts = None
+        for ln in open(self._dir + "/pp_dpm_sclk"):
+            if "*" in ln:
+                mhz = float(ln.split(":")[1].strip().split("Mhz")[0].split("MHz")[0])
+        for name in ("power1_average", "power1_input"):
+            for f in glob.glob(self._dir + "/hwmon/hwmon*/" + name):
+                try:
+                    watts = float(open(f).read()) * 1e-6
+                    break
+                except Exception:
+                    pass
+            if watts is not None:
+                break
+        return mhz, watts
+
+    def _read_smi(self):
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        d = next(iter(json.loads(out).values()))
+        mhz = watts = None
+        for k, v in d.items():
+            kl = k.lower()
+            if "sclk" in kl and "clock speed" in kl:
+                mhz = float(str(v).strip("()").lower().replace("mhz", ""))
+            if "power" in kl and "(w)" in kl and watts is None:
+                watts = float(v)
+        return mhz, watts
+
+    def _run(self):
+        use_smi = self._dir is None
+        while not self._stop.is_set():
+            try:
+                if not use_smi:
+                    mhz, watts = self._read_sysfs()
+                    self.source = "sysfs " + self._dir
+                    if mhz is None and watts is None:
+                        use_smi = True
+                        continue
+                else:
+                    mhz, watts = self._read_smi()
+                    self.source = "rocm-smi"
+                self.samples.append((time.perf_counter(), mhz, watts))
+            except Exception as e:
+                self.error = repr(e)
+                if use_smi:
+                    return
+                use_smi = True
+            self._stop.wait(1.0 if use_smi else self.period)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self, t0: float, t1: float):
+        """mean / min / max over the samples taken inside [t0, t1] (perf_counter seconds)"""
+        rs = [r for r in self.samples if t0 <= r[0] <= t1]
+        out = {"source": self.source, "samples": len(rs), "period_s": self.period, "error": self.error}
+        for name, col in (("sclk_mhz", 1), ("socket_power_w", 2)):
+            v = [r[col] for r in rs if r[col] is not None]
+            out[name] = None if not v else {"mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+        if out["sclk_mhz"]:
+            out["peak_at_sustained_clock_tflops"] = PEAK_BF16_TFLOPS * out["sclk_mhz"]["mean"] / 2400.0
+        return out
+
+
 class KernelTimer:
     """HIP-event bracket around every dwm_gemm_bf16 / dwm_attention_fwd launch, recorded on the
     stream the kernel is launched on; durations are read after the timed region."""
@@ -287,13 +389,13 @@ def _tiled_state_dict(cfg: dict, seed: int = 0) -> dict:
 
 def cpu_baseline(threads: int, layout: bool, step_flops: float):
     """The reference's CPU path (its fp32 PyTorch graph, restated in oracle/ctsd_oracle.py) on the host cores.
-    `value` is the MEASURED full-size figure: one whole denoise step of the same oracle, timed once on a GPU box's host (1526 s on 248
-    threads, round 2, profiles/r2_cpu_full_step.json) - a whole step does not fit a bench run.  Timed IN THIS RUN, as the bounded
-    sample: full-depth CFG forwards of the step's model on 6 views x 1 frame and 6 views x 2 frames (1/16 and 2/16 of the images of the
+    `value` / `cores` are what THIS run measured (below), extrapolated to the step; the one whole denoise step ever timed on a GPU box's
+    host (1526 s on 248 threads, round 2, another host, profiles/r2_cpu_full_step.json) is cited under `cited_full_step` only - a whole
+    step does not fit a bench run.  Timed IN THIS RUN, as the bounded sample: full-depth CFG forwards of the step's model on 6 views x 1 frame and 6 views x 2 frames (1/16 and 2/16 of the images of the
     timed step; every layer, the full width, the full text length, the layout adapter when the step has it).  A step's FLOPs are linear
     in the number of images except for the temporal attention (0.7 %); the two samples show how far the host's time is
-    (`sample_linearity` = t(2 frames) / (2 t(1 frame))), and their extrapolations to 16 frames ride along - they are faster than the
-    measured full step (the small samples fit the host's caches better), which is why they are not `value`."""
+    (`sample_linearity` = t(2 frames) / (2 t(1 frame))); `value` is the 2-frame sample's extrapolation to 16 frames (it flatters the
+    CPU: the small samples fit the host's caches better than the full step does)."""
     from oracle import ctsd_oracle as O
     from opendwm_amd.dit import model_flops
     torch.set_num_threads(threads)
@@ -325,17 +427,20 @@ def cpu_baseline(threads: int, layout: bool, step_flops: float):
                       f"{os.cpu_count()} host CPUs; weights tiled from a seeded block in {t_weights:.0f} s (untimed)",
                seconds_measured=secs[2], seconds_by_frames={str(k): v for k, v in secs.items()}, sample_linearity=secs[2] / (2.0 * secs[1]),
                extrapolated_from_samples=extrap, sample_flop=sample_flops, step_flop=step_flops, finite=finite)
+    # `value` and `cores` describe what THIS run measured (the 2-frame sample on `threads` threads, extrapolated linearly to the
+    # step's 16 frames).  The one full-size step ever timed (round 2, another host, 248 threads) is cited beside it, never as `value`,
+    # and only when it is the same model variant as this run's.
+    res["value_source"] = "extrapolated from this run's 2-frame sample (seconds_measured) on `cores` threads"
     try:
         m = json.load(open(os.path.join(ROOT, "profiles", "r2_cpu_full_step.json")))
-        res["cited_full_step"] = dict(value=m["denoise_steps_per_s"], seconds_per_step=m["seconds_per_step"], threads=m["threads"],
-                                      host_cores=m["host_cores"], variant=m["variant"], source="profiles/r2_cpu_full_step.json "
-                                      "(scripts/cpu_full_step.py: one FULL-SIZE step of the same oracle, timed once in round 2)")
-        # the full-size measurement is the figure; the in-run samples (above) say how this run's host compares
-        res["value"] = m["denoise_steps_per_s"]
-        res["cores"] = m["threads"]
-        res["value_source"] = "cited_full_step (one full-size step, measured); this run's samples: extrapolated_from_samples"
+        want = "text+layout" if layout else "text-only"
+        cited = dict(value=m["denoise_steps_per_s"], seconds_per_step=m["seconds_per_step"], threads=m["threads"],
+                     host_cores=m["host_cores"], variant=m["variant"], source="profiles/r2_cpu_full_step.json "
+                     "(scripts/cpu_full_step.py: one FULL-SIZE step of the same oracle, timed once in round 2 on another host)")
+        cited["same_variant_as_this_run"] = str(m["variant"]).startswith(want)
+        res["cited_full_step"] = cited
     except Exception:
-        res["value_source"] = "extrapolated from this run's 2-frame sample (no full-size measurement on file)"
+        pass
     return res
 
 
@@ -963,8 +1068,13 @@ def main():
                 timer.enabled = i >= warmup and not args.graph
                 den.step(i % ninf)
 
+            sampler = ClockPowerSampler(dev.index or 0).start() if rank == 0 else None
             dt = D.timed_steps(step, steps, warmup, dev)
+            t_end = time.perf_counter()
             timer.enabled = False
+            if sampler is not None:
+                sampler.stop()
+                timer.clock_power = sampler.summary(t_end - dt, t_end)
             finite = bool(torch.isfinite(den.latents).all().item())
         finally:
             timer.uninstall()
@@ -1026,8 +1136,9 @@ def main():
                                                     "launch, gemm_bf16_kernel otherwise (all epilogues; split in by_kernel)",
                          "achieved": gm.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gm.get("tflops") or 0.0) / PEAK_BF16_TFLOPS, "traffic": gemm_traffic(gm.get("by_kernel")),
-                         "traffic_unit": "HBM bytes per launch, launch-weighted over by_kernel (each kernel's own rocprofv3 PMC row: FETCH_SIZE x 2 "
-                                         "+ WRITE_SIZE in separate passes of this command, scripts/pmc_traffic.sh)",
+                         "traffic_unit": "L2 -> fabric bytes per launch (TCC_EA request counters: FETCH_SIZE x 2 + WRITE_SIZE in separate rocprofv3 PMC "
+                                         "passes of this command, scripts/pmc_traffic.sh; each kernel's own row, launch-weighted over by_kernel).  "
+                                         "Infinity-Cache (MALL) hits are counted, so this is an UPPER bound of the HBM bytes",
                          "by_kernel": {k: {kk: vv for kk, vv in v.items() if kk != "ms"} |
                                        {"share_of_step_time": (v["ms"] / args.steps) / step_ms, "traffic": pmc_traffic(k),
                                         "traffic_source": pmc_traffic_file(k)}
@@ -1056,7 +1167,12 @@ def main():
                 "algorithmic_bytes_per_launch": timer.small_bytes / asm["launches"], "launches": asm["launches"],
                 "avg_launch_us": asm["avg_us"], "share_of_step_time": (asm["ms"] / args.steps) / step_ms},
             "whole_step_mfma_frac": step_flop / (step_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+            "clock_power": getattr(timer, "clock_power", None),
         }
+        cp = line["clock_power"]
+        if cp and cp.get("peak_at_sustained_clock_tflops") and gm.get("tflops"):
+            # the same launches against what the matrix pipes deliver at the clock the board sustained during this run
+            line["roofline"]["frac_of_peak_at_sustained_clock"] = gm["tflops"] / cp["peak_at_sustained_clock_tflops"]
         if pre is not None:
             line["preflight"] = pre
         if other is not None:

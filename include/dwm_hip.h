@@ -18,7 +18,10 @@
  *   - every function returns 0 on success, a negative DWM_E* code on invalid
  *     arguments (surfaced as RuntimeError by the Python shim) and the positive
  *     hipError_t value if the launch itself failed;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no global mutable state that a result depends on, and no
+ *     environment reads - kernel selection comes from the argument structs only
+ *     (what is process-wide: per-kernel "attribute set" flags and the device's CU
+ *     count, both idempotent, and two relaxed-atomic launch counters for diagnostics).
  */
 #ifndef DWM_HIP_H
 #define DWM_HIP_H
@@ -119,7 +122,8 @@ typedef struct dwm_gemm_args {
     void* C32; int64_t ldc32;
     /* tile configuration: 0 = automatic, 1 = 256 x 256 x 64 tiles (one 8-wave workgroup per CU), 2 = 256 x 128 x 32 tiles
      * (two 4-wave workgroups per CU; chosen automatically where it cuts the padded columns, e.g. N = 320 / 640; not with
-     * C32; split-K grids keep the 256 x 256 tile), 3 = automatic and the 4-wave kernels (gemm_bf16_4w.hip) may serve the launch */
+     * C32; split-K grids keep the 256 x 256 tile), 3 = automatic and the 4-wave kernels (gemm_bf16_4w.hip) may serve the launch,
+     * 4 = as 3, their fast form only (A/B measurements) */
     int32_t tile;
 } dwm_gemm_args;
 
@@ -127,10 +131,10 @@ int dwm_gemm_bf16(const dwm_gemm_args* args, void* stream);
 /* args->tile == 3 ("automatic, 4-wave kernels allowed": what the MMDiT inference forward passes): launches without row maps / taps /
  * split-K and with M % 256 == N % 256 == 0, K % 64 == 0, K >= 128 run the same epilogues on a 4-wave main loop (gemm_bf16_4w.hip; 412
  * against 434 ms per denoise step, profiles/README.md); every other caller keeps the 8-wave kernels, on which the whole GPU suite
- * has run.  Environment DWM_GEMM4W (read at the first call): 1 = every covered launch, 0 = never.  This counts the launches served. */
+ * has run.  (The library reads no environment: the Python host side maps DWM_GEMM4W=1 / 0 / f to tile 3 / 0 / 4 per call.)  This counts
+ * the launches served (a relaxed atomic: diagnostics, the library's only process-wide mutable state besides lazily set kernel attributes). */
 int64_t dwm_gemm4w_launches(void);
-/* ... and how many of them ran the general form of those kernels (ragged M / N, A row map, taps, per-image residual row): only
- * with DWM_GEMM4W=2 - that form was written without a GPU at hand at the end of round 4 and is off until validated. */
+/* ... and how many of them ran the general form of those kernels (ragged M / N, A row map, taps, per-image residual row). */
 int64_t dwm_gemm4w_launches_general(void);
 
 /* ------------------------------------------------------------------------

@@ -354,7 +354,9 @@ class AlphaBlender(nn.Module):
         """fp32 alpha[batch] (crossview_temporal.py:33-51).  Read-only for the caller: the tensor is kept and handed out again while
         neither the mix factor (its storage, its version, the optimizer step: the HIP AdamW writes through the raw pointer) nor
         the indicator (the same tensor object at the same version; held here, so its address cannot be reused) changed - the
-        UNet asks 54 times per denoise step, five tiny launches each."""
+        UNet asks 54 times per denoise step, five tiny launches each.  A write through `.data` (EMA copy, weight surgery, an
+        optimizer that is not this package's) changes none of those: call `blocks.STORE.bump()` (or the model's
+        `_invalidate_packed()`, which `load_state_dict` / `.to()` do) after it, as for every packed weight copy."""
         mfp, ind = self.mix_factor, image_only_indicator
         if mfp.is_cuda and torch.cuda.is_current_stream_capturing():
             return self._alpha(ind, batch)      # a captured graph derives alpha from the indicator on every replay, as before

@@ -1352,7 +1352,11 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     // (automatic: 64 queries per wave from L = 1024 on - the UNet's spatial self-attention at L = 1792: 808-843 against 685-715 TFLOP/s;
     //  "full" temporal attention, 19 frames x 448 tokens = 8512 in the shipped UniMLVG example: 628 against 522 TFLOP/s,
     //  profiles/r5y_microbench_attention.log; variant bits 0-3 = 1 keeps 32)
-    const int qt = (a->variant & 15) == 2 || ((a->variant & 15) == 0 && L - P.kbeg >= 1024) ? 2 : 1;
+    // (the automatic rule covers what was measured: unmasked inference launches whose 256-query blocks still fill the CUs; masked,
+    //  LSE-producing (training) and small-grid launches keep 32 queries per wave unless the caller asks)
+    const int64_t blocks64 = (int64_t)P.n_problems * P.heads * ((P.qend + 255) / 256);
+    const bool auto64 = (a->variant & 15) == 0 && L - P.kbeg >= 1024 && P.mask_mode == 0 && P.lse == nullptr && blocks64 >= 512;
+    const int qt = (a->variant & 15) == 2 || auto64 ? 2 : 1;
     const int qblock = qt * 128;
     P.nqb = (int)((P.qend + qblock - 1) / qblock);
     // heads per workgroup: amortises the per-workgroup fixed cost (variant bits 8..11 override: 1..15).
@@ -1472,12 +1476,10 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
         // bit 13: the alternating MFMA order of its tile loop; bit 14: start stagger (DWM_ATTN_STAGGER=n sets the stagger unit).
         {
             const int nqt = (P.qend + 31) >> 5;
-            static const int env_res4 = [] { const char* v = getenv("DWM_ATTN_RES4"); return (v == nullptr || v[0] == '\0') ? -1 : (int)(v[0] - '0'); }();
-            const bool want4 = env_res4 >= 0 ? env_res4 != 0 : ((a->variant >> 12) & 1) != 0;
+            const bool want4 = ((a->variant >> 12) & 1) != 0;
             if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
-                const bool ilv = env_res4 > 0 ? env_res4 == 2 : ((a->variant >> 13) & 1) != 0;
-                static const int env_stag = [] { const char* v = getenv("DWM_ATTN_STAGGER"); return v == nullptr || v[0] == '\0' ? -1 : atoi(v); }();
-                P.stagger = env_stag >= 0 ? env_stag : ((a->variant >> 14) & 1);     // start stagger in units of 8128 cycles, default off
+                const bool ilv = ((a->variant >> 13) & 1) != 0;
+                P.stagger = (a->variant >> 14) & 1;     // start stagger in units of 8128 cycles, default off
                 return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
             }
         }

@@ -1067,14 +1067,16 @@ extern "C" int dwm_gemm_f32(const dwm_gemm_args* a, void* stream) {
     return e == hipSuccess ? DWM_OK : (int)e;
 }
 
-// gemm_bf16_4w.hip: the 4-wave main loop under the same epilogues, opt-in (DWM_GEMM4W=1); -1 = not a launch it covers
-int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream);
+// gemm_bf16_4w.hip: the 4-wave main loop under the same epilogues (dwm_gemm_args.tile == 3 / 4); -1 = not a launch it covers
+int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream, bool fast_only);
 
 extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a_in, void* stream) {
     if (a_in == nullptr) return DWM_EINVAL;
-    // tile == 3: "automatic, and the 4-wave kernels may serve the launch" (what the MMDiT inference forward asks for)
+    // tile == 3: "automatic, and the 4-wave kernels may serve the launch" (what the MMDiT inference forward asks for); 4: the same,
+    // their fast form only
     dwm_gemm_args a_copy;
-    const bool allow4w = a_in->tile == 3;
+    const bool allow4w = a_in->tile == 3 || a_in->tile == 4;
+    const bool fast_only4w = a_in->tile == 4;
     if (allow4w) { a_copy = *a_in; a_copy.tile = 0; }
     const dwm_gemm_args* a = allow4w ? &a_copy : a_in;
     if (a == nullptr || a->A == nullptr || a->W == nullptr || (a->C == nullptr && a->C32 == nullptr)) return DWM_EINVAL;
@@ -1105,12 +1107,10 @@ extern "C" int dwm_gemm_bf16(const dwm_gemm_args* a_in, void* stream) {
     }
     if (a->C32 != nullptr && a->epilogue != DWM_EPI_RESID) return DWM_EUNSUPPORTED;
     {
-        // DWM_GEMM4W: unset = as the caller asks (tile == 3), 1 = every covered launch, 0 = never, f = as the caller asks but only the
-        // fast form (gemm_bf16_4w.hip)
-        static const int env4w = [] { const char* v = getenv("DWM_GEMM4W"); return (v == nullptr || v[0] == '\0' || v[0] == 'f') ? -1 : (v[0] != '0' ? 1 : 0); }();
-        const bool use4w = env4w < 0 ? allow4w : env4w == 1;
+        // (kernel selection comes from the arguments only: the library reads no environment)
+        const bool use4w = allow4w;
         if (use4w && !DWM_RESERVED(a->reserved) && a->lda % 64 == 0) {
-            const int rc4 = dwm_gemm4w_try(a, stream);
+            const int rc4 = dwm_gemm4w_try(a, stream, fast_only4w);
             if (rc4 >= 0) return rc4;
         }
     }

@@ -1,7 +1,7 @@
 // bf16 GEMM with the fused epilogues of gemm_bf16.hip on a 4-WAVE main loop:  C[M,Nout] = epi(A[M,K] · W[N,K]^T)
 //
-// Used where the caller asks for it (dwm_gemm_args.tile == 3: the MMDiT inference forward and the MMDiT train step; or environment
-// DWM_GEMM4W=1 for every covered launch).  The other callers (UNet, VAEs) keep the 8-wave kernels of gemm_bf16.hip: measured slower
+// Used where the caller asks for it (dwm_gemm_args.tile == 3 / 4: the MMDiT inference forward and the MMDiT train step; the Python
+// host side maps environment DWM_GEMM4W=1 to tile 3 on every call - the library itself reads no environment).  The other callers (UNet, VAEs) keep the 8-wave kernels of gemm_bf16.hip: measured slower
 // on this tile for the UNet's N = 320 / 640 shapes (profiles/r5a_*: 73.9 -> 75.6 ms per step).
 //
 // Geometry = what hipBLASLt's gfx950 kernel for these shapes does (Custom_Cijk_Alik_Bljk_..._MT256x256x64_MI16x16x1, disassembled
@@ -24,6 +24,8 @@
 // residual + blend, on the fp32 stream (RF32, no bf16 copy) or in bf16.
 // Covered launches (everything else stays on gemm_bf16.hip): no row maps, no taps, no split-K, M % 256 == N % 256 == K % 64 == 0.
 // General form (template parameter GEN): ragged M / N, the A row map, taps, the per-image residual row - see dwm_gemm4w_try.
+#include <atomic>
+
 #include "common.h"
 #include "dwm_hip.h"
 
@@ -459,9 +461,10 @@ gemm4w_kernel(const dwm_gemm_args p, const G4Params gp) {
     }
 }
 
-int64_t g_launches = 0;                           // launches served by this file in this process (dwm_gemm4w_launches)
-
-int64_t g_launches_gen = 0;                       // ... of them in the general form
+// launches served by this file in this process (dwm_gemm4w_launches) and, of them, in the general form: diagnostics counters, the only
+// process-wide state of this file - atomic (relaxed), any thread may launch (autograd's backward thread does)
+std::atomic<int64_t> g_launches{0};
+std::atomic<int64_t> g_launches_gen{0};
 
 template <int EPI, bool RF32, int RS, bool GEN = false>
 int launch4w(const dwm_gemm_args* a, const G4Params& gp, hipStream_t s) {
@@ -472,8 +475,8 @@ int launch4w(const dwm_gemm_args* a, const G4Params& gp, hipStream_t s) {
         attr = true;
     }
     hipLaunchKernelGGL((gemm4w_kernel<EPI, RF32, RS, GEN>), dim3((unsigned)(gp.ntm * gp.ntn)), dim3(256), LDS_BYTES, s, *a, gp);
-    ++g_launches;
-    if (GEN) ++g_launches_gen;
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    if (GEN) g_launches_gen.fetch_add(1, std::memory_order_relaxed);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }
@@ -487,9 +490,8 @@ int launch4w(const dwm_gemm_args* a, const G4Params& gp, hipStream_t s) {
 //   general form (GEN; validated on the GPU in round 5, profiles/r5a_*: 22-call battery against fp64 / conv2d and the 8-wave kernels,
 //   393.8 -> 389.4 ms per denoise step on one box): ragged M / N (N % 8 == 0; GEGLU / RMSHEAD: N % 64 == 0), an A row map, taps
 //   (implicit convolution), the per-image residual row (res_mod < 0) - no OUTPUT row map, no split-K.
-int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream) {
-    // DWM_GEMM4W=f: the fast form only (A/B measurements of the general form)
-    static const bool fast_only = [] { const char* v = getenv("DWM_GEMM4W"); return v != nullptr && v[0] == 'f'; }();
+int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream, bool fast_only) {
+    // fast_only (dwm_gemm_args.tile == 4): the fast form only (A/B measurements of the general form)
     const int64_t lim = 1ll << 31;
     if (a->c_map.rw > 0 || a->split_k > 1 || a->tile == 1 || a->tile == 2) return -1;        // (tile 1 / 2: an 8-wave configuration was asked for)
     if (a->K % BK != 0 || a->K < 2 * BK) return -1;        // (one K step: a known bad corner of the request form)
@@ -578,5 +580,5 @@ int dwm_gemm4w_try(const dwm_gemm_args* a, void* stream) {
 #undef DWM4_GO
 }
 
-extern "C" int64_t dwm_gemm4w_launches(void) { return g_launches; }
-extern "C" int64_t dwm_gemm4w_launches_general(void) { return g_launches_gen; }
+extern "C" int64_t dwm_gemm4w_launches(void) { return g_launches.load(std::memory_order_relaxed); }
+extern "C" int64_t dwm_gemm4w_launches_general(void) { return g_launches_gen.load(std::memory_order_relaxed); }

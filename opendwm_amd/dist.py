@@ -112,14 +112,19 @@ def preflight(device: torch.device = None, mbytes: int = 64) -> dict:
     import socket
     host = int.from_bytes(hashlib.sha256(socket.gethostname().encode()).digest()[:7], "little")
     index = device.index if on_gpu and device.index is not None else (torch.cuda.current_device() if on_gpu else -1 - rank)
-    mine = torch.tensor([host, device_identity(device) if on_gpu else -1 - rank, index, os.getpid()], dtype=torch.int64, device=dev)
+    visible = torch.cuda.device_count() if on_gpu else 0
+    mine = torch.tensor([host, device_identity(device) if on_gpu else -1 - rank, index, os.getpid(), visible], dtype=torch.int64, device=dev)
     got = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)
-    ids = [tuple(int(v) for v in t.tolist()) for t in got]
-    if on_gpu:
-        check_distinct_devices(ids)
-    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True, distinct_devices=on_gpu,
-                hosts=len({i[0] for i in ids}))
+    rows = [tuple(int(v) for v in t.tolist()) for t in got]
+    ids = [r[:4] for r in rows]
+    checked = check_distinct_devices(ids, [r[4] for r in rows]) if on_gpu else False
+    # what the first multi-GPU run needs to diagnose itself: who answered, from where, on which physical device
+    info.update(allreduce_mbytes=mbytes, allreduce_ms=1e3 * max_over_ranks(dt, device), allreduce_sum_ok=True,
+                distinct_devices=(True if checked else "unchecked") if on_gpu else False,
+                hosts=len({i[0] for i in ids}), ranks_seen=len(rows),
+                ranks=[dict(rank=r, host_hash=f"{i[0]:014x}", pci=pci_string(i[1]), device_index=i[2], pid=i[3], visible_devices=v[4])
+                       for r, (i, v) in enumerate(zip(ids, rows))])
     return info
 
 
@@ -144,19 +149,35 @@ def device_identity(device: torch.device) -> int:
         return -1
 
 
-def check_distinct_devices(ids) -> None:
-    """ids: one (host hash, PCI identity, device index, pid) per rank - or (host hash, device index, pid).  Raises if two ranks
-    of one host selected the same device: the same PCI address AND the same index (ranks that each see only their own GPU all
-    report index 0 with different addresses; partitions of one GPU share the address and differ in the index)."""
+def pci_string(identity: int):
+    """device_identity() as "dddd:bb:dd" (None if the build does not report it)"""
+    if identity is None or identity < 0:
+        return None
+    return f"{identity >> 16:04x}:{(identity >> 8) & 0xff:02x}:{identity & 0xff:02x}"
+
+
+def check_distinct_devices(ids, visible=None) -> bool:
+    """ids: one (host hash, PCI identity, device index, pid) per rank - or (host hash, device index, pid); visible: the number of
+    GPUs each rank sees (optional).  Raises if two ranks of one host selected the same device: the same PCI address AND the same
+    index (ranks that each see only their own GPU all report index 0 with different addresses; partitions of one GPU share the
+    address and differ in the index).  Returns True if the check was made, False if it had to be skipped."""
     key = [t[:-1] for t in ids]
     if any(len(t) == 4 and t[1] < 0 for t in ids):
-        # this PyTorch build does not report PCI addresses: ranks that each see only their own GPU all report (host, -1, 0) and
-        # cannot be told apart - a correct launch must not be aborted on that; warn and skip the check
+        # this PyTorch build does not report PCI addresses.  Ranks that see ALL GPUs of their node (torchrun's default: more than
+        # one visible device) are still told apart by (host, index): a duplicate there is two ranks on one GPU.  Ranks that each see
+        # only their own GPU all report (host, -1, 0) and cannot be told apart - a correct launch must not be aborted on that.
+        if visible is not None and len(visible) == len(ids) and all(v > 1 for v in visible):
+            hk = [(t[0], t[2]) for t in ids]
+            if len(set(hk)) != len(hk):
+                raise RuntimeError(f"preflight: ranks share a GPU: (host hash, PCI identity, device index, pid) = {list(ids)}")
+            return True
         import warnings
-        warnings.warn("preflight: the device PCI identity is not available in this PyTorch build; the distinct-device check is skipped")
-        return
+        warnings.warn("preflight: the device PCI identity is not available in this PyTorch build and every rank sees one device; "
+                      "the distinct-device check is skipped")
+        return False
     if len(set(key)) != len(key):
         raise RuntimeError(f"preflight: ranks share a GPU: (host hash, [PCI identity,] device index, pid) = {list(ids)}")
+    return True
 
 
 def measure_allreduce(nbytes: int, device: torch.device = None, dtype: torch.dtype = torch.float32, repeat: int = 3) -> float:

@@ -288,6 +288,8 @@ class DiTCrossviewTemporalConditionModel(_Base):
                 m._cache = {}
             if hasattr(m, "_wcache"):
                 m._wcache = {}
+            if hasattr(m, "_alpha_cache"):
+                m._alpha_cache = None            # AlphaBlender.get_alpha (also keyed on STORE.step, bumped below)
         self._adapter_cache = (None, None)
         from .blocks import STORE
         STORE.bump()

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -273,7 +274,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                 raise RuntimeError(f"gemm: {name} must be a padded grid when c_grid is given")
     g.reserved = _debug
     g.split_k = split_k
-    g.tile = 3 if (tile == 0 and getattr(_G4W, "on", False)) else tile          # 3: automatic + the 4-wave kernels may serve the launch
+    g.tile = _gemm_tile_request(tile)
     # split-K scratch (fp32 partial tiles): only handed over when the kernel's own rule can take it
     if split_k != 1 and epilogue in (EPI_PLAIN, EPI_RESID) and ((M + 255) // 256) * ((N + 255) // 256) <= 128 and K >= 1024:
         ws = _gemm_workspace(a.device)
@@ -287,8 +288,32 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 # ("automatic, and the 4-wave kernels may serve the launch").  Everything else - UNet, VAEs, direct ops.gemm calls - keeps the 8-wave
 # kernels.  The switch is per thread (no module global to race on between models / streams driven from different threads); autograd
 # runs backward on its own thread, so the training Functions re-open the scope there (`scope_of` / `capture_scope`).
-# Environment DWM_GEMM4W=0 / 1 overrides it in the library.
+# Environment DWM_GEMM4W (read HERE, on the host side - the library takes its kernel selection from dwm_gemm_args only): 0 = never,
+# 1 = every automatic-tile launch, f = as the scope asks but the fast form only (dwm_gemm_args.tile = 4).
 _G4W = threading.local()
+_G4W_ENV = os.environ.get("DWM_GEMM4W", "")
+
+
+# Environment DWM_ATTN_VARIANT (an integer, e.g. 0x1000): bits OR-ed into dwm_attn_args.variant of every ops.attention call (A/B
+# measurements of the attention kernels; the library reads no environment).  DWM_ATTN_RES4=1 / 2 = bits 12 / 12 + 13 (round 5's name).
+_ATTN_ENV_VARIANT = int(os.environ.get("DWM_ATTN_VARIANT", "0") or "0", 0) | \
+    {"1": 1 << 12, "2": (1 << 12) | (1 << 13)}.get(os.environ.get("DWM_ATTN_RES4", "")[:1], 0)
+
+
+def _gemm_tile_request(tile: int) -> int:
+    """dwm_gemm_args.tile of one launch: the caller's explicit configuration (1 / 2), else 3 / 4 ("automatic, and the 4-wave kernels may
+    serve the launch" / "... their fast form only") inside a gemm_4wave_scope or under DWM_GEMM4W=1"""
+    if tile != 0:
+        return tile
+    env = _G4W_ENV[:1]
+    on = getattr(_G4W, "on", False)
+    if env == "0":
+        return 0
+    if env == "f":
+        return 4 if on else 0
+    if env not in ("", "0"):
+        return 3
+    return 3 if on else 0
 
 
 def gemm_4wave_enabled() -> bool:
@@ -598,7 +623,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     receives the negative log2-domain log-sum-exp the backward needs."""
     a = _lib.AttnArgs()
     keep = _attn_args(a, q, k, v, out, rowmap, heads, q1, k1, v1, out1, scale, group_mask, dense_mask)
-    a.variant = variant
+    a.variant = variant | _ATTN_ENV_VARIANT
     if lse is not None:
         if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != a.n_problems * heads * (a.L0 + a.L1):
             raise RuntimeError("lse: fp32 contiguous [n_problems, heads, L0+L1] expected")

@@ -393,8 +393,13 @@ class CTSDTrainer:
         # unscaled before the clip, and a step whose gradients hold an inf / nan is SKIPPED and halves the scale.
         self.grad_scaler = None
         if self.training_config.get("enable_grad_scaler", False):
-            if self.common_config.get("distribution_framework", "ddp") != "ddp":
-                raise NotImplementedError("enable_grad_scaler with distribution_framework != 'ddp' (ShardedGradScaler / FSDP) - SURVEY.md s2")
+            # ctsd.py:1040-1048: a plain GradScaler unless torch.distributed is initialised AND the framework is fsdp (then the
+            # reference takes ShardedGradScaler, which belongs to the FSDP wrap this package does not build) - a single-process run of
+            # a shipped fsdp config gets the plain scaler, as in the reference
+            import torch.distributed as _dist
+            if (self.common_config.get("distribution_framework", "ddp") != "ddp" and _dist.is_available() and _dist.is_initialized()):
+                raise NotImplementedError("enable_grad_scaler with distribution_framework != 'ddp' in a distributed run "
+                                          "(ShardedGradScaler / FSDP) - SURVEY.md s2")
             dev_type = next(model.parameters()).device.type
             self.grad_scaler = torch.amp.GradScaler(dev_type)
         self.weighting_scheme = weighting_scheme

@@ -390,3 +390,11 @@ def test_preflight_device_check_is_per_host():
     D.check_distinct_devices([(11, 0x500, i, 60 + i) for i in range(4)])
     with pytest.raises(RuntimeError, match="share a GPU"):
         D.check_distinct_devices([(11, 0x500, 0, 1), (11, 0x600, 0, 2), (11, 0x500, 0, 3)])
+    # no PCI identity in the build: ranks that see all GPUs of the node are still checked by (host, index); ranks that see one
+    # device each cannot be told apart - skipped (False), never an abort of a correct launch
+    assert D.check_distinct_devices([(11, -1, i, 70 + i) for i in range(8)], [8] * 8) is True
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        D.check_distinct_devices([(11, -1, 0, 1), (11, -1, 1, 2), (11, -1, 1, 3)], [8, 8, 8])
+    with pytest.warns(UserWarning):
+        assert D.check_distinct_devices([(11, -1, 0, 80 + i) for i in range(8)], [1] * 8) is False
+    assert D.pci_string(0x00012a00) == "0001:2a:00" and D.pci_string(-1) is None
