@@ -98,6 +98,10 @@ class ParamStore:
 
 
 STORE = ParamStore()
+# inference: fold the softmax scale and log2(e) into the q RMSNorm weights (Attention.packed "rms_ps") and tell the attention kernels so
+PRESCALE_Q = True
+# dwm_attn_args.variant bits OR-ed into the inference blocks' attention calls (kernel selection; 0 = the library's choice)
+ATTN_VARIANT = 0
 
 
 def _bf(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -239,21 +243,34 @@ class Attention(nn.Module):
                 return w, b
             pk = {}
             pk["wqkv"], pk["bqkv"] = fuse(self.to_q, self.to_k, self.to_v)
+            # "rms": the q / k RMSNorm weights per column of the fused projection; "rms_ps" (inference): the same with the softmax scale
+            # and log2(e) folded into the q columns, so that the attention kernels take the scores as log2-domain without rescaling
+            # their Q fragments (dwm_attn_args.variant bit 15; one rounding of q instead of two).  Training keeps "rms".
+            def rms_cols(nq, nk, fold):
+                wq = nq.weight.detach().float() * (self.dim_head ** -0.5 * 1.4426950408889634) if fold else nq.weight
+                return torch.cat([_bf(wq).repeat(self.heads), _bf(nk.weight).repeat(self.heads)]).contiguous()
             if self.has_qk_norm:
-                pk["rms"] = torch.cat([_bf(self.norm_q.weight).repeat(self.heads),
-                                       _bf(self.norm_k.weight).repeat(self.heads)]).contiguous()
+                pk["rms"] = rms_cols(self.norm_q, self.norm_k, False)
+                pk["rms_ps"] = rms_cols(self.norm_q, self.norm_k, True)
             if self.added_kv:
                 pk["wadd"], pk["badd"] = fuse(self.add_q_proj, self.add_k_proj, self.add_v_proj)
                 if self.has_qk_norm:
-                    pk["rms_add"] = torch.cat([_bf(self.norm_added_q.weight).repeat(self.heads),
-                                               _bf(self.norm_added_k.weight).repeat(self.heads)]).contiguous()
+                    pk["rms_add"] = rms_cols(self.norm_added_q, self.norm_added_k, False)
+                    pk["rms_add_ps"] = rms_cols(self.norm_added_q, self.norm_added_k, True)
             return pk
         return STORE.cached(self, make)
 
+    @property
+    def attn_variant(self) -> int:
+        """dwm_attn_args.variant bits that go with what `project_qkv` produces: bit 15 when q leaves it pre-scaled"""
+        return ops.ATTN_Q_PRESCALED if (self.has_qk_norm and PRESCALE_Q) else 0
+
     def project_qkv(self, x: torch.Tensor, added: bool = False) -> torch.Tensor:
-        """x [rows, dim] -> fused [rows, 3*inner] with q,k RMS-normalised per head."""
+        """x [rows, dim] -> fused [rows, 3*inner] with q,k RMS-normalised per head (q scaled by head_dim^-1/2 log2(e) as well when
+        `attn_variant` says so: pass that to ops.attention)."""
         pk = self.packed()
-        w, b, rms = (pk["wadd"], pk["badd"], pk.get("rms_add")) if added else (pk["wqkv"], pk["bqkv"], pk.get("rms"))
+        ps = "_ps" if self.attn_variant else ""
+        w, b, rms = (pk["wadd"], pk["badd"], pk.get("rms_add" + ps)) if added else (pk["wqkv"], pk["bqkv"], pk.get("rms" + ps))
         if rms is None:
             return ops.gemm(x, w, b)
         if self.dim_head != 64:
@@ -310,12 +327,13 @@ class JointTransformerBlock(nn.Module):
         ao = _act_like(h)
         cao = _act_like(c)
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, ops.rowmap_identity(n_img, N), self.heads,
-                      q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cao)
+                      q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cao, variant=self.attn.attn_variant | ATTN_VARIANT)
         to_out = self.attn.to_out[0]
         _resid_into(h, ao, _bf(to_out.weight), _bf(to_out.bias), gate=sl(mod, 2), rows_per_gate=N)
         if self.use_dual_attention:
             qkv2 = self.attn2.project_qkv(nh2)
-            ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], ao, ops.rowmap_identity(n_img, N), self.heads)
+            ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], ao, ops.rowmap_identity(n_img, N), self.heads,
+                          variant=self.attn2.attn_variant | ATTN_VARIANT)
             to_out2 = self.attn2.to_out[0]
             _resid_into(h, ao, _bf(to_out2.weight), _bf(to_out2.bias), gate=sl(mod, 8), rows_per_gate=N)
         nh = ops.layernorm(h, eps=1e-6, scale=sl(mod, 4), shift=sl(mod, 3), rows_per_mod=N, out=nh, x32=x32)
@@ -438,7 +456,7 @@ class VTSelfAttentionBlock(nn.Module):
         qkv = self.attn1.project_qkv(y)
         ao = y     # norm1 output is dead once qkv exists
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, rowmap, self.heads,
-                      group_mask=group_mask, dense_mask=dense_mask)
+                      group_mask=group_mask, dense_mask=dense_mask, variant=self.attn1.attn_variant | ATTN_VARIANT)
         to_out = self.attn1.to_out[0]
         _resid_into(xs, ao, _bf(to_out.weight), _bf(to_out.bias))
 

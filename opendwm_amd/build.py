@@ -15,14 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdwm_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_bf16_4w.hip", "gemm_tn.hip", "attention.hip", "attention_res4.hip", "attention_bwd.hip", "norm.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_bf16_4w.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_bwd.hip", "norm.hip",
            "elementwise.hip", "vae.hip", "train.hip", "fp32path.hip"]
 # translation units built without -amdgpu-mfma-vgpr-form (accumulators allowed into AGPRs): the 4-wave GEMM keeps the 256 accumulator
 # registers of a wave there, the one-wave-per-SIMD attention the output accumulators of up to five query tiles
-AGPR_SOURCES: set = {"gemm_bf16_4w.hip", "attention_res4.hip"}
-# per-file flags.  attention_res4.hip: the row-sum adds of its tile loop must stay scalar (left alone the SLP vectoriser packs the adds
+AGPR_SOURCES: set = {"gemm_bf16_4w.hip", "attention_stream.hip"}
+# per-file flags.  attention_stream.hip: the row-sum adds of its tile loop must stay scalar (left alone the SLP vectoriser packs the adds
 # of two slices into v_pk_add_f32 bunched behind the later one; packed fp32 VALU beside MFMAs costs more than the adds it replaces)
-FILE_FLAGS: dict = {"attention_res4.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS: dict = {"attention_stream.hip": ["-fno-slp-vectorize"]}
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's unified file) so the VALU epilogues / softmax read them
 # without v_accvgpr_read/write copies
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]

@@ -1339,7 +1339,7 @@ void launch_attn(const AttnParams& P, hipStream_t s) {
 }  // namespace
 
 // attention_res4.hip
-int dwm_attn_res4_launch(const dwm_attn::AttnParams& P, unsigned nblk, size_t lds, bool ilv, hipStream_t s);
+int dwm_attn_stream_launch(const dwm_attn::AttnParams& P, unsigned nblk, hipStream_t s);
 
 extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
     AttnParams P;
@@ -1468,20 +1468,12 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             if (nwc < 1 || nwc > 12) return DWM_EINVAL;
             P.nwc = nwc;
         }
-        // one-wave-per-SIMD form (attention_res4.hip: 4 waves, all query tiles of a wave in one pass over the keys): 8..20 query
-        // tiles (225 <= L <= 608).  OPT-IN (variant bit 12, or DWM_ATTN_RES4=1 / 2 for every covered launch): validated on the GPU
-        // (tests/test_round5_kernels_gpu.py) but measured SLOWER than attn_res_kernel - 620 against 750-760 TFLOP/s at L = 602
-        // (profiles/r5i_*): its tile loop is faster (34-35 k against ~45 k cycles per head) but the fetch of the next head between two
-        // heads costs ~22 k cycles however it is issued (attention_res4.hip: res4_copy_head), against 7 k hidden in the skew of 12 waves.
-        // bit 13: the alternating MFMA order of its tile loop; bit 14: start stagger (DWM_ATTN_STAGGER=n sets the stagger unit).
+        // one-wave-per-SIMD streaming form (attention_stream.hip: 4 waves, all query tiles of a wave in one pass over the keys, V
+        // double-buffered in LDS, K fragments from global memory, Q in AGPRs): 8..20 query tiles (225 <= L <= 608), variant bit 12.
         {
             const int nqt = (P.qend + 31) >> 5;
             const bool want4 = ((a->variant >> 12) & 1) != 0;
-            if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
-                const bool ilv = ((a->variant >> 13) & 1) != 0;
-                P.stagger = (a->variant >> 14) & 1;     // start stagger in units of 8128 cycles, default off
-                return dwm_attn_res4_launch(P, nblk, lds, ilv, s);
-            }
+            if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) return dwm_attn_stream_launch(P, nblk, s);
         }
         static bool attr_set = false;
         if (!attr_set) {

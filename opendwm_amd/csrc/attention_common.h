@@ -40,7 +40,6 @@ struct AttnParams {
     float scale;
     int n_problems, heads, nqb;
     int nwc;                 // attn_res_kernel: compute waves
-    int stagger;             // attn_res4_kernel: start stagger in units of 8128 cycles per (workgroup / 8 mod 8); 0 = none
     int safe_softmax;        // attn_res_kernel: online softmax (running max) for every unit instead of the max-free fast path
     int hpb;                 // heads per workgroup (forward); fd_heads then divides by heads / hpb
     FastDiv fd_nqb, fd_heads, fd_gs, fd_G, fd_ppm;
@@ -208,6 +207,10 @@ inline int fill_params(const dwm_attn_args* a, AttnParams& P) {
     P.n_problems = (int)a->n_problems; P.heads = a->heads;
     P.scale = a->scale;
     P.scale_log2 = a->scale * 1.4426950408889634f;
+    if ((a->variant >> 15) & 1) {         // Q arrives with scale * log2(e) folded in by its producer: the scores are log2-domain already
+        P.scale_log2 = 1.f;
+        P.scale = 0.6931471805599453f;
+    }
     P.mask_mode = a->mask_mode; P.mask = a->mask;
     P.mask_G = (int)a->mask_G; P.group_size = (int)a->group_size; P.p_per_mask = (int)a->p_per_mask;
     P.inv_group_size = a->group_size > 0 ? 1.f / (float)a->group_size : 0.f;

@@ -294,6 +294,9 @@ _G4W = threading.local()
 _G4W_ENV = os.environ.get("DWM_GEMM4W", "")
 
 
+ATTN_Q_PRESCALED = 1 << 15      # dwm_attn_args.variant: q arrives with scale * log2(e) folded in by its producer
+ATTN_STREAM = 1 << 12           # ... the one-wave-per-SIMD streaming form of the resident kernel (attention_stream.hip) where it covers the launch
+
 # Environment DWM_ATTN_VARIANT (an integer, e.g. 0x1000): bits OR-ed into dwm_attn_args.variant of every ops.attention call (A/B
 # measurements of the attention kernels; the library reads no environment).  DWM_ATTN_RES4=1 / 2 = bits 12 / 12 + 13 (round 5's name).
 _ATTN_ENV_VARIANT = int(os.environ.get("DWM_ATTN_VARIANT", "0") or "0", 0) | \

@@ -8,9 +8,11 @@ by the first call of round 5 (profiles/r5a_*), now defaults:
   * `DiTCrossviewTemporalConditionModel.stack_modulation` (dit.py): the AdaLN modulation rows of all joint blocks and norm_out from
     ONE stacked GEMM per forward (host-side restructuring over validated kernels) - small model against the oracle and against
     the per-block forward, three temporal types, and the stack rebuilt after a state-dict load.
-  * attn_res4_kernel (attention_res4.hip; opt-in, variant bit 12): the resident attention kernel with ONE wave per SIMD and up to five
-    query tiles per wave - every remainder class of its tile schedule, both softmax paths, both MFMA orders, item seams, a strided
-    row map - against the fp32 reference and against attn_res_kernel.  Correct, measured slower than attn_res_kernel (its header).
+  * attn_stream_kernel (attention_stream.hip, round 6; variant bit 12): the resident attention kernel with ONE wave per SIMD and up to
+    five query tiles per wave, V double-buffered in LDS, K fragments from global memory, Q in AGPRs (round 5's attn_res4_kernel with its
+    head seam removed) - every remainder class of its tile schedule, both softmax paths, item seams (one and several heads per item), a
+    strided row map, Q with the softmax scale folded in by the producer (variant bit 15) - against the fp32 reference and against
+    attn_res_kernel.
 (attn_res2_kernel, the 8-wave / two-tiles-per-wave form of round 4, measured 20 % SLOWER than attn_res_kernel - 611 against 769
 TFLOP/s at L = 602, profiles/r5a_microbench_attn_res2.log - and was deleted.)
 """
@@ -153,8 +155,8 @@ def _run_battery(mode, path):
 
 pytestmark = [pytest.mark.gpu]
 bf16 = torch.bfloat16
-R4 = 1 << 12                                           # variant bit 12: attn_res4_kernel (opt-in: one wave per SIMD, 2..5 query tiles per wave)
-FLIP = 1 << 13                                         # ... with the alternating MFMA order of its tile loop
+R4 = 1 << 12                                           # variant bit 12: attn_stream_kernel (one wave per SIMD, 2..5 query tiles per wave)
+PRE = 1 << 15                                          # variant bit 15: Q arrives with scale * log2(e) folded in
 
 
 @pytest.fixture(scope="module")
@@ -175,7 +177,7 @@ def _run(ops, qkv, cqkv, I, N, Lc, heads, rm, variant):
     return out, cout
 
 
-# attn_res4_kernel (variant bit 12) serves unmasked self-attention with 8..19 query tiles of 32 (225 <= L <= 608); wave w of its 4 takes nqt / 4
+# attn_stream_kernel (variant bit 12) serves unmasked self-attention with 8..19 query tiles of 32 (225 <= L <= 608); wave w of its 4 takes nqt / 4
 # (+ 1 for w < nqt % 4) adjacent tiles.  Sequence lengths: every tile count 8..19 (each split 2..5 tiles per wave, ragged and full last
 # tiles / key steps, one and two segments) + three lengths below the range (they stay on attn_res_kernel: same answers expected)
 @pytest.mark.parametrize("scale", [1.0, 8.0], ids=["unit_scores", "huge_scores_fallback"])
@@ -193,7 +195,7 @@ def test_attention_one_wave_per_simd_forms(dev, scale, I, N, Lc, heads):
                        q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
     base, cbase = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, 0)
     errs, same = {"old": max(rel_err(base, r0), rel_err(cbase, r1) if Lc else 0.0)}, {}
-    for variant in (R4, R4 | (heads << 8), R4 | 16, R4 | 16 | (heads << 8), R4 | FLIP, R4 | FLIP | 16, R4 | (1 << 14)):
+    for variant in (R4, R4 | (heads << 8), R4 | (1 << 8), R4 | 16, R4 | 16 | (heads << 8)):
         out, cout = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, variant)
         errs[variant] = max(rel_err(out, r0), rel_err(cout, r1) if Lc else 0.0)
         same[variant] = bool(torch.equal(out, base) and (not Lc or torch.equal(cout, cbase)))
@@ -229,6 +231,31 @@ def test_attention_one_wave_per_simd_across_item_seams(dev, I, N, Lc, heads, hs)
     assert max(errs) < TOL_KERNEL and whole < TOL_KERNEL
 
 
+@pytest.mark.parametrize("I,N,Lc,heads", [(3, 448, 154, 4), (2, 300, 0, 2)])
+def test_attention_prescaled_q(dev, I, N, Lc, heads):
+    """variant bit 15: the producer folded scale * log2(e) into Q (one rounding instead of two) - every kernel then takes the scores as
+    log2-domain; same answers as the scaled form within the rounding of Q"""
+    from opendwm_amd import ops
+    D = heads * 64
+    qkv = _rand((I * N, 3 * D), dev, 31)
+    cqkv = _rand((I * Lc, 3 * D), dev, 32) if Lc else None
+    rm = ops.rowmap_identity(I, N)
+    f, cf = qkv.float(), (cqkv.float() if Lc else None)
+    r0, r1 = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads,
+                       q1=cf[:, :D] if Lc else None, k1=cf[:, D:2 * D] if Lc else None, v1=cf[:, 2 * D:] if Lc else None)
+    c = 0.125 * 1.4426950408889634
+    qkv2, cqkv2 = qkv.clone(), (cqkv.clone() if Lc else None)
+    qkv2[:, :D] = (f[:, :D] * c).to(bf16)
+    if Lc:
+        cqkv2[:, :D] = (cf[:, :D] * c).to(bf16)
+    errs = {}
+    for variant in (PRE, PRE | R4, PRE | 32, PRE | R4 | 16):
+        out, cout = _run(ops, qkv2, cqkv2, I, N, Lc, heads, rm, variant)
+        errs[variant] = max(rel_err(out, r0), rel_err(cout, r1) if Lc else 0.0)
+    _log("attention_prescaled_q", I=I, N=N, Lc=Lc, heads=heads, **{str(k): v for k, v in errs.items()})
+    assert all(e < TOL_KERNEL for e in errs.values()), errs
+
+
 def test_attention_one_wave_per_simd_temporal_rowmap_multihead(dev):
     """through a strided row map (row-wise temporal attention: L = frames x row width), 24 heads in groups of 6"""
     from opendwm_amd import ops
@@ -240,7 +267,7 @@ def test_attention_one_wave_per_simd_temporal_rowmap_multihead(dev):
     f = qkv.float()
     ref, _ = _attn_ref(f[:, :D], f[:, D:2 * D], f[:, 2 * D:], rm.rows().to(dev), heads)
     errs = {}
-    for variant in (R4 | (6 << 8), R4 | (4 << 8), R4, R4 | FLIP, 0):
+    for variant in (R4 | (6 << 8), R4 | (4 << 8), R4 | (1 << 8), R4, 0):
         out = torch.full((R, D), float("nan"), dtype=bf16, device=dev)
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant)
         errs[variant] = rel_err(out, ref)
