@@ -1146,7 +1146,9 @@ def main():
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),
                          "share_of_step_time": (gm.get("ms", 0.0) / args.steps) / step_ms},
-            "roofline_attention": {"bound": "mfma", "kernel": "attn_res_kernel (K / V of a head resident in LDS; joint L=602, dual L=448, row-wise temporal L=448)",
+            "roofline_attention": {"bound": "mfma", "kernel": "attn_stream_kernel (attention_stream.hip: one wave per SIMD, V of a head double-buffered in LDS, K fragments "
+                                                              "from global memory, Q in AGPRs with the softmax scale folded in by the q RMSNorm; joint L=602, dual L=448, "
+                                                              "row-wise temporal L=448; round 5: attn_res_kernel)",
                                    "achieved": at.get("tflops"), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),

@@ -203,9 +203,11 @@ typedef struct dwm_attn_args {
                                                 * fast path with a checked fallback), bit 5 keep the tiled kernel (default for L <= 32:
                                                 * the packed short-sequence kernel; for unmasked self-attention with 64 <= L <= 608:
                                                 * the resident kernel), bit 7 per-wave form of the group-masked kernel, bits 8-11 heads
-                                                * per workgroup / item, bit 12 the one-wave-per-SIMD streaming form of the resident kernel
-                                                * (attention_stream.hip; 225 <= L <= 608).  Bit 15 is not a kernel choice: q arrives with
-                                                * scale * log2(e) folded in by its producer (`scale` is then ignored; forward kernels) */
+                                                * per workgroup / item.  Unmasked self-attention with 225 <= L <= 608 runs the one-wave-per-
+                                                * SIMD streaming form of the resident kernel (attention_stream.hip) by default; bit 13 keeps
+                                                * the 12-wave form (bit 12: the streaming form, as in round 5's opt-in).  Bit 15 is not a
+                                                * kernel choice: q arrives with scale * log2(e) folded in by its producer (`scale` is then
+                                                * ignored; forward kernels) */
     int32_t cross;                             /* 1: cross-attention - queries = segment 0 only, keys / values =
                                                 * segment 1 only (q1, k0, v0, o1 unused: pass q1 = q0, k0 = k1, v0 = v1);
                                                 * diffusers BasicTransformerBlock.attn2 (text conditioning of the SD 2.1 UNet) */

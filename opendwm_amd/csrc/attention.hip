@@ -1469,11 +1469,17 @@ extern "C" int dwm_attention_fwd(const dwm_attn_args* a, void* stream) {
             P.nwc = nwc;
         }
         // one-wave-per-SIMD streaming form (attention_stream.hip: 4 waves, all query tiles of a wave in one pass over the keys, V
-        // double-buffered in LDS, K fragments from global memory, Q in AGPRs): 8..20 query tiles (225 <= L <= 608), variant bit 12.
+        // double-buffered in LDS, K fragments from global memory, Q in AGPRs): the DEFAULT for 8..20 query tiles (225 <= L <= 608) -
+        // 778-808 against 740-755 TFLOP/s at L = 602, 655-690 against 590-610 at L = 448 (profiles/r6g2_*).  Variant bit 13 keeps
+        // attn_res_kernel (A/B measurements, tests), as does an explicit wave count (bits 0-3); bit 12 is accepted as "the
+        // streaming form" for older callers.
         {
             const int nqt = (P.qend + 31) >> 5;
-            const bool want4 = ((a->variant >> 12) & 1) != 0;
-            if (want4 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) return dwm_attn_stream_launch(P, nblk, s);
+            const bool keep12 = ((a->variant >> 13) & 1) != 0;
+            if (!keep12 && nqt >= 8 && nqt <= 20 && (a->variant & 15) == 0) {
+                const int rc4 = dwm_attn_stream_launch(P, nblk, s);
+                if (rc4 >= 0) return rc4;                 // (-1: a launch it does not cover after all - segment displacements, LDS)
+            }
         }
         static bool attr_set = false;
         if (!attr_set) {

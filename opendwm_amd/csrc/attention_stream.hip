@@ -35,7 +35,7 @@ template <int NT>
 struct StRegs {
     bf16x8 qf[NT][4];            // AGPRs ("a" operands of the S MFMAs)
     f32x16 ot[NT][2];            // AGPRs (builtin MFMA accumulators)
-    float ls[NT][2];
+    float ls[NT];                // row sums (one accumulator per tile: its two adds per chunk sit ~50 cycles apart - no chain to break)
     f32x16 s[2];
     bf16x8 p[2][2];
     bf16x8 kf[2][4];             // [key step parity][MFMA m]
@@ -47,9 +47,9 @@ struct StSrc {
     gbf16p k0, v0, q0;
     const int32_t *tab, *ntab;   // row tables (LDS) of the current / next head's item
     int64_t hoff, nhoff;         // column offset of the current / next head
-    int64_t seg1_delta;
     int L, L0, n;                // n: key steps per head
     int l31, half, lane, wave;
+    int vsw;                     // this lane's swizzled 16-byte chunk of a V row in an LDS-DMA request (a lane constant: see st_vdma)
     bool has_next;
     uint32_t nv_lds;             // LDS byte address of the next head's V image
 };
@@ -59,23 +59,27 @@ struct StSrc {
 // of four accumulates on one tuple, early-clobber destination, and the first VALU read of a chain's result >= 11 wait states behind
 // the chain's last MFMA (4 PV MFMAs or an explicit s_nop in between).
 DWM_DEVINL void st_mfma_s_first(f32x16& acc, const bf16x8& k, const bf16x8& q) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(k), "a"(q));
+    // (s_nop 3: where the register allocator keeps a Q tile in arch VGPRs after all - it does in some tile-count forms - it copies the
+    //  fragment into a scratch AGPR tuple right in front of the asm; a v_accvgpr_write -> MFMA A / B operand read needs wait states
+    //  (3 in LLVM's table for the accumulator-write case) that the hazard recogniser cannot place for an asm)
+    asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(k), "a"(q));
 }
 DWM_DEVINL void st_mfma_s(f32x16& acc, const bf16x8& k, const bf16x8& q) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
+    asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
 }
 DWM_DEVINL bf16x8 st_vread(const ResCtx& c, const char* vl, int s2, int dt) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + c.vra[dt] + s2 * (16 * 128)));
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + c.vrb[dt] + s2 * (16 * 128)));
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// row table entry of key step j (j >= n: step j - n of the next head), this lane's key row (clamped to the last row)
+// Row tables of this kernel: one int32 per token, its row's offset from q0 / k0 / v0 in 16-byte units with the segment-1 displacement
+// folded in (the host side refuses launches where that does not fit), padded to whole key steps with the last row's entry - no
+// segment select and no clamp on the way from an entry to an address.
+// row table entry of key step j (j >= n: step j - n of the next head), this lane's key row
 DWM_DEVINL int32_t st_ktab(const StSrc& x, int j) {
     const bool nxt = j >= x.n;
     const int jj = nxt ? j - x.n : j;
-    int key = jj * 32 + x.l31;
-    key = key < x.L ? key : x.L - 1;
-    return (nxt ? x.ntab : x.tab)[key];
+    return (nxt ? x.ntab : x.tab)[jj * 32 + x.l31];
 }
 // one 128-byte row of zeros in device memory: the source of every pad row (keys past the end of a ragged sequence).  A pad key then
 // scores exactly 0 (P' = 1, corrected in the row sum) and its V row is zero - without a branch or an EXEC mask anywhere in the tile loop
@@ -87,8 +91,8 @@ DWM_DEVINL gbf16p st_kptr(const StSrc& x, int j, int32_t tabv) {
     const bool nxt = j >= x.n;
     const int jj = nxt ? j - x.n : j;
     const int key = jj * 32 + x.l31;
-    const gbf16p row = x.k0 + (((int64_t)tabv << 3) + (key < x.L0 ? 0 : x.seg1_delta) + (nxt ? x.nhoff : x.hoff));
-    return (key < x.L ? row : (gbf16p)st_zero_row) + x.half * 8;
+    const gbf16p row = (x.k0 + (nxt ? x.nhoff : x.hoff)) + ((int64_t)(tabv + x.half) << 3);       // (half: the lane's 8 of 16 k values = one unit)
+    return key < x.L ? row : (gbf16p)st_zero_row + x.half * 8;
 }
 DWM_DEVINL void st_kload(bf16x8 (&kf)[4], const gbf16p kp, int m) {
     kf[m] = *(const __attribute__((address_space(1))) bf16x8*)(kp + m * 16);
@@ -96,15 +100,12 @@ DWM_DEVINL void st_kload(bf16x8 (&kf)[4], const gbf16p kp, int m) {
 // one LDS-DMA request of the next head's V rows: piece i = wave + 4 k (8 rows x 128 B, 16 B per lane, lane-linear destination; the chunk
 // swizzle of the image is applied on the source column)
 DWM_DEVINL int32_t st_vtab(const StSrc& x, int k) {
-    int r = k * 32 + x.wave * 8 + (x.lane >> 3);
-    r = r < x.L ? r : x.L - 1;
-    return x.ntab[r];
+    return x.ntab[k * 32 + x.wave * 8 + (x.lane >> 3)];
 }
 DWM_DEVINL void st_vdma(const StSrc& x, int k, int32_t tabv) {
     const int r = k * 32 + x.wave * 8 + (x.lane >> 3);
-    const int cl = x.lane & 7;
-    const gbf16p row = x.v0 + (((int64_t)tabv << 3) + (r < x.L0 ? 0 : x.seg1_delta) + x.nhoff);
-    const gbf16p src = (r < x.L ? row : (gbf16p)st_zero_row) + ((cl ^ (((r >> 1) & 1) << 2)) << 3);
+    // (the chunk swizzle (lane & 7) ^ 4 ((r >> 1) & 1) depends on bit 1 of the row only, which is bit 1 of lane >> 3: x.vsw)
+    const gbf16p src = r < x.L ? (x.v0 + x.nhoff) + ((int64_t)(tabv + x.vsw) << 3) : (gbf16p)st_zero_row + x.vsw * 8;
     const uint32_t dst = x.nv_lds + (uint32_t)(x.wave + 4 * k) * 1024u;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
 }
@@ -127,8 +128,13 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
 #ifndef ST_X_NO_KLOAD
     const gbf16p kp2 = st_kptr(x, k + 2, tk);
 #endif
+    const int32_t tv_now = tv;
 #ifndef ST_X_NO_DMA                                       // (ST_X_*: timing builds only - wrong results)
-    if (x.has_next) st_vdma(x, k, tv);                    // (wave-uniform; the adds of the tile loop are pinned against the sinking it invites)
+#ifndef ST_DMA_LATE
+    // (unconditional - the last head of a workgroup requests its own rows once more: a branch here splits the key step into basic
+    //  blocks, and the compiler then drains the K requests at the head of the second one - `s_waitcnt vmcnt(0)` in every step)
+    st_vdma(x, k, tv_now);
+#endif
     if (!LAST) tv = st_vtab(x, k + 1);
 #endif
 #ifndef ST_X_NO_KLOAD
@@ -162,6 +168,12 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
                     r.ot[tp][mi & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.vf[mi >> 1][mi & 1], r.p[par ^ 1][mi >> 1], fresh ? zero : r.ot[tp][mi & 1], 0, 0, 0);
                 }
                 if (!FIRST && t == 0) r.vf[mi >> 1][mi & 1] = st_vread(c, vlc, mi >> 1, mi & 1);
+#if !defined(ST_X_NO_DMA) && defined(ST_DMA_LATE)
+                // this wave's V request of the next head: in the LAST slot, behind the S MFMAs that wait for the K fragments of step k + 1 -
+                // those counted waits also cover every request in front of them in the queue, so the V request of this step must not sit
+                // there (it would be waited for a few hundred cycles after its issue); the one of step k - 1 is a whole step old by then
+                if (t == NT - 1 && mi == 0) st_vdma(x, k, tv_now);
+#endif
             }
             // slice ch of E(u): scores 2 ch, 2 ch + 1
             {
@@ -169,11 +181,11 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
                 const float pa = __builtin_amdgcn_exp2f(a), pb = __builtin_amdgcn_exp2f(b);
                 // (scalar adds - this file is built with -fno-slp-vectorize: packed fp32 VALU beside MFMAs costs more than the plain
                 //  adds it replaces, MI355X_MICROARCH.md "price of one filler")
-                float acc = r.ls[t][ch & 1];
+                float acc = r.ls[t];
                 acc += pa;
                 acc += pb;
                 asm volatile("" : "+v"(acc));               // pins the adds to their slice too
-                r.ls[t][ch & 1] = acc;
+                r.ls[t] = acc;
                 uint32_t w = pack_bf16x2(pa, pb);
                 asm volatile("" : "+v"(w));                 // pins the convert to its slice
                 pk[ch] = w;
@@ -257,7 +269,7 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     const int l31 = lane & 31;
     const int L = P.L, L0 = P.L0;
     const int Lp = (L + 31) & ~31;
-    const int Lt = (L + 3) & ~3;
+    const int Lt = Lp;                                       // table pitch: whole key steps (pad entries = the last row's)
     char* const vimg0 = smem;                                // two V images, then the row tables
     int32_t* const tabs = (int32_t*)(smem + 2 * Lp * 128);
     int32_t* const otab = tabs + 2 * Lt;
@@ -266,17 +278,29 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     ResCtx c;
     c.kimg = nullptr; c.vimg = vimg0; c.rowtab = tabs;
     c.L = L; c.L0 = L0; c.nsub = Lp >> 5;
-    c.l31 = l31; c.half = half; c.kswz = 0;
-    {
-        const int tr_u = lane & 15, tr_g = (lane >> 4) & 1;
+    c.kswz = 0;
+    StSrc x;
+    // this lane's constants of the tile loop (row / chunk offsets of its fragment reads and requests), derived from an OPAQUE copy of the
+    // lane id at the top of every head: as kernel-lifetime values they are live across the head seam - where the next head's 80 Q
+    // registers are in flight - and the 5-tile form spilled three of them there; their reloads in front of the tile loop are pending
+    // loads in the compiler's bookkeeping at the loop's head, which made it drain the K requests (vmcnt(0)) in every trip
+    auto lane_consts = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int hf = ln >> 5;
+        c.l31 = ln & 31; c.half = hf;
+        const int tr_u = ln & 15, tr_g = (ln >> 4) & 1;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const int dcol = dt * 32 + tr_g * 16 + (tr_u & 3) * 4;
-            const int keyA = half * 4 + (tr_u >> 2), keyB = keyA + 8;
+            const int keyA = hf * 4 + (tr_u >> 2), keyB = keyA + 8;
             c.vra[dt] = keyA * 128 + (((dcol >> 3) ^ (((keyA >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
             c.vrb[dt] = keyB * 128 + (((dcol >> 3) ^ (((keyB >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
         }
-    }
+        x.l31 = ln & 31; x.half = hf; x.lane = ln; x.wave = wave;
+        x.vsw = (ln & 7) ^ ((((ln >> 3) >> 1) & 1) << 2);
+    };
+    lane_consts();
     const int hpb = P.hpb;
     const int n_items = P.n_problems * (int)P.fd_heads.d;
     const int n_my = ((int)blockIdx.x < n_items) ? (n_items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -290,10 +314,11 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     };
     auto build_tab = [&](int32_t* tab, int32_t* ot, uint32_t prob) {
         const int64_t base0 = seg0_base(P.rm, (int)prob);
-        for (int l = tid; l < L; l += NW * 64) {
+        for (int lp = tid; lp < Lp; lp += NW * 64) {
+            const int l = lp < L ? lp : L - 1;
             const int64_t r0 = l < L0 ? seg0_row(P.rm, base0, l) : 0;
-            if (tab != nullptr) tab[l] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1) >> 3);
-            if (ot != nullptr) ot[l] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1) >> 3);
+            if (tab != nullptr) tab[lp] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1 + P.seg1_delta) >> 3);
+            if (ot != nullptr) ot[lp] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1 + P.oseg1_delta) >> 3);
         }
     };
     const int n = c.nsub;
@@ -301,11 +326,8 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     const float n_pad = (float)(Lp - L);
     const float scale_log2 = P.scale_log2;
 
-    StSrc x;
     x.k0 = (gbf16p)P.k0; x.v0 = (gbf16p)P.v0; x.q0 = (gbf16p)P.q0;
-    x.seg1_delta = P.seg1_delta;
     x.L = L; x.L0 = L0; x.n = n;
-    x.l31 = l31; x.half = half; x.lane = lane; x.wave = wave;
 
     // this lane's Q row of tile t of a head (rows past the last query: the last one - same Q, same output, same bytes stored)
     typedef const __attribute__((address_space(3))) int32_t* ltab_t;          // row tables: LDS reads (ds_read), never flat ones
@@ -313,7 +335,7 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
         int lq = (t0 + t) * 32 + l31;
         lq = lq < P.qend ? lq : P.qend - 1;
         asm volatile("" : "+v"(lq));               // (opaque: the row's kernel-invariant address parts are NOT to be kept across the tile loop)
-        return x.q0 + (((int64_t)tab[lq] << 3) + (lq < L0 ? 0 : P.seg1_delta) + ho + half * 8);
+        return (x.q0 + ho) + ((int64_t)(tab[lq] + half) << 3);
     };
     // development aid (-DDWM_ATTN_TRACE): shader-clock stamps of the 4 waves of workgroups 0-7 at 8 points of every head, written to the
     // (otherwise unused) lse buffer as int64 [8 workgroups][4 waves][64 heads][8] (scripts/experiments/attn_trace_stream.py)
@@ -337,14 +359,27 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             for (int ks = 0; ks < 4; ++ks) qn[t][ks] = *(const __attribute__((address_space(1))) bf16x8*)(qp + ks * 16);
         }
     };
+    // (behind an asm `s_waitcnt vmcnt(0)` the compiler still counts the K fragments requested before it as pending loads; merged with
+    //  the loop's own state at the head of the tile loop that made it drain every request - vmcnt(0) - once per two key steps in the
+    //  5-tile form.  The empty asm makes the fragments the results of this statement: nothing pending.)
+    auto launder_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(r.kf[i][0]), "+v"(r.kf[i][1]), "+v"(r.kf[i][2]), "+v"(r.kf[i][3]));
+    };
     // (the empty asm DEFINES the fragments as accumulator-class registers: without it the compiler keeps them in arch VGPRs and copies
     //  each one into a scratch AGPR tuple in front of every S MFMA - 4 extra instructions per MFMA and, worse, a v_accvgpr_write -> MFMA
     //  read without the wait states the hazard needs, which it cannot see inside the asm: wrong scores.  check_stream_asm.py audits it.)
-    auto take_q = [&](const bf16x8 (&qn)[NT][4]) {
+    auto take_q = [&](bf16x8 (&qn)[NT][4]) {
+        if (scale_log2 != 1.f) {                              // (one wave-uniform branch, not one per fragment)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qn[t][ks] = scale_frag(qn[t][ks], scale_log2);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) r.qf[t][ks] = scale_log2 == 1.f ? qn[t][ks] : scale_frag(qn[t][ks], scale_log2);
+            for (int ks = 0; ks < 4; ++ks) r.qf[t][ks] = qn[t][ks];
             asm volatile("" : "+a"(r.qf[t][0]), "+a"(r.qf[t][1]), "+a"(r.qf[t][2]), "+a"(r.qf[t][3]));
         }
     };
@@ -371,7 +406,8 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             st_kload(r.kf[0], kp0, m);
             st_kload(r.kf[1], kp1, m);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), as the builtin: the compiler's own bookkeeping sees the drain
+        launder_k();
         take_q(q0);
     }
     __syncthreads();
@@ -394,8 +430,12 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
 
         // ---- the unit: this wave's NT tiles against all keys of the head
         DWM_TRS(0);
+#ifdef DWM_ATTN_TRACE
+        trs[6] = 0;
+#endif
+        lane_consts();
 #pragma unroll
-        for (int t = 0; t < NT; ++t) r.ls[t][0] = r.ls[t][1] = 0.f;
+        for (int t = 0; t < NT; ++t) r.ls[t] = 0.f;
         {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             r.ot[NT - 1][0] = zero;                                // (the other tiles' first PV MFMAs take C = 0)
@@ -411,6 +451,9 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
         int32_t tk = st_ktab(x, 2), tv = st_vtab(x, 0);
         asm volatile("s_nop 15" : "+v"(r.s[0]));              // E(0, 0) follows at once: the wait states the compiler cannot know about
         st_block<NT, 0, true, false>(r, c, x, 0, tk, tv);
+        // (a drain the compiler sees, once per head: whatever it still counts as pending here - a spill reload of the head's set-up in the
+        //  5-tile form - is merged into its state at the head of the loop below and made it drain the K requests there in every trip)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         DWM_TRS(1);
         int k = 1;
         for (; k + 2 < n; k += 2) {
@@ -430,16 +473,13 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
         uint32_t ntab_a = (uint32_t)(uintptr_t)(ltab_t)ntab, otab_a = (uint32_t)(uintptr_t)(ltab_t)otab;
         asm volatile("" : "+s"(ntab_a), "+s"(otab_a));
         const ltab_t ntab_l = (ltab_t)(uintptr_t)ntab_a, otab_l = (ltab_t)(uintptr_t)otab_a;
-        bf16x8 qn[NT][4];
-        load_q(qn, ntab_l, nhoff);                              // (unconditional - the last head of a workgroup requests its own rows once more: a
-                                                                //  conditional hand-over would keep the old fragments live beside the new ones)
         // row sums: the two lanes of a query, minus the pad keys' contribution (exactly 1 each); acceptance test of the fast path
         bool ok = !force_safe;
         const float lmin = n_pad > 0.f ? 0.015625f : 5.421010862e-20f;
         float l_tot[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float l_half = r.ls[t][0] + r.ls[t][1];
+            const float l_half = r.ls[t];
             const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
             l_tot[t] = (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1])) - n_pad;
             ok = ok && (l_tot[t] >= lmin) && (l_tot[t] <= 1.8446744e19f);
@@ -448,7 +488,7 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             int lq = (t0 + t) * 32 + l31;
             lq = lq < P.qend ? lq : P.qend - 1;
             asm volatile("" : "+v"(lq));
-            return P.o0 + ((int64_t)otab_l[lq] << 3) + (lq < L0 ? 0 : P.oseg1_delta) + hoff;
+            return (P.o0 + hoff) + ((int64_t)otab_l[lq] << 3);
         };
 #ifdef ST_X_NO_FALLBACK
         ok = true;
@@ -464,15 +504,25 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {                                                // wave-uniform: redo the unit by the online softmax (st_fallback_tile)
+#ifdef DWM_ATTN_TRACE
+            trs[6] = 0x7fffffffu;                               // (trace builds: slot 6 flags a unit that took the fallback; l_tot of tile 0 in slot 7... see below)
+#endif
 #pragma unroll 1
             for (int t = 0; t < NT; ++t)
-                st_fallback_tile((const bf16_t*)q_ptr((ltab_t)tab, hoff, t), out_ptr(t), P.k0 + hoff, P.v0 + hoff, tab, P.seg1_delta, L, L0, n, scale_log2);
+                st_fallback_tile((const bf16_t*)q_ptr((ltab_t)tab, hoff, t), out_ptr(t), P.k0 + hoff, P.v0 + hoff, tab, 0, L, L0, n, scale_log2);
         }
+        // ---- the next head's Q rows: requested behind the stores (requested in front of them, their 80 registers are parked in the
+        //      accumulator file under the normalisation - which needs the data, i.e. waits for it before the first store is issued).
+        //      Unconditional - the last head of a workgroup requests its own rows once more: a conditional hand-over would keep the
+        //      old fragments live beside the new ones.
+        bf16x8 qn[NT][4];
+        load_q(qn, ntab_l, nhoff);
         // ---- head seam: everything this wave requested has landed (its V requests of the next head, Q, the first K fragments; the
         //      stores too - vmcnt counts them), the tables of the head after the next, one barrier
         DWM_TRS(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), as the builtin: the compiler's own bookkeeping sees the drain
         DWM_TRS(4);
+        launder_k();
         take_q(qn);
         if constexpr (NODD) {                                   // the next head's steps 0 / 1 were requested into sets 1 / 0
 #pragma unroll
@@ -539,8 +589,13 @@ int dwm_attn_stream_launch(const dwm_attn::AttnParams& P, unsigned nblk, hipStre
         (void)hipFuncSetAttribute((const void*)attn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int Lp = (P.L + 31) & ~31, Lt = (P.L + 3) & ~3;
-    const size_t lds = (size_t)2 * Lp * 128 + (size_t)3 * Lt * sizeof(int32_t);
+    // the row tables hold offsets from q0 / k0 / v0 / o0 with the segment-1 displacement folded in, in 16-byte units as int32: both
+    // displacements must be whole units and every offset must fit (otherwise: -1, the caller keeps attn_res_kernel)
+    const int64_t lim = 1ll << 33;
+    if (P.seg1_delta % 8 != 0 || P.oseg1_delta % 8 != 0 || P.seg1_delta <= -lim || P.seg1_delta >= lim || P.oseg1_delta <= -lim || P.oseg1_delta >= lim) return -1;
+    const int Lp = (P.L + 31) & ~31;
+    const size_t lds = (size_t)2 * Lp * 128 + (size_t)3 * Lp * sizeof(int32_t);
+    if (lds > 160 * 1024) return -1;
     hipLaunchKernelGGL(attn_stream_kernel, dim3(nblk), dim3(256), lds, s, P);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;

@@ -295,7 +295,8 @@ _G4W_ENV = os.environ.get("DWM_GEMM4W", "")
 
 
 ATTN_Q_PRESCALED = 1 << 15      # dwm_attn_args.variant: q arrives with scale * log2(e) folded in by its producer
-ATTN_STREAM = 1 << 12           # ... the one-wave-per-SIMD streaming form of the resident kernel (attention_stream.hip) where it covers the launch
+ATTN_STREAM = 1 << 12           # ... the one-wave-per-SIMD streaming form of the resident kernel (attention_stream.hip): the library's default where it covers the launch
+ATTN_RES12 = 1 << 13            # ... keep the 12-wave resident kernel there (A/B measurements)
 
 # Environment DWM_ATTN_VARIANT (an integer, e.g. 0x1000): bits OR-ed into dwm_attn_args.variant of every ops.attention call (A/B
 # measurements of the attention kernels; the library reads no environment).  DWM_ATTN_RES4=1 / 2 = bits 12 / 12 + 13 (round 5's name).

@@ -110,15 +110,16 @@ n_fresh = 0
 for k, (ln, t, a) in enumerate(flat):
     if a and t.startswith("v_mfma"):
         src = aregs(t.split(",")[2])
-        for j in range(max(0, k - 3), k):
+        states = 0                                            # wait states between the write and the MFMA (s_nop N = N + 1, anything else 1)
+        for j in range(k - 1, max(-1, k - 4), -1):
             ln2, t2, _ = flat[j]
             if t2.startswith(("v_accvgpr_write", "scratch_load", "global_load")) and (aregs(t2.split(",")[0]) & src):
                 n_fresh += 1
-                if n_fresh <= 5:
-                    problems.append(("q-operand", ln, f"AGPR operand written {k - j} instructions earlier (line {ln2})", t))
+                if states < 4:
+                    problems.append(("q-operand", ln, f"AGPR operand written {k - j} instructions earlier (line {ln2}) with {states} wait states", t))
                 break
-if n_fresh > 5:
-    problems.append(("q-operand", 0, f"... {n_fresh} asm MFMAs in all", ""))
+            m = re.match(r"s_nop (\d+)", t2)
+            states += int(m.group(1)) + 1 if m else 1
 
 n_qloads = 0
 pending = {}                    # register -> line of the load
@@ -148,7 +149,8 @@ for ln, raw in enumerate(text, 1):
             problems.append(("q-load", ln, f"a{min(hit)} named before its load (line {pending[min(hit)]}) was waited for", body))
             for rg in hit:
                 pending.pop(rg, None)
-print(f"{kernels} kernels, {n_asm} asm MFMAs checked, {n_qloads} in-place Q loads checked, {len(problems)} problems")
+print(f"{kernels} kernels, {n_asm} asm MFMAs checked, {n_fresh} of them with a Q fragment copied in front (it lives in arch VGPRs there), "
+      f"{n_qloads} in-place Q loads checked, {len(problems)} problems")
 for p in problems[:40]:
     print(p)
 sys.exit(1 if problems else 0)

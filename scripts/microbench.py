@@ -366,8 +366,8 @@ if __name__ == "__main__":
         bench_attn([0, 32 | 1])
     if "attnr" in what:                  # the resident kernel's launches only
         bench_attn([0], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
-    if "attnr4" in what:                 # 12-wave kernel (default) against the one-wave-per-SIMD streaming form (bit 12); bit 15: Q arrives pre-scaled
-        bench_attn([0, 1 << 12, (1 << 12) | (1 << 15), 1 << 15], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
+    if "attnr4" in what:                 # the one-wave-per-SIMD streaming form (default, 0) against the 12-wave kernel (bit 13); bit 15: Q arrives pre-scaled
+        bench_attn([1 << 13, 0, 1 << 15, (1 << 13) | (1 << 15)], only=("joint L=602", "dual L=448", "temporal rowwise L=448"))
     if "attnfull" in what:
         bench_attn_full()
     if "attnunet" in what:
