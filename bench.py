@@ -325,6 +325,18 @@ def pmc_traffic(kernel: str):
     return None
 
 
+def pmc_dram(kernel: str):
+    """the part of `pmc_traffic(kernel)` that HBM (not the Infinity Cache) served, from the TCC_EA0_*_DRAM request counters of the same
+    committed PMC file (round 6 on; None where the file has no such pass)"""
+    for name in PMC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]
+        except Exception:
+            continue
+        return (d.get("dram") or {}).get("dram_bytes_per_launch_est")
+    return None
+
+
 def pmc_traffic_file(kernel: str):
     """the committed PMC file that holds `kernel`'s traffic (the newest one that has a row for it)"""
     for name in PMC_FILES:
@@ -349,7 +361,7 @@ def gemm_traffic(by_kernel: dict):
     return tot / n if n else None
 
 
-PMC_FILES = ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json")
+PMC_FILES = ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json")
 
 
 def pmc_source() -> str:
@@ -1141,7 +1153,7 @@ def main():
                                          "Infinity-Cache (MALL) hits are counted, so this is an UPPER bound of the HBM bytes",
                          "by_kernel": {k: {kk: vv for kk, vv in v.items() if kk != "ms"} |
                                        {"share_of_step_time": (v["ms"] / args.steps) / step_ms, "traffic": pmc_traffic(k),
-                                        "traffic_source": pmc_traffic_file(k)}
+                                        "traffic_dram_est": pmc_dram(k), "traffic_source": pmc_traffic_file(k)}
                                        for k, v in (gm.get("by_kernel") or {}).items()},
                          "algorithmic_flop_per_launch": (gm.get("flops") or 0.0) / max(gm.get("launches") or 1, 1),
                          "launches": gm.get("launches"), "avg_launch_us": gm.get("avg_us"),

@@ -59,13 +59,10 @@ struct StSrc {
 // of four accumulates on one tuple, early-clobber destination, and the first VALU read of a chain's result >= 11 wait states behind
 // the chain's last MFMA (4 PV MFMAs or an explicit s_nop in between).
 DWM_DEVINL void st_mfma_s_first(f32x16& acc, const bf16x8& k, const bf16x8& q) {
-    // (s_nop 3: where the register allocator keeps a Q tile in arch VGPRs after all - it does in some tile-count forms - it copies the
-    //  fragment into a scratch AGPR tuple right in front of the asm; a v_accvgpr_write -> MFMA A / B operand read needs wait states
-    //  (3 in LLVM's table for the accumulator-write case) that the hazard recogniser cannot place for an asm)
-    asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(k), "a"(q));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(k), "a"(q));
 }
 DWM_DEVINL void st_mfma_s(f32x16& acc, const bf16x8& k, const bf16x8& q) {
-    asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
 }
 DWM_DEVINL bf16x8 st_vread(const ResCtx& c, const char* vl, int s2, int dt) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl + c.vra[dt] + s2 * (16 * 128)));
@@ -124,6 +121,11 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
     constexpr int PB = (NT & 1) ? KP : 0;                 // parity of unit (k, 0): k * NT mod 2
     const char* const vlc = c.vimg + k * 4096;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (the Q fragments as accumulator-class values at the head of every key step: should the register allocator hold a tile in arch
+    //  VGPRs across a step, its copies into the accumulator file land HERE - far in front of the asm MFMAs that read them - and not as
+    //  v_accvgpr_write right before an MFMA, whose wait states the hazard recogniser cannot place for an asm; check_stream_asm.py audits it)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(r.qf[t][0]), "+a"(r.qf[t][1]), "+a"(r.qf[t][2]), "+a"(r.qf[t][3]));
     // (the requests of this step use the entries read a step ago; the reads for the next step are issued now)
 #ifndef ST_X_NO_KLOAD
     const gbf16p kp2 = st_kptr(x, k + 2, tk);
@@ -230,6 +232,32 @@ DWM_DEVINL void st_store_tile(const uint4 (&v)[4], bf16_t* op, int half) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) *(uint4*)(op + dt * 32 + (2 * gp + half) * 8) = v[dt * 2 + gp];
+}
+// The same tile as FOUR stores of 16 rows x 64 contiguous bytes instead of four of 32 rows x 32 bytes.  A store instruction costs the
+// CU's vector memory path one request per 128-byte line it touches (measured: ~140 cycles for a store of 32 rows, 77 KiB per head at
+// ~9 B / cycle, three waves' worth at once at every head seam, profiles/r6g3_attn_stream_timeline_L602.txt); halving the lines per
+// instruction halves that.  After st_pack_tile lane (q, half) holds the 16-byte chunks half, 2 + half, 4 + half, 6 + half of ITS row q
+// (v[0..3]).  One v_permlane16_swap per dword between the lanes of rows q and q + 16 (q < 16) turns that into
+//     lanes q:      row q  chunks half, 4 + half        and   row q + 16  chunks half, 4 + half
+//     lanes q + 16: row q  chunks 2 + half, 6 + half    and   row q + 16  chunks 2 + half, 6 + half
+// so that the four lanes (q, 0), (q, 1), (q + 16, 0), (q + 16, 1) store chunks 0..3 (then 4..7) of one row in one instruction.
+// op_lo / op_hi: this lane's pointers to rows (l31 & 15) and (l31 & 15) + 16 of the tile.
+DWM_DEVINL void st_store_tile64(const uint4 (&v)[4], bf16_t* op_lo, bf16_t* op_hi, int l31, int half) {
+    uint32_t y[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, x[4] = {v[1].x, v[1].y, v[1].z, v[1].w};      // chunks half / 2 + half
+    uint32_t z[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, w[4] = {v[3].x, v[3].y, v[3].z, v[3].w};      // chunks 4 + half / 6 + half
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // lanes 16-31 (48-63) of the first operand <-> lanes 0-15 (32-47) of the second
+        const auto a = __builtin_amdgcn_permlane16_swap(y[i], x[i], false, false);
+        y[i] = a[0]; x[i] = a[1];             // y: rows q (lanes q: chunk half, lanes q + 16: chunk 2 + half); x: rows q + 16, the same chunks
+        const auto b = __builtin_amdgcn_permlane16_swap(z[i], w[i], false, false);
+        z[i] = b[0]; w[i] = b[1];             // z: rows q, chunks 4 + half / 6 + half; w: rows q + 16
+    }
+    const int ch = ((l31 >> 4) << 1) + half;                      // this lane's chunk inside a 64-byte run
+    *(uint4*)(op_lo + ch * 8) = make_uint4(y[0], y[1], y[2], y[3]);
+    *(uint4*)(op_lo + 32 + ch * 8) = make_uint4(z[0], z[1], z[2], z[3]);
+    *(uint4*)(op_hi + ch * 8) = make_uint4(x[0], x[1], x[2], x[3]);
+    *(uint4*)(op_hi + 32 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // The fallback of one query tile (a unit whose fast-path sums left the safe range: the textbook online softmax from global memory,
@@ -451,9 +479,6 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
         int32_t tk = st_ktab(x, 2), tv = st_vtab(x, 0);
         asm volatile("s_nop 15" : "+v"(r.s[0]));              // E(0, 0) follows at once: the wait states the compiler cannot know about
         st_block<NT, 0, true, false>(r, c, x, 0, tk, tv);
-        // (a drain the compiler sees, once per head: whatever it still counts as pending here - a spill reload of the head's set-up in the
-        //  5-tile form - is merged into its state at the head of the loop below and made it drain the K requests there in every trip)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
         DWM_TRS(1);
         int k = 1;
         for (; k + 2 < n; k += 2) {
@@ -484,12 +509,13 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             l_tot[t] = (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1])) - n_pad;
             ok = ok && (l_tot[t] >= lmin) && (l_tot[t] <= 1.8446744e19f);
         }
-        auto out_ptr = [&](int t) -> bf16_t* {
-            int lq = (t0 + t) * 32 + l31;
+        auto out_row = [&](int t, int row) -> bf16_t* {            // output row `row` (0..31) of tile t (rows past the last query: the last one)
+            int lq = (t0 + t) * 32 + row;
             lq = lq < P.qend ? lq : P.qend - 1;
             asm volatile("" : "+v"(lq));
             return (P.o0 + hoff) + ((int64_t)otab_l[lq] << 3);
         };
+        auto out_ptr = [&](int t) -> bf16_t* { return out_row(t, l31); };
 #ifdef ST_X_NO_FALLBACK
         ok = true;
 #endif
@@ -500,7 +526,11 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
                 const f32x16 o[2] = {r.ot[t][0], r.ot[t][1]};
                 uint4 pkd[4];
                 st_pack_tile(o, l_tot[t], pkd);
-                st_store_tile(pkd, out_ptr(t), half);
+                // (the 64-byte-run form measured +3..4 % on the whole kernel with 2..4 tiles per wave - L = 448: 664-695 against 648-668
+                //  TFLOP/s - and -2 % with 5, where its second row pointer and eight swaps per tile sit in the one place three waves are
+                //  serialised on the store path anyway: profiles/r6g5_*)
+                if constexpr (NT <= 4) st_store_tile64(pkd, out_row(t, l31 & 15), out_row(t, (l31 & 15) + 16), l31, half);
+                else st_store_tile(pkd, out_ptr(t), half);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {                                                // wave-uniform: redo the unit by the online softmax (st_fallback_tile)
