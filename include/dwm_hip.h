@@ -524,6 +524,20 @@ int dwm_groupnorm_bwd(const void* x, const void* dz, void* dx, int64_t I, int64_
                       const void* gamma, const void* beta, int32_t silu, int32_t accumulate, float* stats,
                       float* dgamma, float* dbeta, const dwm_rowmap2d* dz_map, const dwm_gn_imgmap* img_map, void* stream);
 
+/* Block permutation: dst block (i0, i1, i2, i3) <- src block at i0*sstride[0] + i1*sstride[1] + i2*sstride[2] + i3*sstride[3]
+ * (strides in blocks), blocks of `block_bytes` contiguous bytes (a multiple of 16; both buffers 16-byte aligned), dst dense in the
+ * order (i0, i1, i2, i3).  The pack / unpack around the frame-shard all-to-all (opendwm_amd/sharding.py: "my frames, all token rows" <->
+ * "all frames, my token rows" - no reference counterpart, the reference never shards a sample): one launch per direction instead of a
+ * torch permute + contiguous / copy_ pair. */
+typedef struct dwm_block_permute_args {
+    const void* src;
+    void* dst;
+    int64_t block_bytes;
+    int64_t n[4];
+    int64_t sstride[4];
+} dwm_block_permute_args;
+int dwm_block_permute(const dwm_block_permute_args* args, void* stream);
+
 /* y fp32 [rows, ldy] (+)= x bf16 [rows, ldx] */
 int dwm_cast_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols,
                          int32_t accumulate, void* stream);

@@ -89,6 +89,10 @@ class FrameMix(C.Structure):
     _fields_ = [("n_out", _i32), ("f0", _i32 * 64), ("f1", _i32 * 64), ("w0", _f32 * 64), ("w1", _f32 * 64)]
 
 
+class BlockPermuteArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("block_bytes", C.c_int64), ("n", C.c_int64 * 4), ("sstride", C.c_int64 * 4)]
+
+
 class RowCombineArgs(C.Structure):
     _fields_ = [
         ("a", _vp), ("lda", _i64), ("gate_a", _vp), ("ld_gate_a", _i64), ("rows_per_gate_a", _i64),
@@ -180,6 +184,7 @@ SIGNATURES = {
     "dwm_rmsnorm_heads_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dwm_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "dwm_adamw_multi": (_i32, [_vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "dwm_block_permute": (_i32, [C.POINTER(BlockPermuteArgs), _vp]),
     "dwm_cast_bf16_to_f32": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
     "dwm_groupnorm_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
                                  C.POINTER(RowMap2D), C.POINTER(GnImgMap), _vp]),

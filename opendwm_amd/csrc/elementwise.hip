@@ -553,3 +553,61 @@ extern "C" int dwm_add_inplace(void* y, const void* x, int64_t n, void* stream) 
                        (bf16_t*)y, (const bf16_t*)x, n / 8);
     return finish();
 }
+
+
+// ---- block permutation (frame-shard pack / unpack, see dwm_hip.h): one workgroup row per destination block
+namespace {
+struct BlockPermP {
+    const char* src; char* dst;
+    int64_t block_bytes, sstride[4];
+    FastDiv d1, d2, d3;                           // divisors n[1] * n[2] * n[3], n[2] * n[3], n[3]
+    uint32_t chunks;                              // workgroups per block
+};
+__global__ void __launch_bounds__(256)
+block_permute_kernel(const BlockPermP p) {
+    const uint32_t blk = blockIdx.x / p.chunks, ch = blockIdx.x - blk * p.chunks;
+    const uint32_t i0 = fdiv(blk, p.d1), r0 = blk - i0 * p.d1.d;
+    const uint32_t i1 = fdiv(r0, p.d2), r1 = r0 - i1 * p.d2.d;
+    const uint32_t i2 = fdiv(r1, p.d3), i3 = r1 - i2 * p.d3.d;
+    const char* __restrict__ s = p.src + ((int64_t)i0 * p.sstride[0] + (int64_t)i1 * p.sstride[1] + (int64_t)i2 * p.sstride[2] + (int64_t)i3 * p.sstride[3]) * p.block_bytes;
+    char* __restrict__ d = p.dst + (int64_t)blk * p.block_bytes;
+    const int64_t per = ((p.block_bytes / 16 + p.chunks - 1) / p.chunks + 255) / 256 * 256 * 16;      // bytes of this block per workgroup
+    const int64_t lo = (int64_t)ch * per, hi = lo + per < p.block_bytes ? lo + per : p.block_bytes;
+    for (int64_t o = lo + (int64_t)threadIdx.x * 16; o < hi; o += 4 * 256 * 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (o + u * 4096 < hi) v[u] = *(const uint4*)(s + o + u * 4096);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (o + u * 4096 < hi) *(uint4*)(d + o + u * 4096) = v[u];
+    }
+}
+}  // namespace
+
+extern "C" int dwm_block_permute(const dwm_block_permute_args* a, void* stream) {
+    if (a == nullptr || a->src == nullptr || a->dst == nullptr) return DWM_EINVAL;
+    if (a->block_bytes <= 0 || a->block_bytes % 16 != 0 || !dwm_aligned16(a->src) || !dwm_aligned16(a->dst)) return DWM_EALIGN;
+    int64_t nb = 1;
+    for (int i = 0; i < 4; ++i) {
+        if (a->n[i] <= 0 || a->sstride[i] < 0) return DWM_EINVAL;
+        nb *= a->n[i];
+    }
+    if (nb >= (1ll << 24)) return DWM_EUNSUPPORTED;
+    BlockPermP p;
+    p.src = (const char*)a->src; p.dst = (char*)a->dst; p.block_bytes = a->block_bytes;
+    for (int i = 0; i < 4; ++i) p.sstride[i] = a->sstride[i];
+    p.d1 = make_fastdiv((uint32_t)(a->n[1] * a->n[2] * a->n[3]));
+    p.d2 = make_fastdiv((uint32_t)(a->n[2] * a->n[3]));
+    p.d3 = make_fastdiv((uint32_t)a->n[3]);
+    // enough workgroups to fill the chip: >= 2048 in all, each with >= 16 KiB where the blocks are that large
+    int64_t chunks = (2048 + nb - 1) / nb;
+    const int64_t maxc = (a->block_bytes + 16383) / 16384;
+    if (chunks > maxc) chunks = maxc;
+    if (chunks < 1) chunks = 1;
+    if (nb * chunks >= (1ll << 31)) return DWM_EUNSUPPORTED;
+    p.chunks = (uint32_t)chunks;
+    hipLaunchKernelGGL(block_permute_kernel, dim3((unsigned)(nb * chunks)), dim3(256), 0, (hipStream_t)stream, p);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DWM_OK : (int)e;
+}

@@ -294,6 +294,24 @@ _G4W = threading.local()
 _G4W_ENV = os.environ.get("DWM_GEMM4W", "")
 
 
+def block_permute(src: torch.Tensor, dst: torch.Tensor, dims, src_strides, block_elems: int) -> torch.Tensor:
+    """dst (dense, blocks in the order dims = (n0, n1, n2, n3)) <- src block at sum(i_k * src_strides[k]) (strides in blocks); blocks of
+    `block_elems` contiguous elements.  dwm_block_permute: the pack / unpack of the frame-shard all-to-all (sharding.py)."""
+    if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype):
+        raise RuntimeError("block_permute: contiguous device tensors of one dtype expected")
+    a = _lib.BlockPermuteArgs()
+    a.src, a.dst = src.data_ptr(), dst.data_ptr()
+    a.block_bytes = block_elems * src.element_size()
+    n = 1
+    for i in range(4):
+        a.n[i], a.sstride[i] = dims[i], src_strides[i]
+        n *= dims[i]
+    if n * block_elems != src.numel() or dst.numel() != src.numel():
+        raise RuntimeError("block_permute: dims x block size do not cover the tensors")
+    _lib.check(_lib.load().dwm_block_permute(C.byref(a), _stream()), "dwm_block_permute")
+    return dst
+
+
 ATTN_Q_PRESCALED = 1 << 15      # dwm_attn_args.variant: q arrives with scale * log2(e) folded in by its producer
 ATTN_STREAM = 1 << 12           # ... the one-wave-per-SIMD streaming form of the resident kernel (attention_stream.hip): the library's default where it covers the launch
 ATTN_RES12 = 1 << 13            # ... keep the 12-wave resident kernel there (A/B measurements)

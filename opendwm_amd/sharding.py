@@ -34,6 +34,22 @@ def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group) -> None:
     dist.all_to_all_single(out, inp, group=group)
 
 
+def _permute_blocks(src: torch.Tensor, dims, src_strides, block_elems: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a dense copy of `src`'s blocks in the order `dims`, block (i0..i3) taken from block index sum(i_k * src_strides[k]) of `src`:
+    ONE HIP launch (dwm_block_permute) for device tensors - the pack / unpack of the exchange is not torch glue; host tensors (the
+    gloo CPU tests) go through the equivalent torch view"""
+    out = torch.empty_like(src) if out is None else out
+    if out.numel() != src.numel() or out.dtype != src.dtype or not out.is_contiguous():
+        raise ValueError("_permute_blocks: `out` must be a contiguous tensor of the source's size and dtype")
+    if src.is_cuda:
+        from . import ops
+        return ops.block_permute(src, out, dims, src_strides, block_elems)
+    flat = src.reshape(-1, block_elems)
+    idx = sum(torch.arange(dims[k]).view([-1 if i == k else 1 for i in range(4)]) * src_strides[k] for k in range(4)).reshape(-1)
+    out.view(-1, block_elems).copy_(flat[idx])
+    return out
+
+
 class FrameShard:
     """The frame-axis shard of one rank: rank r of R holds frames [r*T/R, (r+1)*T/R)."""
 
@@ -59,23 +75,27 @@ class FrameShard:
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         R, D = self.size, h.shape[-1]
         hl = height // R
-        send = h.view(B, Tl, V, R, hl, width, D).permute(3, 0, 1, 2, 4, 5, 6).contiguous()        # [dest j][b, tl, v, y, x]
+        blk = hl * width * D                                                                       # one (image, row block): contiguous
+        h = h.contiguous()
+        # pack: [b, tl, v, j] blocks -> [dest j][b, tl, v]
+        send = _permute_blocks(h, (R, B, Tl, V), (1, Tl * V * R, V * R, R), blk)
         recv = torch.empty_like(send)
-        all_to_all_chunks(recv, send, self.group)                                                  # [src j = frame block]
-        hx = out if out is not None else torch.empty((B * R * Tl * V * hl * width, D), dtype=h.dtype, device=h.device)
-        hx.view(B, R, Tl, V, hl, width, D).copy_(recv.permute(1, 0, 2, 3, 4, 5, 6))
-        return hx
+        all_to_all_chunks(recv.view(R, -1), send.view(R, -1), self.group)                          # [src j = frame block][b, tl, v]
+        # unpack: -> [b, j, tl, v] = all frames (j, tl) of my token rows
+        return _permute_blocks(recv, (B, R, Tl, V), (Tl * V, B * Tl * V, V, 1), blk, out=out).view(B * R * Tl * V * hl * width, D)
 
     def rows_to_frames(self, hx: torch.Tensor, B: int, Tl: int, V: int, height: int, width: int,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         R, D = self.size, hx.shape[-1]
         hl = height // R
-        send = hx.view(B, R, Tl, V, hl, width, D).permute(1, 0, 2, 3, 4, 5, 6).contiguous()        # [dest j = frame block]
+        blk = hl * width * D
+        hx = hx.contiguous()
+        # pack: [b, j, tl, v] blocks -> [dest j = frame block][b, tl, v]
+        send = _permute_blocks(hx, (R, B, Tl, V), (Tl * V, R * Tl * V, V, 1), blk)
         recv = torch.empty_like(send)
-        all_to_all_chunks(recv, send, self.group)                                                  # [src j = row block]
-        h = out if out is not None else torch.empty((B * Tl * V * height * width, D), dtype=hx.dtype, device=hx.device)
-        h.view(B, Tl, V, R, hl, width, D).copy_(recv.permute(1, 2, 3, 0, 4, 5, 6))
-        return h
+        all_to_all_chunks(recv.view(R, -1), send.view(R, -1), self.group)                          # [src j = row block][b, tl, v]
+        # unpack: -> [b, tl, v, j] = all token rows of my frames
+        return _permute_blocks(recv, (B, Tl, V, R), (Tl * V, V, 1, B * Tl * V), blk, out=out).view(B * Tl * V * height * width, D)
 
     def gather_frames(self, x: torch.Tensor, frame_dim: int = 1) -> torch.Tensor:
         """all ranks' frame blocks concatenated along `frame_dim` (per-image vectors, final latents)."""
