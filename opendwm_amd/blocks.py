@@ -247,8 +247,10 @@ class Attention(nn.Module):
             # and log2(e) folded into the q columns, so that the attention kernels take the scores as log2-domain without rescaling
             # their Q fragments (dwm_attn_args.variant bit 15; one rounding of q instead of two).  Training keeps "rms".
             def rms_cols(nq, nk, fold):
-                wq = nq.weight.detach().float() * (self.dim_head ** -0.5 * 1.4426950408889634) if fold else nq.weight
-                return torch.cat([_bf(wq).repeat(self.heads), _bf(nk.weight).repeat(self.heads)]).contiguous()
+                wq = _bf(nq.weight)
+                if fold:        # a temporary: converted here, NOT through STORE.bf (its shadow cache is keyed on the tensor's identity)
+                    wq = (nq.weight.detach().float() * (self.dim_head ** -0.5 * 1.4426950408889634)).to(wq.dtype)
+                return torch.cat([wq.repeat(self.heads), _bf(nk.weight).repeat(self.heads)]).contiguous()
             if self.has_qk_norm:
                 pk["rms"] = rms_cols(self.norm_q, self.norm_k, False)
                 pk["rms_ps"] = rms_cols(self.norm_q, self.norm_k, True)

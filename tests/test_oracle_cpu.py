@@ -223,6 +223,30 @@ def test_geglu_pack_matches_kernel_epilogue_contract():
     assert rel_err(mine, ref) < 1e-6
 
 
+def test_packed_prescaled_rms_weights_are_each_norm_s_own():
+    """Attention.packed(): "rms_ps" / "rms_add_ps" = the q RMSNorm weights x head_dim^-1/2 log2(e) (blocks.PRESCALE_Q) | the k weights,
+    per stream.  The scaled q weights are temporaries; a conversion cache keyed on tensor identity (STORE.bf's shadow) handed the
+    context stream the main stream's q weights when the allocator reused the temporary (round 6, found by the two-rank tests)."""
+    from opendwm_amd.blocks import Attention
+    bf16 = torch.bfloat16
+    a = Attention(128, 2, 64, bias=True, added_kv=True, qk_norm="rms_norm", eps=1e-6)
+    g = torch.Generator().manual_seed(3)
+    for n in (a.norm_q, a.norm_k, a.norm_added_q, a.norm_added_k):
+        n.weight.data = 1 + 0.5 * torch.randn(64, generator=g)
+    c = 64 ** -0.5 * 1.4426950408889634
+    from opendwm_amd.blocks import STORE
+    before = set(STORE._shadow)
+    for _ in range(3):                                                # (fresh temporaries each time)
+        a._pk = None
+        pk = a.packed()
+        for key, nq, nk in (("rms", a.norm_q, a.norm_k), ("rms_add", a.norm_added_q, a.norm_added_k)):
+            assert torch.equal(pk[key], torch.cat([nq.weight.to(bf16).repeat(2), nk.weight.to(bf16).repeat(2)]))
+            assert torch.equal(pk[key + "_ps"], torch.cat([(nq.weight.float() * c).to(bf16).repeat(2), nk.weight.to(bf16).repeat(2)]))
+        # ... and no temporary may sit in the identity-keyed cache at all (the stale hit itself needs the allocator's cooperation)
+        assert {k for k in STORE._shadow if k not in before} <= {id(p) for p in a.parameters()}
+        STORE.bump()
+
+
 def test_model_state_dict_keys_equal_reference_tree(small_cfg):
     from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
     m = DiTCrossviewTemporalConditionModel(**small_cfg)
