@@ -217,6 +217,11 @@ typedef struct dwm_attn_args {
 } dwm_attn_args;
 
 int dwm_attention_fwd(const dwm_attn_args* args, void* stream);
+/* Launches of dwm_attention_fwd served by the streaming kernel (attention_stream.hip) in this process (a relaxed atomic: diagnostics).
+ * It covers unmasked two-segment launches only while (q1 - q0) and (o1 - o0) are multiples of 16 bytes and within +-16 GiB (its row
+ * tables hold 32-bit offsets with the displacement folded in); others run attn_res_kernel - same results to bf16 round-off, not the
+ * same bits.  Callers that want one kernel for every launch keep the two segments of q / k / v and of o in one allocation each. */
+int64_t dwm_attn_stream_launches(void);
 
 /* Backward of dwm_attention_fwd (F.scaled_dot_product_attention inside JointAttnProcessor2_0 /
  * AttnProcessor2_0 under autograd).  `fwd` repeats the forward call: q/k/v, the forward OUTPUTS

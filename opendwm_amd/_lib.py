@@ -119,6 +119,7 @@ SIGNATURES = {
     "dwm_gemm_bf16": (_i32, [C.POINTER(GemmArgs), _vp]),
     "dwm_gemm4w_launches": (_i64, []),
     "dwm_gemm4w_launches_general": (_i64, []),
+    "dwm_attn_stream_launches": (_i64, []),
     "dwm_gemm_tn": (_i32, [C.POINTER(GemmTnArgs), _vp]),
     "dwm_attention_fwd": (_i32, [C.POINTER(AttnArgs), _vp]),
     "dwm_attention_bwd": (_i32, [C.POINTER(AttnBwdArgs), _vp]),

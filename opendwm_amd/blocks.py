@@ -267,17 +267,17 @@ class Attention(nn.Module):
         """dwm_attn_args.variant bits that go with what `project_qkv` produces: bit 15 when q leaves it pre-scaled"""
         return ops.ATTN_Q_PRESCALED if (self.has_qk_norm and PRESCALE_Q) else 0
 
-    def project_qkv(self, x: torch.Tensor, added: bool = False) -> torch.Tensor:
+    def project_qkv(self, x: torch.Tensor, added: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [rows, dim] -> fused [rows, 3*inner] with q,k RMS-normalised per head (q scaled by head_dim^-1/2 log2(e) as well when
-        `attn_variant` says so: pass that to ops.attention)."""
+        `attn_variant` says so: pass that to ops.attention).  `out`: the [rows, 3*inner] buffer to fill."""
         pk = self.packed()
         ps = "_ps" if self.attn_variant else ""
         w, b, rms = (pk["wadd"], pk["badd"], pk.get("rms_add" + ps)) if added else (pk["wqkv"], pk["bqkv"], pk.get("rms" + ps))
         if rms is None:
-            return ops.gemm(x, w, b)
+            return ops.gemm(x, w, b, out=out)
         if self.dim_head != 64:
             raise RuntimeError("qk RMSNorm is implemented for head_dim 64 only")
-        return ops.gemm(x, w, b, epilogue=EPI_RMSHEAD, rms_w=rms, rms_ncols=rms.numel(), rms_eps=self.eps)
+        return ops.gemm(x, w, b, epilogue=EPI_RMSHEAD, rms_w=rms, rms_ncols=rms.numel(), rms_eps=self.eps, out=out)
 
 
 class JointTransformerBlock(nn.Module):
@@ -324,10 +324,15 @@ class JointTransformerBlock(nn.Module):
         else:
             nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 1), shift=sl(cmod, 0), rows_per_mod=Lc, x32=x32)
 
-        qkv = self.attn.project_qkv(nh)
-        cqkv = self.attn.project_qkv(nc, added=True)
-        ao = _act_like(h)
-        cao = _act_like(c)
+        # the two segments of q / k / v and of the attention output in ONE allocation each: the streaming attention kernel folds the
+        # distance between the segments into 32-bit row offsets (+-16 GiB) and leaves pairs further apart - which a caching allocator
+        # does hand out - to the 12-wave kernel: same results to bf16 round-off, but not the same bits from one forward to the next
+        rows_h, rows_c = nh.shape[0], nc.shape[0]
+        both = torch.empty(rows_h + rows_c, 3 * D, dtype=nh.dtype, device=nh.device)
+        qkv = self.attn.project_qkv(nh, out=both[:rows_h])
+        cqkv = self.attn.project_qkv(nc, added=True, out=both[rows_h:])
+        ao_both = torch.empty(rows_h + rows_c, D, dtype=nh.dtype, device=nh.device)
+        ao, cao = ao_both[:rows_h], ao_both[rows_h:]
         ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, ops.rowmap_identity(n_img, N), self.heads,
                       q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cao, variant=self.attn.attn_variant | ATTN_VARIANT)
         to_out = self.attn.to_out[0]

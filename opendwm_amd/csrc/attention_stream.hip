@@ -22,6 +22,8 @@
 // wave's V requests, Q, the first K fragments), one barrier.
 // Images, swizzles, row tables, persistent workgroups, the maximum-free fast path with its acceptance test and fallback, zero pad rows
 // and the register-exchange stores are attn_res_kernel's / round 5's.
+#include <atomic>
+
 #include "attention_common.h"
 
 using namespace dwm_attn;
@@ -287,6 +289,9 @@ __device__ __attribute__((noinline)) void st_fallback_tile(const bf16_t* qp, bf1
 // the persistent head loop of one wave with NT query tiles per head (tiles t0 .. t0 + NT - 1); NODD: the number of key steps is odd
 // (a template parameter, not a branch behind the main loop: the two tails - one or two peeled steps - would join with 160 accumulator
 // registers live, and the register allocator reconciles the two paths through scratch memory)
+#ifndef ST_STORE64_MAX_NT
+#define ST_STORE64_MAX_NT 4                    // (experiment builds override: 5 = the 64-byte-run stores for every tile count, 0 = never)
+#endif
 template <int NT, bool NODD>
 DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     constexpr int NW = 4;
@@ -529,7 +534,7 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
                 // (the 64-byte-run form measured +3..4 % on the whole kernel with 2..4 tiles per wave - L = 448: 664-695 against 648-668
                 //  TFLOP/s - and -2 % with 5, where its second row pointer and eight swaps per tile sit in the one place three waves are
                 //  serialised on the store path anyway: profiles/r6g5_*)
-                if constexpr (NT <= 4) st_store_tile64(pkd, out_row(t, l31 & 15), out_row(t, (l31 & 15) + 16), l31, half);
+                if constexpr (NT <= ST_STORE64_MAX_NT) st_store_tile64(pkd, out_row(t, l31 & 15), out_row(t, (l31 & 15) + 16), l31, half);
                 else st_store_tile(pkd, out_ptr(t), half);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -590,6 +595,13 @@ __global__ void __launch_bounds__(256, 1)
 attn_stream_kernel(const AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef ST_X_STAGGER
+    {   // (experiment builds: workgroup classes start ST_X_STAGGER_TICKS of the 100 MHz counter apart - the seams of the classes then fall apart)
+        const uint64_t t_in = __builtin_readcyclecounter();
+        const uint64_t d = (uint64_t)((blockIdx.x >> 3) % ST_X_STAGGER) * ST_X_STAGGER_TICKS;
+        while (__builtin_readcyclecounter() - t_in < d) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     // this wave's query tiles of every head: nqt / 4 (+ 1 for the first nqt % 4 waves) adjacent tiles; the host side launches
     // this kernel for 8 <= nqt <= 20 only (2..5 tiles per wave)
     const int nqt = (P.qend + 31) >> 5;
@@ -613,6 +625,9 @@ attn_stream_kernel(const AttnParams P) {
 
 // Called by dwm_attention_fwd (attention.hip) for the launches this kernel covers: unmasked self-attention whose V rows of a head
 // fit the LDS twice, 8 <= query tiles <= 20 (225 <= L <= 608: two to five tiles per wave).
+static std::atomic<int64_t> g_stream_launches{0};           // launches served (dwm_attn_stream_launches: diagnostics, relaxed)
+extern "C" int64_t dwm_attn_stream_launches(void) { return g_stream_launches.load(std::memory_order_relaxed); }
+
 int dwm_attn_stream_launch(const dwm_attn::AttnParams& P, unsigned nblk, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -620,13 +635,20 @@ int dwm_attn_stream_launch(const dwm_attn::AttnParams& P, unsigned nblk, hipStre
         attr_set = true;
     }
     // the row tables hold offsets from q0 / k0 / v0 / o0 with the segment-1 displacement folded in, in 16-byte units as int32: both
-    // displacements must be whole units and every offset must fit (otherwise: -1, the caller keeps attn_res_kernel)
+    // displacements must be whole units and every offset must fit (otherwise: -1, the caller keeps attn_res_kernel).  Two segments in
+    // SEPARATE allocations may lie further apart than that (+-16 GiB here; a caching allocator on a 288-GB device hands out such
+    // pairs): a caller that wants this kernel for every launch - and with it the same bits from launch to launch - puts the two
+    // segments of q / k / v and of the output into one allocation each (blocks.JointTransformerBlock does).
     const int64_t lim = 1ll << 33;
     if (P.seg1_delta % 8 != 0 || P.oseg1_delta % 8 != 0 || P.seg1_delta <= -lim || P.seg1_delta >= lim || P.oseg1_delta <= -lim || P.oseg1_delta >= lim) return -1;
     const int Lp = (P.L + 31) & ~31;
     const size_t lds = (size_t)2 * Lp * 128 + (size_t)3 * Lp * sizeof(int32_t);
     if (lds > 160 * 1024) return -1;
+#ifdef ST_X_NBLK
+    if (nblk > ST_X_NBLK) nblk = ST_X_NBLK;                 // (experiment builds: fewer workgroups - is the seam's store time a per-CU or a chip-wide limit?)
+#endif
     hipLaunchKernelGGL(attn_stream_kernel, dim3(nblk), dim3(256), lds, s, P);
+    g_stream_launches.fetch_add(1, std::memory_order_relaxed);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;
 }

@@ -373,15 +373,21 @@ def test_unet_full_width_config1_six_frames_vs_oracle_on_device(dev):
     assert out.shape == (nb, 6, 6, 4, 32, 56) and e < TOL
 
 
-def test_full_width_train_gradients_vs_oracle_autograd_on_device(dev):
+@pytest.mark.parametrize("depth", ["slice3"] + (["full24"] if HEAVY else []))
+def test_full_width_train_gradients_vs_oracle_autograd_on_device(dev, depth):
     """BASELINE.json configs[3] geometry at full width on a 3-layer slice (dual joint blocks 0-2, cross-view block after 1,
     temporal block after 2), one sample of 6 views x 4 frames x 32x56 latents: d<prediction, w>/d(parameter) of the HIP
     training path (checkpointed block Functions, hand-written backward kernels, fp32 master weights) against fp32 autograd
-    through the oracle on the device"""
+    through the oracle on the device.  DWM_HEAVY_TESTS=1 adds the FULL depth (24 joint blocks, 13 of them dual, 6 cross-view and 12
+    temporal blocks - the shipped configuration; the oracle's autograd graph takes ~100 GB of the device): result of round 6 in
+    profiles/r6_full_depth_train_gradients.log."""
     from opendwm_amd import train
     from opendwm_amd.dit import DiTCrossviewTemporalConditionModel
-    cfg = O.make_config(num_layers=3, dual_attention_layers=[0, 1, 2], crossview_block_layers=[1], temporal_block_layers=[2],
-                        pos_embed_max_size=64)
+    if depth == "full24":
+        cfg = O.make_config(pos_embed_max_size=64)
+    else:
+        cfg = O.make_config(num_layers=3, dual_attention_layers=[0, 1, 2], crossview_block_layers=[1], temporal_block_layers=[2],
+                            pos_embed_max_size=64)
     gen = torch.Generator().manual_seed(0)
     sd = {n: O.synth_param(n, s, cfg, gen).to(bf16).float() for n, s in O.param_shapes(cfg).items()}
     inp = O.make_inputs(cfg, 1, 4, 6, 32, 56, seed=0)
@@ -420,6 +426,7 @@ def test_full_width_train_gradients_vs_oracle_autograd_on_device(dev):
     glob = (num / den) ** 0.5
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     mix = {n: v for n, v in errs.items() if n.endswith("mix_factor")}
-    _log("full_width_train_gradients", fwd=e_fwd, global_rel=glob, n_params=len(errs), worst=worst, mixers=mix, missing=missing)
+    _log("full_width_train_gradients", depth=depth, layers=cfg["num_layers"], fwd=e_fwd, global_rel=glob, n_params=len(errs), worst=worst,
+         mixers=mix, missing=missing)
     assert not missing, missing
     assert e_fwd < TOL and glob < 3e-2, (e_fwd, glob, worst)
