@@ -289,6 +289,9 @@ __device__ __attribute__((noinline)) void st_fallback_tile(const bf16_t* qp, bf1
 // the persistent head loop of one wave with NT query tiles per head (tiles t0 .. t0 + NT - 1); NODD: the number of key steps is odd
 // (a template parameter, not a branch behind the main loop: the two tails - one or two peeled steps - would join with 160 accumulator
 // registers live, and the register allocator reconciles the two paths through scratch memory)
+#ifndef ST_QLOAD64
+#define ST_QLOAD64 0                           // (experiment builds: 1 = Q rows requested as 64-byte runs)
+#endif
 #ifndef ST_STORE64_MAX_NT
 #define ST_STORE64_MAX_NT 4                    // (experiment builds override: 5 = the 64-byte-run stores for every tile count, 0 = never)
 #endif
@@ -387,9 +390,27 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     auto load_q = [&](bf16x8 (&qn)[NT][4], ltab_t tab, int64_t ho) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+#if ST_QLOAD64
+            // four loads of 16 rows x 64 contiguous bytes instead of four of 32 rows x 32 bytes (half the lines per instruction, as
+            // st_store_tile64): rows (l31 & 15) and (l31 & 15) + 16, this lane's chunk ch of each 64-byte half; take_q undoes the
+            // lane exchange with one v_permlane16_swap per dword pair
+            int ra = l31 & 15;
+            asm volatile("" : "+v"(ra));
+            int la = (t0 + t) * 32 + ra, lb = la + 16;
+            la = la < P.qend ? la : P.qend - 1;
+            lb = lb < P.qend ? lb : P.qend - 1;
+            asm volatile("" : "+v"(la), "+v"(lb));
+            const int ch = ((l31 >> 4) << 1) + half;
+            const gbf16p pa = (x.q0 + ho) + ((int64_t)(tab[la] + ch) << 3), pb = (x.q0 + ho) + ((int64_t)(tab[lb] + ch) << 3);
+            qn[t][0] = *(const __attribute__((address_space(1))) bf16x8*)(pa);
+            qn[t][1] = *(const __attribute__((address_space(1))) bf16x8*)(pb);
+            qn[t][2] = *(const __attribute__((address_space(1))) bf16x8*)(pa + 32);
+            qn[t][3] = *(const __attribute__((address_space(1))) bf16x8*)(pb + 32);
+#else
             const gbf16p qp = q_ptr(tab, ho, t);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qn[t][ks] = *(const __attribute__((address_space(1))) bf16x8*)(qp + ks * 16);
+#endif
         }
     };
     // (behind an asm `s_waitcnt vmcnt(0)` the compiler still counts the K fragments requested before it as pending loads; merged with
@@ -403,6 +424,21 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     //  each one into a scratch AGPR tuple in front of every S MFMA - 4 extra instructions per MFMA and, worse, a v_accvgpr_write -> MFMA
     //  read without the wait states the hazard needs, which it cannot see inside the asm: wrong scores.  check_stream_asm.py audits it.)
     auto take_q = [&](bf16x8 (&qn)[NT][4]) {
+#if ST_QLOAD64
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                u32x4 a = *reinterpret_cast<u32x4*>(&qn[t][2 * pr]), b = *reinterpret_cast<u32x4*>(&qn[t][2 * pr + 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(a[i], b[i], false, false);
+                    a[i] = sw[0]; b[i] = sw[1];
+                }
+                qn[t][2 * pr] = *reinterpret_cast<bf16x8*>(&a);
+                qn[t][2 * pr + 1] = *reinterpret_cast<bf16x8*>(&b);
+            }
+#endif
         if (scale_log2 != 1.f) {                              // (one wave-uniform branch, not one per fragment)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -515,6 +551,8 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             ok = ok && (l_tot[t] >= lmin) && (l_tot[t] <= 1.8446744e19f);
         }
         auto out_row = [&](int t, int row) -> bf16_t* {            // output row `row` (0..31) of tile t (rows past the last query: the last one)
+            asm volatile("" : "+v"(row));                        // (opaque BEFORE the clamp: the clamped row numbers are loop invariants otherwise - ten
+                                                                 //  values hoisted out of the head loop and kept across it in scratch memory at 5 tiles)
             int lq = (t0 + t) * 32 + row;
             lq = lq < P.qend ? lq : P.qend - 1;
             asm volatile("" : "+v"(lq));

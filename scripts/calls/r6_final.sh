@@ -31,9 +31,13 @@ echo "== 4. other lines"; date
 timeout 400 python bench.py --train --steps 4 --warmup 2 > $OUT/bench_train.json 2> $OUT/bench_train.err; grep '^{' $OUT/bench_train.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  train', d['value'], d['unit'], round(d['ms_per_step'],2), 'ms', d.get('approx_mfma_frac'))"
 timeout 400 python bench.py --train --preflight --steps 2 --warmup 1 > $OUT/bench_train_ddp1.json 2> $OUT/bench_train_ddp1.err; grep '^{' $OUT/bench_train_ddp1.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); t=d['config']['ddp']['bucket_timeline']; print('  ddp timeline', {k: t[k] for k in t if k.startswith(('fp32','bf16','backward_ms','buckets'))})"
 timeout 300 python bench.py --unet --steps 10 --warmup 3 > $OUT/bench_unet.json 2> $OUT/bench_unet.err; grep '^{' $OUT/bench_unet.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  unet', d['value'], d['unit'], round(d['ms_per_step'],2), 'ms')"
+timeout 300 python bench.py --unet --graph --steps 10 --warmup 3 > $OUT/bench_unet_graph.json 2> $OUT/bench_unet_graph.err; grep '^{' $OUT/bench_unet_graph.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  unet (HIP graph)', d['value'], d['unit'], round(d['ms_per_step'],2), 'ms')"
 timeout 300 python bench.py --unet --train --steps 4 --warmup 2 > $OUT/bench_unet_train.json 2> $OUT/bench_unet_train.err; grep '^{' $OUT/bench_unet_train.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  unet train', d['value'], d['unit'], round(d['ms_per_step'],2), 'ms')"
 timeout 400 python bench.py --tvae-ar > $OUT/bench_tvae_ar.json 2> $OUT/bench_tvae_ar.err; grep '^{' $OUT/bench_tvae_ar.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('  tvae-ar', d['value'], d['unit'], round(d['ms_per_step'],2), 'ms')"
 timeout 200 python scripts/microbench.py attnr4 attnfull attnunet cv pw > $OUT/microbench_attention.log 2>&1; cut -c1-160 $OUT/microbench_attention.log | tail -22
+echo "== 4b. full-depth training gradients against the oracle's autograd (DWM_HEAVY_TESTS case)"; date
+DWM_HEAVY_TESTS=1 timeout 900 python -m pytest tests/test_fulldepth_gpu.py -q -m gpu -p no:cacheprovider -k "train_gradients" > $OUT/full_depth_train_gradients.log 2>&1; tail -3 $OUT/full_depth_train_gradients.log | cut -c1-200
+grep full_width_train_gradients gpurun_out/gpu_parity.log | cut -c1-600 | tee -a $OUT/full_depth_train_gradients.log
 echo "== 5. smoke"; date
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -2 $OUT/smoke.log
 date
