@@ -318,6 +318,22 @@ def bench_stream32():
         print(json.dumps({"kernel": "ln-mod-dual", "stream": nm, "ms": round(ms, 4), "GBps": round((x.numel() * x.element_size() + 2 * y.numel() * 2) / ms / 1e6, 1)}))
 
 
+def bench_ln32():
+    """layernorm_kernel on the fp32 residual stream at the hidden-state size of the headline config (modulated, one and two outputs) and at
+    the context stream's size; GB/s of the algorithmic bytes (fp32 row in, bf16 row(s) out)"""
+    D = 1536
+    mod = rnd(192, 9 * D)
+    for M, rpm in ((86016, 448), (29568, 154)):
+        x = torch.randn(M, D, device=dev)
+        y, y2 = torch.empty(M, D, device=dev, dtype=torch.bfloat16), torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        for rep in range(2):
+            ms = timeit(lambda: ops.layernorm(x, eps=1e-6, scale=mod[:, D:2 * D], shift=mod[:, :D], rows_per_mod=rpm, out=y, x32=True), iters=20)
+            print(json.dumps({"kernel": "ln-mod", "rows": M, "stream": "fp32", "ms": round(ms, 4), "GBps": round((x.numel() * 4 + y.numel() * 2) / ms / 1e6, 1)}))
+            ms = timeit(lambda: ops.layernorm(x, eps=1e-6, scale=mod[:, D:2 * D], shift=mod[:, :D], rows_per_mod=rpm, out=y,
+                                              scale2=mod[:, 7 * D:8 * D], shift2=mod[:, 6 * D:7 * D], out2=y2, x32=True), iters=20)
+            print(json.dumps({"kernel": "ln-mod-dual", "rows": M, "stream": "fp32", "ms": round(ms, 4), "GBps": round((x.numel() * 4 + 2 * y.numel() * 2) / ms / 1e6, 1)}))
+
+
 def bench_stream32_tiles():
     """the K = 1536 RESID launch on the fp32 stream (34 ms of the step at 852-877 TFLOP/s): 8-wave 256 x 256 (tile 1), two 4-wave
     workgroups per CU on 256 x 128 x 32 (tile 2), the 4-wave 256 x 256 kernel (tile 3) - does a second workgroup per CU overlap the
@@ -378,6 +394,8 @@ if __name__ == "__main__":
         bench_stream32_tiles()
     if "s32" in what:
         bench_stream32()
+    if "ln32" in what:
+        bench_ln32()
     if "gemm" in what:
         bench_gemm()
     if "gemmx" in what:                  # reserved bit 2: the general RESID epilogue instead of its FAST form; bit 0: no epilogue
