@@ -337,6 +337,17 @@ def pmc_dram(kernel: str):
     return None
 
 
+def pmc_mfma_busy(kernel: str):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x GRBM_GUI_ACTIVE) of `kernel` from the same committed PMC file (None if it has no such row)"""
+    for name in PMC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]
+        except Exception:
+            continue
+        return (d.get("mfma") or {}).get("mfma_pipe_utilisation")
+    return None
+
+
 def pmc_traffic_file(kernel: str):
     """the committed PMC file that holds `kernel`'s traffic (the newest one that has a row for it)"""
     for name in PMC_FILES:
@@ -1165,6 +1176,8 @@ def main():
                                    "frac": (at.get("tflops") or 0.0) / PEAK_BF16_TFLOPS,
                                    "launches": at.get("launches"), "avg_launch_us": at.get("avg_us"),
                                    "share_of_step_time": (at.get("ms", 0.0) / args.steps) / step_ms,
+                                   "traffic": pmc_traffic("attn_stream_kernel"), "traffic_source": pmc_traffic_file("attn_stream_kernel"),
+                                   "mfma_pipe_busy": pmc_mfma_busy("attn_stream_kernel"),
                                    "all_attention_launches_tflops": ((at.get("flops") or 0.0) + (asm.get("flops") or 0.0) + (agr.get("flops") or 0.0)) /
                                    max((at.get("ms") or 0.0) + (asm.get("ms") or 0.0) + (agr.get("ms") or 0.0), 1e-9) / 1e9},
             "roofline_attention_crossview": None if not agr else {
