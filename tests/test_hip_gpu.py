@@ -404,18 +404,21 @@ def test_attention_resident_persistent_workgroups_across_item_seams(dev, I, N, L
     """attn_res_kernel as a persistent kernel: more items than CUs (150 x 2 = 300 items, 40 x 12 = 480), so a workgroup walks
     several (problem, head group) items - table rebuilds, the copy pipeline across item seams, both wave geometries - against
     the reference on the first and the LAST problems (the ones a workgroup reaches after its first item), and repeated
-    launches bit-identical"""
+    launches bit-identical.  Both segments of the inputs and of the output live in ONE allocation each, as the model passes them: the
+    default kernel for these lengths (round 6: attn_stream_kernel) takes a two-segment launch only while the segments lie within
+    +-16 GiB, so two launches on separately allocated buffers may be served by different kernels (include/dwm_hip.h,
+    dwm_attn_stream_launches).  Variants: the library's choice, the 12-wave resident kernel (bit 13), its 8-compute-wave geometry."""
     from opendwm_amd import ops
     D = heads * 64
-    qkv = _rand((I * N, 3 * D), dev, 21)
-    cqkv = _rand((I * Lc, 3 * D), dev, 22) if Lc else None
+    qc = _rand((I * (N + Lc), 3 * D), dev, 21)
+    qkv, cqkv = qc[:I * N], (qc[I * N:] if Lc else None)
     rm = ops.rowmap_identity(I, N)
     outs = {}
-    for variant in ((hs << 8), (hs << 8) | 8):
+    for variant in ((hs << 8), (hs << 8) | (1 << 13), (hs << 8) | 8):
         runs = []
         for _ in range(2):
-            out = torch.full((I * N, D), float("nan"), dtype=bf16, device=dev)
-            cout = torch.full((I * Lc, D), float("nan"), dtype=bf16, device=dev) if Lc else None
+            both = torch.full((I * (N + Lc), D), float("nan"), dtype=bf16, device=dev)
+            out, cout = both[:I * N], (both[I * N:] if Lc else None)
             kw = dict(q1=cqkv[:, :D], k1=cqkv[:, D:2 * D], v1=cqkv[:, 2 * D:], out1=cout) if Lc else {}
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], out, rm, heads, variant=variant, **kw)
             runs.append((out, cout))
