@@ -116,8 +116,8 @@ DWM_DEVINL void st_vdma(const StSrc& x, int k, int32_t tabv) {
 // the last slot, the trailing PV).
 // K fragments: S(k, t) reads set KP, S(k+1, 0) (slot NT - 1) set KP ^ 1; the fragments of step k + 2 are requested into set KP right
 // behind the last MFMA that reads it (S(k, NT-1), slot NT - 2): a whole key step of distance.  V fragments are single-buffered: step
-// k's are requested right behind the last PV MFMA of step k - 1 (slot 0).  Slot 0 also issues this wave's V request of the NEXT head
-// and reads the row-table entries of the requests one step ahead (tk: K row of step k + 3, tv: V row of step k + 1).
+// k's are requested right behind the last PV MFMA of step k - 1 (slot 0).  The head of the step reads the row-table entries of the requests
+// one step ahead; this wave's V request of the NEXT head goes out in the last slot, behind the K waits (tk: K row of step k + 3, tv: V row of step k + 1).
 template <int NT, int KP, bool FIRST, bool LAST>
 DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, int32_t& tk, int32_t& tv) {
     constexpr int PB = (NT & 1) ? KP : 0;                 // parity of unit (k, 0): k * NT mod 2
@@ -134,9 +134,7 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
 #endif
     const int32_t tv_now = tv;
 #ifndef ST_X_NO_DMA                                       // (ST_X_*: timing builds only - wrong results)
-#ifndef ST_DMA_LATE
-    // (unconditional - the last head of a workgroup requests its own rows once more: a branch here splits the key step into basic
-    //  blocks, and the compiler then drains the K requests at the head of the second one - `s_waitcnt vmcnt(0)` in every step)
+#ifdef ST_DMA_EARLY                                        // (the first form: the request at the head of the step - see the last slot below)
     st_vdma(x, k, tv_now);
 #endif
     if (!LAST) tv = st_vtab(x, k + 1);
@@ -172,10 +170,14 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
                     r.ot[tp][mi & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.vf[mi >> 1][mi & 1], r.p[par ^ 1][mi >> 1], fresh ? zero : r.ot[tp][mi & 1], 0, 0, 0);
                 }
                 if (!FIRST && t == 0) r.vf[mi >> 1][mi & 1] = st_vread(c, vlc, mi >> 1, mi & 1);
-#if !defined(ST_X_NO_DMA) && defined(ST_DMA_LATE)
+#if !defined(ST_X_NO_DMA) && !defined(ST_DMA_EARLY)
                 // this wave's V request of the next head: in the LAST slot, behind the S MFMAs that wait for the K fragments of step k + 1 -
-                // those counted waits also cover every request in front of them in the queue, so the V request of this step must not sit
-                // there (it would be waited for a few hundred cycles after its issue); the one of step k - 1 is a whole step old by then
+                // the counter is in order, so those counted waits also cover every request in front of them in the queue: a V request
+                // issued at the head of the step is waited for there, 2..4 slots after its issue (shorter than its latency with 2..4
+                // tiles per wave); issued here it is a whole step old at the next wait.  Measured: L = 448 (4 / 3 tiles per wave) 719-741
+                // against 715-720 TFLOP/s, head period 34.8 k against 36.9 k cycles in the trace builds; L = 602 834-855 against 831-836
+                // (profiles/r6p_*).  Unconditional - the last head of a workgroup requests its own rows once more: a branch here splits the
+                // key step into basic blocks, and the compiler then drains the K requests at the head of the second one.
                 if (t == NT - 1 && mi == 0) st_vdma(x, k, tv_now);
 #endif
             }
