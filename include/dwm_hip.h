@@ -218,9 +218,10 @@ typedef struct dwm_attn_args {
 
 int dwm_attention_fwd(const dwm_attn_args* args, void* stream);
 /* Launches of dwm_attention_fwd served by the streaming kernel (attention_stream.hip) in this process (a relaxed atomic: diagnostics).
- * It covers unmasked two-segment launches only while (q1 - q0) and (o1 - o0) are multiples of 16 bytes and within +-16 GiB (its row
- * tables hold 32-bit offsets with the displacement folded in); others run attn_res_kernel - same results to bf16 round-off, not the
- * same bits.  Callers that want one kernel for every launch keep the two segments of q / k / v and of o in one allocation each. */
+ * Two-segment launches: while (q1 - q0) and (o1 - o0) lie within +-16 GiB the kernel folds them into its 32-bit row offsets; pairs
+ * further apart (separate allocations on a 288-GB device can be) run its FAR instantiation, which adds the displacement per row -
+ * the same arithmetic on the same values, bit-identical results (tests/test_round6_gpu.py).  Only displacements that are not
+ * multiples of 16 bytes are left to attn_res_kernel. */
 int64_t dwm_attn_stream_launches(void);
 
 /* Backward of dwm_attention_fwd (F.scaled_dot_product_attention inside JointAttnProcessor2_0 /

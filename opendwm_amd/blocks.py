@@ -325,8 +325,9 @@ class JointTransformerBlock(nn.Module):
             nc = ops.layernorm(c, eps=1e-6, scale=sl(cmod, 1), shift=sl(cmod, 0), rows_per_mod=Lc, x32=x32)
 
         # the two segments of q / k / v and of the attention output in ONE allocation each: the streaming attention kernel folds the
-        # distance between the segments into 32-bit row offsets (+-16 GiB) and leaves pairs further apart - which a caching allocator
-        # does hand out - to the 12-wave kernel: same results to bf16 round-off, but not the same bits from one forward to the next
+        # distance between the segments into 32-bit row offsets while it fits (+-16 GiB) - its fastest form; pairs further apart,
+        # which a caching allocator does hand out, take the form that adds the displacement per row (same bits, a few more
+        # instructions per key step)
         rows_h, rows_c = nh.shape[0], nc.shape[0]
         both = torch.empty(rows_h + rows_c, 3 * D, dtype=nh.dtype, device=nh.device)
         qkv = self.attn.project_qkv(nh, out=both[:rows_h])

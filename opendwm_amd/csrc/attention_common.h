@@ -36,6 +36,7 @@ struct AttnParams {
     bf16_t *dq0, *dk0, *dv0;             // gradients, addressed like q0 / k0 / v0 with ld_d0 / ld_d1
     int64_t ld_d0, ld_d1, dseg1_delta;   // (dq1 - dq0) == (dk1 - dk0) == (dv1 - dv0)
     int64_t oseg1_delta, doseg1_delta;   // o1 - o0, do1 - do0 in elements
+    int stream_far;          // attn_stream_kernel only (set by its launcher): the segment displacements are added per row, not folded into the tables
     float* delta;                        // [n_problems, heads, L] -rowsum(dO * O)
     float scale;
     int n_problems, heads, nqb;

@@ -54,6 +54,7 @@ struct StSrc {
     int vsw;                     // this lane's swizzled 16-byte chunk of a V row in an LDS-DMA request (a lane constant: see st_vdma)
     bool has_next;
     uint32_t nv_lds;             // LDS byte address of the next head's V image
+    int64_t d1;                  // FAR form only: (q1 - q0) == (k1 - k0) == (v1 - v0) in elements, added to the rows of segment 1
 };
 
 // S MFMAs: inline asm, score accumulator in arch VGPRs (the VALU reads it), K fragment from arch VGPRs, Q fragment from AGPRs.
@@ -86,11 +87,15 @@ DWM_DEVINL int32_t st_ktab(const StSrc& x, int j) {
 __device__ const uint4 st_zero_row[8] = {};
 
 // this lane's K row of key step j (its 16 bytes of MFMA m are at + m * 16 elements)
+// FAR (here and below): the two segments of the launch lie further apart than the 32-bit table entries can fold in (+-16 GiB): the tables
+// then hold each row's offset inside its own segment and the displacement is added per row (three more vector instructions per address)
+template <bool FAR>
 DWM_DEVINL gbf16p st_kptr(const StSrc& x, int j, int32_t tabv) {
     const bool nxt = j >= x.n;
     const int jj = nxt ? j - x.n : j;
     const int key = jj * 32 + x.l31;
-    const gbf16p row = (x.k0 + (nxt ? x.nhoff : x.hoff)) + ((int64_t)(tabv + x.half) << 3);       // (half: the lane's 8 of 16 k values = one unit)
+    gbf16p row = (x.k0 + (nxt ? x.nhoff : x.hoff)) + ((int64_t)(tabv + x.half) << 3);             // (half: the lane's 8 of 16 k values = one unit)
+    if constexpr (FAR) row += key >= x.L0 ? x.d1 : (int64_t)0;
     return key < x.L ? row : (gbf16p)st_zero_row + x.half * 8;
 }
 DWM_DEVINL void st_kload(bf16x8 (&kf)[4], const gbf16p kp, int m) {
@@ -101,10 +106,13 @@ DWM_DEVINL void st_kload(bf16x8 (&kf)[4], const gbf16p kp, int m) {
 DWM_DEVINL int32_t st_vtab(const StSrc& x, int k) {
     return x.ntab[k * 32 + x.wave * 8 + (x.lane >> 3)];
 }
+template <bool FAR>
 DWM_DEVINL void st_vdma(const StSrc& x, int k, int32_t tabv) {
     const int r = k * 32 + x.wave * 8 + (x.lane >> 3);
     // (the chunk swizzle (lane & 7) ^ 4 ((r >> 1) & 1) depends on bit 1 of the row only, which is bit 1 of lane >> 3: x.vsw)
-    const gbf16p src = r < x.L ? (x.v0 + x.nhoff) + ((int64_t)(tabv + x.vsw) << 3) : (gbf16p)st_zero_row + x.vsw * 8;
+    gbf16p row = (x.v0 + x.nhoff) + ((int64_t)(tabv + x.vsw) << 3);
+    if constexpr (FAR) row += r >= x.L0 ? x.d1 : (int64_t)0;
+    const gbf16p src = r < x.L ? row : (gbf16p)st_zero_row + x.vsw * 8;
     const uint32_t dst = x.nv_lds + (uint32_t)(x.wave + 4 * k) * 1024u;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
 }
@@ -118,7 +126,7 @@ DWM_DEVINL void st_vdma(const StSrc& x, int k, int32_t tabv) {
 // behind the last MFMA that reads it (S(k, NT-1), slot NT - 2): a whole key step of distance.  V fragments are single-buffered: step
 // k's are requested right behind the last PV MFMA of step k - 1 (slot 0).  The head of the step reads the row-table entries of the requests
 // one step ahead; this wave's V request of the NEXT head goes out in the last slot, behind the K waits (tk: K row of step k + 3, tv: V row of step k + 1).
-template <int NT, int KP, bool FIRST, bool LAST>
+template <int NT, int KP, bool FIRST, bool LAST, bool FAR>
 DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, int32_t& tk, int32_t& tv) {
     constexpr int PB = (NT & 1) ? KP : 0;                 // parity of unit (k, 0): k * NT mod 2
     const char* const vlc = c.vimg + k * 4096;
@@ -130,12 +138,12 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
     for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(r.qf[t][0]), "+a"(r.qf[t][1]), "+a"(r.qf[t][2]), "+a"(r.qf[t][3]));
     // (the requests of this step use the entries read a step ago; the reads for the next step are issued now)
 #ifndef ST_X_NO_KLOAD
-    const gbf16p kp2 = st_kptr(x, k + 2, tk);
+    const gbf16p kp2 = st_kptr<FAR>(x, k + 2, tk);
 #endif
     const int32_t tv_now = tv;
 #ifndef ST_X_NO_DMA                                       // (ST_X_*: timing builds only - wrong results)
 #ifdef ST_DMA_EARLY                                        // (the first form: the request at the head of the step - see the last slot below)
-    st_vdma(x, k, tv_now);
+    st_vdma<FAR>(x, k, tv_now);
 #endif
     if (!LAST) tv = st_vtab(x, k + 1);
 #endif
@@ -178,7 +186,7 @@ DWM_DEVINL void st_block(StRegs<NT>& r, const ResCtx& c, const StSrc& x, int k, 
                 // against 715-720 TFLOP/s, head period 34.8 k against 36.9 k cycles in the trace builds; L = 602 834-855 against 831-836
                 // (profiles/r6p_*).  Unconditional - the last head of a workgroup requests its own rows once more: a branch here splits the
                 // key step into basic blocks, and the compiler then drains the K requests at the head of the second one.
-                if (t == NT - 1 && mi == 0) st_vdma(x, k, tv_now);
+                if (t == NT - 1 && mi == 0) st_vdma<FAR>(x, k, tv_now);
 #endif
             }
             // slice ch of E(u): scores 2 ch, 2 ch + 1
@@ -297,7 +305,7 @@ __device__ __attribute__((noinline)) void st_fallback_tile(const bf16_t* qp, bf1
 #ifndef ST_STORE64_MAX_NT
 #define ST_STORE64_MAX_NT 4                    // (experiment builds override: 5 = the 64-byte-run stores for every tile count, 0 = never)
 #endif
-template <int NT, bool NODD>
+template <int NT, bool NODD, bool FAR>
 DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     constexpr int NW = 4;
     const int tid = threadIdx.x;
@@ -352,11 +360,13 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     };
     auto build_tab = [&](int32_t* tab, int32_t* ot, uint32_t prob) {
         const int64_t base0 = seg0_base(P.rm, (int)prob);
-        for (int lp = tid; lp < Lp; lp += NW * 64) {
+        int lp0 = (int)threadIdx.x;                             // (re-read, opaque: a kernel-lifetime copy of the thread index is the first thing
+        asm volatile("" : "+v"(lp0));                           //  the register allocator spills across the head loop)
+        for (int lp = lp0; lp < Lp; lp += NW * 64) {
             const int l = lp < L ? lp : L - 1;
             const int64_t r0 = l < L0 ? seg0_row(P.rm, base0, l) : 0;
-            if (tab != nullptr) tab[lp] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1 + P.seg1_delta) >> 3);
-            if (ot != nullptr) ot[lp] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1 + P.oseg1_delta) >> 3);
+            if (tab != nullptr) tab[lp] = (int32_t)((l < L0 ? r0 * P.ld0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ld1 + (FAR ? 0 : P.seg1_delta)) >> 3);
+            if (ot != nullptr) ot[lp] = (int32_t)((l < L0 ? r0 * P.ldo0 : ((int64_t)prob * P.L1 + (l - L0)) * P.ldo1 + (FAR ? 0 : P.oseg1_delta)) >> 3);
         }
     };
     const int n = c.nsub;
@@ -365,7 +375,7 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     const float scale_log2 = P.scale_log2;
 
     x.k0 = (gbf16p)P.k0; x.v0 = (gbf16p)P.v0; x.q0 = (gbf16p)P.q0;
-    x.L = L; x.L0 = L0; x.n = n;
+    x.L = L; x.L0 = L0; x.n = n; x.d1 = P.seg1_delta;
 
     // this lane's Q row of tile t of a head (rows past the last query: the last one - same Q, same output, same bytes stored)
     typedef const __attribute__((address_space(3))) int32_t* ltab_t;          // row tables: LDS reads (ds_read), never flat ones
@@ -373,7 +383,9 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
         int lq = (t0 + t) * 32 + l31;
         lq = lq < P.qend ? lq : P.qend - 1;
         asm volatile("" : "+v"(lq));               // (opaque: the row's kernel-invariant address parts are NOT to be kept across the tile loop)
-        return (x.q0 + ho) + ((int64_t)(tab[lq] + half) << 3);
+        gbf16p row = (x.q0 + ho) + ((int64_t)(tab[lq] + half) << 3);
+        if constexpr (FAR) row += lq >= L0 ? P.seg1_delta : (int64_t)0;
+        return row;
     };
     // development aid (-DDWM_ATTN_TRACE): shader-clock stamps of the 4 waves of workgroups 0-7 at 8 points of every head, written to the
     // (otherwise unused) lse buffer as int64 [8 workgroups][4 waves][64 heads][8] (scripts/experiments/attn_trace_stream.py)
@@ -403,7 +415,8 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             lb = lb < P.qend ? lb : P.qend - 1;
             asm volatile("" : "+v"(la), "+v"(lb));
             const int ch = ((l31 >> 4) << 1) + half;
-            const gbf16p pa = (x.q0 + ho) + ((int64_t)(tab[la] + ch) << 3), pb = (x.q0 + ho) + ((int64_t)(tab[lb] + ch) << 3);
+            gbf16p pa = (x.q0 + ho) + ((int64_t)(tab[la] + ch) << 3), pb = (x.q0 + ho) + ((int64_t)(tab[lb] + ch) << 3);
+            if constexpr (FAR) { pa += la >= L0 ? P.seg1_delta : (int64_t)0; pb += lb >= L0 ? P.seg1_delta : (int64_t)0; }
             qn[t][0] = *(const __attribute__((address_space(1))) bf16x8*)(pa);
             qn[t][1] = *(const __attribute__((address_space(1))) bf16x8*)(pb);
             qn[t][2] = *(const __attribute__((address_space(1))) bf16x8*)(pa + 32);
@@ -468,10 +481,10 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
     __syncthreads();
     {
         x.tab = tabs; x.ntab = tabs; x.hoff = hoff; x.nhoff = hoff; x.has_next = true; x.nv_lds = lds0;
-        for (int k = 0; k < n; ++k) st_vdma(x, k, st_vtab(x, k));
+        for (int k = 0; k < n; ++k) st_vdma<FAR>(x, k, st_vtab(x, k));
         bf16x8 q0[NT][4];
         load_q(q0, (ltab_t)tabs, hoff);
-        const gbf16p kp0 = st_kptr(x, 0, st_ktab(x, 0)), kp1 = st_kptr(x, 1, st_ktab(x, 1));
+        const gbf16p kp0 = st_kptr<FAR>(x, 0, st_ktab(x, 0)), kp1 = st_kptr<FAR>(x, 1, st_ktab(x, 1));
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             st_kload(r.kf[0], kp0, m);
@@ -521,19 +534,19 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
         }
         int32_t tk = st_ktab(x, 2), tv = st_vtab(x, 0);
         asm volatile("s_nop 15" : "+v"(r.s[0]));              // E(0, 0) follows at once: the wait states the compiler cannot know about
-        st_block<NT, 0, true, false>(r, c, x, 0, tk, tv);
+        st_block<NT, 0, true, false, FAR>(r, c, x, 0, tk, tv);
         DWM_TRS(1);
         int k = 1;
         for (; k + 2 < n; k += 2) {
-            st_block<NT, 1, false, false>(r, c, x, k, tk, tv);
-            st_block<NT, 0, false, false>(r, c, x, k + 1, tk, tv);
+            st_block<NT, 1, false, false, FAR>(r, c, x, k, tk, tv);
+            st_block<NT, 0, false, false, FAR>(r, c, x, k + 1, tk, tv);
         }
         DWM_TRS(7);
         if constexpr (NODD) {                                   // two steps left: k (odd), k + 1 = n - 1
-            st_block<NT, 1, false, false>(r, c, x, k, tk, tv);
-            st_block<NT, 0, false, true>(r, c, x, k + 1, tk, tv);
+            st_block<NT, 1, false, false, FAR>(r, c, x, k, tk, tv);
+            st_block<NT, 0, false, true, FAR>(r, c, x, k + 1, tk, tv);
         } else {
-            st_block<NT, 1, false, true>(r, c, x, k, tk, tv);
+            st_block<NT, 1, false, true, FAR>(r, c, x, k, tk, tv);
         }
         DWM_TRS(2);
         // ---- the next head's Q rows.  (The table pointers are made opaque here: left alone the compiler computes the five Q
@@ -558,7 +571,9 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
             int lq = (t0 + t) * 32 + row;
             lq = lq < P.qend ? lq : P.qend - 1;
             asm volatile("" : "+v"(lq));
-            return (P.o0 + hoff) + ((int64_t)otab_l[lq] << 3);
+            bf16_t* orow = (P.o0 + hoff) + ((int64_t)otab_l[lq] << 3);
+            if constexpr (FAR) orow += lq >= L0 ? P.oseg1_delta : (int64_t)0;
+            return orow;
         };
         auto out_ptr = [&](int t) -> bf16_t* { return out_row(t, l31); };
 #ifdef ST_X_NO_FALLBACK
@@ -584,7 +599,7 @@ DWM_DEVINL void st_heads(const AttnParams& P, char* smem, int t0) {
 #endif
 #pragma unroll 1
             for (int t = 0; t < NT; ++t)
-                st_fallback_tile((const bf16_t*)q_ptr((ltab_t)tab, hoff, t), out_ptr(t), P.k0 + hoff, P.v0 + hoff, tab, 0, L, L0, n, scale_log2);
+                st_fallback_tile((const bf16_t*)q_ptr((ltab_t)tab, hoff, t), out_ptr(t), P.k0 + hoff, P.v0 + hoff, tab, FAR ? P.seg1_delta : (int64_t)0, L, L0, n, scale_log2);
         }
         // ---- the next head's Q rows: requested behind the stores (requested in front of them, their 80 registers are parked in the
         //      accumulator file under the normalisation - which needs the data, i.e. waits for it before the first store is issued).
@@ -649,15 +664,28 @@ attn_stream_kernel(const AttnParams P) {
     const int cnt = q4 + (wave < x4 ? 1 : 0);
     const int t0 = wave * q4 + (wave < x4 ? wave : x4);
     const bool nodd = (((P.L + 31) >> 5) & 1) != 0;
-    switch (cnt * 2 + (nodd ? 1 : 0)) {
-        case 4: st_heads<2, false>(P, smem, t0); break;
-        case 5: st_heads<2, true>(P, smem, t0); break;
-        case 6: st_heads<3, false>(P, smem, t0); break;
-        case 7: st_heads<3, true>(P, smem, t0); break;
-        case 8: st_heads<4, false>(P, smem, t0); break;
-        case 9: st_heads<4, true>(P, smem, t0); break;
-        case 10: st_heads<5, false>(P, smem, t0); break;
-        default: st_heads<5, true>(P, smem, t0); break;
+    if (P.stream_far == 0) {
+        switch (cnt * 2 + (nodd ? 1 : 0)) {
+            case 4: st_heads<2, false, false>(P, smem, t0); break;
+            case 5: st_heads<2, true, false>(P, smem, t0); break;
+            case 6: st_heads<3, false, false>(P, smem, t0); break;
+            case 7: st_heads<3, true, false>(P, smem, t0); break;
+            case 8: st_heads<4, false, false>(P, smem, t0); break;
+            case 9: st_heads<4, true, false>(P, smem, t0); break;
+            case 10: st_heads<5, false, false>(P, smem, t0); break;
+            default: st_heads<5, true, false>(P, smem, t0); break;
+        }
+    } else {                                              // segments further apart than the folded 32-bit entries reach
+        switch (cnt * 2 + (nodd ? 1 : 0)) {
+            case 4: st_heads<2, false, true>(P, smem, t0); break;
+            case 5: st_heads<2, true, true>(P, smem, t0); break;
+            case 6: st_heads<3, false, true>(P, smem, t0); break;
+            case 7: st_heads<3, true, true>(P, smem, t0); break;
+            case 8: st_heads<4, false, true>(P, smem, t0); break;
+            case 9: st_heads<4, true, true>(P, smem, t0); break;
+            case 10: st_heads<5, false, true>(P, smem, t0); break;
+            default: st_heads<5, true, true>(P, smem, t0); break;
+        }
     }
 }
 
@@ -674,20 +702,23 @@ int dwm_attn_stream_launch(const dwm_attn::AttnParams& P, unsigned nblk, hipStre
         (void)hipFuncSetAttribute((const void*)attn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    // the row tables hold offsets from q0 / k0 / v0 / o0 with the segment-1 displacement folded in, in 16-byte units as int32: both
-    // displacements must be whole units and every offset must fit (otherwise: -1, the caller keeps attn_res_kernel).  Two segments in
-    // SEPARATE allocations may lie further apart than that (+-16 GiB here; a caching allocator on a 288-GB device hands out such
-    // pairs): a caller that wants this kernel for every launch - and with it the same bits from launch to launch - puts the two
-    // segments of q / k / v and of the output into one allocation each (blocks.JointTransformerBlock does).
+    // the row tables hold offsets from q0 / k0 / v0 / o0 in 16-byte units as int32: both segment displacements must be whole units
+    // (otherwise: -1, the caller keeps attn_res_kernel).  Within +-16 GiB the displacement is folded into the segment-1 entries (no
+    // select on the way from an entry to an address); two segments in SEPARATE allocations may lie further apart - a caching
+    // allocator on a 288-GB device hands out such pairs - and run the FAR instantiation: entries relative to each segment, the
+    // displacement added per row.  Same arithmetic on the same values either way: the results are bit-identical
+    // (tests/test_round6_gpu.py places the segments 20 GiB apart).
+    if (P.seg1_delta % 8 != 0 || P.oseg1_delta % 8 != 0) return -1;
     const int64_t lim = 1ll << 33;
-    if (P.seg1_delta % 8 != 0 || P.oseg1_delta % 8 != 0 || P.seg1_delta <= -lim || P.seg1_delta >= lim || P.oseg1_delta <= -lim || P.oseg1_delta >= lim) return -1;
+    dwm_attn::AttnParams Pk = P;
+    Pk.stream_far = (P.seg1_delta <= -lim || P.seg1_delta >= lim || P.oseg1_delta <= -lim || P.oseg1_delta >= lim) ? 1 : 0;
     const int Lp = (P.L + 31) & ~31;
     const size_t lds = (size_t)2 * Lp * 128 + (size_t)3 * Lp * sizeof(int32_t);
     if (lds > 160 * 1024) return -1;
 #ifdef ST_X_NBLK
     if (nblk > ST_X_NBLK) nblk = ST_X_NBLK;                 // (experiment builds: fewer workgroups - is the seam's store time a per-CU or a chip-wide limit?)
 #endif
-    hipLaunchKernelGGL(attn_stream_kernel, dim3(nblk), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(attn_stream_kernel, dim3(nblk), dim3(256), lds, s, Pk);
     g_stream_launches.fetch_add(1, std::memory_order_relaxed);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DWM_OK : (int)e;

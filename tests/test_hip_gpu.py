@@ -405,9 +405,8 @@ def test_attention_resident_persistent_workgroups_across_item_seams(dev, I, N, L
     several (problem, head group) items - table rebuilds, the copy pipeline across item seams, both wave geometries - against
     the reference on the first and the LAST problems (the ones a workgroup reaches after its first item), and repeated
     launches bit-identical.  Both segments of the inputs and of the output live in ONE allocation each, as the model passes them: the
-    default kernel for these lengths (round 6: attn_stream_kernel) takes a two-segment launch only while the segments lie within
-    +-16 GiB, so two launches on separately allocated buffers may be served by different kernels (include/dwm_hip.h,
-    dwm_attn_stream_launches).  Variants: the library's choice, the 12-wave resident kernel (bit 13), its 8-compute-wave geometry."""
+    default kernel for these lengths (round 6: attn_stream_kernel) has one form for segments within +-16 GiB and one for pairs
+    further apart (bit-identical: tests/test_round6_gpu.py; include/dwm_hip.h, dwm_attn_stream_launches).  Variants: the library's choice, the 12-wave resident kernel (bit 13), its 8-compute-wave geometry."""
     from opendwm_amd import ops
     D = heads * 64
     qc = _rand((I * (N + Lc), 3 * D), dev, 21)

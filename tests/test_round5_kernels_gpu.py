@@ -181,8 +181,8 @@ def _served():
 
 
 def _run(ops, qkv, cqkv, I, N, Lc, heads, rm, variant):
-    # (both output segments in one allocation, as blocks.JointTransformerBlock passes them: attn_stream_kernel takes a two-segment launch
-    #  only while the segments lie within +-16 GiB of each other - include/dwm_hip.h, dwm_attn_stream_launches)
+    # (both output segments in one allocation, as blocks.JointTransformerBlock passes them: attn_stream_kernel's folded-offset form; the
+    #  form for segments more than +-16 GiB apart is tests/test_round6_gpu.py's - include/dwm_hip.h, dwm_attn_stream_launches)
     D = heads * 64
     both = torch.full((qkv.shape[0] + I * Lc, D), float("nan"), dtype=bf16, device=qkv.device)
     out = both[:qkv.shape[0]]
@@ -237,8 +237,8 @@ def test_attention_one_wave_per_simd_across_item_seams(dev, I, N, Lc, heads, hs)
     d = _run(ops, qkv, cqkv, I, N, Lc, heads, rm, K12 | (hs << 8))
     assert (n1 - n0, served() - n1) == (2, 0)                     # the streaming kernel served a and b, the 12-wave kernel d
     # two launches of one kernel: bit-identical.  (Round 6 saw launches differ by single bf16 roundings in ~2e-5 of the elements: with
-    # the segments in SEPARATE allocations one launch's pair lay within the streaming kernel's +-16 GiB and the other's did not - that
-    # one ran the 12-wave kernel.  profiles/README.md, round 6.)
+    # the segments in SEPARATE allocations one launch's pair lay within +-16 GiB and the other's did not - which the kernel's first
+    # form left to the 12-wave kernel.  profiles/README.md, round 6.)
     rep = max(rel_err(a[0], b[0]), rel_err(a[1], b[1]) if Lc else 0.0)
     if rep > 0:                                                   # where: problem / head / row histogram of the differing elements
         for nm, x, y, rows in (("seg0", a[0], b[0], N), ("seg1", a[1], b[1], Lc)) if Lc else (("seg0", a[0], b[0], N),):
