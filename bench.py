@@ -1200,6 +1200,8 @@ def main():
         if cp and cp.get("peak_at_sustained_clock_tflops") and gm.get("tflops"):
             # the same launches against what the matrix pipes deliver at the clock the board sustained during this run
             line["roofline"]["frac_of_peak_at_sustained_clock"] = gm["tflops"] / cp["peak_at_sustained_clock_tflops"]
+            if at.get("tflops"):
+                line["roofline_attention"]["frac_of_peak_at_sustained_clock"] = at["tflops"] / cp["peak_at_sustained_clock_tflops"]
         if pre is not None:
             line["preflight"] = pre
         if other is not None:
