@@ -130,3 +130,32 @@ def test_dropin_classes_are_diffusers_types_when_diffusers_imports(tmp_path, sma
     assert dit._Base is __import__("torch").nn.Module
     assert out["dit_keys"] == sorted(dit.DiTCrossviewTemporalConditionModel(**small_cfg).state_dict().keys())
     assert out["unet_keys"] == sorted(unet.UNetCrossviewTemporalConditionModel(**_unet_small()).state_dict().keys())
+
+
+def test_kernel_selection_is_mapped_on_the_host_side(monkeypatch):
+    """The C library reads no environment (round 6): `opendwm_amd.ops` maps DWM_GEMM4W / gemm_4wave_scope to dwm_gemm_args.tile
+    (0 = library's choice on the 8-wave kernels, 3 = the 4-wave kernels may serve the launch, 4 = their fast form only; an explicit
+    tile 1 / 2 of the caller always wins) and DWM_ATTN_VARIANT / DWM_ATTN_RES4 to bits OR-ed into dwm_attn_args.variant."""
+    import importlib
+    from opendwm_amd import ops
+    cases = {"": (0, 3), "0": (0, 0), "1": (3, 3), "f": (0, 4)}               # env -> (outside a scope, inside gemm_4wave_scope(True))
+    for env, (outside, inside) in cases.items():
+        monkeypatch.setattr(ops, "_G4W_ENV", env)
+        assert ops._gemm_tile_request(0) == outside, env
+        with ops.gemm_4wave_scope(True):
+            assert ops._gemm_tile_request(0) == inside, env
+            assert ops._gemm_tile_request(1) == 1 and ops._gemm_tile_request(2) == 2
+            with ops.gemm_4wave_scope(False):
+                assert ops._gemm_tile_request(0) == (3 if env == "1" else 0), env
+        assert ops._gemm_tile_request(0) == outside
+    assert ops.ATTN_Q_PRESCALED == 1 << 15 and ops.ATTN_STREAM == 1 << 12 and ops.ATTN_RES12 == 1 << 13
+    for env, want in ((dict(DWM_ATTN_VARIANT="0x2000"), 1 << 13), (dict(DWM_ATTN_VARIANT="4096", DWM_ATTN_RES4=""), 1 << 12),
+                      (dict(DWM_ATTN_RES4="2"), (1 << 12) | (1 << 13)), ({}, 0)):
+        for k in ("DWM_ATTN_VARIANT", "DWM_ATTN_RES4"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert importlib.reload(ops)._ATTN_ENV_VARIANT == want, env
+    for k in ("DWM_ATTN_VARIANT", "DWM_ATTN_RES4"):
+        monkeypatch.delenv(k, raising=False)
+    importlib.reload(ops)
